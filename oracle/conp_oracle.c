@@ -1,0 +1,1078 @@
+/* ---------------------------------------------------------------------------------------------
+ * conp_oracle.c  --  TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT PATH.
+ *
+ * A plain-C, single-threaded CPU restatement of the constant-potential charge-solve hot path
+ * of srtee/lammps-USER-CONP2 (fix_conp.cpp + km_ewald.cpp, low-memory Ewald provider, one MPI
+ * rank).  It exists so that the HIP library can be checked against the reference's algorithm
+ * on identical inputs, and so that bench.py can time a CPU baseline ("cpu_baseline.kind =
+ * port").  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Every function cites the reference file:line whose arithmetic (operation order included) it
+ * follows; citations are relative to /root/reference.  No reference source text is copied:
+ * this file is C, uses its own data model (flat arrays, CSR neighbour lists, explicit
+ * "atoms view" instead of LAMMPS classes) and restates the loops from the mathematics.
+ *
+ * PARITY PIN (see DESIGN.md "Oracle"): the reference itself cannot be built in this image
+ * (it needs the LAMMPS 27May2021 headers and library, which are absent, and writing stand-ins
+ * for them is not allowed).  The oracle is therefore pinned by the only known-answer vector the
+ * reference's tests hold for this path: tests/dilute/persist.log:112,143 (G vector
+ * 0.77236341; step-0 electrode charge 0.044057154 / -0.044057154, |sum| < 1e-15, ffield etypes,
+ * dV = 1 V) -- checked in tests/test_oracle_pin.py -- plus the deck-level invariants of
+ * SURVEY.md section 4.
+ * ------------------------------------------------------------------------------------------- */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* LAMMPS math_const.h values (used at km_ewald.cpp:85-89, fix_conp.cpp:783) */
+#define ORC_PI   3.14159265358979323846
+#define ORC_PIS  1.77245385090551602729 /* sqrt(pi) */
+#define ORC_4PI  12.56637061435917295384
+
+/* erfc polynomial constants, fix_conp.cpp:53-60 */
+#define ORC_EWALD_F 1.12837917
+#define ORC_EWALD_P 0.3275911
+#define ORC_A1 0.254829592
+#define ORC_A2 (-0.284496736)
+#define ORC_A3 1.421413741
+#define ORC_A4 (-1.453152027)
+#define ORC_A5 1.061405429
+#define ORC_ERFC_MAX 5.8
+
+#define ORC_NEIGHMASK 0x3FFFFFFF /* LAMMPS lmptype.h SBBITS=30 */
+
+#define ORC_MAX(a, b) ((a) > (b) ? (a) : (b))
+
+/* =============================================================================================
+ * K-space tables  (km_ewald.cpp:63-132 conp_setup, :277-283 rms, :285-364 make_kvecs_ewald,
+ * :366-381 make_ug_from_kvecs, :383-424 make_kxy_list_from_kvecs)
+ * ===========================================================================================*/
+typedef struct {
+  double g_ewald, accuracy, slab_volfactor;
+  int slabflag;
+  double xprd, yprd, zprd, volume, gsqmx, ug_tot;
+  double unitk[3];
+  int kxmax, kymax, kzmax, kmax, kmax3d;
+  int kcount, kcount_flat, kcount_expand;
+  int kcount_dims[7];
+  int *kxvecs, *kyvecs, *kzvecs, *kxy_list, *kz_list;
+  double *ug;
+} orc_kspace;
+
+/* km_ewald.cpp:277-283 */
+static double orc_rms(double g_ewald, int km, double prd, long long natoms, double q2) {
+  double value = 2.0 * q2 * g_ewald / prd * sqrt(1.0 / (ORC_PI * km * natoms)) *
+                 exp(-ORC_PI * ORC_PI * km * km / (g_ewald * g_ewald * prd * prd));
+  return value;
+}
+
+/* enumerates the half-space k list in the reference order; if ks->kxvecs == NULL only counts.
+ * km_ewald.cpp:285-361 */
+static void orc_enumerate_kvecs(orc_kspace *ks) {
+  int k, l, m, ic, kcount = 0;
+  const int kmaxes[3] = {ks->kxmax, ks->kymax, ks->kzmax};
+  double unitksq[3], sqk;
+  int fill = ks->kxvecs != NULL;
+  for (ic = 0; ic < 7; ++ic) ks->kcount_dims[ic] = 0;
+  /* axes: (k,0,0) (0,l,0) (0,0,m)  :297-310 */
+  for (ic = 0; ic < 3; ++ic) {
+    unitksq[ic] = ks->unitk[ic] * ks->unitk[ic];
+    for (m = 1; m <= kmaxes[ic]; ++m) {
+      sqk = m * m * unitksq[ic];
+      if (sqk <= ks->gsqmx) {
+        if (fill) {
+          if (ic == 0) ks->kxvecs[kcount] = m;
+          else if (ic == 1) ks->kyvecs[kcount] = m;
+          else ks->kzvecs[kcount] = m;
+        }
+        ++kcount;
+        ++ks->kcount_dims[ic];
+      }
+    }
+  }
+  /* planes: (k,+-l,0) (0,k,+-l) (k,0,+-l)  :318-342 */
+  for (ic = 3; ic < 6; ++ic) {
+    int icA = (ic == 4) ? 1 : 0;
+    int icB = (ic == 3) ? 1 : 2;
+    for (k = 1; k <= kmaxes[icA]; ++k) {
+      for (l = 1; l <= kmaxes[icB]; ++l) {
+        sqk = k * k * unitksq[icA] + l * l * unitksq[icB];
+        if (sqk <= ks->gsqmx) {
+          if (fill) {
+            int *va = (icA == 0) ? ks->kxvecs : ks->kyvecs;
+            int *vb = (icB == 1) ? ks->kyvecs : ks->kzvecs;
+            va[kcount] = k; vb[kcount] = l;
+            va[kcount + 1] = k; vb[kcount + 1] = -l;
+          }
+          kcount += 2;
+          ++ks->kcount_dims[ic];
+        }
+      }
+    }
+  }
+  /* bulk: (k,+-l,+-m)  :346-359 */
+  for (k = 1; k <= kmaxes[0]; ++k)
+    for (l = 1; l <= kmaxes[1]; ++l)
+      for (m = 1; m <= kmaxes[2]; ++m) {
+        sqk = k * k * unitksq[0] + l * l * unitksq[1] + m * m * unitksq[2];
+        if (sqk <= ks->gsqmx) {
+          if (fill) {
+            int s;
+            for (s = 0; s < 4; ++s) {
+              ks->kxvecs[kcount + s] = k;
+              ks->kyvecs[kcount + s] = (s < 2) ? l : -l;
+              ks->kzvecs[kcount + s] = (s % 2 == 0) ? m : -m;
+            }
+          }
+          kcount += 4;
+          ++ks->kcount_dims[6];
+        }
+      }
+  ks->kcount = kcount;
+  ks->kcount_flat = ks->kcount_dims[0] + ks->kcount_dims[1] + ks->kcount_dims[2] + 2 * ks->kcount_dims[3];
+  ks->kcount_expand = ks->kcount_dims[4] + ks->kcount_dims[5] + 2 * ks->kcount_dims[6];
+}
+
+void orc_kspace_destroy(orc_kspace *ks) {
+  if (!ks) return;
+  free(ks->kxvecs); free(ks->kyvecs); free(ks->kzvecs);
+  free(ks->kxy_list); free(ks->kz_list); free(ks->ug);
+  free(ks);
+}
+
+/* qsqsum = sum of q^2 over ALL atoms at setup time (km_ewald.cpp:72-79); accuracy is the
+ * ABSOLUTE force accuracy handed over by LAMMPS KSpace (relative accuracy * two_charge_force). */
+orc_kspace *orc_kspace_create(double g_ewald, double accuracy, double slab_volfactor, int slabflag,
+                              double xprd, double yprd, double zprd, double qsqsum,
+                              long long natoms, double qqrd2e, double dielectric) {
+  orc_kspace *ks = (orc_kspace *)calloc(1, sizeof(orc_kspace));
+  double q2, zprd_slab, err, gsqxmx, gsqymx, gsqzmx;
+  int k, kf, kxy, kloc, kx, ky;
+  ks->g_ewald = g_ewald; ks->accuracy = accuracy; ks->slab_volfactor = slab_volfactor;
+  ks->slabflag = slabflag; ks->xprd = xprd; ks->yprd = yprd; ks->zprd = zprd;
+  q2 = qsqsum * qqrd2e / dielectric;                         /* :79 */
+  zprd_slab = zprd * slab_volfactor;                         /* :84 */
+  ks->volume = xprd * yprd * zprd_slab;                      /* :85 */
+  ks->unitk[0] = 2.0 * ORC_PI / xprd;                        /* :87-89 */
+  ks->unitk[1] = 2.0 * ORC_PI / yprd;
+  ks->unitk[2] = 2.0 * ORC_PI / zprd_slab;
+  ks->kxmax = ks->kymax = ks->kzmax = 1;                     /* :93-113 */
+  err = orc_rms(g_ewald, ks->kxmax, xprd, natoms, q2);
+  while (err > accuracy) { ks->kxmax++; err = orc_rms(g_ewald, ks->kxmax, xprd, natoms, q2); }
+  err = orc_rms(g_ewald, ks->kymax, yprd, natoms, q2);
+  while (err > accuracy) { ks->kymax++; err = orc_rms(g_ewald, ks->kymax, yprd, natoms, q2); }
+  err = orc_rms(g_ewald, ks->kzmax, zprd_slab, natoms, q2);
+  while (err > accuracy) { ks->kzmax++; err = orc_rms(g_ewald, ks->kzmax, zprd_slab, natoms, q2); }
+  ks->kmax = ORC_MAX(ks->kxmax, ks->kymax);                  /* :115-117 */
+  ks->kmax = ORC_MAX(ks->kmax, ks->kzmax);
+  ks->kmax3d = 4 * ks->kmax * ks->kmax * ks->kmax + 6 * ks->kmax * ks->kmax + 3 * ks->kmax;
+  gsqxmx = ks->unitk[0] * ks->unitk[0] * ks->kxmax * ks->kxmax;   /* :120-126 */
+  gsqymx = ks->unitk[1] * ks->unitk[1] * ks->kymax * ks->kymax;
+  gsqzmx = ks->unitk[2] * ks->unitk[2] * ks->kzmax * ks->kzmax;
+  ks->gsqmx = ORC_MAX(gsqxmx, gsqymx);
+  ks->gsqmx = ORC_MAX(ks->gsqmx, gsqzmx);
+  ks->gsqmx *= 1.00001;
+  /* the reference sizes every table by kmax3d; the oracle sizes by the actual count (two passes) */
+  orc_enumerate_kvecs(ks);
+  ks->kxvecs = (int *)calloc((size_t)ks->kcount + 4, sizeof(int));
+  ks->kyvecs = (int *)calloc((size_t)ks->kcount + 4, sizeof(int));
+  ks->kzvecs = (int *)calloc((size_t)ks->kcount + 4, sizeof(int));
+  ks->ug = (double *)calloc((size_t)ks->kcount + 4, sizeof(double));
+  orc_enumerate_kvecs(ks);
+  { /* make_ug_from_kvecs :366-381 */
+    double g_ewald_sq_inv = 1.0 / (g_ewald * g_ewald);
+    double preu = 4.0 * ORC_PI / ks->volume, sqk;
+    ks->ug_tot = 0;
+    for (k = 0; k < ks->kcount; ++k) {
+      sqk = ks->kxvecs[k] * ks->kxvecs[k] * ks->unitk[0] * ks->unitk[0];
+      sqk += ks->kyvecs[k] * ks->kyvecs[k] * ks->unitk[1] * ks->unitk[1];
+      sqk += ks->kzvecs[k] * ks->kzvecs[k] * ks->unitk[2] * ks->unitk[2];
+      ks->ug[k] = preu * exp(-0.25 * sqk * g_ewald_sq_inv) / sqk;
+      ks->ug_tot += 2 * ks->ug[k];
+    }
+  }
+  /* make_kxy_list_from_kvecs :383-424 */
+  ks->kxy_list = (int *)calloc((size_t)ks->kcount_expand + 2, sizeof(int));
+  ks->kz_list = (int *)calloc((size_t)ks->kcount_expand + 2, sizeof(int));
+  kf = ks->kcount_flat;
+  for (k = 0; k < ks->kcount_dims[4]; ++k) {
+    ks->kxy_list[k] = ks->kyvecs[kf] + ks->kcount_dims[0] - 1;
+    ks->kz_list[k] = ks->kzvecs[kf] + ks->kcount_dims[0] + ks->kcount_dims[1] - 1;
+    kf += 2;
+  }
+  for (k = ks->kcount_dims[4]; k < ks->kcount_dims[4] + ks->kcount_dims[5]; ++k) {
+    ks->kxy_list[k] = ks->kxvecs[kf] - 1;
+    ks->kz_list[k] = ks->kzvecs[kf] + ks->kcount_dims[0] + ks->kcount_dims[1] - 1;
+    kf += 2;
+  }
+  kxy = ks->kcount_dims[0] + ks->kcount_dims[1] + ks->kcount_dims[2];
+  kloc = ks->kcount_dims[4] + ks->kcount_dims[5];
+  for (k = 0; k < ks->kcount_dims[6]; ++k) {
+    kx = ks->kxvecs[kf]; ky = ks->kyvecs[kf];
+    while (ks->kxvecs[kxy] != kx || ks->kyvecs[kxy] != ky) kxy += 2;
+    ks->kxy_list[kloc] = kxy;
+    ks->kxy_list[kloc + 1] = kxy + 1;
+    ks->kz_list[kloc] = ks->kzvecs[kf] + ks->kcount_dims[0] + ks->kcount_dims[1] - 1;
+    ks->kz_list[kloc + 1] = ks->kz_list[kloc];
+    kf += 4;
+    kloc += 2;
+  }
+  return ks;
+}
+
+/* getters (ctypes-friendly) */
+void orc_kspace_info(const orc_kspace *ks, int *iout /*[16]*/, double *dout /*[8]*/) {
+  int i;
+  iout[0] = ks->kcount; iout[1] = ks->kcount_flat; iout[2] = ks->kcount_expand;
+  iout[3] = ks->kxmax; iout[4] = ks->kymax; iout[5] = ks->kzmax; iout[6] = ks->kmax; iout[7] = ks->kmax3d;
+  for (i = 0; i < 7; ++i) iout[8 + i] = ks->kcount_dims[i];
+  iout[15] = ks->slabflag;
+  dout[0] = ks->unitk[0]; dout[1] = ks->unitk[1]; dout[2] = ks->unitk[2];
+  dout[3] = ks->volume; dout[4] = ks->gsqmx; dout[5] = ks->ug_tot; dout[6] = ks->g_ewald; dout[7] = ks->accuracy;
+}
+void orc_kspace_tables(const orc_kspace *ks, int *kx, int *ky, int *kz, double *ug, int *kxy_list, int *kz_list) {
+  memcpy(kx, ks->kxvecs, sizeof(int) * ks->kcount);
+  memcpy(ky, ks->kyvecs, sizeof(int) * ks->kcount);
+  memcpy(kz, ks->kzvecs, sizeof(int) * ks->kcount);
+  memcpy(ug, ks->ug, sizeof(double) * ks->kcount);
+  memcpy(kxy_list, ks->kxy_list, sizeof(int) * ks->kcount_expand);
+  memcpy(kz_list, ks->kz_list, sizeof(int) * ks->kcount_expand);
+}
+
+/* =============================================================================================
+ * Structure factors of the electrolyte  (km_ewald.cpp:668-780 sincos_b)
+ * x: [n][3] AoS, q: [n], echeck: [n] (+1 group1, -1 group2, 0 electrolyte; fix_conp.cpp:599-605).
+ * Only atoms 0..nlocal-1 with echeck==0 && q!=0 enter (:686).  Output sfacrl/sfacim[kcount].
+ * Work tables cs/sn are [kcount_flat][jmax], k-major / atom-contiguous like the reference.
+ * Returns jmax.
+ * ===========================================================================================*/
+int orc_sincos_b(const orc_kspace *ks, int nlocal, const double *x, const double *q, const int *echeck,
+                 double *sfacrl, double *sfacim) {
+  int i, j, m, ic, kf, jmax = 0;
+  const int kflat = ks->kcount_flat;
+  double *cs, *sn, *qj;
+  const int *kcd = ks->kcount_dims;
+  for (i = 0; i < nlocal; ++i) if (echeck[i] == 0 && q[i] != 0) ++jmax;
+  memset(sfacrl, 0, sizeof(double) * ks->kcount);   /* km_ewald.cpp:160-161 (there: kmax3d) */
+  memset(sfacim, 0, sizeof(double) * ks->kcount);
+  if (jmax == 0) return 0;
+  cs = (double *)malloc(sizeof(double) * (size_t)kflat * jmax);
+  sn = (double *)malloc(sizeof(double) * (size_t)kflat * jmax);
+  qj = (double *)malloc(sizeof(double) * jmax);
+#define CS(k, jj) cs[(size_t)(k) * jmax + (jj)]
+#define SN(k, jj) sn[(size_t)(k) * jmax + (jj)]
+  j = 0;
+  for (i = 0; i < nlocal; ++i) {                      /* :685-697 */
+    if (echeck[i] == 0 && q[i] != 0) {
+      qj[j] = q[i];
+      kf = 0;
+      for (ic = 0; ic < 3; ++ic) {
+        double xdotk = ks->unitk[ic] * x[3 * i + ic];
+        CS(kf, j) = cos(xdotk);
+        SN(kf, j) = sin(xdotk);
+        kf += kcd[ic];
+      }
+      ++j;
+    }
+  }
+  kf = 0;
+  for (ic = 0; ic < 3; ++ic) {                        /* :699-724 axis recurrences */
+    double tr = 0, ti = 0;
+    for (j = 0; j < jmax; ++j) { tr += qj[j] * CS(kf, j); ti += qj[j] * SN(kf, j); }
+    sfacrl[kf] = tr; sfacim[kf] = ti;
+    for (m = 1; m < kcd[ic]; ++m) {
+      double *c1 = &CS(kf + m, 0), *s1 = &SN(kf + m, 0);
+      const double *c0 = &CS(kf + m - 1, 0), *s0 = &SN(kf + m - 1, 0);
+      const double *cb = &CS(kf, 0), *sb = &SN(kf, 0);
+      tr = 0; ti = 0;
+      for (j = 0; j < jmax; ++j) {
+        c1[j] = c0[j] * cb[j] - s0[j] * sb[j];
+        s1[j] = s0[j] * cb[j] + c0[j] * sb[j];
+        tr += qj[j] * c1[j];
+        ti += qj[j] * s1[j];
+      }
+      sfacrl[kf + m] = tr; sfacim[kf + m] = ti;
+    }
+    kf += kcd[ic];
+  }
+  for (m = 0; m < kcd[3]; ++m) {                      /* :728-754 (k,+-l,0) */
+    int kx = ks->kxvecs[kf] - 1;
+    int ky = ks->kyvecs[kf] + kcd[0] - 1;
+    double tr0 = 0, ti0 = 0, tr1 = 0, ti1 = 0;
+    double *c0 = &CS(kf, 0), *s0 = &SN(kf, 0), *c1 = &CS(kf + 1, 0), *s1 = &SN(kf + 1, 0);
+    const double *cx = &CS(kx, 0), *sx = &SN(kx, 0), *cy = &CS(ky, 0), *sy = &SN(ky, 0);
+    for (j = 0; j < jmax; ++j) {
+      c0[j] = cx[j] * cy[j] - sx[j] * sy[j];
+      s0[j] = cx[j] * sy[j] + sx[j] * cy[j];
+      tr0 += qj[j] * c0[j];
+      ti0 += qj[j] * s0[j];
+      c1[j] = cx[j] * cy[j] + sx[j] * sy[j];
+      s1[j] = -cx[j] * sy[j] + sx[j] * cy[j];
+      tr1 += qj[j] * c1[j];
+      ti1 += qj[j] * s1[j];
+    }
+    sfacrl[kf] = tr0; sfacim[kf] = ti0; sfacrl[kf + 1] = tr1; sfacim[kf + 1] = ti1;
+    kf += 2;
+  }
+  for (m = 0; m < ks->kcount_expand; ++m) {           /* :761-779 (..,+-m) pairs */
+    const double *cxy = &CS(ks->kxy_list[m], 0), *sxy = &SN(ks->kxy_list[m], 0);
+    const double *cz = &CS(ks->kz_list[m], 0), *sz = &SN(ks->kz_list[m], 0);
+    double tr0 = 0, ti0 = 0, tr1 = 0, ti1 = 0;
+    for (j = 0; j < jmax; ++j) {
+      tr0 += qj[j] * (cxy[j] * cz[j] - sxy[j] * sz[j]);
+      ti0 += qj[j] * (cxy[j] * sz[j] + sxy[j] * cz[j]);
+      tr1 += qj[j] * (cxy[j] * cz[j] + sxy[j] * sz[j]);
+      ti1 += qj[j] * (-cxy[j] * sz[j] + sxy[j] * cz[j]);
+    }
+    sfacrl[kf] = tr0; sfacim[kf] = ti0; sfacrl[kf + 1] = tr1; sfacim[kf + 1] = ti1;
+    kf += 2;
+  }
+#undef CS
+#undef SN
+  free(cs); free(sn); free(qj);
+  return jmax;
+}
+
+/* =============================================================================================
+ * Electrode phase tables, low-memory form  (km_ewald.cpp:426-475 sincos_a_ele, lowmem branch;
+ * :510-531 transposition into csk/snk[eleall][kcount_flat])
+ * xele: [ne][3] coordinates in eleall order.  csk/snk: [ne][kflat] atom-major.
+ * ===========================================================================================*/
+void orc_ele_trig(const orc_kspace *ks, int ne, const double *xele, double *csk, double *snk) {
+  const int kflat = ks->kcount_flat;
+  const int *kcd = ks->kcount_dims;
+  int i, m, ic, kf;
+  for (i = 0; i < ne; ++i) {
+    double *c = csk + (size_t)i * kflat, *s = snk + (size_t)i * kflat;
+    kf = 0;
+    for (ic = 0; ic < 3; ++ic) {
+      double xdotk = ks->unitk[ic] * xele[3 * i + ic];
+      c[kf] = cos(xdotk);
+      s[kf] = sin(xdotk);
+      for (m = 1; m < kcd[ic]; ++m) {                 /* :452-458 */
+        c[kf + m] = c[kf + m - 1] * c[kf] - s[kf + m - 1] * s[kf];
+        s[kf + m] = s[kf + m - 1] * c[kf] + c[kf + m - 1] * s[kf];
+      }
+      kf += kcd[ic];
+    }
+    for (m = 0; m < kcd[3]; ++m) {                    /* :464-477 */
+      int kx = ks->kxvecs[kf] - 1;
+      int ky = ks->kyvecs[kf] + kcd[0] - 1;
+      c[kf] = c[kx] * c[ky] - s[kx] * s[ky];
+      s[kf] = c[kx] * s[ky] + s[kx] * c[ky];
+      c[kf + 1] = c[kx] * c[ky] + s[kx] * s[ky];
+      s[kf + 1] = -c[kx] * s[ky] + s[kx] * c[ky];
+      kf += 2;
+    }
+  }
+}
+
+/* km_ewald.cpp:533-558 kz_expand: regenerate the 2*kexp expanded phases of one electrode atom */
+static void orc_kz_expand(const orc_kspace *ks, const double *c, const double *s, double *ce, double *se) {
+  int k;
+  for (k = 0; k < ks->kcount_expand; ++k) {
+    double cxy = c[ks->kxy_list[k]], sxy = s[ks->kxy_list[k]];
+    double cz = c[ks->kz_list[k]], sz = s[ks->kz_list[k]];
+    ce[2 * k] = cxy * cz - sxy * sz;
+    se[2 * k] = sxy * cz + cxy * sz;
+    ce[2 * k + 1] = cxy * cz + sxy * sz;
+    se[2 * k + 1] = sxy * cz - cxy * sz;
+  }
+}
+
+/* =============================================================================================
+ * k-space b projection, lowmem  (km_ewald.cpp:789-825 bbb_from_sincos_b, else-branch)
+ * bbb[ne] is overwritten, in eleall order.
+ * ===========================================================================================*/
+void orc_bbb_from_sincos_b(const orc_kspace *ks, int ne, const double *csk, const double *snk,
+                           const double *sfacrl, const double *sfacim, double *bbb) {
+  const int kflat = ks->kcount_flat, kexp = ks->kcount_expand;
+  double *ce = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
+  double *se = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
+  int i, k;
+  for (i = 0; i < ne; ++i) {
+    const double *c = csk + (size_t)i * kflat, *s = snk + (size_t)i * kflat;
+    double bbbtmp = 0;
+    orc_kz_expand(ks, c, s, ce, se);
+    for (k = 0; k < kflat; ++k) bbbtmp -= 2 * ks->ug[k] * (c[k] * sfacrl[k] + s[k] * sfacim[k]);
+    for (k = 0; k < 2 * kexp; ++k)
+      bbbtmp -= 2 * ks->ug[kflat + k] * (ce[k] * sfacrl[kflat + k] + se[k] * sfacim[kflat + k]);
+    bbb[i] = bbbtmp;
+  }
+  free(ce); free(se);
+}
+
+/* km_ewald.cpp:827-847 slabcorr: bbb[i] -= z_i * sum_{j not electrode} 4 pi q_j z_j / V */
+double orc_slabcorr(const orc_kspace *ks, int nlocal, const double *x, const double *q, const int *echeck,
+                    int ne, const double *xele, double *bbb) {
+  double slabcorr = 0.0;
+  int i;
+  for (i = 0; i < nlocal; ++i)
+    if (echeck[i] == 0) slabcorr += 4 * q[i] * ORC_PI * x[3 * i + 2] / ks->volume;
+  for (i = 0; i < ne; ++i) bbb[i] -= xele[3 * i + 2] * slabcorr;
+  return slabcorr;
+}
+
+/* =============================================================================================
+ * k-space part of A, lowmem, single rank  (km_ewald.cpp:584-666 aaa_from_sincos_a else-branch,
+ * :560-582 ewald_dot_ij).  aaa: [ne][ne] row = eleall index (one rank: ele == eleall).
+ * Fills ONE orientation of each unordered pair by the parity rule (:625-640), the diagonal
+ * (:631-634) and the slab term for j <= i (:647-665).  Caller zeroes aaa first (fix_conp.cpp:792).
+ * ===========================================================================================*/
+void orc_aaa_from_sincos_a(const orc_kspace *ks, int ne, const double *csk, const double *snk,
+                           const double *xele, double *aaa) {
+  const int kflat = ks->kcount_flat, kexp = ks->kcount_expand;
+  const double CON_2overPIS = 2.0 / ORC_PIS;
+  double *cie = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
+  double *sie = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
+  double *cje = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
+  double *sje = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
+  int i, j, k, pass;
+  for (i = 0; i < ne; ++i) {
+    const double *ci = csk + (size_t)i * kflat, *si = snk + (size_t)i * kflat;
+    orc_kz_expand(ks, ci, si, cie, sie);
+    for (pass = 0; pass < 2; ++pass) {
+      int j0 = pass == 0 ? i % 2 : i + 1, j1 = pass == 0 ? i : ne;
+      for (j = j0; j < j1; j += 2) {
+        const double *cj = csk + (size_t)j * kflat, *sj = snk + (size_t)j * kflat;
+        double aaatmp = 0;
+        orc_kz_expand(ks, cj, sj, cje, sje);
+        for (k = 0; k < kflat; ++k) aaatmp += 2 * ks->ug[k] * (ci[k] * cj[k] + si[k] * sj[k]);
+        for (k = 0; k < 2 * kexp; ++k) aaatmp += 2 * ks->ug[kflat + k] * (cie[k] * cje[k] + sie[k] * sje[k]);
+        aaa[(size_t)i * ne + j] = aaatmp;
+      }
+    }
+    aaa[(size_t)i * ne + i] = ks->ug_tot - CON_2overPIS * ks->g_ewald;
+  }
+  if (ks->slabflag == 1) {
+    double CON_4PIoverV = ORC_4PI / ks->volume;
+    for (i = 0; i < ne; ++i)
+      for (j = 0; j <= i; ++j) aaa[(size_t)i * ne + j] += CON_4PIoverV * xele[3 * i + 2] * xele[3 * j + 2];
+  }
+  free(cie); free(sie); free(cje); free(sje);
+}
+
+/* =============================================================================================
+ * Real-space kernels  (fix_conp.cpp:1446-1454 erfcr_sqrt, :1467-1475 eta_potential_A / eta_potential)
+ * ===========================================================================================*/
+double orc_erfcr_sqrt(double a2_r2) {
+  if (a2_r2 < ORC_ERFC_MAX * ORC_ERFC_MAX) {
+    double a_r = sqrt(a2_r2);
+    double expm2 = exp(-a2_r2);
+    double t = 1.0 / (1.0 + ORC_EWALD_P * a_r);
+    return t * (ORC_A1 + t * (ORC_A2 + t * (ORC_A3 + t * (ORC_A4 + t * ORC_A5)))) * expm2 / a_r;
+  }
+  return 0.;
+}
+static double orc_eta_potential_A(double eta, double rsq) {
+  double etarij2 = eta * eta * rsq / 2;
+  return -orc_erfcr_sqrt(etarij2) * eta / sqrt(2);
+}
+static double orc_eta_potential(double eta, double rsq) {
+  double etarij2 = eta * eta * rsq;
+  return -orc_erfcr_sqrt(etarij2) * eta;
+}
+
+/* LAMMPS-style half neighbour list in CSR form: for ii<inum, i=ilist[ii], neighbours are
+ * neigh[first[i] .. first[i]+numneigh[i]-1] (entries may carry special-bond bits). */
+typedef struct {
+  int inum;
+  const int *ilist, *numneigh, *first, *neigh;
+} orc_list;
+
+typedef struct {
+  int nlocal, nghost, ntypes;
+  const double *x;     /* [nall][3] */
+  double *q;           /* [nall]  (electrode entries are overwritten by update_charge) */
+  const int *type, *tag, *echeck; /* [nall] */
+} orc_atoms;
+
+/* =============================================================================================
+ * FixConp restatement, one MPI rank
+ * ===========================================================================================*/
+typedef struct {
+  /* command / force-field parameters */
+  double eta, tolerance, evscale, g_ewald, cut_coul;
+  int ff_flag;      /* 0 NORMAL(slab), 1 FFIELD, 2 NOSLAB   fix_conp.cpp:68 */
+  int zneutr, nullneutral, minimizer /*0 CG, 1 INV*/, maxiter, newton, qinit, one_electrode;
+  int ntypes;
+  double *cutsq;    /* [(ntypes+1)^2] */
+  double boxlo_z, zprd;
+  orc_kspace *ks;
+  /* bookkeeping (fix_conp.cpp:468-539) */
+  int elenum, elenum_all, elytenum, maxtag_all;
+  int *ele2tag, *ele2eleall, *tag2eleall, *eleall2tag, *eleall2ele, *elecheck_eleall, *elebuf2eleall;
+  int *tag2local, tag2local_n;
+  /* linear algebra state */
+  double *aaa_all, *bbb_all, *eleallq, *elesetq, *eleinitq, *bbb;
+  double *csk, *snk, *xele_all;
+  double totsetq, scalar_output, totinve_e, slabcorr_last;
+  int runstage, cg_iters;
+  orc_atoms at;
+  orc_list alist, blist;
+} orc_fix;
+
+orc_fix *orc_fix_create(double eta, int ff_flag, int zneutr, int nullneutral, int minimizer, int maxiter,
+                        double tolerance, int newton, int qinit, int one_electrode, double evscale,
+                        int ntypes, const double *cutsq, double cut_coul, double boxlo_z, double zprd,
+                        orc_kspace *ks) {
+  orc_fix *f = (orc_fix *)calloc(1, sizeof(orc_fix));
+  size_t nc = (size_t)(ntypes + 1) * (ntypes + 1);
+  f->eta = eta; f->ff_flag = ff_flag; f->zneutr = zneutr; f->nullneutral = nullneutral;
+  f->minimizer = minimizer; f->maxiter = maxiter; f->tolerance = tolerance; f->newton = newton;
+  f->qinit = qinit; f->one_electrode = one_electrode; f->evscale = evscale; f->ntypes = ntypes;
+  f->cutsq = (double *)malloc(sizeof(double) * nc);
+  memcpy(f->cutsq, cutsq, sizeof(double) * nc);
+  f->cut_coul = cut_coul; f->boxlo_z = boxlo_z; f->zprd = zprd; f->ks = ks;
+  f->g_ewald = ks->g_ewald;
+  return f;
+}
+
+void orc_fix_destroy(orc_fix *f) {
+  if (!f) return;
+  free(f->cutsq); free(f->ele2tag); free(f->ele2eleall); free(f->tag2eleall); free(f->eleall2tag);
+  free(f->eleall2ele); free(f->elecheck_eleall); free(f->elebuf2eleall); free(f->tag2local);
+  free(f->aaa_all); free(f->bbb_all); free(f->eleallq); free(f->elesetq); free(f->eleinitq); free(f->bbb);
+  free(f->csk); free(f->snk); free(f->xele_all);
+  free(f);
+}
+
+void orc_fix_set_atoms(orc_fix *f, int nlocal, int nghost, const double *x, double *q, const int *type,
+                       const int *tag, const int *echeck) {
+  int i, maxtag = 0;
+  f->at.nlocal = nlocal; f->at.nghost = nghost; f->at.x = x; f->at.q = q; f->at.type = type;
+  f->at.tag = tag; f->at.echeck = echeck; f->at.ntypes = f->ntypes;
+  for (i = 0; i < nlocal; ++i) maxtag = ORC_MAX(maxtag, tag[i]);
+  if (maxtag + 1 > f->tag2local_n) {
+    f->tag2local = (int *)realloc(f->tag2local, sizeof(int) * (maxtag + 1));
+    f->tag2local_n = maxtag + 1;
+  }
+  for (i = 0; i < f->tag2local_n; ++i) f->tag2local[i] = -1;
+  for (i = 0; i < nlocal; ++i) f->tag2local[tag[i]] = i;  /* atom->map(tag) for owned atoms */
+}
+
+void orc_fix_set_lists(orc_fix *f, int a_inum, const int *a_ilist, const int *a_numneigh, const int *a_first,
+                       const int *a_neigh, int b_inum, const int *b_ilist, const int *b_numneigh,
+                       const int *b_first, const int *b_neigh) {
+  f->alist.inum = a_inum; f->alist.ilist = a_ilist; f->alist.numneigh = a_numneigh;
+  f->alist.first = a_first; f->alist.neigh = a_neigh;
+  f->blist.inum = b_inum; f->blist.ilist = b_ilist; f->blist.numneigh = b_numneigh;
+  f->blist.first = b_first; f->blist.neigh = b_neigh;
+}
+
+/* fix_conp.cpp:468-539 post_neighbor (nprocs == 1: displs = {0}, elebuf2eleall = ele2eleall) plus
+ * the tag2eleall sizing of linalg_init (:413-416). */
+void orc_fix_post_neighbor(orc_fix *f) {
+  const orc_atoms *at = &f->at;
+  int i, j, elenum = 0, elenum_all_old = f->elenum_all;
+  if (f->tag2eleall == NULL) { /* linalg_init, runstage 0 */
+    int maxtag = 0;
+    for (i = 0; i < at->nlocal; ++i) maxtag = ORC_MAX(at->tag[i], maxtag);
+    f->maxtag_all = maxtag;
+    f->tag2eleall = (int *)malloc(sizeof(int) * (maxtag + 1));
+  }
+  for (i = 0; i < at->nlocal; ++i) if (at->echeck[i]) ++elenum;
+  f->elytenum = at->nlocal - elenum;
+  if (elenum > f->elenum || f->ele2tag == NULL) {
+    f->ele2tag = (int *)realloc(f->ele2tag, sizeof(int) * (elenum + 1));
+    f->ele2eleall = (int *)realloc(f->ele2eleall, sizeof(int) * (elenum + 1));
+    f->bbb = (double *)realloc(f->bbb, sizeof(double) * (elenum + 1));
+  }
+  f->elenum = elenum;
+  j = 0;
+  for (i = 0; i < at->nlocal; ++i) if (at->echeck[i]) f->ele2tag[j++] = at->tag[i];
+  f->elenum_all = elenum; /* single rank: displssum */
+  if (f->elenum_all > elenum_all_old) {
+    size_t n = (size_t)f->elenum_all;
+    f->eleall2tag = (int *)realloc(f->eleall2tag, sizeof(int) * n);
+    f->elecheck_eleall = (int *)realloc(f->elecheck_eleall, sizeof(int) * n);
+    f->eleall2ele = (int *)realloc(f->eleall2ele, sizeof(int) * (n + 1));
+    f->aaa_all = (double *)realloc(f->aaa_all, sizeof(double) * n * n);
+    f->bbb_all = (double *)realloc(f->bbb_all, sizeof(double) * n);
+    f->eleallq = (double *)realloc(f->eleallq, sizeof(double) * n);
+    f->elebuf2eleall = (int *)realloc(f->elebuf2eleall, sizeof(int) * n);
+    f->elesetq = (double *)realloc(f->elesetq, sizeof(double) * n);
+    f->eleinitq = (double *)realloc(f->eleinitq, sizeof(double) * n);
+    for (i = 0; i < f->elenum_all; i++) f->elecheck_eleall[i] = 0;
+    for (i = 0; i < f->maxtag_all + 1; i++) f->tag2eleall[i] = f->elenum_all;
+    f->eleall2ele[f->elenum_all] = -1;
+    for (i = 0; i < f->elenum_all; ++i) f->eleall2tag[i] = f->ele2tag[i]; /* Allgatherv of one rank */
+    for (i = 0; i < f->elenum_all; ++i) f->tag2eleall[f->eleall2tag[i]] = i;
+  }
+  j = 0;
+  for (i = 0; i < f->elenum_all; ++i) f->eleall2ele[i] = -1;
+  for (i = 0; i < at->nlocal; ++i) {
+    if (at->echeck[i]) {
+      f->ele2eleall[j] = f->tag2eleall[at->tag[i]];
+      f->eleall2ele[f->ele2eleall[j]] = j;
+      ++j;
+    }
+  }
+  for (i = 0; i < f->elenum; ++i) f->elebuf2eleall[i] = f->ele2eleall[i];
+}
+
+/* fix_conp.cpp:641-648 b_comm with one rank: brecv[elebuf2eleall[i]] = bsend[i] */
+static void orc_b_comm(const orc_fix *f, const double *bsend, double *brecv) {
+  int iall;
+  for (iall = 0; iall < f->elenum_all; ++iall) brecv[f->elebuf2eleall[iall]] = bsend[iall];
+}
+
+/* gathers electrode coordinates in eleall order (what sincos_a_ele + b_comm achieve, km_ewald.cpp:437) */
+static void orc_gather_xele(orc_fix *f) {
+  int i, c;
+  f->xele_all = (double *)realloc(f->xele_all, sizeof(double) * 3 * (size_t)f->elenum_all);
+  for (i = 0; i < f->elenum; ++i) {
+    int iloc = f->tag2local[f->ele2tag[i]];
+    for (c = 0; c < 3; ++c) f->xele_all[3 * f->ele2eleall[i] + c] = f->at.x[3 * iloc + c];
+  }
+}
+
+/* fix_conp.cpp:1209-1279 alist_coul_cal: ele-ele real-space pairs into m[elei*Ne + eleallj] */
+static void orc_alist_coul_cal(orc_fix *f, double *m) {
+  const orc_atoms *at = &f->at;
+  const orc_list *L = &f->alist;
+  const int nt1 = f->ntypes + 1;
+  int ii, jj;
+  double cut_coulsq = f->cut_coul * f->cut_coul;
+  double cut_erfc = ORC_ERFC_MAX * ORC_ERFC_MAX / (f->g_ewald * f->g_ewald);
+  if (cut_coulsq > cut_erfc) cut_coulsq = cut_erfc;
+  for (ii = 0; ii < L->inum; ii++) {
+    int i = L->ilist[ii];
+    int itype = at->type[i];
+    int ecib = !!at->echeck[i];
+    double xtmp = at->x[3 * i], ytmp = at->x[3 * i + 1], ztmp = at->x[3 * i + 2];
+    const int *jlist = L->neigh + L->first[i];
+    int jnum = L->numneigh[i];
+    for (jj = 0; jj < jnum; jj++) {
+      int j = jlist[jj] & ORC_NEIGHMASK;
+      int ecjb = !!at->echeck[j];
+      if (ecib && ecjb) {
+        double delx = xtmp - at->x[3 * j], dely = ytmp - at->x[3 * j + 1], delz = ztmp - at->x[3 * j + 2];
+        double rsq = delx * delx + dely * dely + delz * delz;
+        int jtype = at->type[j];
+        if (rsq < f->cutsq[itype * nt1 + jtype]) {
+          if (rsq < cut_coulsq) {
+            double dudq = orc_erfcr_sqrt(f->g_ewald * f->g_ewald * rsq) * f->g_ewald;
+            int elealli, eleallj, elei;
+            dudq += orc_eta_potential_A(f->eta, rsq);
+            elealli = f->tag2eleall[at->tag[i]];
+            eleallj = f->tag2eleall[at->tag[j]];
+            elei = f->eleall2ele[elealli];
+            if (j < at->nlocal || !(!f->newton && eleallj > elealli))
+              m[(size_t)elei * f->elenum_all + eleallj] += dudq;
+          }
+        }
+      }
+    }
+  }
+}
+
+/* fix_conp.cpp:1281-1365 blist_coul_cal: ele-elyte real-space pairs into m[elei] (local ele order) */
+static void orc_blist_coul_cal(orc_fix *f, double *m) {
+  const orc_atoms *at = &f->at;
+  const orc_list *L = &f->blist;
+  const int nt1 = f->ntypes + 1;
+  int ii, jj, elei;
+  double cut_coulsq = f->cut_coul * f->cut_coul;
+  double cut_erfc = ORC_ERFC_MAX * ORC_ERFC_MAX / (f->g_ewald * f->g_ewald);
+  double *newtonbuf = NULL;
+  if (cut_coulsq > cut_erfc) cut_coulsq = cut_erfc;
+  if (f->newton) newtonbuf = (double *)calloc(f->elenum_all, sizeof(double));
+  for (ii = 0; ii < L->inum; ii++) {
+    int i = L->ilist[ii];
+    int ecib = at->echeck[i] != 0;
+    int itype = at->type[i];
+    double xtmp = at->x[3 * i], ytmp = at->x[3 * i + 1], ztmp = at->x[3 * i + 2];
+    const int *jlist = L->neigh + L->first[i];
+    int jnum = L->numneigh[i];
+    for (jj = 0; jj < jnum; jj++) {
+      int j = jlist[jj] & ORC_NEIGHMASK;
+      int ecjb = at->echeck[j] != 0;
+      if ((ecib ^ ecjb) && (f->newton || ecib || j < at->nlocal)) {
+        double delx = xtmp - at->x[3 * j], dely = ytmp - at->x[3 * j + 1], delz = ztmp - at->x[3 * j + 2];
+        double rsq = delx * delx + dely * dely + delz * delz;
+        int jtype = at->type[j];
+        if (rsq < f->cutsq[itype * nt1 + jtype]) {
+          if (rsq < cut_coulsq) {
+            double dudq = orc_erfcr_sqrt(f->g_ewald * f->g_ewald * rsq) * f->g_ewald;
+            dudq += orc_eta_potential(f->eta, rsq);
+            if (ecib) {
+              elei = f->eleall2ele[f->tag2eleall[at->tag[i]]];
+              m[elei] -= at->q[j] * dudq;
+            } else if (j < at->nlocal) {
+              int elej = f->eleall2ele[f->tag2eleall[at->tag[j]]];
+              m[elej] -= at->q[i] * dudq;
+            } else if (f->newton) {
+              newtonbuf[f->tag2eleall[at->tag[j]]] -= at->q[i] * dudq;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (f->newton) {
+    for (elei = 0; elei < f->elenum; ++elei) m[elei] += newtonbuf[f->tag2eleall[f->ele2tag[elei]]];
+    free(newtonbuf);
+  }
+}
+
+/* fix_conp.cpp:777-861 a_cal (one rank) */
+void orc_fix_a_cal(orc_fix *f) {
+  const int ne = f->elenum_all;
+  const double CON_s2overPIS = sqrt(2.0) / ORC_PIS;
+  double *aaa = (double *)calloc((size_t)f->elenum * ne, sizeof(double));
+  double *aaa_perm;
+  int i, j;
+  /* kspmod->a_cal: a_read (electrode tables) + aaa_from_sincos_a.  The k-space routine works in
+   * eleall numbering; with one rank row "i" of aaa is local electrode i -> permute rows. */
+  orc_gather_xele(f);
+  f->csk = (double *)realloc(f->csk, sizeof(double) * (size_t)ne * f->ks->kcount_flat);
+  f->snk = (double *)realloc(f->snk, sizeof(double) * (size_t)ne * f->ks->kcount_flat);
+  orc_ele_trig(f->ks, ne, f->xele_all, f->csk, f->snk);
+  aaa_perm = (double *)calloc((size_t)ne * ne, sizeof(double));
+  orc_aaa_from_sincos_a(f->ks, ne, f->csk, f->snk, f->xele_all, aaa_perm);
+  for (i = 0; i < f->elenum; ++i)
+    memcpy(aaa + (size_t)i * ne, aaa_perm + (size_t)f->ele2eleall[i] * ne, sizeof(double) * ne);
+  free(aaa_perm);
+  for (i = 0; i < f->elenum; ++i) aaa[(size_t)i * ne + f->ele2eleall[i]] += CON_s2overPIS * f->eta; /* :796-801 */
+  orc_alist_coul_cal(f, aaa);
+  /* Allgatherv of rows (:816-822): one rank, rows are in local ele order -> rank-major == local */
+  memcpy(f->aaa_all, aaa, sizeof(double) * (size_t)f->elenum * ne);
+  free(aaa);
+  for (i = 1; i < ne; ++i)                              /* :826-831 symmetrise */
+    for (j = 0; j < i; ++j) {
+      f->aaa_all[(size_t)i * ne + j] += f->aaa_all[(size_t)j * ne + i];
+      f->aaa_all[(size_t)j * ne + i] = f->aaa_all[(size_t)i * ne + j];
+    }
+  f->runstage = 1;
+}
+
+/* fix_conp.cpp:609-637 b_setq_cal */
+void orc_fix_b_setq_cal(orc_fix *f) {
+  const orc_atoms *at = &f->at;
+  double zlo = f->boxlo_z, zprd = f->zprd;
+  double zprd_half = 0.5 * zprd; /* domain->zprd_half */
+  double zhalf = zprd_half + zlo;
+  int iloc;
+  for (iloc = 0; iloc < f->elenum_all; ++iloc) f->elecheck_eleall[iloc] = 0;
+  for (iloc = 0; iloc < f->elenum; ++iloc) {
+    int iall = f->ele2eleall[iloc];
+    int i = f->tag2local[f->ele2tag[iloc]];
+    int eci = at->echeck[i];
+    if (f->ff_flag == 1) {
+      if (eci == 1 && at->x[3 * i + 2] < zhalf) f->bbb[iloc] = -f->evscale * (at->x[3 * i + 2] / zprd + 1);
+      else f->bbb[iloc] = -f->evscale * at->x[3 * i + 2] / zprd;
+    } else f->bbb[iloc] = -0.5 * f->evscale * eci;
+    f->elecheck_eleall[iall] = eci;
+  }
+  orc_b_comm(f, f->bbb, f->bbb_all);
+  if (f->runstage == 1) f->runstage = 2;
+}
+
+/* Row-major LU inverse with partial pivoting (stands in for dgetrf_/dgetri_, fix_conp.cpp:947-949;
+ * LAPACK's blocked operation order is vendor-specific and not reproduced). Returns 0 on success. */
+int orc_lu_inverse(int n, double *a) {
+  int *piv = (int *)malloc(sizeof(int) * n);
+  double *inv = (double *)malloc(sizeof(double) * (size_t)n * n);
+  double *col = (double *)malloc(sizeof(double) * n);
+  int i, j, k, info = 0;
+  for (k = 0; k < n; ++k) {
+    int p = k;
+    double big = fabs(a[(size_t)k * n + k]);
+    for (i = k + 1; i < n; ++i) if (fabs(a[(size_t)i * n + k]) > big) { big = fabs(a[(size_t)i * n + k]); p = i; }
+    piv[k] = p;
+    if (big == 0.0) { info = k + 1; break; }
+    if (p != k) for (j = 0; j < n; ++j) { double t = a[(size_t)k * n + j]; a[(size_t)k * n + j] = a[(size_t)p * n + j]; a[(size_t)p * n + j] = t; }
+    for (i = k + 1; i < n; ++i) {
+      double l = a[(size_t)i * n + k] / a[(size_t)k * n + k];
+      double *ri = a + (size_t)i * n;
+      const double *rk = a + (size_t)k * n;
+      ri[k] = l;
+      for (j = k + 1; j < n; ++j) ri[j] -= l * rk[j];
+    }
+  }
+  if (info == 0) {
+    /* solve A X = I column by column with the permutation applied to the right-hand side */
+    for (j = 0; j < n; ++j) {
+      for (i = 0; i < n; ++i) col[i] = 0.0;
+      col[j] = 1.0;
+      for (k = 0; k < n; ++k) if (piv[k] != k) { double t = col[k]; col[k] = col[piv[k]]; col[piv[k]] = t; }
+      for (i = 0; i < n; ++i) { double s = col[i]; const double *ri = a + (size_t)i * n; for (k = 0; k < i; ++k) s -= ri[k] * col[k]; col[i] = s; }
+      for (i = n - 1; i >= 0; --i) { double s = col[i]; const double *ri = a + (size_t)i * n; for (k = i + 1; k < n; ++k) s -= ri[k] * col[k]; col[i] = s / ri[i]; }
+      for (i = 0; i < n; ++i) inv[(size_t)i * n + j] = col[i];
+    }
+    memcpy(a, inv, sizeof(double) * (size_t)n * n);
+  }
+  free(piv); free(inv); free(col);
+  return info;
+}
+
+/* fix_conp.cpp:982-1067 inv_project.  eleallz: z of each electrode atom in eleall order (zneutr).
+ * Operates in place on aaa[n*n]; returns totinve of the first projection (the <e,e> log value / evscale). */
+double orc_inv_project(int n, double *aaa, int nullneutral, int zneutr, const double *eleallz, double zhalf) {
+  double *ainve = (double *)malloc(sizeof(double) * n);
+  double ainvtmp, totinve = 0, totinve_first;
+  size_t idx1d = 0;
+  int i, j;
+  for (i = 0; i < n; i++) {
+    ainvtmp = 0;
+    for (j = 0; j < n; j++) { ainvtmp += aaa[idx1d]; idx1d++; }
+    totinve += ainvtmp;
+    ainve[i] = ainvtmp;
+  }
+  totinve_first = totinve;
+  if (nullneutral) {
+    if (totinve * totinve > 1e-8) {
+      idx1d = 0;
+      for (i = 0; i < n; i++)
+        for (j = 0; j < n; j++) { aaa[idx1d] -= ainve[i] * ainve[j] / totinve; idx1d++; }
+    }
+    if (zneutr) {
+      idx1d = 0;
+      totinve = 0;
+      for (i = 0; i < n; i++) {
+        ainvtmp = 0;
+        for (j = 0; j < n; j++) { if (eleallz[j] > zhalf) ainvtmp += aaa[idx1d]; idx1d++; }
+        ainve[i] = ainvtmp;
+        if (eleallz[i] > zhalf) totinve += ainvtmp;
+      }
+      if (totinve * totinve > 1e-8) {
+        idx1d = 0;
+        for (i = 0; i < n; i++)
+          for (j = 0; j < n; j++) { aaa[idx1d] -= ainve[i] * ainve[j] / totinve; idx1d++; }
+      }
+    }
+  }
+  free(ainve);
+  return totinve_first;
+}
+
+static void orc_fix_inv_project(orc_fix *f) {
+  int i;
+  double *z = (double *)malloc(sizeof(double) * f->elenum_all);
+  orc_gather_xele(f);
+  for (i = 0; i < f->elenum_all; ++i) z[i] = f->xele_all[3 * i + 2];
+  f->totinve_e = orc_inv_project(f->elenum_all, f->aaa_all, f->nullneutral, f->zneutr, z,
+                                 0.5 * f->zprd + f->boxlo_z);
+  free(z);
+}
+
+/* fix_conp.cpp:932-980 inv */
+int orc_fix_inv(orc_fix *f) {
+  int info = 0;
+  if (f->runstage == 2) {
+    info = orc_lu_inverse(f->elenum_all, f->aaa_all);
+    if (info == 0 && !f->one_electrode) orc_fix_inv_project(f);
+    f->runstage = 3;
+  }
+  return info;
+}
+
+/* fix_conp.cpp:864-930 cg: neutrality-constrained CG on the un-projected A, x0 = 0 */
+int orc_cg(int n, const double *aaa, const double *bbb, double *q, int maxiter, double tolerance) {
+  double *res = (double *)malloc(sizeof(double) * n), *p = (double *)malloc(sizeof(double) * n),
+         *ap = (double *)malloc(sizeof(double) * n);
+  double alpha, beta, ptap, lresnorm, netr, tmp, lgamma, gamma, avenetr;
+  int iter, i, j, converged_at = 0;
+  for (i = 0; i < n; i++) q[i] = 0.0;
+  lresnorm = 0.0;
+  netr = 0.0;
+  for (i = 0; i < n; ++i) {
+    res[i] = bbb[i];
+    for (j = 0; j < n; ++j) { tmp = aaa[(size_t)i * n + j] * q[j]; res[i] -= tmp; }
+    netr += res[i];
+    lresnorm += res[i] * res[i];
+  }
+  avenetr = netr / n;
+  for (i = 0; i < n; i++) p[i] = res[i] - avenetr;
+  lresnorm -= netr * avenetr;
+  lgamma = lresnorm;
+  for (iter = 1; iter < maxiter; ++iter) {
+    for (i = 0; i < n; ++i) {
+      ap[i] = 0.0;
+      for (j = 0; j < n; ++j) ap[i] += aaa[(size_t)i * n + j] * p[j];
+    }
+    ptap = 0.0;
+    for (i = 0; i < n; ++i) ptap += p[i] * ap[i];
+    alpha = lresnorm / ptap;
+    gamma = lgamma;
+    lgamma = 0.0;
+    netr = 0.0;
+    for (i = 0; i < n; ++i) {
+      q[i] = q[i] + alpha * p[i];
+      res[i] = res[i] - alpha * ap[i];
+      lgamma += res[i] * res[i];
+      netr += res[i];
+    }
+    avenetr = netr / n;
+    lgamma -= netr * avenetr;
+    beta = lgamma / gamma;
+    lresnorm = 0.0;
+    for (i = 0; i < n; i++) {
+      p[i] = beta * p[i] + res[i] - avenetr;
+      lresnorm += res[i] * p[i];
+    }
+    if (lresnorm / n < tolerance) { converged_at = iter; break; }
+  }
+  free(res); free(p); free(ap);
+  return converged_at; /* 0 = hit maxiter */
+}
+
+/* fix_conp.cpp:698-718 equation_solve */
+int orc_fix_equation_solve(orc_fix *f) {
+  if (f->minimizer == 0) {
+    f->cg_iters = orc_cg(f->elenum_all, f->aaa_all, f->bbb_all, f->eleallq, f->maxiter, f->tolerance);
+    return 0;
+  }
+  return orc_fix_inv(f);
+}
+
+/* row dot product standing in for BLAS ddot_ (fix_conp.cpp:1093,1138): plain left-to-right sum */
+static double orc_ddot(int n, const double *a, const double *b) {
+  double s = 0;
+  int i;
+  for (i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+/* fix_conp.cpp:1071-1116 get_setq */
+void orc_fix_get_setq(orc_fix *f) {
+  int iall, iloc;
+  if (f->minimizer == 0) {
+    for (iall = 0; iall < f->elenum_all; ++iall) f->elesetq[iall] = f->eleallq[iall];
+  } else {
+    for (iloc = 0; iloc < f->elenum; ++iloc) {
+      iall = f->ele2eleall[iloc];
+      f->bbb[iloc] = orc_ddot(f->elenum_all, f->aaa_all + (size_t)iall * f->elenum_all, f->bbb_all);
+    }
+    orc_b_comm(f, f->bbb, f->elesetq);
+  }
+  f->totsetq = 0;
+  for (iloc = 0; iloc < f->elenum; ++iloc) {
+    iall = f->ele2eleall[iloc];
+    if (f->elecheck_eleall[iall] == 1) f->totsetq += f->elesetq[iall];
+  }
+  if (f->qinit) {
+    for (iloc = 0; iloc < f->elenum; ++iloc) f->bbb[iloc] = f->at.q[f->tag2local[f->ele2tag[iloc]]];
+    orc_b_comm(f, f->bbb, f->eleinitq);
+  }
+  if (f->one_electrode) orc_fix_inv_project(f);
+}
+
+/* fix_conp.cpp:426-464 linalg_setup (runstage 0): a_cal, b_setq_cal, equation_solve, get_setq */
+int orc_fix_linalg_setup(orc_fix *f) {
+  int info;
+  orc_fix_a_cal(f);
+  orc_fix_b_setq_cal(f);
+  info = orc_fix_equation_solve(f);
+  orc_fix_get_setq(f);
+  return info;
+}
+
+/* fix_conp.cpp:677-695 update_bk / km_ewald.cpp:153-167 b_cal */
+void orc_fix_b_cal(orc_fix *f, int coulyes) {
+  const orc_kspace *ks = f->ks;
+  const orc_atoms *at = &f->at;
+  double *sr = (double *)malloc(sizeof(double) * (ks->kcount + 1));
+  double *si = (double *)malloc(sizeof(double) * (ks->kcount + 1));
+  double *ball = (double *)malloc(sizeof(double) * (f->elenum_all + 1));
+  int i;
+  orc_sincos_b(ks, at->nlocal, at->x, at->q, at->echeck, sr, si);
+  orc_bbb_from_sincos_b(ks, f->elenum_all, f->csk, f->snk, sr, si, ball); /* eleall order */
+  if (ks->slabflag) f->slabcorr_last = orc_slabcorr(ks, at->nlocal, at->x, at->q, at->echeck, f->elenum_all, f->xele_all, ball);
+  for (i = 0; i < f->elenum; ++i) f->bbb[i] = ball[f->ele2eleall[i]];     /* local ele order */
+  if (coulyes) orc_blist_coul_cal(f, f->bbb);
+  orc_b_comm(f, f->bbb, f->bbb_all);
+  free(sr); free(si); free(ball);
+}
+
+/* fix_conp.cpp:1120-1161 update_charge */
+void orc_fix_update_charge(orc_fix *f, double potdiff) {
+  const orc_atoms *at = &f->at;
+  int i, iall, iloc;
+  const int nall = at->nlocal + at->nghost;
+  double netcharge_left = 0;
+  if (f->minimizer == 1) {
+    for (iloc = 0; iloc < f->elenum; ++iloc) {
+      iall = f->ele2eleall[iloc];
+      f->bbb[iloc] = orc_ddot(f->elenum_all, f->aaa_all + (size_t)iall * f->elenum_all, f->bbb_all);
+    }
+    orc_b_comm(f, f->bbb, f->eleallq);
+  }
+  for (iall = 0; iall < f->elenum_all; ++iall)
+    if (f->elecheck_eleall[iall] == 1) netcharge_left += f->eleallq[iall];
+  for (i = 0; i < nall; ++i) {
+    if (!at->echeck[i]) continue;
+    iall = f->tag2eleall[at->tag[i]];
+    at->q[i] = f->eleallq[iall] + potdiff * f->elesetq[iall];
+    if (f->qinit) at->q[i] += f->eleinitq[iall];
+  }
+  f->scalar_output = potdiff * f->totsetq + netcharge_left;
+}
+
+/* fix_conp.cpp:543-573 pre_force (the every-Nevery gate is the caller's) */
+void orc_fix_pre_force(orc_fix *f, double potdiff) {
+  orc_fix_b_cal(f, 1);
+  orc_fix_equation_solve(f);
+  orc_fix_update_charge(f, potdiff);
+}
+
+/* getters */
+void orc_fix_sizes(const orc_fix *f, int *out /*[8]*/) {
+  out[0] = f->elenum; out[1] = f->elenum_all; out[2] = f->elytenum; out[3] = f->maxtag_all;
+  out[4] = f->runstage; out[5] = f->cg_iters; out[6] = 0; out[7] = 0;
+}
+void orc_fix_scalars(const orc_fix *f, double *out /*[4]*/) {
+  out[0] = f->totsetq; out[1] = f->scalar_output; out[2] = f->totinve_e; out[3] = f->slabcorr_last;
+}
+void orc_fix_get_maps(const orc_fix *f, int *ele2tag, int *ele2eleall, int *eleall2tag, int *eleall2ele,
+                      int *elecheck_eleall, int *elebuf2eleall, int *tag2eleall) {
+  memcpy(ele2tag, f->ele2tag, sizeof(int) * f->elenum);
+  memcpy(ele2eleall, f->ele2eleall, sizeof(int) * f->elenum);
+  memcpy(eleall2tag, f->eleall2tag, sizeof(int) * f->elenum_all);
+  memcpy(eleall2ele, f->eleall2ele, sizeof(int) * (f->elenum_all + 1));
+  memcpy(elecheck_eleall, f->elecheck_eleall, sizeof(int) * f->elenum_all);
+  memcpy(elebuf2eleall, f->elebuf2eleall, sizeof(int) * f->elenum_all);
+  memcpy(tag2eleall, f->tag2eleall, sizeof(int) * (f->maxtag_all + 1));
+}
+void orc_fix_get_matrix(const orc_fix *f, double *aaa) { memcpy(aaa, f->aaa_all, sizeof(double) * (size_t)f->elenum_all * f->elenum_all); }
+void orc_fix_set_matrix(orc_fix *f, const double *aaa, int runstage) { memcpy(f->aaa_all, aaa, sizeof(double) * (size_t)f->elenum_all * f->elenum_all); f->runstage = runstage; }
+void orc_fix_get_vectors(const orc_fix *f, double *bbb_all, double *eleallq, double *elesetq) {
+  if (bbb_all) memcpy(bbb_all, f->bbb_all, sizeof(double) * f->elenum_all);
+  if (eleallq) memcpy(eleallq, f->eleallq, sizeof(double) * f->elenum_all);
+  if (elesetq) memcpy(elesetq, f->elesetq, sizeof(double) * f->elenum_all);
+}
+void orc_fix_get_trig(const orc_fix *f, double *csk, double *snk) {
+  size_t n = (size_t)f->elenum_all * f->ks->kcount_flat;
+  memcpy(csk, f->csk, sizeof(double) * n);
+  memcpy(snk, f->snk, sizeof(double) * n);
+}
+/* direct call of the real-space b loop for isolated tests: out[elenum] zeroed then accumulated */
+void orc_fix_blist_only(orc_fix *f, double *out_local) {
+  int i;
+  for (i = 0; i < f->elenum; ++i) out_local[i] = 0.0;
+  orc_blist_coul_cal(f, out_local);
+}
+void orc_fix_alist_only(orc_fix *f, double *out /*[elenum*Ne]*/) {
+  memset(out, 0, sizeof(double) * (size_t)f->elenum * f->elenum_all);
+  orc_alist_coul_cal(f, out);
+}
+
+/* =============================================================================================
+ * Multi-rank index bookkeeping restated for nprocs simulated ranks (fix_conp.cpp:468-539):
+ * given, per rank, the tags of its owned electrode atoms in local storage order at the FIRST
+ * post_neighbor (tags_first) and at the CURRENT one (tags_now), produce the permanent numbering
+ * and the gather permutation.  counts_*[r] = electrode atoms on rank r; arrays are rank-major.
+ * ===========================================================================================*/
+void orc_multirank_maps(int nprocs, const int *counts_first, const int *tags_first, const int *counts_now,
+                        const int *tags_now, int maxtag, int *eleall2tag, int *tag2eleall, int *displs_now,
+                        int *elebuf2eleall) {
+  int r, i, n = 0, pos = 0;
+  for (r = 0; r < nprocs; ++r) n += counts_first[r];
+  for (i = 0; i <= maxtag; ++i) tag2eleall[i] = n;             /* sentinel :521 */
+  for (i = 0; i < n; ++i) eleall2tag[i] = tags_first[i];       /* Allgatherv :523 */
+  for (i = 0; i < n; ++i) tag2eleall[eleall2tag[i]] = i;       /* :524 */
+  for (r = 0; r < nprocs; ++r) { displs_now[r] = pos; pos += counts_now[r]; }   /* :504-508 */
+  for (i = 0; i < pos; ++i) elebuf2eleall[i] = tag2eleall[tags_now[i]];         /* :528-535 */
+}
