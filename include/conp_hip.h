@@ -1,0 +1,175 @@
+/* =============================================================================================
+ * conp_hip.h -- C ABI of libconp_hip.so: the MI355X-native constant-potential charge solver that
+ * drops into LAMMPS behind the `fix conp` / KSpaceModule surface of srtee/lammps-USER-CONP2.
+ *
+ * Boundary rules
+ *   - plain C: opaque handle, scalars, caller-owned pointers + sizes; no C++/torch types;
+ *   - every function returns 0 on success or a negative conp_status; the message is available from
+ *     conp_last_error() (thread-local).  The reference aborts through error->all(FLERR,msg)
+ *     (fix_conp.cpp:86,107,127,...): the LAMMPS glue turns a non-zero status into exactly that call;
+ *   - calls are synchronous with respect to the host thread unless the name ends in _async/_device;
+ *     internally everything is ordered on one HIP stream (conp_fix_set_stream);
+ *   - the library never falls back to a CPU path: without a usable gfx950 device every compute
+ *     entry point fails with CONP_ERR_NO_DEVICE.
+ *
+ * Each entry point cites the reference interface it replaces (file:line in /root/reference).
+ * INTEGRATION.md shows the binding a maintainer adds to fix_conp.cpp / kspacemodule.h.
+ * ===========================================================================================*/
+#ifndef CONP_HIP_H
+#define CONP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONP_ABI_VERSION 1
+
+typedef enum {
+  CONP_OK = 0,
+  CONP_ERR_ARG = -1,        /* illegal fix command / argument (fix_conp.cpp:86,107,127,143,...) */
+  CONP_ERR_STATE = -2,      /* call out of order (e.g. pre_force before setup) */
+  CONP_ERR_NO_DEVICE = -3,  /* no gfx950 device / HIP runtime failure */
+  CONP_ERR_NUMERIC = -4,    /* "Inversion failed!" (fix_conp.cpp:956) */
+  CONP_ERR_IO = -5          /* A-matrix file problems (fix_conp.cpp:737,745) */
+} conp_status;
+
+enum { CONP_FF_NORMAL = 0, CONP_FF_FFIELD = 1, CONP_FF_NOSLAB = 2 };   /* fix_conp.cpp:68 */
+enum { CONP_SOLVER_CG = 0, CONP_SOLVER_INV = 1 };                      /* fix_conp.cpp:67 */
+
+typedef struct conp_fix conp_fix; /* opaque: one `fix conp` instance on one GPU */
+
+/* ---- parsed `fix ID group1 conp Nevery group2 eta DV logfile [keywords]` (fix_conp.cpp:79-201) ---- */
+typedef struct {
+  int everynum;            /* arg[3]  :102 */
+  double eta;              /* arg[5]  :110 */
+  double potdiff;          /* arg[6] if numeric :116 */
+  int potdiff_is_variable; /* arg[6] = v_name :112-114 (the glue evaluates the variable each step :1143) */
+  int ff_flag;             /* ffield / noslab :126-133 */
+  int zneutr, matout, pppm, split, qinit, lowmem, nullneutral, ehgo; /* :160-169 */
+  int a_matrix_f;          /* 0 none, 1 org, 2 inv :134-145 */
+  char a_matrix_file[512];
+  int smartlist, eletypenum, eletypes[32]; /* etypes :146-159 */
+  int minimizer, maxiter;  /* new keywords `cg [maxiter N] [tol X]`; defaults 1 / 100 (:88-90) */
+  double tolerance;        /* default 1e-6 (:89) */
+  char logfile[512];       /* arg[7] :119 */
+  char group2[128];        /* arg[4] :104 */
+} conp_fix_args;
+
+/* Parses arg[3..narg-1] of the fix command exactly like the reference constructor (same keywords, same
+ * error conditions; unknown keyword -> CONP_ERR_ARG with the reference's message).  ntypes bounds etypes. */
+int conp_parse_fix_args(int narg, const char *const *arg, int ntypes, conp_fix_args *out);
+
+/* ---- constants LAMMPS supplies (force->, domain->, kspace->; SURVEY.md 8b "inputs crossing") ---- */
+typedef struct {
+  double qqrd2e, qqr2e, qe2f, dielectric;         /* force-> (km_ewald.cpp:79, fix_conp.cpp:412) */
+  int newton_pair;                                /* force->newton_pair (fix_conp.cpp:198) */
+  double g_ewald, accuracy, slab_volfactor;       /* force->kspace-> (km_ewald.cpp:66-69); accuracy ABSOLUTE */
+  int slabflag;
+  double xprd, yprd, zprd, boxlo_z;               /* domain-> (km_ewald.cpp:81-83, fix_conp.cpp:616-619) */
+  int ntypes;
+  const double *cutsq;                            /* coulpair->cutsq flattened [(ntypes+1)*(ntypes+1)] (fix_conp.cpp:1235) */
+  double cut_coul;                                /* *coulpair->extract("cut_coul") (fix_conp.cpp:1237) */
+  int one_electrode;                              /* groupbit == jgroupbit (fix_conp.cpp:295) */
+  int device;                                     /* HIP device ordinal of this rank */
+  int rank, nranks;                               /* shard id for the multi-GPU path (section "sharding") */
+} conp_env;
+
+/* FixConp::FixConp + FixConp::init (fix_conp.cpp:79-201, 245-300) */
+int conp_fix_create(const conp_fix_args *args, const conp_env *env, conp_fix **out);
+void conp_fix_destroy(conp_fix *fix);   /* FixConp::~FixConp :205-229 */
+const char *conp_last_error(void);
+int conp_abi_version(void);
+
+/* ---- LAMMPS-owned per-atom arrays, re-fetched before every hook (may be reallocated on re-neighbour) ---- */
+typedef struct {
+  int nlocal, nghost;
+  const double *x;     /* atom->x flattened [nall][3] */
+  double *q;           /* atom->q [nall]; electrode entries (owned + ghost) are overwritten by pre_force */
+  const int *type;     /* atom->type [nall] */
+  const int *tag;      /* atom->tag [nall] (tagint == int, fix_conp.cpp:474) */
+  const int *echeck;   /* electrode_check(i) for i < nall: +1 group1, -1 group2, 0 else (fix_conp.cpp:599-605) */
+} conp_atoms;
+
+/* LAMMPS half neighbour list (NeighList inum/ilist/numneigh/firstneigh) with firstneigh flattened by the glue:
+ * neighbours of i are neigh[first[i] .. first[i]+numneigh[i]); entries may carry special-bond bits (NEIGHMASK). */
+typedef struct {
+  int inum;
+  const int *ilist;     /* [inum] */
+  const int *numneigh;  /* [nall] */
+  const int *first;     /* [nall] */
+  const int *neigh;
+  int64_t nneigh;       /* length of neigh */
+} conp_neighlist;
+
+/* FixConp::init_list (fix_conp.cpp:365-378): which = 0 alist (ele-ele, occasional), 1 blist (ele-elyte, perpetual),
+ * 2 both (generic list without etypes).  The pointers must stay valid until the next hook returns. */
+int conp_fix_init_list(conp_fix *fix, int which, const conp_neighlist *list);
+
+/* ---- Fix hooks ---- */
+int conp_fix_setup_post_neighbor(conp_fix *fix, const conp_atoms *atoms); /* fix_conp.cpp:382-385 (linalg_init + post_neighbor) */
+int conp_fix_setup_pre_force(conp_fix *fix, const conp_atoms *atoms, int64_t ntimestep, double potdiff); /* :387-391 */
+int conp_fix_post_neighbor(conp_fix *fix, const conp_atoms *atoms);       /* :468-539 */
+int conp_fix_pre_force(conp_fix *fix, const conp_atoms *atoms, int64_t ntimestep, double potdiff); /* :543-573 */
+double conp_fix_compute_scalar(const conp_fix *fix);                      /* :592-595 */
+
+/* finer-grained pieces of the same path (same names as the reference's methods) */
+int conp_fix_linalg_setup(conp_fix *fix, const conp_atoms *atoms);        /* :426-464 a_cal, b_setq_cal, equation_solve, get_setq */
+int conp_fix_a_cal(conp_fix *fix, const conp_atoms *atoms);               /* :777-861 */
+int conp_fix_b_cal(conp_fix *fix, const conp_atoms *atoms);               /* :677-695 */
+int conp_fix_equation_solve(conp_fix *fix);                               /* :698-718 */
+int conp_fix_update_charge(conp_fix *fix, const conp_atoms *atoms, double potdiff); /* :1120-1161 */
+
+/* ---- KSpaceModule provider surface (kspacemodule.h:30-40), Ewald provider (km_ewald.cpp) ---- */
+int conp_km_conp_setup(conp_fix *fix, double qsqsum, int64_t natoms);     /* km_ewald.cpp:63-132 (qsqsum: Allreduce'd sum q^2 :72-78) */
+int conp_km_a_cal(conp_fix *fix, const conp_atoms *atoms, double *aaa /*[Ne*Ne], host, overwritten: k-space part only*/); /* :147-151 */
+int conp_km_b_cal(conp_fix *fix, const conp_atoms *atoms, double *bbb /*[Ne] eleall order, host*/);                          /* :153-167 */
+
+/* ---- state read-back for parity tests and for the glue (public members fix_conp.h:58-85) ---- */
+typedef struct {
+  int elenum, elenum_all, elytenum, maxtag_all, runstage;
+  int kcount, kcount_flat, kcount_expand, kxmax, kymax, kzmax, kmax, kmax3d;
+  int kcount_dims[7];
+  int cg_iterations;
+  double unitk[3], volume, gsqmx, ug_tot, totsetq, scalar_output, totinve, slabcorr;
+  int64_t n_blist_pairs, n_alist_pairs, n_elyte_charged;
+} conp_info;
+int conp_fix_info(const conp_fix *fix, conp_info *out);
+/* integer tables; pass NULL for those not wanted.  Sizes: kcount / kcount_expand */
+int conp_fix_get_ktables(const conp_fix *fix, int *kxvecs, int *kyvecs, int *kzvecs, double *ug, int *kxy_list, int *kz_list);
+/* maps: ele2tag[elenum] ele2eleall[elenum] eleall2tag[Ne] eleall2ele[Ne+1] elecheck_eleall[Ne] elebuf2eleall[Ne] tag2eleall[maxtag+1] */
+int conp_fix_get_maps(const conp_fix *fix, int *ele2tag, int *ele2eleall, int *eleall2tag, int *eleall2ele,
+                      int *elecheck_eleall, int *elebuf2eleall, int *tag2eleall);
+int conp_fix_get_matrix(conp_fix *fix, double *aaa_all /*[Ne*Ne]*/);   /* A, or projected A^-1 after inv() */
+int conp_fix_set_matrix(conp_fix *fix, const double *aaa_all, int runstage); /* a_read 'org'/'inv' path :721-773 (file parsing is the glue's) */
+int conp_fix_get_vectors(conp_fix *fix, double *bbb_all, double *eleallq, double *elesetq); /* each [Ne] or NULL */
+int conp_fix_get_sfac(conp_fix *fix, double *sfacrl, double *sfacim);  /* [kcount], reference k order (km_ewald.cpp:782-786) */
+int conp_fix_get_ele_trig(conp_fix *fix, double *csk, double *snk);    /* [Ne][kcount_flat] (km_ewald.cpp:261-268 lowmem) */
+/* inv_project on a caller-supplied matrix (bit-exact electroneutrality projection, fix_conp.cpp:982-1067) */
+int conp_inv_project(conp_fix *fix, int n, double *aaa, int nullneutral, int zneutr, const double *eleallz, double zhalf,
+                     double *totinve_out);
+
+/* ---- device-resident operation (bench, GPU-resident MD engines, multi-GPU) -------------------------------------
+ * x/q are DEVICE pointers with the same layout as conp_atoms.x/q; nothing crosses PCIe.  One charge update =
+ *   conp_fix_b_cal_device  (this rank's shard of b into the bound b buffer: its k-shard for ALL rows + its rows of
+ *                           the real-space term; slab term on rank 0) -> [caller: all-reduce b over ranks] ->
+ *   conp_fix_solve_device  (rows [row0,row1) of q = S b (+ dV S d) into the bound q buffer) ->
+ *                          [caller: all-gather q] -> conp_fix_scatter_device (q[i] for owned+ghost electrode atoms).
+ * With nranks == 1 conp_fix_pre_force_device runs all three back to back. */
+int conp_fix_set_stream(conp_fix *fix, void *hip_stream);
+int conp_fix_bind_device_buffers(conp_fix *fix, double *d_b /*[Ne]*/, double *d_q /*[Ne]*/);
+int conp_fix_row_range(const conp_fix *fix, int *row0, int *row1);
+int conp_fix_b_cal_device(conp_fix *fix, const double *d_x, const double *d_q);
+int conp_fix_solve_device(conp_fix *fix, double potdiff);
+int conp_fix_scatter_device(conp_fix *fix, double *d_q_atoms, double potdiff);
+int conp_fix_pre_force_device(conp_fix *fix, const double *d_x, double *d_q, double potdiff);
+/* per-kernel timing of the last N updates via HIP events on the library's stream (bench.py roofline leg) */
+int conp_fix_profile(conp_fix *fix, int enable);
+int conp_fix_profile_read(conp_fix *fix, int *nkernels, const char **names /*[16]*/, double *avg_ms /*[16]*/, int *counts /*[16]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONP_HIP_H */

@@ -1,0 +1,358 @@
+"""ctypes binding of include/conp_hip.h and a thin driver that calls the hooks in the order LAMMPS does."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import systems as _systems
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class ConpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[conp status {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def library_path():
+    return os.path.join(HERE, "libconp_hip.so")
+
+
+class conp_fix_args(C.Structure):
+    _fields_ = [("everynum", C.c_int), ("eta", C.c_double), ("potdiff", C.c_double), ("potdiff_is_variable", C.c_int),
+                ("ff_flag", C.c_int), ("zneutr", C.c_int), ("matout", C.c_int), ("pppm", C.c_int), ("split", C.c_int),
+                ("qinit", C.c_int), ("lowmem", C.c_int), ("nullneutral", C.c_int), ("ehgo", C.c_int),
+                ("a_matrix_f", C.c_int), ("a_matrix_file", C.c_char * 512), ("smartlist", C.c_int),
+                ("eletypenum", C.c_int), ("eletypes", C.c_int * 32), ("minimizer", C.c_int), ("maxiter", C.c_int),
+                ("tolerance", C.c_double), ("logfile", C.c_char * 512), ("group2", C.c_char * 128)]
+
+
+class conp_env(C.Structure):
+    _fields_ = [("qqrd2e", C.c_double), ("qqr2e", C.c_double), ("qe2f", C.c_double), ("dielectric", C.c_double),
+                ("newton_pair", C.c_int), ("g_ewald", C.c_double), ("accuracy", C.c_double),
+                ("slab_volfactor", C.c_double), ("slabflag", C.c_int), ("xprd", C.c_double), ("yprd", C.c_double),
+                ("zprd", C.c_double), ("boxlo_z", C.c_double), ("ntypes", C.c_int), ("cutsq", C.POINTER(C.c_double)),
+                ("cut_coul", C.c_double), ("one_electrode", C.c_int), ("device", C.c_int), ("rank", C.c_int),
+                ("nranks", C.c_int)]
+
+
+class conp_atoms(C.Structure):
+    _fields_ = [("nlocal", C.c_int), ("nghost", C.c_int), ("x", C.POINTER(C.c_double)), ("q", C.POINTER(C.c_double)),
+                ("type", C.POINTER(C.c_int)), ("tag", C.POINTER(C.c_int)), ("echeck", C.POINTER(C.c_int))]
+
+
+class conp_neighlist(C.Structure):
+    _fields_ = [("inum", C.c_int), ("ilist", C.POINTER(C.c_int)), ("numneigh", C.POINTER(C.c_int)),
+                ("first", C.POINTER(C.c_int)), ("neigh", C.POINTER(C.c_int)), ("nneigh", C.c_int64)]
+
+
+class conp_info(C.Structure):
+    _fields_ = [("elenum", C.c_int), ("elenum_all", C.c_int), ("elytenum", C.c_int), ("maxtag_all", C.c_int),
+                ("runstage", C.c_int), ("kcount", C.c_int), ("kcount_flat", C.c_int), ("kcount_expand", C.c_int),
+                ("kxmax", C.c_int), ("kymax", C.c_int), ("kzmax", C.c_int), ("kmax", C.c_int), ("kmax3d", C.c_int),
+                ("kcount_dims", C.c_int * 7), ("cg_iterations", C.c_int), ("unitk", C.c_double * 3),
+                ("volume", C.c_double), ("gsqmx", C.c_double), ("ug_tot", C.c_double), ("totsetq", C.c_double),
+                ("scalar_output", C.c_double), ("totinve", C.c_double), ("slabcorr", C.c_double),
+                ("n_blist_pairs", C.c_int64), ("n_alist_pairs", C.c_int64), ("n_elyte_charged", C.c_int64)]
+
+
+# every symbol include/conp_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
+SYMBOLS = [
+    "conp_parse_fix_args", "conp_fix_create", "conp_fix_destroy", "conp_last_error", "conp_abi_version",
+    "conp_fix_init_list", "conp_fix_setup_post_neighbor", "conp_fix_setup_pre_force", "conp_fix_post_neighbor",
+    "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
+    "conp_fix_equation_solve", "conp_fix_update_charge", "conp_km_conp_setup", "conp_km_a_cal", "conp_km_b_cal",
+    "conp_fix_info", "conp_fix_get_ktables", "conp_fix_get_maps", "conp_fix_get_matrix", "conp_fix_set_matrix",
+    "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_fix_set_stream",
+    "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
+    "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
+]
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    lib.conp_last_error.restype = C.c_char_p
+    lib.conp_parse_fix_args.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(conp_fix_args)]
+    lib.conp_fix_create.argtypes = [C.POINTER(conp_fix_args), C.POINTER(conp_env), C.POINTER(vp)]
+    lib.conp_fix_destroy.argtypes = [vp]
+    lib.conp_fix_destroy.restype = None
+    lib.conp_fix_init_list.argtypes = [vp, C.c_int, C.POINTER(conp_neighlist)]
+    for n in ("conp_fix_setup_post_neighbor", "conp_fix_post_neighbor", "conp_fix_linalg_setup", "conp_fix_a_cal",
+              "conp_fix_b_cal"):
+        getattr(lib, n).argtypes = [vp, C.POINTER(conp_atoms)]
+    for n in ("conp_fix_setup_pre_force", "conp_fix_pre_force"):
+        getattr(lib, n).argtypes = [vp, C.POINTER(conp_atoms), C.c_int64, C.c_double]
+    lib.conp_fix_compute_scalar.argtypes = [vp]
+    lib.conp_fix_compute_scalar.restype = C.c_double
+    lib.conp_fix_equation_solve.argtypes = [vp]
+    lib.conp_fix_update_charge.argtypes = [vp, C.POINTER(conp_atoms), C.c_double]
+    lib.conp_km_conp_setup.argtypes = [vp, C.c_double, C.c_int64]
+    lib.conp_km_a_cal.argtypes = [vp, C.POINTER(conp_atoms), dp]
+    lib.conp_km_b_cal.argtypes = [vp, C.POINTER(conp_atoms), dp]
+    lib.conp_fix_info.argtypes = [vp, C.POINTER(conp_info)]
+    lib.conp_fix_get_ktables.argtypes = [vp, ip, ip, ip, dp, ip, ip]
+    lib.conp_fix_get_maps.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip]
+    lib.conp_fix_get_matrix.argtypes = [vp, dp]
+    lib.conp_fix_set_matrix.argtypes = [vp, dp, C.c_int]
+    lib.conp_fix_get_vectors.argtypes = [vp, dp, dp, dp]
+    lib.conp_fix_get_sfac.argtypes = [vp, dp, dp]
+    lib.conp_fix_get_ele_trig.argtypes = [vp, dp, dp]
+    lib.conp_inv_project.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, dp, C.c_double, dp]
+    lib.conp_fix_set_stream.argtypes = [vp, vp]
+    lib.conp_fix_bind_device_buffers.argtypes = [vp, vp, vp]
+    lib.conp_fix_row_range.argtypes = [vp, ip, ip]
+    lib.conp_fix_b_cal_device.argtypes = [vp, vp, vp]
+    lib.conp_fix_solve_device.argtypes = [vp, C.c_double]
+    lib.conp_fix_scatter_device.argtypes = [vp, vp, C.c_double]
+    lib.conp_fix_pre_force_device.argtypes = [vp, vp, vp, C.c_double]
+    lib.conp_fix_profile.argtypes = [vp, C.c_int]
+    lib.conp_fix_profile_read.argtypes = [vp, ip, C.POINTER(C.c_char_p), dp, ip]
+    _LIB = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def parse_fix_command(tokens: Sequence[str], ntypes: int) -> conp_fix_args:
+    """tokens = the whole `fix` command split on whitespace: ID group1 conp Nevery group2 eta DV logfile [keywords]"""
+    lib = load_library()
+    arr = (C.c_char_p * len(tokens))(*[t.encode() for t in tokens])
+    out = conp_fix_args()
+    rc = lib.conp_parse_fix_args(len(tokens), arr, ntypes, C.byref(out))
+    if rc != 0:
+        raise ConpError(rc, lib.conp_last_error().decode())
+    return out
+
+
+def fix_command_for(s: "_systems.System", extra: Sequence[str] = ()) -> list:
+    """the fix command the reference's decks would use for this system"""
+    toks = ["e", "eleleft", "conp", "1", "eleright", repr(float(s.eta)), repr(float(s.potdiff)), "log_conp"]
+    if s.eletypes is not None:
+        toks += ["etypes", str(len(s.eletypes))] + [str(t) for t in s.eletypes]
+    if s.ff_flag == 1:
+        toks.append("ffield")
+    elif s.ff_flag == 2:
+        toks.append("noslab")
+    if s.zneutr:
+        toks.append("zneutr")
+    return toks + list(extra)
+
+
+class FixConp:
+    """Drives one `fix conp` instance through the C ABI the way LAMMPS' Modify drives the reference fix:
+    init_list -> setup_post_neighbor -> setup_pre_force -> [post_neighbor] -> pre_force ...."""
+
+    def __init__(self, s: "_systems.System", extra_args: Sequence[str] = (), device: int = 0, rank: int = 0,
+                 nranks: int = 1, one_electrode: bool = False):
+        self.lib = load_library()
+        self.s = s
+        self.args = parse_fix_command(fix_command_for(s, extra_args), s.ntypes)
+        self._cutsq = np.ascontiguousarray(s.cutsq_table())
+        env = conp_env(qqrd2e=_systems.QQRD2E, qqr2e=_systems.QQR2E, qe2f=_systems.QE2F, dielectric=1.0,
+                       newton_pair=int(s.newton), g_ewald=s.g_ewald, accuracy=s.accuracy,
+                       slab_volfactor=s.slab_volfactor, slabflag=s.slabflag, xprd=float(s.prd[0]), yprd=float(s.prd[1]),
+                       zprd=float(s.prd[2]), boxlo_z=float(s.boxlo[2]), ntypes=s.ntypes, cutsq=_dptr(self._cutsq),
+                       cut_coul=s.cutoff, one_electrode=int(one_electrode), device=device, rank=rank, nranks=nranks)
+        self.h = C.c_void_p()
+        self._check(self.lib.conp_fix_create(C.byref(self.args), C.byref(env), C.byref(self.h)))
+        self._keep = {}
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ConpError(rc, self.lib.conp_last_error().decode())
+
+    # -- views -----------------------------------------------------------------------------------
+    def atoms_view(self, at) -> conp_atoms:
+        x = np.ascontiguousarray(at.x, dtype=np.float64)
+        self._keep["atoms"] = (x, at.q, at.type, at.tag, at.echeck)
+        return conp_atoms(nlocal=at.nlocal, nghost=at.nghost, x=_dptr(x), q=_dptr(at.q), type=_iptr(at.type),
+                          tag=_iptr(at.tag), echeck=_iptr(at.echeck))
+
+    def init_list(self, which: int, lst):
+        neigh = lst.neigh if lst.neigh.size else np.zeros(1, np.int32)
+        self._keep[f"list{which}"] = (lst.ilist, lst.numneigh, lst.first, neigh)
+        v = conp_neighlist(inum=lst.inum, ilist=_iptr(lst.ilist), numneigh=_iptr(lst.numneigh), first=_iptr(lst.first),
+                           neigh=_iptr(neigh), nneigh=int(lst.neigh.size))
+        self._check(self.lib.conp_fix_init_list(self.h, which, C.byref(v)))
+
+    def init_lists(self, alist, blist):
+        if alist is blist:
+            self.init_list(2, alist)
+        else:
+            self.init_list(0, alist)
+            self.init_list(1, blist)
+
+    # -- hooks (same names as the reference's Fix methods) ---------------------------------------------
+    def setup_post_neighbor(self, at):
+        self._check(self.lib.conp_fix_setup_post_neighbor(self.h, C.byref(self.atoms_view(at))))
+
+    def setup_pre_force(self, at, ntimestep=0, potdiff=None):
+        pd = self.s.potdiff if potdiff is None else potdiff
+        self._check(self.lib.conp_fix_setup_pre_force(self.h, C.byref(self.atoms_view(at)), ntimestep, pd))
+
+    def linalg_setup(self, at):
+        self._check(self.lib.conp_fix_linalg_setup(self.h, C.byref(self.atoms_view(at))))
+
+    def post_neighbor(self, at):
+        self._check(self.lib.conp_fix_post_neighbor(self.h, C.byref(self.atoms_view(at))))
+
+    def pre_force(self, at, ntimestep=0, potdiff=None):
+        pd = self.s.potdiff if potdiff is None else potdiff
+        self._check(self.lib.conp_fix_pre_force(self.h, C.byref(self.atoms_view(at)), ntimestep, pd))
+
+    def a_cal(self, at):
+        self._check(self.lib.conp_fix_a_cal(self.h, C.byref(self.atoms_view(at))))
+
+    def b_cal(self, at):
+        self._check(self.lib.conp_fix_b_cal(self.h, C.byref(self.atoms_view(at))))
+
+    def equation_solve(self):
+        self._check(self.lib.conp_fix_equation_solve(self.h))
+
+    def update_charge(self, at, potdiff=None):
+        pd = self.s.potdiff if potdiff is None else potdiff
+        self._check(self.lib.conp_fix_update_charge(self.h, C.byref(self.atoms_view(at)), pd))
+
+    def compute_scalar(self):
+        return float(self.lib.conp_fix_compute_scalar(self.h))
+
+    # -- provider surface ------------------------------------------------------------------------
+    def km_conp_setup(self, qsqsum, natoms):
+        self._check(self.lib.conp_km_conp_setup(self.h, qsqsum, natoms))
+
+    def km_b_cal(self, at):
+        b = np.zeros(self.info().elenum_all)
+        self._check(self.lib.conp_km_b_cal(self.h, C.byref(self.atoms_view(at)), _dptr(b)))
+        return b
+
+    def km_a_cal(self, at):
+        ne = self.info().elenum_all
+        a = np.zeros((ne, ne))
+        self._check(self.lib.conp_km_a_cal(self.h, C.byref(self.atoms_view(at)), _dptr(a)))
+        return a
+
+    # -- read-back -------------------------------------------------------------------------------
+    def info(self) -> conp_info:
+        o = conp_info()
+        self._check(self.lib.conp_fix_info(self.h, C.byref(o)))
+        return o
+
+    def ktables(self):
+        i = self.info()
+        K, E = i.kcount, max(i.kcount_expand, 1)
+        kx, ky, kz = (np.zeros(K, np.int32) for _ in range(3))
+        ug = np.zeros(K); kxy = np.zeros(E, np.int32); kzl = np.zeros(E, np.int32)
+        self._check(self.lib.conp_fix_get_ktables(self.h, _iptr(kx), _iptr(ky), _iptr(kz), _dptr(ug), _iptr(kxy), _iptr(kzl)))
+        return dict(kxvecs=kx, kyvecs=ky, kzvecs=kz, ug=ug, kxy_list=kxy[:i.kcount_expand], kz_list=kzl[:i.kcount_expand])
+
+    def maps(self):
+        i = self.info()
+        n, na, mt = i.elenum, i.elenum_all, i.maxtag_all
+        m = dict(ele2tag=np.zeros(n, np.int32), ele2eleall=np.zeros(n, np.int32), eleall2tag=np.zeros(na, np.int32),
+                 eleall2ele=np.zeros(na + 1, np.int32), elecheck_eleall=np.zeros(na, np.int32),
+                 elebuf2eleall=np.zeros(na, np.int32), tag2eleall=np.zeros(mt + 1, np.int32))
+        self._check(self.lib.conp_fix_get_maps(self.h, *[_iptr(m[k]) for k in (
+            "ele2tag", "ele2eleall", "eleall2tag", "eleall2ele", "elecheck_eleall", "elebuf2eleall", "tag2eleall")]))
+        return m
+
+    def matrix(self):
+        ne = self.info().elenum_all
+        a = np.zeros((ne, ne))
+        self._check(self.lib.conp_fix_get_matrix(self.h, _dptr(a)))
+        return a
+
+    def set_matrix(self, a, runstage):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self._check(self.lib.conp_fix_set_matrix(self.h, _dptr(a), runstage))
+
+    def vectors(self):
+        ne = self.info().elenum_all
+        b, q, sq = np.zeros(ne), np.zeros(ne), np.zeros(ne)
+        self._check(self.lib.conp_fix_get_vectors(self.h, _dptr(b), _dptr(q), _dptr(sq)))
+        return b, q, sq
+
+    def sfac(self):
+        K = self.info().kcount
+        sr, si = np.zeros(K), np.zeros(K)
+        self._check(self.lib.conp_fix_get_sfac(self.h, _dptr(sr), _dptr(si)))
+        return sr, si
+
+    def ele_trig(self):
+        i = self.info()
+        c = np.zeros((i.elenum_all, i.kcount_flat)); s = np.zeros((i.elenum_all, i.kcount_flat))
+        self._check(self.lib.conp_fix_get_ele_trig(self.h, _dptr(c), _dptr(s)))
+        return c, s
+
+    def inv_project(self, a, nullneutral=True, zneutr=False, eleallz=None, zhalf=0.0):
+        a = np.ascontiguousarray(a, dtype=np.float64).copy()
+        n = a.shape[0]
+        z = np.zeros(n) if eleallz is None else np.ascontiguousarray(eleallz, dtype=np.float64)
+        tot = C.c_double()
+        self._check(self.lib.conp_inv_project(self.h, n, _dptr(a), int(nullneutral), int(zneutr), _dptr(z), zhalf, C.byref(tot)))
+        return a, tot.value
+
+    # -- device-resident path --------------------------------------------------------------------
+    def set_stream(self, stream_ptr: int):
+        self._check(self.lib.conp_fix_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def bind_device_buffers(self, d_b: Optional[int], d_q: Optional[int]):
+        self._check(self.lib.conp_fix_bind_device_buffers(self.h, C.c_void_p(d_b or 0), C.c_void_p(d_q or 0)))
+
+    def row_range(self):
+        a, b = C.c_int(), C.c_int()
+        self._check(self.lib.conp_fix_row_range(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def b_cal_device(self, d_x: int, d_q: int):
+        self._check(self.lib.conp_fix_b_cal_device(self.h, C.c_void_p(d_x), C.c_void_p(d_q)))
+
+    def solve_device(self, potdiff):
+        self._check(self.lib.conp_fix_solve_device(self.h, potdiff))
+
+    def scatter_device(self, d_q_atoms: int, potdiff):
+        self._check(self.lib.conp_fix_scatter_device(self.h, C.c_void_p(d_q_atoms), potdiff))
+
+    def pre_force_device(self, d_x: int, d_q: int, potdiff):
+        self._check(self.lib.conp_fix_pre_force_device(self.h, C.c_void_p(d_x), C.c_void_p(d_q), potdiff))
+
+    def profile(self, enable: bool):
+        self._check(self.lib.conp_fix_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        n = C.c_int()
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        cnt = (C.c_int * 16)()
+        self._check(self.lib.conp_fix_profile_read(self.h, C.byref(n), names, ms, cnt))
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+    def close(self):
+        if self.h:
+            self.lib.conp_fix_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,942 @@
+// Host orchestration of one `fix conp` instance on one MI355X and the C ABI of include/conp_hip.h.
+// Method names mirror FixConp / KSpaceModuleEwald (fix_conp.h:37-74, kspacemodule.h:30-40); citations are
+// file:line in /root/reference.  There is no CPU fallback: every compute entry point needs the HIP device.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/conp_hip.h"
+#include "conp_host.hpp"
+#include "conp_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct ConpError : std::runtime_error {
+  int code;
+  ConpError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_TRY(expr)                                                                                     \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      throw ConpError(CONP_ERR_NO_DEVICE, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  void reserve(size_t count) {
+    if (count <= n) return;
+    if (p) { (void)hipFree(p); p = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    n = count;
+  }
+  void upload(const T *h, size_t count, hipStream_t s) {
+    reserve(count);
+    if (count) HIP_TRY(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
+  void zero(hipStream_t s) { if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+// per-kernel timing with HIP events on the library's stream (bench.py's roofline leg)
+struct Profiler {
+  bool on = false;
+  struct Rec { std::string name; hipEvent_t a, b; };
+  std::vector<Rec> pending;
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<double, int>> acc;
+  std::vector<std::string> names_keep;
+  void begin(const char *name, hipStream_t s) {
+    if (!on) return;
+    Rec r; r.name = name;
+    (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+    pending.push_back(r);
+  }
+  void end(hipStream_t s) { if (on && !pending.empty()) (void)hipEventRecord(pending.back().b, s); }
+  void collect() {
+    for (auto &r : pending) {
+      (void)hipEventSynchronize(r.b);
+      float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b);
+      if (!acc.count(r.name)) order.push_back(r.name);
+      auto &e = acc[r.name]; e.first += ms; e.second += 1;
+      (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    pending.clear();
+  }
+  void reset() { collect(); acc.clear(); order.clear(); }
+};
+
+// rocSOLVER is loaded lazily: the once-per-run LU inverse stands where the reference calls LAPACK dgetrf_/dgetri_
+// (fix_conp.cpp:947-949); nothing on the per-step path touches it.
+struct RocSolver {
+  void *h_solver = nullptr, *h_blas = nullptr, *handle = nullptr;
+  int (*create)(void **) = nullptr;
+  int (*destroy)(void *) = nullptr;
+  int (*set_stream)(void *, hipStream_t) = nullptr;
+  int (*dgetrf)(void *, int, int, double *, int, int *, int *) = nullptr;
+  int (*dgetri)(void *, int, double *, int, int *, int *) = nullptr;
+  void load() {
+    if (handle) return;
+    h_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h_blas) h_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    h_solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h_solver) h_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h_blas || !h_solver) throw ConpError(CONP_ERR_NO_DEVICE, std::string("cannot load rocsolver/rocblas: ") + dlerror());
+    create = reinterpret_cast<int (*)(void **)>(dlsym(h_blas, "rocblas_create_handle"));
+    destroy = reinterpret_cast<int (*)(void *)>(dlsym(h_blas, "rocblas_destroy_handle"));
+    set_stream = reinterpret_cast<int (*)(void *, hipStream_t)>(dlsym(h_blas, "rocblas_set_stream"));
+    dgetrf = reinterpret_cast<int (*)(void *, int, int, double *, int, int *, int *)>(dlsym(h_solver, "rocsolver_dgetrf"));
+    dgetri = reinterpret_cast<int (*)(void *, int, double *, int, int *, int *)>(dlsym(h_solver, "rocsolver_dgetri"));
+    if (!create || !set_stream || !dgetrf || !dgetri) throw ConpError(CONP_ERR_NO_DEVICE, "rocsolver symbols missing");
+    if (create(&handle) != 0) throw ConpError(CONP_ERR_NO_DEVICE, "rocblas_create_handle failed");
+  }
+  ~RocSolver() { if (handle && destroy) destroy(handle); }
+};
+
+}  // namespace
+
+using namespace conp;
+
+struct conp_fix {
+  conp_fix_args args{};
+  conp_env env{};
+  std::vector<double> cutsq_h;
+  // host state
+  KTables kt;
+  KPlan plan;
+  EleIndex idx;
+  PairRows brows, arows;
+  ListView alist, blist;
+  bool have_alist = false, have_blist = false, kspace_ready = false;
+  int runstage = 0;          // fix_conp.cpp:181-183
+  int ne_pad = 0, nl = 0, nl_pad = 0, nall = 0, nsplit = 1;
+  int rt0 = 0, rt1 = 0, row0 = 0, row1 = 0;
+  double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
+  int cg_iterations = 0;
+  std::vector<double> csk_h, snk_h, xele_h, d_vec_h;
+  std::vector<int> atom2eleall_h, elyte_idx_h;
+  // device state
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
+      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
+      d_cg_ap, d_cg_scal;
+  DevBuf<double2> d_Xt, d_Yt, d_Zt;
+  DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
+      d_elecheck, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
+  DevBuf<unsigned char> d_mask;
+  double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
+  int n_slab_part = 0;
+  DevPlan dplan{};
+  Profiler prof;
+  RocSolver solver;
+
+  ~conp_fix() {
+    prof.collect();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+
+  RealParams real_params() const {
+    RealParams rp;
+    rp.g_ewald = env.g_ewald; rp.eta = args.eta;
+    double cut_coulsq = env.cut_coul * env.cut_coul;                  // fix_conp.cpp:1237-1240
+    const double cut_erfc = 5.8 * 5.8 / (env.g_ewald * env.g_ewald);
+    if (cut_coulsq > cut_erfc) cut_coulsq = cut_erfc;
+    rp.cut_coulsq = cut_coulsq; rp.ntypes = env.ntypes; rp.cutsq = d_cutsq.p;
+    return rp;
+  }
+
+  void sync() { HIP_TRY(hipStreamSynchronize(stream)); }
+
+  // ---------------------------------------------------------------------------------------------
+  void init_device() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw ConpError(CONP_ERR_NO_DEVICE, "no HIP device visible: libconp_hip has no CPU fallback");
+    if (env.device < 0 || env.device >= ndev) throw ConpError(CONP_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(env.device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, env.device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+      throw ConpError(CONP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIP_TRY(hipStreamCreate(&stream));
+    own_stream = true;
+    d_cutsq.upload(cutsq_h, stream);
+    d_scalars.reserve(16);
+    d_scalars.zero(stream);
+  }
+
+  // km_ewald.cpp:63-132 conp_setup
+  void km_conp_setup(double qsqsum, int64_t natoms) {
+    kt.build(env.g_ewald, env.accuracy, env.slab_volfactor, env.slabflag, env.xprd, env.yprd, env.zprd, qsqsum, natoms,
+             env.qqrd2e, env.dielectric);
+    plan.build(kt);
+    std::vector<int> ikx(plan.n_row_tiles * 64, 0), iky(plan.n_row_tiles * 64, 0), sgn(plan.n_row_tiles * 64, 0);
+    for (int p = 0; p < plan.np; ++p) { ikx[p] = plan.p_ikx[p]; iky[p] = plan.p_iky[p]; sgn[p] = plan.p_sgn[p]; }
+    d_p_ikx.upload(ikx, stream); d_p_iky.upload(iky, stream); d_p_sgn.upload(sgn, stream);
+    d_wfull.upload(plan.wfull, stream);
+    d_sf_row_a.upload(plan.sf_row_a, stream); d_sf_col_c.upload(plan.sf_col_c, stream);
+    d_k_sign.upload(plan.k_sign, stream); d_k_p.upload(plan.k_p, stream); d_k_m.upload(plan.k_m, stream);
+    dplan = DevPlan{plan.np, plan.nz, plan.NB, plan.MT, plan.n_row_tiles, plan.n_col_tiles, plan.R_pad, plan.C_pad,
+                    plan.kxmax, plan.kymax, d_p_ikx.p, d_p_iky.p, d_p_sgn.p, d_wfull.p};
+    d_G.reserve((size_t)plan.R_pad * plan.C_pad); d_Gw.reserve((size_t)plan.R_pad * plan.C_pad);
+    d_G.zero(stream); d_Gw.zero(stream);
+    // k-shard: contiguous row tiles per rank
+    rt0 = (int)((long long)plan.n_row_tiles * env.rank / env.nranks);
+    rt1 = (int)((long long)plan.n_row_tiles * (env.rank + 1) / env.nranks);
+    if ((size_t)plan.C_pad * 16 * 8 + 512 > 160 * 1024)
+      throw ConpError(CONP_ERR_ARG, "kz table too long for the b-projection kernel's LDS slice (C_pad > 1276)");
+    sync();
+    kspace_ready = true;
+  }
+
+  // fix_conp.cpp:393-424 linalg_init
+  void linalg_init(const conp_atoms *at) {
+    if (runstage != 0 || idx.initialised) return;
+    if (args.pppm) throw ConpError(CONP_ERR_ARG, "Fix conp couldn't detect a pppm/conp kspace style (which is required with the pppm flag)");
+    double qsqsum = 0.0;                                   // km_ewald.cpp:72-78 (one rank)
+    for (int i = 0; i < at->nlocal; i++) qsqsum += at->q[i] * at->q[i];
+    km_conp_setup(qsqsum, (int64_t)at->nlocal);
+    evscale = env.qe2f / env.qqr2e;                        // :412
+    idx.linalg_init(at->nlocal, at->tag);
+  }
+
+  void upload_atoms_static(const conp_atoms *at) {
+    nall = at->nlocal + at->nghost;
+    d_type.upload(at->type, nall, stream);
+    atom2eleall_h.assign(nall, -1);
+    for (int i = 0; i < nall; ++i)
+      if (at->echeck[i]) atom2eleall_h[i] = (at->tag[i] <= idx.maxtag_all) ? idx.tag2eleall[at->tag[i]] : -1;
+    d_atom2eleall.upload(atom2eleall_h, stream);
+    d_x.reserve((size_t)nall * 3); d_q.reserve(nall);
+  }
+
+  // fix_conp.cpp:468-539 post_neighbor
+  void post_neighbor(const conp_atoms *at) {
+    if (!idx.initialised) throw ConpError(CONP_ERR_STATE, "post_neighbor before setup_post_neighbor");
+    if (!have_blist) throw ConpError(CONP_ERR_STATE, "post_neighbor: no neighbor list (init_list not called)");
+    bool elyte_grew = false;
+    const bool grew = idx.post_neighbor(at->nlocal, at->tag, at->echeck, &elyte_grew);
+    const int ne = idx.elenum_all;
+    if (grew) {
+      ne_pad = (ne + 127) / 128 * 128;
+      d_A.reserve((size_t)ne * ne);
+      d_bk.reserve(ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(ne_pad); d_eleallq_own.reserve(ne_pad); d_qele.reserve(ne_pad);
+      d_elesetq.reserve(ne_pad); d_eleinitq.reserve(ne_pad); d_ele_z.reserve(ne_pad); d_elecheck.reserve(ne_pad);
+      d_ainve.reserve(ne_pad);
+      d_bk.zero(stream); d_breal.zero(stream); d_b_own.zero(stream); d_eleallq_own.zero(stream); d_qele.zero(stream);
+      d_elesetq.zero(stream); d_eleinitq.zero(stream);
+      if (!d_b) d_b = d_b_own.p;
+      if (!d_eleallq) d_eleallq = d_eleallq_own.p;
+      row0 = (int)((long long)ne * env.rank / env.nranks);
+      row1 = (int)((long long)ne * (env.rank + 1) / env.nranks);
+    }
+    upload_atoms_static(at);
+    // electrolyte atoms that enter the structure factors (km_ewald.cpp:686) -- list fixed until the next re-neighbour
+    elyte_idx_h.clear();
+    for (int i = 0; i < at->nlocal; ++i) if (at->echeck[i] == 0 && at->q[i] != 0) elyte_idx_h.push_back(i);
+    nl = (int)elyte_idx_h.size();
+    // atoms are consumed in chunks of 32; the splits want an even share of chunks
+    nl_pad = std::max(32, (nl + 31) / 32 * 32);
+    d_elyte_idx.upload(elyte_idx_h, stream);
+    const int rows_tiles = std::max(1, (rt1 - rt0) * plan.n_col_tiles);
+    const int nchunks = nl_pad / 32;
+    nsplit = std::max(1, std::min(nchunks, (512 + rows_tiles - 1) / rows_tiles));
+    d_Xt.reserve((size_t)(plan.kxmax + 1) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
+    d_Zt.reserve((size_t)plan.nz * nl_pad); d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 255) / 256 + 1);
+    d_Gpart.reserve((size_t)nsplit * plan.R_pad * plan.C_pad);
+    // real-space rows of b
+    build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
+    d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
+    sync();
+  }
+
+  void gather_xele(const conp_atoms *at) {
+    const int ne = idx.elenum_all;
+    xele_h.assign((size_t)ne * 3, 0.0);
+    for (int i = 0; i < idx.elenum; ++i) {
+      const int iloc = idx.tag2local[idx.ele2tag[i]];
+      for (int c = 0; c < 3; ++c) xele_h[3 * (size_t)idx.ele2eleall[i] + c] = at->x[3 * (size_t)iloc + c];
+    }
+  }
+
+  // km_ewald.cpp:134-145 a_read: electrode phase tables (electrodes are immobile: filled once, appendix D)
+  void km_a_read(const conp_atoms *at) {
+    const int ne = idx.elenum_all;
+    gather_xele(at);
+    electrode_trig(kt, ne, xele_h.data(), csk_h, snk_h);
+    std::vector<double> Rp, Tz, z(ne_pad, 0.0);
+    electrode_plan_tables(kt, plan, ne, ne_pad, csk_h, snk_h, Rp, Tz);
+    for (int i = 0; i < ne; ++i) z[i] = xele_h[3 * (size_t)i + 2];
+    d_Rp.upload(Rp, stream); d_Tz.upload(Tz, stream); d_ele_z.upload(z, stream);
+    sync();
+  }
+
+  void upload_xq(const conp_atoms *at) {
+    HIP_TRY(hipMemcpyAsync(d_x.p, at->x, (size_t)nall * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_q.p, at->q, (size_t)nall * sizeof(double), hipMemcpyHostToDevice, stream));
+  }
+
+  // km_ewald.cpp:147-151 + :584-666 : k-space part of A into d_A (strict lower triangle + diagonal + slab on j <= i)
+  void km_a_cal_device() {
+    const int ne = idx.elenum_all;
+    d_A.zero(stream);
+    prof.begin("a_kspace", stream);
+    launch_a_kspace(stream, dplan, ne, ne_pad, d_Rp.p, d_Tz.p, d_A.p);
+    prof.end(stream);
+  }
+
+  // fix_conp.cpp:777-861 a_cal
+  void a_cal(const conp_atoms *at) {
+    if (!have_alist) throw ConpError(CONP_ERR_STATE, "a_cal: no electrode neighbor list (init_list not called)");
+    const int ne = idx.elenum_all;
+    km_a_read(at);
+    km_a_cal_device();
+    const double MY_PIS = 1.77245385090551602729;
+    const double diag_k = kt.ug_tot - (2.0 / MY_PIS) * kt.g_ewald;      // km_ewald.cpp:631-634
+    const double diag_self = (std::sqrt(2.0) / MY_PIS) * args.eta;      // fix_conp.cpp:796-801
+    const double pref = 12.56637061435917295384 / kt.volume;            // MY_4PI/volume km_ewald.cpp:648
+    launch_a_diag_slab(stream, ne, diag_k, diag_self, kt.slabflag == 1, pref, d_ele_z.p, d_A.p);
+    build_a_rows(alist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, arows);
+    d_a_rowptr.upload(arows.row_ptr, stream); d_a_ele.upload(arows.ele_atom, stream);
+    d_a_oth.upload(arows.oth_atom, stream); d_a_col.upload(arows.col, stream);
+    upload_xq(at);
+    prof.begin("a_real", stream);
+    launch_a_real(stream, ne, d_a_rowptr.p, d_a_ele.p, d_a_oth.p, d_a_col.p, d_x.p, d_type.p, real_params(), d_A.p);
+    prof.end(stream);
+    launch_a_symmetrise(stream, ne, d_A.p);
+    sync();
+    runstage = 1;
+  }
+
+  // fix_conp.cpp:609-637 b_setq_cal (host: Ne scalars)
+  void b_setq_cal(const conp_atoms *at) {
+    const int ne = idx.elenum_all;
+    const double zprd = env.zprd, zhalf = 0.5 * env.zprd + env.boxlo_z;
+    d_vec_h.assign(ne_pad, 0.0);
+    std::fill(idx.elecheck_eleall.begin(), idx.elecheck_eleall.end(), 0);
+    for (int iloc = 0; iloc < idx.elenum; ++iloc) {
+      const int iall = idx.ele2eleall[iloc];
+      const int i = idx.tag2local[idx.ele2tag[iloc]];
+      const int eci = at->echeck[i];
+      const double z = at->x[3 * (size_t)i + 2];
+      double v;
+      if (args.ff_flag == CONP_FF_FFIELD) {
+        if (eci == 1 && z < zhalf) v = -evscale * (z / zprd + 1);
+        else v = -evscale * z / zprd;
+      } else v = -0.5 * evscale * eci;
+      d_vec_h[idx.elebuf2eleall[iloc]] = v;   // b_comm with one rank
+      idx.elecheck_eleall[iall] = eci;
+    }
+    std::vector<int> ec(ne_pad, 0);
+    for (int i = 0; i < ne; ++i) ec[i] = idx.elecheck_eleall[i];
+    d_elecheck.upload(ec, stream);
+    HIP_TRY(hipMemcpyAsync(d_b, d_vec_h.data(), ne * sizeof(double), hipMemcpyHostToDevice, stream));
+    sync();
+    if (runstage == 1) runstage = 2;
+  }
+
+  // fix_conp.cpp:982-1067 inv_project on device, bit-exact operation order
+  void inv_project_device(int n, double *A, const std::vector<double> *eleallz, double zhalf) {
+    d_ainve.reserve(n);
+    launch_inv_project(stream, n, A, 0, nullptr, d_ainve.p, d_scalars.p + 4, 0);
+    HIP_TRY(hipMemcpyAsync(&totinve, d_scalars.p + 4, sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    if (args.nullneutral) {
+      launch_inv_project_apply(stream, n, A, d_ainve.p, d_scalars.p + 4);
+      if (args.zneutr) {
+        std::vector<unsigned char> mask(n, 0);
+        for (int i = 0; i < n; ++i) mask[i] = (*eleallz)[i] > zhalf;
+        d_mask.upload(mask, stream);
+        launch_inv_project(stream, n, A, 1, d_mask.p, d_ainve.p, d_scalars.p + 5, 1);
+      }
+    }
+    sync();
+  }
+
+  void inv_project() {
+    const int ne = idx.elenum_all;
+    std::vector<double> z(ne);
+    for (int i = 0; i < ne; ++i) z[i] = xele_h[3 * (size_t)i + 2];
+    inv_project_device(ne, d_A.p, &z, 0.5 * env.zprd + env.boxlo_z);
+  }
+
+  // fix_conp.cpp:932-980 inv
+  void inv() {
+    if (runstage == 2 && args.a_matrix_f < 2) {
+      const int ne = idx.elenum_all;
+      solver.load();
+      solver.set_stream(solver.handle, stream);
+      d_ipiv.reserve(ne + 1); d_info.reserve(2);
+      prof.begin("lu_inverse", stream);
+      int rc = solver.dgetrf(solver.handle, ne, ne, d_A.p, ne, d_ipiv.p, d_info.p);
+      rc |= solver.dgetri(solver.handle, ne, d_A.p, ne, d_ipiv.p, d_info.p + 1);
+      prof.end(stream);
+      int info[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(info, d_info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+      sync();
+      if (rc != 0 || info[0] != 0 || info[1] != 0) throw ConpError(CONP_ERR_NUMERIC, "Inversion failed!");
+      if (!env.one_electrode) inv_project();
+    }
+    if (runstage == 2) runstage = 3;
+  }
+
+  // fix_conp.cpp:864-930 cg
+  void cg() {
+    const int ne = idx.elenum_all;
+    d_cg_res.reserve(ne); d_cg_p.reserve(ne); d_cg_ap.reserve(ne); d_cg_scal.reserve(8); d_cg_done.reserve(1);
+    d_cg_done.zero(stream);
+    prof.begin("cg", stream);
+    launch_cg_init(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_scal.p);
+    int done = 0, iter = 1;
+    while (iter < args.maxiter && !done) {
+      const int batch_end = std::min(args.maxiter, iter + 8);
+      for (; iter < batch_end; ++iter)
+        launch_cg_iter(stream, ne, d_A.p, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_ap.p, d_cg_scal.p, args.tolerance,
+                       d_cg_done.p, iter);
+      HIP_TRY(hipMemcpyAsync(&done, d_cg_done.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      sync();
+    }
+    prof.end(stream);
+    double sc[8];
+    HIP_TRY(hipMemcpyAsync(sc, d_cg_scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    cg_iterations = done ? (int)sc[6] : 0;
+  }
+
+  // fix_conp.cpp:698-718 equation_solve
+  void equation_solve() {
+    if (args.minimizer == CONP_SOLVER_CG) cg();
+    else inv();
+  }
+
+  // fix_conp.cpp:1071-1116 get_setq
+  void get_setq(const conp_atoms *at) {
+    const int ne = idx.elenum_all;
+    if (args.minimizer == CONP_SOLVER_CG) {
+      HIP_TRY(hipMemcpyAsync(d_elesetq.p, d_eleallq, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    } else {
+      launch_gemv_rows(stream, ne, 0, ne, d_A.p, d_b, d_elesetq.p);
+    }
+    launch_left_sum(stream, ne, d_elecheck.p, d_elesetq.p, d_scalars.p + 0);
+    HIP_TRY(hipMemcpyAsync(&totsetq, d_scalars.p + 0, sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (args.qinit) {
+      std::vector<double> qi(ne_pad, 0.0);
+      for (int iloc = 0; iloc < idx.elenum; ++iloc) qi[idx.elebuf2eleall[iloc]] = at->q[idx.tag2local[idx.ele2tag[iloc]]];
+      d_eleinitq.upload(qi, stream);
+    }
+    sync();
+    if (env.one_electrode) inv_project();
+  }
+
+  // fix_conp.cpp:426-464 linalg_setup
+  void linalg_setup(const conp_atoms *at) {
+    if (runstage != 0) return;
+    if (args.a_matrix_f == 0) a_cal(at);
+    else throw ConpError(CONP_ERR_STATE, "org/inv matrix files: load the matrix with conp_fix_set_matrix before setup");
+    b_setq_cal(at);
+    equation_solve();
+    get_setq(at);
+  }
+
+  // ---- per-step device path -------------------------------------------------------------------
+  // km_ewald.cpp:153-167 b_cal + fix_conp.cpp:1281-1365 blist_coul_cal, this rank's shard, into d_b
+  void b_cal_device(const double *dx, const double *dq, bool coulyes) {
+    const int ne = idx.elenum_all;
+    prof.begin("elyte_phase", stream);
+    launch_elyte_phase(stream, nl, nl_pad, d_elyte_idx.p, dx, dq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
+                       plan.kymax, plan.nz, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
+    prof.end(stream);
+    prof.begin("sk_gemm", stream);
+    launch_sk_gemm(stream, dplan, nl_pad, nsplit, rt0, rt1, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_Gpart.p);
+    prof.end(stream);
+    prof.begin("sk_reduce", stream);
+    launch_sk_reduce(stream, dplan, nsplit, rt0, rt1, d_Gpart.p, d_G.p, d_Gw.p);
+    prof.end(stream);
+    prof.begin("b_project", stream);
+    launch_b_project(stream, dplan, ne, ne_pad, rt0 * 8, rt1 * 8, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
+    prof.end(stream);
+    if (coulyes) {
+      prof.begin("b_real", stream);
+      launch_b_real(stream, row0, row1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), d_breal.p);
+      prof.end(stream);
+    }
+    const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
+    prof.begin("b_combine", stream);
+    launch_b_combine(stream, ne, coulyes ? row0 : 0, coulyes ? row1 : 0, 1, d_bk.p, d_breal.p, slab, d_ele_z.p,
+                     d_slab_part.p, n_slab_part, 4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
+    prof.end(stream);
+  }
+
+  // fix_conp.cpp:1135-1139: rows [row0,row1) of eleallq = S b (inverse solver), or the CG solve
+  void solve_device() {
+    const int ne = idx.elenum_all;
+    if (args.minimizer == CONP_SOLVER_INV) {
+      if (runstage < 3) throw ConpError(CONP_ERR_STATE, "solve before the inverse exists");
+      prof.begin("gemv", stream);
+      launch_gemv_rows(stream, ne, row0, row1, d_A.p, d_b, d_eleallq);
+      prof.end(stream);
+    } else {
+      cg();
+    }
+  }
+
+  // fix_conp.cpp:1149-1159: charges for owned + ghost electrode atoms, scalar output
+  void scatter_device(double *d_q_atoms, double potdiff) {
+    const int ne = idx.elenum_all;
+    prof.begin("charge_write", stream);
+    launch_charge_from_solution(stream, ne, 0, ne, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr, potdiff,
+                                d_qele.p);
+    launch_left_sum(stream, ne, d_elecheck.p, d_eleallq, d_scalars.p + 1);
+    if (d_q_atoms) launch_scatter_charge(stream, nall, d_atom2eleall.p, d_qele.p, d_q_atoms);
+    prof.end(stream);
+  }
+
+  void finish_scalar(double potdiff) {
+    double h[3];
+    HIP_TRY(hipMemcpyAsync(h, d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    scalar_output = potdiff * totsetq + h[1];   // :1159
+    slabcorr = h[2];
+  }
+
+  // fix_conp.cpp:1120-1161 update_charge (host-buffer flavour)
+  void update_charge(const conp_atoms *at, double potdiff) {
+    const int ne = idx.elenum_all;
+    if (args.minimizer == CONP_SOLVER_INV) solve_device();
+    scatter_device(nullptr, potdiff);
+    std::vector<double> qe(ne);
+    HIP_TRY(hipMemcpyAsync(qe.data(), d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+    finish_scalar(potdiff);
+    const int n = at->nlocal + at->nghost;
+    for (int i = 0; i < n; ++i) {        // owned and ghost electrode atoms :1153-1158
+      if (!at->echeck[i]) continue;
+      at->q[i] = qe[idx.tag2eleall[at->tag[i]]];
+    }
+  }
+
+  // fix_conp.cpp:677-695 b_cal / update_bk
+  void b_cal(const conp_atoms *at) {
+    if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
+    upload_xq(at);
+    b_cal_device(d_x.p, d_q.p, true);
+  }
+
+  // fix_conp.cpp:543-573 pre_force
+  void pre_force(const conp_atoms *at, int64_t ntimestep, double potdiff) {
+    if (runstage < 2) throw ConpError(CONP_ERR_STATE, "pre_force before setup_pre_force");
+    if (ntimestep % args.everynum != 0) return;
+    b_cal(at);
+    if (args.minimizer == CONP_SOLVER_CG) equation_solve();
+    update_charge(at, potdiff);
+  }
+};
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+#define CONP_GUARD_BEGIN try {
+#define CONP_GUARD_END                                                   \
+  }                                                                      \
+  catch (const ConpError &e) { g_last_error = e.what(); return e.code; } \
+  catch (const std::exception &e) { g_last_error = e.what(); return CONP_ERR_STATE; } \
+  return CONP_OK;
+
+extern "C" {
+
+const char *conp_last_error(void) { return g_last_error.c_str(); }
+int conp_abi_version(void) { return CONP_ABI_VERSION; }
+
+// fix_conp.cpp:79-176.  arg[0..2] = ID group1 conp ; arg[3] Nevery ; arg[4] group2 ; arg[5] eta ; arg[6] DV ; arg[7] log
+int conp_parse_fix_args(int narg, const char *const *arg, int ntypes, conp_fix_args *out) {
+  CONP_GUARD_BEGIN
+  if (!out) throw ConpError(CONP_ERR_ARG, "null output");
+  std::memset(out, 0, sizeof(*out));
+  if (narg < 8) throw ConpError(CONP_ERR_ARG, "Illegal fix conp command (too few input parameters)");
+  auto numeric = [&](const char *s, const char *what) {
+    char *end = nullptr;
+    const double v = std::strtod(s, &end);
+    if (end == s || *end != '\0') throw ConpError(CONP_ERR_ARG, std::string("Expected floating point parameter instead of '") + s + "' in " + what);
+    return v;
+  };
+  auto inumeric = [&](const char *s, const char *what) {
+    char *end = nullptr;
+    const long v = std::strtol(s, &end, 10);
+    if (end == s || *end != '\0') throw ConpError(CONP_ERR_ARG, std::string("Expected integer parameter instead of '") + s + "' in " + what);
+    return (int)v;
+  };
+  out->maxiter = 100; out->tolerance = 0.000001; out->minimizer = CONP_SOLVER_INV;   // :88-90
+  out->lowmem = 1; out->nullneutral = 1; out->ff_flag = CONP_FF_NORMAL;
+  out->everynum = inumeric(arg[3], "fix conp Nevery");
+  if (out->everynum <= 0) throw ConpError(CONP_ERR_ARG, "Illegal fix conp command (Nevery must be positive)");
+  std::snprintf(out->group2, sizeof(out->group2), "%s", arg[4]);
+  out->eta = numeric(arg[5], "fix conp eta");
+  if (std::strncmp(arg[6], "v_", 2) == 0) out->potdiff_is_variable = 1;
+  else out->potdiff = numeric(arg[6], "fix conp DV");
+  std::snprintf(out->logfile, sizeof(out->logfile), "%s", arg[7]);
+  for (int iarg = 8; iarg < narg; ++iarg) {
+    const char *a = arg[iarg];
+    if (!std::strcmp(a, "ffield")) {
+      if (out->ff_flag == CONP_FF_NOSLAB) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (ffield and noslab cannot both be chosen)");
+      out->ff_flag = CONP_FF_FFIELD;
+    } else if (!std::strcmp(a, "noslab")) {
+      if (out->ff_flag == CONP_FF_FFIELD) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (ffield and noslab cannot both be chosen)");
+      out->ff_flag = CONP_FF_NOSLAB;
+    } else if (!std::strcmp(a, "org") || !std::strcmp(a, "inv")) {
+      if (out->a_matrix_f != 0) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (A matrix file specified more than once)");
+      out->a_matrix_f = !std::strcmp(a, "org") ? 1 : 2;
+      if (++iarg >= narg) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (No A matrix filename given)");
+      std::snprintf(out->a_matrix_file, sizeof(out->a_matrix_file), "%s", arg[iarg]);
+    } else if (!std::strcmp(a, "etypes")) {
+      if (++iarg >= narg - 1) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (Insufficient input entries for etypes)");
+      out->eletypenum = inumeric(arg[iarg], "fix conp etypes");
+      if (out->eletypenum < 0 || out->eletypenum > 32) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (etypes count out of range)");
+      for (int i = 0; i < out->eletypenum; ++i) {
+        if (++iarg >= narg) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (Insufficient input entries for etypes)");
+        out->eletypes[i] = inumeric(arg[iarg], "fix conp etypes");
+      }
+      for (int i = 0; i < out->eletypenum; ++i)
+        if (out->eletypes[i] > ntypes) throw ConpError(CONP_ERR_ARG, "Invalid fix conp command (Invalid atom type in etypes)");
+      out->smartlist = 1;
+    } else if (!std::strcmp(a, "zneutr")) out->zneutr = 1;
+    else if (!std::strcmp(a, "matout")) out->matout = 1;
+    else if (!std::strcmp(a, "pppm")) out->pppm = 1;
+    else if (!std::strcmp(a, "split")) out->split = 1;
+    else if (!std::strcmp(a, "qinit")) out->qinit = 1;
+    else if (!std::strcmp(a, "himem")) out->lowmem = 0;
+    else if (!std::strcmp(a, "nonneutral")) out->nullneutral = 0;
+    else if (!std::strcmp(a, "ehgo")) out->ehgo = 1;
+    else if (!std::strcmp(a, "cg")) {          // new: v1.1 cannot reach its CG solver; v0.9 had a selector
+      out->minimizer = CONP_SOLVER_CG;
+      while (iarg + 2 < narg + 0 && (!std::strcmp(arg[iarg + 1], "maxiter") || !std::strcmp(arg[iarg + 1], "tol"))) {
+        if (!std::strcmp(arg[iarg + 1], "maxiter")) out->maxiter = inumeric(arg[iarg + 2], "fix conp cg maxiter");
+        else out->tolerance = numeric(arg[iarg + 2], "fix conp cg tol");
+        iarg += 2;
+      }
+    } else {
+      throw ConpError(CONP_ERR_ARG, std::string("Invalid fix conp commmand (unknown option: ") + a + ")");
+    }
+  }
+  CONP_GUARD_END
+}
+
+int conp_fix_create(const conp_fix_args *args, const conp_env *env, conp_fix **out) {
+  CONP_GUARD_BEGIN
+  if (!args || !env || !out) throw ConpError(CONP_ERR_ARG, "null argument");
+  if (args->ehgo) throw ConpError(CONP_ERR_ARG, "ehgo pair mode is not available in the HIP provider yet");
+  if (args->split) throw ConpError(CONP_ERR_ARG, "split provider is not available in the HIP provider (experimental in the reference)");
+  if (env->nranks < 1 || env->rank < 0 || env->rank >= env->nranks) throw ConpError(CONP_ERR_ARG, "bad rank/nranks");
+  std::unique_ptr<conp_fix> f(new conp_fix());
+  f->args = *args;
+  f->env = *env;
+  const size_t nc = (size_t)(env->ntypes + 1) * (env->ntypes + 1);
+  f->cutsq_h.assign(env->cutsq, env->cutsq + nc);
+  f->env.cutsq = nullptr;
+  f->init_device();
+  *out = f.release();
+  CONP_GUARD_END
+}
+
+void conp_fix_destroy(conp_fix *fix) { delete fix; }
+
+int conp_fix_init_list(conp_fix *f, int which, const conp_neighlist *l) {
+  CONP_GUARD_BEGIN
+  if (!f || !l) throw ConpError(CONP_ERR_ARG, "null argument");
+  ListView v; v.inum = l->inum; v.ilist = l->ilist; v.numneigh = l->numneigh; v.first = l->first; v.neigh = l->neigh;
+  if (which == 0 || which == 2) { f->alist = v; f->have_alist = true; }
+  if (which == 1 || which == 2) { f->blist = v; f->have_blist = true; }
+  if (which < 0 || which > 2) throw ConpError(CONP_ERR_ARG, "init_list: which must be 0, 1 or 2");
+  CONP_GUARD_END
+}
+
+int conp_fix_setup_post_neighbor(conp_fix *f, const conp_atoms *at) {
+  CONP_GUARD_BEGIN
+  f->linalg_init(at);
+  f->post_neighbor(at);
+  CONP_GUARD_END
+}
+
+int conp_fix_post_neighbor(conp_fix *f, const conp_atoms *at) {
+  CONP_GUARD_BEGIN
+  f->post_neighbor(at);
+  CONP_GUARD_END
+}
+
+int conp_fix_linalg_setup(conp_fix *f, const conp_atoms *at) {
+  CONP_GUARD_BEGIN
+  f->linalg_setup(at);
+  CONP_GUARD_END
+}
+
+int conp_fix_setup_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimestep, double potdiff) {
+  CONP_GUARD_BEGIN
+  f->linalg_setup(at);
+  f->pre_force(at, ntimestep, potdiff);
+  CONP_GUARD_END
+}
+
+int conp_fix_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimestep, double potdiff) {
+  CONP_GUARD_BEGIN
+  f->pre_force(at, ntimestep, potdiff);
+  CONP_GUARD_END
+}
+
+double conp_fix_compute_scalar(const conp_fix *f) { return f->scalar_output; }
+
+int conp_fix_a_cal(conp_fix *f, const conp_atoms *at) {
+  CONP_GUARD_BEGIN
+  f->a_cal(at);
+  CONP_GUARD_END
+}
+
+int conp_fix_b_cal(conp_fix *f, const conp_atoms *at) {
+  CONP_GUARD_BEGIN
+  f->b_cal(at);
+  f->sync();
+  CONP_GUARD_END
+}
+
+int conp_fix_equation_solve(conp_fix *f) {
+  CONP_GUARD_BEGIN
+  f->equation_solve();
+  CONP_GUARD_END
+}
+
+int conp_fix_update_charge(conp_fix *f, const conp_atoms *at, double potdiff) {
+  CONP_GUARD_BEGIN
+  f->update_charge(at, potdiff);
+  CONP_GUARD_END
+}
+
+int conp_km_conp_setup(conp_fix *f, double qsqsum, int64_t natoms) {
+  CONP_GUARD_BEGIN
+  f->km_conp_setup(qsqsum, natoms);
+  CONP_GUARD_END
+}
+
+int conp_km_a_cal(conp_fix *f, const conp_atoms *at, double *aaa) {
+  CONP_GUARD_BEGIN
+  const int ne = f->idx.elenum_all;
+  f->km_a_read(at);
+  f->km_a_cal_device();
+  const double MY_PIS = 1.77245385090551602729;
+  launch_a_diag_slab(f->stream, ne, f->kt.ug_tot - (2.0 / MY_PIS) * f->kt.g_ewald, 0.0, f->kt.slabflag == 1,
+                     12.56637061435917295384 / f->kt.volume, f->d_ele_z.p, f->d_A.p);
+  HIP_TRY(hipMemcpyAsync(aaa, f->d_A.p, (size_t)ne * ne * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  CONP_GUARD_END
+}
+
+int conp_km_b_cal(conp_fix *f, const conp_atoms *at, double *bbb) {
+  CONP_GUARD_BEGIN
+  if (f->d_Rp.n == 0) f->km_a_read(at);
+  if (at->nlocal + at->nghost != f->nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
+  f->upload_xq(at);
+  f->b_cal_device(f->d_x.p, f->d_q.p, false);
+  HIP_TRY(hipMemcpyAsync(bbb, f->d_b, f->idx.elenum_all * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  CONP_GUARD_END
+}
+
+int conp_fix_info(const conp_fix *f, conp_info *o) {
+  CONP_GUARD_BEGIN
+  std::memset(o, 0, sizeof(*o));
+  o->elenum = f->idx.elenum; o->elenum_all = f->idx.elenum_all; o->elytenum = f->idx.elytenum;
+  o->maxtag_all = f->idx.maxtag_all; o->runstage = f->runstage;
+  o->kcount = f->kt.kcount; o->kcount_flat = f->kt.kcount_flat; o->kcount_expand = f->kt.kcount_expand;
+  o->kxmax = f->kt.kxmax; o->kymax = f->kt.kymax; o->kzmax = f->kt.kzmax; o->kmax = f->kt.kmax; o->kmax3d = f->kt.kmax3d;
+  for (int i = 0; i < 7; ++i) o->kcount_dims[i] = f->kt.kcount_dims[i];
+  o->cg_iterations = f->cg_iterations;
+  for (int i = 0; i < 3; ++i) o->unitk[i] = f->kt.unitk[i];
+  o->volume = f->kt.volume; o->gsqmx = f->kt.gsqmx; o->ug_tot = f->kt.ug_tot; o->totsetq = f->totsetq;
+  o->scalar_output = f->scalar_output; o->totinve = f->totinve; o->slabcorr = f->slabcorr;
+  o->n_blist_pairs = f->brows.npairs(); o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
+  CONP_GUARD_END
+}
+
+int conp_fix_get_ktables(const conp_fix *f, int *kx, int *ky, int *kz, double *ug, int *kxy_list, int *kz_list) {
+  CONP_GUARD_BEGIN
+  if (!f->kspace_ready) throw ConpError(CONP_ERR_STATE, "k tables not built");
+  const size_t K = f->kt.kcount, E = f->kt.kcount_expand;
+  if (kx) std::memcpy(kx, f->kt.kxvecs.data(), K * sizeof(int));
+  if (ky) std::memcpy(ky, f->kt.kyvecs.data(), K * sizeof(int));
+  if (kz) std::memcpy(kz, f->kt.kzvecs.data(), K * sizeof(int));
+  if (ug) std::memcpy(ug, f->kt.ug.data(), K * sizeof(double));
+  if (kxy_list) std::memcpy(kxy_list, f->kt.kxy_list.data(), E * sizeof(int));
+  if (kz_list) std::memcpy(kz_list, f->kt.kz_list.data(), E * sizeof(int));
+  CONP_GUARD_END
+}
+
+int conp_fix_get_maps(const conp_fix *f, int *ele2tag, int *ele2eleall, int *eleall2tag, int *eleall2ele,
+                      int *elecheck_eleall, int *elebuf2eleall, int *tag2eleall) {
+  CONP_GUARD_BEGIN
+  const EleIndex &x = f->idx;
+  auto cp = [](int *dst, const std::vector<int> &v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(int)); };
+  cp(ele2tag, x.ele2tag); cp(ele2eleall, x.ele2eleall); cp(eleall2tag, x.eleall2tag); cp(eleall2ele, x.eleall2ele);
+  cp(elecheck_eleall, x.elecheck_eleall); cp(elebuf2eleall, x.elebuf2eleall); cp(tag2eleall, x.tag2eleall);
+  CONP_GUARD_END
+}
+
+int conp_fix_get_matrix(conp_fix *f, double *aaa) {
+  CONP_GUARD_BEGIN
+  const size_t ne = f->idx.elenum_all;
+  HIP_TRY(hipMemcpyAsync(aaa, f->d_A.p, ne * ne * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  CONP_GUARD_END
+}
+
+int conp_fix_set_matrix(conp_fix *f, const double *aaa, int runstage) {
+  CONP_GUARD_BEGIN
+  const size_t ne = f->idx.elenum_all;
+  f->d_A.reserve(ne * ne);
+  HIP_TRY(hipMemcpyAsync(f->d_A.p, aaa, ne * ne * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  f->sync();
+  f->runstage = runstage;
+  CONP_GUARD_END
+}
+
+int conp_fix_get_vectors(conp_fix *f, double *bbb_all, double *eleallq, double *elesetq) {
+  CONP_GUARD_BEGIN
+  const size_t nb = f->idx.elenum_all * sizeof(double);
+  if (bbb_all) HIP_TRY(hipMemcpyAsync(bbb_all, f->d_b, nb, hipMemcpyDeviceToHost, f->stream));
+  if (eleallq) HIP_TRY(hipMemcpyAsync(eleallq, f->d_eleallq, nb, hipMemcpyDeviceToHost, f->stream));
+  if (elesetq) HIP_TRY(hipMemcpyAsync(elesetq, f->d_elesetq.p, nb, hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  CONP_GUARD_END
+}
+
+int conp_fix_get_sfac(conp_fix *f, double *sr, double *si) {
+  CONP_GUARD_BEGIN
+  const int K = f->kt.kcount;
+  f->d_sfr.reserve(K); f->d_sfi.reserve(K);
+  launch_sfac_gather(f->stream, K, f->plan.C_pad, KPlan::PT, f->plan.MT, f->d_sf_row_a.p, f->d_sf_col_c.p, f->d_k_sign.p,
+                     f->d_k_p.p, f->d_k_m.p, f->d_G.p, f->d_sfr.p, f->d_sfi.p);
+  HIP_TRY(hipMemcpyAsync(sr, f->d_sfr.p, K * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipMemcpyAsync(si, f->d_sfi.p, K * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  CONP_GUARD_END
+}
+
+int conp_fix_get_ele_trig(conp_fix *f, double *csk, double *snk) {
+  CONP_GUARD_BEGIN
+  if (f->csk_h.empty()) throw ConpError(CONP_ERR_STATE, "electrode tables not built (a_cal / a_read first)");
+  std::memcpy(csk, f->csk_h.data(), f->csk_h.size() * sizeof(double));
+  std::memcpy(snk, f->snk_h.data(), f->snk_h.size() * sizeof(double));
+  CONP_GUARD_END
+}
+
+int conp_inv_project(conp_fix *f, int n, double *aaa, int nullneutral, int zneutr, const double *eleallz, double zhalf,
+                     double *totinve_out) {
+  CONP_GUARD_BEGIN
+  DevBuf<double> dA;
+  dA.upload(aaa, (size_t)n * n, f->stream);
+  const int save_nn = f->args.nullneutral, save_zn = f->args.zneutr;
+  f->args.nullneutral = nullneutral; f->args.zneutr = zneutr;
+  std::vector<double> z(eleallz ? eleallz : aaa, (eleallz ? eleallz : aaa) + n);
+  try { f->inv_project_device(n, dA.p, &z, zhalf); } catch (...) { f->args.nullneutral = save_nn; f->args.zneutr = save_zn; throw; }
+  f->args.nullneutral = save_nn; f->args.zneutr = save_zn;
+  HIP_TRY(hipMemcpyAsync(aaa, dA.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  if (totinve_out) *totinve_out = f->totinve;
+  CONP_GUARD_END
+}
+
+int conp_fix_set_stream(conp_fix *f, void *s) {
+  CONP_GUARD_BEGIN
+  f->sync();
+  if (f->own_stream && f->stream) { (void)hipStreamDestroy(f->stream); f->own_stream = false; }
+  f->stream = static_cast<hipStream_t>(s);
+  CONP_GUARD_END
+}
+
+int conp_fix_bind_device_buffers(conp_fix *f, double *d_b, double *d_q) {
+  CONP_GUARD_BEGIN
+  f->sync();
+  const size_t nb = f->idx.elenum_all * sizeof(double);
+  if (d_b) { if (f->d_b && nb) HIP_TRY(hipMemcpy(d_b, f->d_b, nb, hipMemcpyDeviceToDevice)); f->d_b = d_b; }
+  if (d_q) { if (f->d_eleallq && nb) HIP_TRY(hipMemcpy(d_q, f->d_eleallq, nb, hipMemcpyDeviceToDevice)); f->d_eleallq = d_q; }
+  CONP_GUARD_END
+}
+
+int conp_fix_row_range(const conp_fix *f, int *r0, int *r1) {
+  CONP_GUARD_BEGIN
+  *r0 = f->row0; *r1 = f->row1;
+  CONP_GUARD_END
+}
+
+int conp_fix_b_cal_device(conp_fix *f, const double *dx, const double *dq) {
+  CONP_GUARD_BEGIN
+  if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "b_cal_device before setup");
+  f->b_cal_device(dx, dq, true);
+  CONP_GUARD_END
+}
+
+int conp_fix_solve_device(conp_fix *f, double potdiff) {
+  CONP_GUARD_BEGIN
+  (void)potdiff;
+  f->solve_device();
+  CONP_GUARD_END
+}
+
+int conp_fix_scatter_device(conp_fix *f, double *d_q_atoms, double potdiff) {
+  CONP_GUARD_BEGIN
+  f->scatter_device(d_q_atoms, potdiff);
+  CONP_GUARD_END
+}
+
+int conp_fix_pre_force_device(conp_fix *f, const double *dx, double *dq, double potdiff) {
+  CONP_GUARD_BEGIN
+  if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "pre_force_device before setup");
+  f->b_cal_device(dx, dq, true);
+  f->solve_device();
+  f->scatter_device(dq, potdiff);
+  CONP_GUARD_END
+}
+
+int conp_fix_profile(conp_fix *f, int enable) {
+  CONP_GUARD_BEGIN
+  f->sync();
+  f->prof.reset();
+  f->prof.on = enable != 0;
+  CONP_GUARD_END
+}
+
+int conp_fix_profile_read(conp_fix *f, int *nk, const char **names, double *avg_ms, int *counts) {
+  CONP_GUARD_BEGIN
+  f->sync();
+  f->prof.collect();
+  f->prof.names_keep = f->prof.order;
+  int n = 0;
+  for (const auto &nm : f->prof.names_keep) {
+    if (n >= 16) break;
+    const auto &e = f->prof.acc[nm];
+    names[n] = f->prof.names_keep[n].c_str();
+    avg_ms[n] = e.second ? e.first / e.second : 0.0;
+    counts[n] = e.second;
+    ++n;
+  }
+  *nk = n;
+  CONP_GUARD_END
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+// Host-side setup and bookkeeping.  See conp_host.hpp.
+#include "conp_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+
+namespace conp {
+
+static constexpr double MY_PI = 3.14159265358979323846;  // LAMMPS math_const.h
+
+// ------------------------------------------------------------------------------------------------
+// KTables
+// ------------------------------------------------------------------------------------------------
+namespace {
+// RMS force-error estimate of an axis truncated at km (km_ewald.cpp:277-283)
+double axis_rms(double g, int km, double prd, int64_t natoms, double q2) {
+  return 2.0 * q2 * g / prd * std::sqrt(1.0 / (MY_PI * km * natoms)) *
+         std::exp(-MY_PI * MY_PI * km * km / (g * g * prd * prd));
+}
+}  // namespace
+
+void KTables::build(double g, double acc, double slabf, int slab, double xprd, double yprd, double zprd,
+                    double qsqsum, int64_t natoms, double qqrd2e, double dielectric) {
+  g_ewald = g; accuracy = acc; slab_volfactor = slabf; slabflag = slab;
+  const double q2 = qsqsum * qqrd2e / dielectric;       // :79
+  const double zprd_slab = zprd * slab_volfactor;       // :84
+  volume = xprd * yprd * zprd_slab;
+  unitk[0] = 2.0 * MY_PI / xprd;
+  unitk[1] = 2.0 * MY_PI / yprd;
+  unitk[2] = 2.0 * MY_PI / zprd_slab;
+  const double prds[3] = {xprd, yprd, zprd_slab};
+  int kmaxes[3];
+  for (int c = 0; c < 3; ++c) {                         // :93-113
+    int km = 1;
+    while (axis_rms(g, km, prds[c], natoms, q2) > acc) ++km;
+    kmaxes[c] = km;
+  }
+  kxmax = kmaxes[0]; kymax = kmaxes[1]; kzmax = kmaxes[2];
+  kmax = std::max(kxmax, std::max(kymax, kzmax));
+  kmax3d = 4 * kmax * kmax * kmax + 6 * kmax * kmax + 3 * kmax;
+  const double gx = unitk[0] * unitk[0] * kxmax * kxmax;  // :120-126
+  const double gy = unitk[1] * unitk[1] * kymax * kymax;
+  const double gz = unitk[2] * unitk[2] * kzmax * kzmax;
+  gsqmx = std::max(gx, std::max(gy, gz));
+  gsqmx *= 1.00001;
+
+  double usq[3];
+  for (int c = 0; c < 3; ++c) usq[c] = unitk[c] * unitk[c];
+  kxvecs.clear(); kyvecs.clear(); kzvecs.clear();
+  for (int &d : kcount_dims) d = 0;
+  auto push = [&](int a, int b, int c) { kxvecs.push_back(a); kyvecs.push_back(b); kzvecs.push_back(c); };
+  // axes :297-310
+  for (int c = 0; c < 3; ++c)
+    for (int m = 1; m <= kmaxes[c]; ++m) {
+      double sqk = m * m * usq[c];
+      if (sqk <= gsqmx) { push(c == 0 ? m : 0, c == 1 ? m : 0, c == 2 ? m : 0); ++kcount_dims[c]; }
+    }
+  // coordinate planes :318-342 : (k,+-l,0) (0,k,+-l) (k,0,+-l)
+  const int planeA[3] = {0, 1, 0}, planeB[3] = {1, 2, 2};
+  for (int pl = 0; pl < 3; ++pl) {
+    const int ca = planeA[pl], cb = planeB[pl];
+    for (int k = 1; k <= kmaxes[ca]; ++k)
+      for (int l = 1; l <= kmaxes[cb]; ++l) {
+        double sqk = k * k * usq[ca] + l * l * usq[cb];
+        if (sqk <= gsqmx) {
+          for (int sg = 1; sg >= -1; sg -= 2) {
+            int v[3] = {0, 0, 0};
+            v[ca] = k; v[cb] = sg * l;
+            push(v[0], v[1], v[2]);
+          }
+          ++kcount_dims[3 + pl];
+        }
+      }
+  }
+  // bulk :346-359 : (k,l,m) (k,l,-m) (k,-l,m) (k,-l,-m)
+  for (int k = 1; k <= kxmax; ++k)
+    for (int l = 1; l <= kymax; ++l)
+      for (int m = 1; m <= kzmax; ++m) {
+        double sqk = k * k * usq[0] + l * l * usq[1] + m * m * usq[2];
+        if (sqk <= gsqmx) {
+          push(k, l, m); push(k, l, -m); push(k, -l, m); push(k, -l, -m);
+          ++kcount_dims[6];
+        }
+      }
+  kcount = (int)kxvecs.size();
+  kcount_flat = kcount_dims[0] + kcount_dims[1] + kcount_dims[2] + 2 * kcount_dims[3];
+  kcount_expand = kcount_dims[4] + kcount_dims[5] + 2 * kcount_dims[6];
+
+  // ug :366-381
+  ug.assign(kcount, 0.0);
+  const double g_ewald_sq_inv = 1.0 / (g_ewald * g_ewald);
+  const double preu = 4.0 * MY_PI / volume;
+  ug_tot = 0;
+  for (int k = 0; k < kcount; ++k) {
+    double sqk = kxvecs[k] * kxvecs[k] * unitk[0] * unitk[0];
+    sqk += kyvecs[k] * kyvecs[k] * unitk[1] * unitk[1];
+    sqk += kzvecs[k] * kzvecs[k] * unitk[2] * unitk[2];
+    ug[k] = preu * std::exp(-0.25 * sqk * g_ewald_sq_inv) / sqk;
+    ug_tot += 2 * ug[k];
+  }
+
+  // gather lists :383-424
+  kxy_list.assign(kcount_expand, 0);
+  kz_list.assign(kcount_expand, 0);
+  const int zbase = kcount_dims[0] + kcount_dims[1] - 1;
+  int kf = kcount_flat, e = 0;
+  for (int n = 0; n < kcount_dims[4]; ++n, ++e, kf += 2) {
+    kxy_list[e] = kyvecs[kf] + kcount_dims[0] - 1;
+    kz_list[e] = kzvecs[kf] + zbase;
+  }
+  for (int n = 0; n < kcount_dims[5]; ++n, ++e, kf += 2) {
+    kxy_list[e] = kxvecs[kf] - 1;
+    kz_list[e] = kzvecs[kf] + zbase;
+  }
+  int kxy = kcount_dims[0] + kcount_dims[1] + kcount_dims[2];
+  for (int n = 0; n < kcount_dims[6]; ++n, e += 2, kf += 4) {
+    while (kxvecs[kxy] != kxvecs[kf] || kyvecs[kxy] != kyvecs[kf]) kxy += 2;
+    kxy_list[e] = kxy;
+    kxy_list[e + 1] = kxy + 1;
+    kz_list[e] = kz_list[e + 1] = kzvecs[kf] + zbase;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// KPlan
+// ------------------------------------------------------------------------------------------------
+void KPlan::build(const KTables &kt) {
+  kxmax = kt.kcount_dims[0];
+  kymax = kt.kcount_dims[1];
+  nz = kt.kcount_dims[2] + 1;
+  const int d0 = kt.kcount_dims[0], d1 = kt.kcount_dims[1], d2 = kt.kcount_dims[2], d3 = kt.kcount_dims[3];
+  // planar list: origin, x axis, y axis, (k,+-l) in the reference's flat order
+  p_ikx.assign(1, 0); p_iky.assign(1, 0); p_sgn.assign(1, 1);
+  flat2p.assign(kt.kcount_flat, -1);
+  for (int f = 0; f < kt.kcount_flat; ++f) {
+    if (f >= d0 + d1 && f < d0 + d1 + d2) continue;  // z axis
+    flat2p[f] = (int)p_ikx.size();
+    p_ikx.push_back(std::abs(kt.kxvecs[f]));
+    p_iky.push_back(std::abs(kt.kyvecs[f]));
+    p_sgn.push_back(kt.kyvecs[f] < 0 ? -1 : 1);
+  }
+  np = (int)p_ikx.size();
+  // reference k index -> (p, m, sign)
+  k_p.assign(kt.kcount, 0); k_m.assign(kt.kcount, 0); k_sign.assign(kt.kcount, 1);
+  for (int f = 0; f < kt.kcount_flat; ++f) {
+    if (flat2p[f] < 0) { k_p[f] = 0; k_m[f] = kt.kzvecs[f]; k_sign[f] = 1; }
+    else { k_p[f] = flat2p[f]; k_m[f] = 0; k_sign[f] = 1; }
+  }
+  for (int e = 0; e < kt.kcount_expand; ++e) {
+    const int k0 = kt.kcount_flat + 2 * e;
+    const int p = flat2p[kt.kxy_list[e]];
+    const int m = kt.kz_list[e] - (d0 + d1) + 1;
+    k_p[k0] = p; k_m[k0] = m; k_sign[k0] = 1;
+    k_p[k0 + 1] = p; k_m[k0 + 1] = m; k_sign[k0 + 1] = -1;
+  }
+  (void)d3;
+  // tile geometry: choose NB (16-col fragments per wave, 4 col groups per workgroup) to minimise padded columns
+  int best_nb = 1; long best_pad = -1;
+  for (int nb = 1; nb <= 5; ++nb) {
+    const int mt = 32 * nb;
+    const long tiles = (nz + mt - 1) / mt;
+    const long pad = tiles * mt;
+    if (best_pad < 0 || pad < best_pad || (pad == best_pad && nb > best_nb)) { best_pad = pad; best_nb = nb; }
+  }
+  NB = best_nb; MT = 32 * NB;
+  n_col_tiles = (nz + MT - 1) / MT;
+  n_row_tiles = (np + PT - 1) / PT;
+  R_pad = n_row_tiles * 2 * PT;
+  C_pad = n_col_tiles * 2 * MT;
+  // weights w(p,m) = sum over listed signs of 2 ug
+  w.assign((size_t)np * nz, 0.0);
+  for (int k = 0; k < kt.kcount; ++k) w[(size_t)k_p[k] * nz + k_m[k]] += 2.0 * kt.ug[k];
+  wfull.assign((size_t)R_pad * C_pad, 0.0);
+  for (int p = 0; p < np; ++p)
+    for (int m = 0; m < nz; ++m) {
+      const double ww = w[(size_t)p * nz + m];
+      wfull[(size_t)row_a(p) * C_pad + col_c(m)] = ww;
+      wfull[(size_t)row_a(p) * C_pad + col_s(m)] = ww;
+      wfull[(size_t)row_b(p) * C_pad + col_c(m)] = ww;
+      wfull[(size_t)row_b(p) * C_pad + col_s(m)] = ww;
+    }
+  sf_row_a.assign(kt.kcount, 0); sf_col_c.assign(kt.kcount, 0);
+  for (int k = 0; k < kt.kcount; ++k) { sf_row_a[k] = row_a(k_p[k]); sf_col_c[k] = col_c(k_m[k]); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// electrode phase tables
+// ------------------------------------------------------------------------------------------------
+void electrode_trig(const KTables &kt, int ne, const double *xele, std::vector<double> &csk, std::vector<double> &snk) {
+  const int kflat = kt.kcount_flat;
+  csk.assign((size_t)ne * kflat, 0.0);
+  snk.assign((size_t)ne * kflat, 0.0);
+  for (int i = 0; i < ne; ++i) {
+    double *c = csk.data() + (size_t)i * kflat, *s = snk.data() + (size_t)i * kflat;
+    int kf = 0;
+    for (int ic = 0; ic < 3; ++ic) {           // km_ewald.cpp:436-458 : libm cos/sin then angle-addition recurrence
+      const double xdotk = kt.unitk[ic] * xele[3 * i + ic];
+      c[kf] = std::cos(xdotk);
+      s[kf] = std::sin(xdotk);
+      for (int m = 1; m < kt.kcount_dims[ic]; ++m) {
+        c[kf + m] = c[kf + m - 1] * c[kf] - s[kf + m - 1] * s[kf];
+        s[kf + m] = s[kf + m - 1] * c[kf] + c[kf + m - 1] * s[kf];
+      }
+      kf += kt.kcount_dims[ic];
+    }
+    for (int m = 0; m < kt.kcount_dims[3]; ++m, kf += 2) {   // :464-477
+      const int kx = kt.kxvecs[kf] - 1, ky = kt.kyvecs[kf] + kt.kcount_dims[0] - 1;
+      c[kf] = c[kx] * c[ky] - s[kx] * s[ky];
+      s[kf] = c[kx] * s[ky] + s[kx] * c[ky];
+      c[kf + 1] = c[kx] * c[ky] + s[kx] * s[ky];
+      s[kf + 1] = -c[kx] * s[ky] + s[kx] * c[ky];
+    }
+  }
+}
+
+void electrode_plan_tables(const KTables &kt, const KPlan &plan, int ne, int ne_pad, const std::vector<double> &csk,
+                           const std::vector<double> &snk, std::vector<double> &Rp, std::vector<double> &Tz) {
+  const int kflat = kt.kcount_flat;
+  Rp.assign((size_t)plan.R_pad * ne_pad, 0.0);
+  Tz.assign((size_t)plan.C_pad * ne_pad, 0.0);
+  const int zoff = kt.kcount_dims[0] + kt.kcount_dims[1];
+  for (int i = 0; i < ne; ++i) {
+    Rp[(size_t)plan.row_a(0) * ne_pad + i] = 1.0;   // origin: cos 0
+    Tz[(size_t)plan.col_c(0) * ne_pad + i] = 1.0;   // m = 0
+  }
+  for (int f = 0; f < kflat; ++f) {
+    const int p = plan.flat2p[f];
+    if (p >= 0) {
+      double *ra = Rp.data() + (size_t)plan.row_a(p) * ne_pad, *rb = Rp.data() + (size_t)plan.row_b(p) * ne_pad;
+      for (int i = 0; i < ne; ++i) { ra[i] = csk[(size_t)i * kflat + f]; rb[i] = snk[(size_t)i * kflat + f]; }
+    } else {
+      const int m = f - zoff + 1;
+      double *tc = Tz.data() + (size_t)plan.col_c(m) * ne_pad, *ts = Tz.data() + (size_t)plan.col_s(m) * ne_pad;
+      for (int i = 0; i < ne; ++i) { tc[i] = csk[(size_t)i * kflat + f]; ts[i] = snk[(size_t)i * kflat + f]; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EleIndex
+// ------------------------------------------------------------------------------------------------
+void EleIndex::linalg_init(int nlocal, const int *tag) {   // fix_conp.cpp:413-416 (one rank: Allreduce MAX is the local max)
+  int maxtag = 0;
+  for (int i = 0; i < nlocal; ++i) maxtag = std::max(tag[i], maxtag);
+  maxtag_all = maxtag;
+  tag2eleall.assign((size_t)maxtag_all + 1, 0);
+  elenum = elenum_all = elytenum = 0;
+  initialised = true;
+}
+
+void EleIndex::map_atoms(int nlocal, const int *tag) {
+  int maxtag = maxtag_all;
+  for (int i = 0; i < nlocal; ++i) maxtag = std::max(maxtag, tag[i]);
+  tag2local.assign((size_t)maxtag + 1, -1);
+  for (int i = 0; i < nlocal; ++i) tag2local[tag[i]] = i;
+}
+
+bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool *elyte_grew) {
+  if (!initialised) throw std::logic_error("post_neighbor before linalg_init");
+  const int elytenum_old = elytenum, elenum_all_old = elenum_all;
+  int n = 0;
+  for (int i = 0; i < nlocal; ++i) if (echeck[i]) ++n;            // :480-484
+  elenum = n;
+  elytenum = nlocal - elenum;
+  ele2tag.resize(elenum);
+  ele2eleall.resize(elenum);
+  int j = 0;
+  for (int i = 0; i < nlocal; ++i) if (echeck[i]) ele2tag[j++] = tag[i];   // :493-498
+  elenum_all = elenum;                                           // one rank: sum of elenum_list
+  const bool grew = elenum_all > elenum_all_old;
+  if (grew) {                                                    // :510-525
+    eleall2tag.assign(ele2tag.begin(), ele2tag.end());           // Allgatherv of one rank
+    elecheck_eleall.assign(elenum_all, 0);
+    eleall2ele.assign((size_t)elenum_all + 1, -1);
+    elebuf2eleall.assign(elenum_all, 0);
+    std::fill(tag2eleall.begin(), tag2eleall.end(), elenum_all); // sentinel :521
+    for (int i = 0; i < elenum_all; ++i) tag2eleall[eleall2tag[i]] = i;
+  }
+  for (int i = 0; i < elenum_all; ++i) eleall2ele[i] = -1;       // :527
+  eleall2ele[elenum_all] = -1;
+  j = 0;
+  for (int i = 0; i < nlocal; ++i)
+    if (echeck[i]) {
+      ele2eleall[j] = tag2eleall[tag[i]];
+      eleall2ele[ele2eleall[j]] = j;
+      ++j;
+    }
+  for (int i = 0; i < elenum; ++i) elebuf2eleall[i] = ele2eleall[i];  // Allgatherv :535
+  if (elyte_grew) *elyte_grew = elytenum > elytenum_old;
+  map_atoms(nlocal, tag);
+  return grew;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PairRows
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct RawPair { int row, ele, oth, col; };
+void finish_rows(std::vector<RawPair> &raw, int ne, bool with_col, PairRows &out) {
+  out.row_ptr.assign((size_t)ne + 1, 0);
+  for (const auto &r : raw) ++out.row_ptr[r.row + 1];
+  for (int i = 0; i < ne; ++i) out.row_ptr[i + 1] += out.row_ptr[i];
+  std::vector<int> fill(out.row_ptr.begin(), out.row_ptr.end() - 1);
+  out.ele_atom.resize(raw.size());
+  out.oth_atom.resize(raw.size());
+  out.col.resize(with_col ? raw.size() : 0);
+  for (const auto &r : raw) {   // stable: list order is kept inside each row
+    const int pos = fill[r.row]++;
+    out.ele_atom[pos] = r.ele;
+    out.oth_atom[pos] = r.oth;
+    if (with_col) out.col[pos] = r.col;
+  }
+}
+}  // namespace
+
+void build_b_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
+                  PairRows &out) {
+  std::vector<RawPair> raw;
+  for (int ii = 0; ii < l.inum; ++ii) {
+    const int i = l.ilist[ii];
+    const bool ecib = echeck[i] != 0;
+    const int *jlist = l.neigh + l.first[i];
+    const int jnum = l.numneigh[i];
+    for (int jj = 0; jj < jnum; ++jj) {
+      const int j = jlist[jj] & NEIGHMASK;
+      const bool ecjb = echeck[j] != 0;
+      if ((ecib ^ ecjb) && (newton || ecib || j < nlocal)) {     // fix_conp.cpp:1326-1327
+        if (ecib) raw.push_back({idx.tag2eleall[tag[i]], i, j, 0});           // :1339-1342
+        else if (j < nlocal) raw.push_back({idx.tag2eleall[tag[j]], j, i, 0}); // :1343-1346
+        else if (newton) raw.push_back({idx.tag2eleall[tag[j]], j, i, 0});     // :1347-1350 (newtonbuf row)
+      }
+    }
+  }
+  finish_rows(raw, idx.elenum_all, false, out);
+}
+
+void build_a_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
+                  PairRows &out) {
+  std::vector<RawPair> raw;
+  for (int ii = 0; ii < l.inum; ++ii) {
+    const int i = l.ilist[ii];
+    if (!echeck[i]) continue;
+    const int *jlist = l.neigh + l.first[i];
+    const int jnum = l.numneigh[i];
+    const int elealli = idx.tag2eleall[tag[i]];
+    for (int jj = 0; jj < jnum; ++jj) {
+      const int j = jlist[jj] & NEIGHMASK;
+      if (!echeck[j]) continue;                                   // :1255 ecib && ecjb
+      const int eleallj = idx.tag2eleall[tag[j]];
+      if (j < nlocal || !(!newton && eleallj > elealli))          // :1268
+        raw.push_back({elealli, i, j, eleallj});
+    }
+  }
+  finish_rows(raw, idx.elenum_all, true, out);
+}
+
+}  // namespace conp

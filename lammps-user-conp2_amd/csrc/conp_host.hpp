@@ -1,0 +1,108 @@
+// Host-side (CPU, integer / setup) pieces of the MI355X constant-potential solver:
+//   KTables   : the Ewald k-vector tables in the reference's order (bit-exact index contract)
+//   KPlan     : the (planar p, kz m) factorisation of those tables that the HIP kernels work on
+//   EleIndex  : electrode index bookkeeping of FixConp::post_neighbor
+//   PairRows  : LAMMPS half lists -> electrode-row CSR for the real-space kernels
+// Pure C++17, no HIP.  Reference citations are file:line in /root/reference.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace conp {
+
+constexpr int NEIGHMASK = 0x3FFFFFFF;  // LAMMPS lmptype.h (SBBITS 30); used at fix_conp.cpp:1253,1324
+
+// ------------------------------------------------------------------------------------------------
+// KTables: km_ewald.cpp:63-132 (conp_setup), :277-283 (rms), :285-364 (make_kvecs_ewald),
+//          :366-381 (make_ug_from_kvecs), :383-424 (make_kxy_list_from_kvecs)
+// ------------------------------------------------------------------------------------------------
+struct KTables {
+  double g_ewald = 0, accuracy = 0, slab_volfactor = 1, volume = 0, gsqmx = 0, ug_tot = 0;
+  double unitk[3] = {0, 0, 0};
+  int slabflag = 0;
+  int kxmax = 0, kymax = 0, kzmax = 0, kmax = 0, kmax3d = 0;
+  int kcount = 0, kcount_flat = 0, kcount_expand = 0;
+  int kcount_dims[7] = {0, 0, 0, 0, 0, 0, 0};
+  std::vector<int> kxvecs, kyvecs, kzvecs, kxy_list, kz_list;
+  std::vector<double> ug;
+
+  void build(double g_ewald, double accuracy_abs, double slab_volfactor, int slabflag, double xprd, double yprd,
+             double zprd, double qsqsum, int64_t natoms, double qqrd2e, double dielectric);
+};
+
+// ------------------------------------------------------------------------------------------------
+// KPlan: every half-space k of the reference list is (planar vector p = (kx, +-ky), kz index m >= 0, sign of kz).
+// The structure factors of all of them follow from four real matrix products over the electrolyte atoms j
+//     G[(p,a|b)][(m,c|s)] = sum_j  q_j {cos,sin}(theta_pj) * {cos,sin}(m uz z_j)
+// (S_re(p,+-m) = CC -+ SS, S_im(p,+-m) = SC +- CS), and the k-space b vector / A matrix are bilinear forms in G
+// weighted by w(p,m) = sum over the signs present of 2 ug.  Rows/cols are laid out for the MFMA tiles.
+// ------------------------------------------------------------------------------------------------
+struct KPlan {
+  static constexpr int PT = 64;   // planar vectors per row tile (128 G rows: 64 'a' rows then 64 'b' rows)
+  int kxmax = 0, kymax = 0, nz = 0;  // nz = kzmax + 1 (m = 0 .. kzmax)
+  int np = 0;                        // planar vectors incl. the origin (index 0)
+  std::vector<int> p_ikx, p_iky, p_sgn;   // per p: |kx|, |ky|, sign of ky (+1/-1); origin = (0,0,+1)
+  std::vector<int> flat2p;                // reference flat index (x axis, y axis, (k,+-l,0)) -> p ; z-axis entries -> -1
+  std::vector<int> k_p, k_m, k_sign;      // per reference k index
+  int NB = 1;                             // 16-col fragments per wave (cols per col tile = 64*NB = MT 'c' cols + MT 's' cols)
+  int MT = 32;                            // kz values per col tile (= 32*NB)
+  int n_row_tiles = 0, n_col_tiles = 0, R_pad = 0, C_pad = 0;
+  std::vector<double> w;                  // [np][nz] weights
+  std::vector<double> wfull;              // [R_pad][C_pad] weights expanded to G's layout (0 in padding)
+  std::vector<int> sf_row_a, sf_col_c;    // per reference k: G row of (p,'a') and col of (m,'c') (b row = +PT, s col = +MT)
+
+  int row_a(int p) const { return (p / PT) * (2 * PT) + (p % PT); }
+  int row_b(int p) const { return row_a(p) + PT; }
+  int col_c(int m) const { return (m / MT) * (2 * MT) + (m % MT); }
+  int col_s(int m) const { return col_c(m) + MT; }
+
+  void build(const KTables &kt);
+};
+
+// electrode phase tables.  csk/snk: [ne][kcount_flat] exactly as km_ewald.cpp:426-477 (lowmem) computes them;
+// Rp: [R_pad][ne_pad] planar cos/sin rows in G's row layout, Tz: [C_pad][ne_pad] z cos/sin in G's col layout.
+void electrode_trig(const KTables &kt, int ne, const double *xele /*[ne][3]*/, std::vector<double> &csk,
+                    std::vector<double> &snk);
+void electrode_plan_tables(const KTables &kt, const KPlan &plan, int ne, int ne_pad, const std::vector<double> &csk,
+                           const std::vector<double> &snk, std::vector<double> &Rp, std::vector<double> &Tz);
+
+// ------------------------------------------------------------------------------------------------
+// EleIndex: FixConp::post_neighbor (fix_conp.cpp:468-539) + linalg_init's tag2eleall sizing (:413-416), one rank.
+// ------------------------------------------------------------------------------------------------
+struct EleIndex {
+  int elenum = 0, elenum_all = 0, elytenum = 0, maxtag_all = -1;
+  std::vector<int> ele2tag, ele2eleall, tag2eleall, eleall2tag, eleall2ele, elecheck_eleall, elebuf2eleall;
+  std::vector<int> tag2local;   // atom->map(tag) for owned atoms
+  bool initialised = false;
+
+  void linalg_init(int nlocal, const int *tag);
+  // returns true when elenum_all grew (the reference then reallocates A, b, q ... :510-525)
+  bool post_neighbor(int nlocal, const int *tag, const int *echeck, bool *elyte_grew);
+  void map_atoms(int nlocal, const int *tag);
+};
+
+// ------------------------------------------------------------------------------------------------
+// PairRows: pairs of a LAMMPS half list regrouped by electrode row (global eleall index), keeping list order
+// inside each row.  Restates the membership logic of blist_coul_cal (fix_conp.cpp:1313-1353) and
+// alist_coul_cal (:1242-1276); the distance tests stay in the kernel because x changes every step.
+// ------------------------------------------------------------------------------------------------
+struct PairRows {
+  std::vector<int> row_ptr;   // [Ne+1]
+  std::vector<int> ele_atom;  // per pair: atom index of the electrode member (owned or ghost)
+  std::vector<int> oth_atom;  // per pair: atom index of the partner (b: electrolyte atom; a: second electrode atom)
+  std::vector<int> col;       // a-list only: eleall index of the partner
+  int64_t npairs() const { return (int64_t)ele_atom.size(); }
+};
+
+struct ListView {
+  int inum = 0;
+  const int *ilist = nullptr, *numneigh = nullptr, *first = nullptr, *neigh = nullptr;
+};
+
+void build_b_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
+                  PairRows &out);
+void build_a_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
+                  PairRows &out);
+
+}  // namespace conp

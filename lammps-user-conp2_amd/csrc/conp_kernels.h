@@ -1,0 +1,60 @@
+// Launch wrappers of the gfx950 kernels (conp_kernels.hip).  All pointers are device pointers unless noted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace conp {
+
+struct DevPlan {              // device copy of KPlan geometry
+  int np, nz, NB, MT, n_row_tiles, n_col_tiles, R_pad, C_pad, kxmax, kymax;
+  const int *p_ikx, *p_iky, *p_sgn;   // [n_row_tiles*64] padded (padding: 0,0,0 -> sgn 0 marks "no vector")
+  const double *wfull;                // [R_pad][C_pad]
+};
+
+struct RealParams {           // real-space pair kernels
+  double g_ewald, eta, cut_coulsq;    // cut_coulsq already min(cut_coul^2, (5.8/g)^2)  fix_conp.cpp:1237-1240
+  int ntypes;
+  const double *cutsq;                // [(ntypes+1)^2]
+};
+
+// ---- per-step electrolyte path -----------------------------------------------------------------
+void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, double2 *Xt, double2 *Yt,
+                        double2 *Zt, double *qc, double *slab_part, int *n_slab_part);
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, int nl_pad, int nsplit, int rt0, int rt1, const double2 *Xt,
+                    const double2 *Yt, const double2 *Zt, const double *qc, double *Gpart);
+void launch_sk_reduce(hipStream_t s, const DevPlan &pl, int nsplit, int rt0, int rt1, const double *Gpart, double *G,
+                      double *Gw);
+void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, int MT, const int *sf_row_a, const int *sf_col_c,
+                        const int *k_sign, const int *k_p, const int *k_m, const double *G, double *sfacrl, double *sfacim);
+void launch_b_project(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, int rf0, int rf1, const double *Gw,
+                      const double *Rp, const double *Tz, double *bk /*[ne_pad] overwritten*/);
+void launch_b_real(hipStream_t s, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
+                   const double *x, const double *q, const int *type, RealParams rp, double *b_real /*[ne] rows row0..row1 written*/);
+// b = bk (if add_k) + b_real (rows row0..row1) - z*slab (if slab); everything else 0: the shard's contribution
+void launch_b_combine(hipStream_t s, int ne, int row0, int row1, int add_k, const double *bk, const double *b_real,
+                      int slab, const double *ele_z, const double *slab_part, int n_slab_part, double slab_pref,
+                      double *b_out, double *slab_out);
+void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);
+void launch_charge_from_solution(hipStream_t s, int ne, int row0, int row1, const double *eleallq, const double *elesetq,
+                                 const double *eleinitq, double potdiff, double *q_ele);
+void launch_scatter_charge(hipStream_t s, int nall, const int *atom2eleall, const double *q_ele, double *q_atoms);
+void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);
+
+// ---- once-per-run matrix work ------------------------------------------------------------------
+void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A);
+void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, int slab, double pref, const double *ele_z,
+                        double *A);
+void launch_a_real(hipStream_t s, int ne, const int *row_ptr, const int *ele_atom, const int *oth_atom, const int *col,
+                   const double *x, const int *type, RealParams rp, double *A);
+void launch_a_symmetrise(hipStream_t s, int ne, double *A);
+void launch_inv_project(hipStream_t s, int n, double *A, int use_mask, const unsigned char *mask, double *ainve,
+                        double *totinve /*device scalar*/, int apply);
+void launch_inv_project_apply(hipStream_t s, int n, double *A, const double *ainve, const double *totinve);
+// CG (fix_conp.cpp:864-930): state vectors on device; returns via *d_done
+void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, double *q, double *res, double *p,
+                    double *scal /*[8]*/);
+void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *res, double *p, double *ap, double *scal,
+                    double tolerance, int *done, int iter);
+
+}  // namespace conp

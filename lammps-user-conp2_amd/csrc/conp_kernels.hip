@@ -1,0 +1,731 @@
+// gfx950 (MI355X, CDNA4) kernels of the constant-potential charge solver.  wave = 64 lanes.
+//
+// Data model: every half-space Ewald vector of the reference list (km_ewald.cpp:285-361) is
+// (planar vector p, kz index m, sign).  With a_pj = q_j cos(theta_pj), b_pj = q_j sin(theta_pj),
+// c_mj = cos(m uz z_j), s_mj = sin(m uz z_j) the four real products
+//        G[(p,a|b)][(m,c|s)] = sum_j {a,b}_pj {c,s}_mj
+// hold all structure factors (km_ewald.cpp:668-780): S_re(p,+-m) = CC -+ SS,  S_im(p,+-m) = SC +- CS.
+// That contraction over the electrolyte atoms is the per-step hot spot and runs on the FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64).  Fragment layout used throughout (verified on hardware, tools/microbench):
+//   A operand: lane l holds A[row = l & 15][k = l >> 4];  B operand: lane l holds B[k = l >> 4][col = l & 15];
+//   C/D: register r of lane l is C[row = (l >> 4) + 4 r][col = l & 15].
+#include "conp_kernels.h"
+
+namespace conp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ================================================================================================
+// 1. electrolyte phase tables  (km_ewald.cpp:685-724: libm cos/sin of unitk*x, then the angle-addition
+//    recurrence c_m = c_{m-1} c_1 - s_{m-1} s_1, s_m = s_{m-1} c_1 + c_{m-1} s_1)
+//    Xt[kx][j], Yt[ky][j], Zt[m][j] as (cos, sin), k-major / atom-contiguous like the reference's cs/sn.
+//    Row 0 of each table is (1, 0).  Also compacts q and emits per-block partial sums of q*z (slab, :835-841).
+// ================================================================================================
+__global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, const int *__restrict__ elyte_idx,
+                                                          const double *__restrict__ x, const double *__restrict__ q,
+                                                          double ux, double uy, double uz, int kxmax, int kymax, int nz,
+                                                          double2 *__restrict__ Xt, double2 *__restrict__ Yt,
+                                                          double2 *__restrict__ Zt, double *__restrict__ qc,
+                                                          double *__restrict__ slab_part) {
+#pragma clang fp contract(off)
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double qz = 0.0;
+  if (j < nl_pad) {
+    double xx = 0, yy = 0, zz = 0, qq = 0;
+    if (j < nl) {
+      const int i = elyte_idx[j];
+      xx = x[3 * i]; yy = x[3 * i + 1]; zz = x[3 * i + 2]; qq = q[i];
+    }
+    qc[j] = qq;
+    qz = qq * zz;
+    const double ang[3] = {ux * xx, uy * yy, uz * zz};
+    const int nrow[3] = {kxmax + 1, kymax + 1, nz};
+    double2 *tab[3] = {Xt, Yt, Zt};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double c1, s1;
+      sincos(ang[c], &s1, &c1);
+      double2 *t = tab[c] + j;
+      t[0] = make_double2(1.0, 0.0);
+      double cm = c1, sm = s1;
+      if (nrow[c] > 1) t[(size_t)nl_pad] = make_double2(c1, s1);
+      for (int m = 2; m < nrow[c]; ++m) {
+        const double cn = cm * c1 - sm * s1;
+        const double sn = sm * c1 + cm * s1;
+        cm = cn; sm = sn;
+        t[(size_t)m * nl_pad] = make_double2(cm, sm);
+      }
+    }
+  }
+  // block partial of sum q z
+  __shared__ double red[4];
+  double v = wave_sum(qz);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) slab_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, double2 *Xt, double2 *Yt,
+                        double2 *Zt, double *qc, double *slab_part, int *n_slab_part) {
+  const int nb = (nl_pad + 255) / 256;
+  *n_slab_part = nb;
+  hipLaunchKernelGGL(elyte_phase_kernel, dim3(nb), dim3(256), 0, s, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
+                     kymax, nz, Xt, Yt, Zt, qc, slab_part);
+}
+
+// ================================================================================================
+// 2. structure-factor contraction on the FP64 matrix cores.
+//    Workgroup = 512 threads = 8 waves = 2 row halves x 4 column groups; macro tile = 128 G rows (64 planar
+//    vectors: 64 'a' rows then 64 'b' rows) x 64*NB G cols (MT = 32*NB kz values: MT 'c' cols then MT 's' cols).
+//    The atoms are split over `nsplit` workgroups per tile; each walks its atoms in chunks of J = 32:
+//      (i)  all threads build the operand panel in LDS, panel[feature][atom]:
+//             features 0..127      : a_pj / b_pj from the X/Y phase tables (one complex product + q)
+//             features 128..128+2MT: c_mj / s_mj copied from the Z table
+//           row stride J+2 doubles -> conflict-free ds_read_b64 of MFMA fragments (16 rows x 2 atoms per 32 lanes);
+//      (ii) 8 k-steps of 4 atoms: per wave 4 A fragments x NB B fragments -> 4*NB MFMAs.
+//    Partial tiles go to Gpart[split][R_pad][C_pad]; sk_reduce sums them in a fixed order (deterministic).
+// ================================================================================================
+constexpr int SK_J = 32;
+constexpr int SK_LD = SK_J + 2;
+
+template <int NB>
+__global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, int nl_pad, int nsplit, int rt0,
+                                                         const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
+                                                         const double2 *__restrict__ Zt, const double *__restrict__ qc,
+                                                         double *__restrict__ Gpart) {
+  constexpr int MT = 32 * NB;
+  constexpr int NF = 128 + 2 * MT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *panel = reinterpret_cast<double *>(smem);   // [NF][SK_LD]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int rh = wave & 1, cg = wave >> 1;
+  int work = blockIdx.x;
+  const int split = work % nsplit; work /= nsplit;
+  const int ct = work % pl.n_col_tiles;
+  const int rt = rt0 + work / pl.n_col_tiles;
+
+  const int nchunks = nl_pad / SK_J;
+  const int c0 = (int)((long long)nchunks * split / nsplit), c1 = (int)((long long)nchunks * (split + 1) / nsplit);
+
+  // per-thread constants of the generation phase
+  const int gj = t & 31, gs = t >> 5;   // atom within chunk, sub-index 0..15
+  int g_xoff[4], g_yoff[4];
+  double g_sgn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = rt * 64 + r * 16 + gs;
+    g_xoff[r] = pl.p_ikx[p];
+    g_yoff[r] = pl.p_iky[p];
+    g_sgn[r] = (double)pl.p_sgn[p];   // 0 for padding rows
+  }
+
+  d4 acc[4][NB];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < NB; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int fr = lane & 15, fk = lane >> 4;
+  const double *a_base = panel + (64 * rh + fr) * SK_LD + fk;
+  const double *b_base = panel + (128 + 16 * NB * cg + fr) * SK_LD + fk;
+
+  for (int ch = c0; ch < c1; ++ch) {
+    const size_t jg = (size_t)ch * SK_J + gj;
+    // ---- (i) operand panel ----
+    {
+      const double qq = qc[jg];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double2 X = Xt[(size_t)g_xoff[r] * nl_pad + jg];
+        const double2 Y = Yt[(size_t)g_yoff[r] * nl_pad + jg];
+        const double sg = g_sgn[r];
+        // (kx, sg*ky): cos = cx cy - sg sx sy ; sin = sg cx sy + sx cy   (km_ewald.cpp:739-747)
+        const double cth = X.x * Y.x - sg * (X.y * Y.y);
+        const double sth = sg * (X.x * Y.y) + X.y * Y.x;
+        const double live = sg * sg;   // 1 for real vectors, 0 for padding
+        const int pl_ = r * 16 + gs;
+        panel[pl_ * SK_LD + gj] = live * (qq * cth);
+        panel[(64 + pl_) * SK_LD + gj] = live * (qq * sth);
+      }
+#pragma unroll
+      for (int r = 0; r < 2 * NB; ++r) {
+        const int ml = r * 16 + gs;
+        const int m = ct * MT + ml;
+        double2 Z = make_double2(0.0, 0.0);
+        if (m < pl.nz) Z = Zt[(size_t)m * nl_pad + jg];
+        panel[(128 + ml) * SK_LD + gj] = Z.x;
+        panel[(128 + MT + ml) * SK_LD + gj] = Z.y;
+      }
+    }
+    __syncthreads();
+    // ---- (ii) MFMA over the chunk ----
+#pragma unroll
+    for (int ks = 0; ks < SK_J / 4; ++ks) {
+      double af[4], bf[NB];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) af[f] = a_base[(16 * f) * SK_LD + 4 * ks];
+#pragma unroll
+      for (int g = 0; g < NB; ++g) bf[g] = b_base[(16 * g) * SK_LD + 4 * ks];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < NB; ++g) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+    }
+    __syncthreads();
+  }
+  // ---- partial tile out ----
+  double *out = Gpart + (size_t)split * pl.R_pad * pl.C_pad;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 128 + 64 * rh + 16 * f + fk + 4 * r;
+        const int col = ct * (2 * MT) + 16 * NB * cg + 16 * g + fr;
+        out[(size_t)row * pl.C_pad + col] = acc[f][g][r];
+      }
+}
+
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, int nl_pad, int nsplit, int rt0, int rt1, const double2 *Xt,
+                    const double2 *Yt, const double2 *Zt, const double *qc, double *Gpart) {
+  const int nblk = (rt1 - rt0) * pl.n_col_tiles * nsplit;
+  if (nblk <= 0) return;
+  const size_t lds = (size_t)(128 + 64 * pl.NB) * SK_LD * sizeof(double);
+#define SK_CASE(N)                                                                                              \
+  case N:                                                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_gemm_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        (int)lds);                                                                              \
+    hipLaunchKernelGGL(sk_gemm_kernel<N>, dim3(nblk), dim3(512), lds, s, pl, nl_pad, nsplit, rt0, Xt, Yt, Zt, qc, \
+                       Gpart);                                                                                  \
+    break;
+  switch (pl.NB) {
+    SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5)
+    default: break;
+  }
+#undef SK_CASE
+}
+
+// G = sum over splits (fixed order), Gw = w * G.  Only rows of tiles [rt0, rt1) are touched.
+__global__ __launch_bounds__(256) void sk_reduce_kernel(int C_pad, size_t plane, int nsplit, size_t e0, size_t e1,
+                                                        const double *__restrict__ Gpart, const double *__restrict__ wfull,
+                                                        double *__restrict__ G, double *__restrict__ Gw) {
+  for (size_t e = e0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (size_t)gridDim.x * blockDim.x) {
+    double sum = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) sum += Gpart[(size_t)sp * plane + e];
+    G[e] = sum;
+    Gw[e] = wfull[e] * sum;
+  }
+}
+
+void launch_sk_reduce(hipStream_t s, const DevPlan &pl, int nsplit, int rt0, int rt1, const double *Gpart, double *G,
+                      double *Gw) {
+  const size_t plane = (size_t)pl.R_pad * pl.C_pad;
+  const size_t e0 = (size_t)rt0 * 128 * pl.C_pad, e1 = (size_t)rt1 * 128 * pl.C_pad;
+  if (e1 <= e0) return;
+  int nb = (int)((e1 - e0 + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(sk_reduce_kernel, dim3(nb), dim3(256), 0, s, pl.C_pad, plane, nsplit, e0, e1, Gpart, pl.wfull, G, Gw);
+}
+
+// structure factors in the reference's k order (parity read-back; km_ewald.cpp sfacrl_all / sfacim_all)
+__global__ void sfac_gather_kernel(int kcount, int C_pad, int PT, int MT, const int *__restrict__ row_a,
+                                   const int *__restrict__ col_c, const int *__restrict__ k_sign,
+                                   const int *__restrict__ k_p, const int *__restrict__ k_m, const double *__restrict__ G,
+                                   double *__restrict__ sr, double *__restrict__ si) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= kcount) return;
+  const size_t ra = (size_t)row_a[k] * C_pad, rb = (size_t)(row_a[k] + PT) * C_pad;
+  const int cc = col_c[k], cs = col_c[k] + MT;
+  const double CC = G[ra + cc], CS = G[ra + cs], SC = G[rb + cc], SS = G[rb + cs];
+  const double sg = (double)k_sign[k];
+  // (p,+m): Sr = CC - SS, Si = CS + SC ; (p,-m): Sr = CC + SS, Si = SC - CS   (km_ewald.cpp:768-773)
+  sr[k] = CC - sg * SS;
+  si[k] = SC + sg * CS;
+}
+
+void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, int MT, const int *sf_row_a, const int *sf_col_c,
+                        const int *k_sign, const int *k_p, const int *k_m, const double *G, double *sfacrl, double *sfacim) {
+  hipLaunchKernelGGL(sfac_gather_kernel, dim3((kcount + 255) / 256), dim3(256), 0, s, kcount, C_pad, PT, MT, sf_row_a,
+                     sf_col_c, k_sign, k_p, k_m, G, sfacrl, sfacim);
+}
+
+// ================================================================================================
+// 3. k-space b vector (km_ewald.cpp:789-825):  b_i = - sum_{r,t} Rp[r][i] * Gw[r][t] * Tz[t][i]
+//    One workgroup (4 waves) per 16 electrode atoms: H = Gw(16-row fragment) x Tz(slice in LDS) on MFMA, then
+//    the Hadamard with Rp and the column sum in the epilogue.  Row fragments [rf0, rf1) only (k-shard).
+// ================================================================================================
+__global__ __launch_bounds__(256) void b_project_kernel(int C_pad, int ne_pad, int rf0, int rf1,
+                                                        const double *__restrict__ Gw, const double *__restrict__ Rp,
+                                                        const double *__restrict__ Tz, double *__restrict__ bk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *tz = reinterpret_cast<double *>(smem);          // [C_pad][16]
+  double *red = tz + (size_t)C_pad * 16;                   // [4 waves][16]
+  const int i0 = blockIdx.x * 16;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int e = t; e < C_pad * 16; e += 256) tz[e] = Tz[(size_t)(e >> 4) * ne_pad + i0 + (e & 15)];
+  __syncthreads();
+  const int fr = lane & 15, fk = lane >> 4;
+  double part = 0.0;
+  for (int rf = rf0 + wave; rf < rf1; rf += 4) {
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *arow = Gw + (size_t)(16 * rf + fr) * C_pad + fk;
+    const double *brow = tz + fk * 16 + fr;
+#pragma unroll 8
+    for (int ts = 0; ts < C_pad / 4; ++ts) acc = MFMA_F64(arow[4 * ts], brow[64 * ts], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part += Rp[(size_t)(16 * rf + fk + 4 * r) * ne_pad + i0 + fr] * acc[r];
+  }
+  part += __shfl_xor(part, 16, 64);
+  part += __shfl_xor(part, 32, 64);
+  if (lane < 16) red[wave * 16 + lane] = part;
+  __syncthreads();
+  if (t < 16) bk[i0 + t] = -((red[t] + red[16 + t]) + (red[32 + t] + red[48 + t]));
+}
+
+void launch_b_project(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, int rf0, int rf1, const double *Gw,
+                      const double *Rp, const double *Tz, double *bk) {
+  const size_t lds = ((size_t)pl.C_pad * 16 + 64) * sizeof(double);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(b_project_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 16), dim3(256), lds, s, pl.C_pad, ne_pad, rf0, rf1, Gw, Rp, Tz, bk);
+}
+
+// ================================================================================================
+// 4. real-space kernels.  erfc(x)/r through the reference's 5-term polynomial (fix_conp.cpp:53-60, 1446-1454)
+// ================================================================================================
+__device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
+#pragma clang fp contract(off)
+  if (a2_r2 < 5.8 * 5.8) {
+    const double a_r = sqrt(a2_r2);
+    const double expm2 = exp(-a2_r2);
+    const double t = 1.0 / (1.0 + 0.3275911 * a_r);
+    return t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2 / a_r;
+  }
+  return 0.0;
+}
+
+// one wave per electrode row (global eleall index): b_real[row] = - sum_pairs q_j [erfc(g r) - erfc(eta r)] / r
+// (fix_conp.cpp:1313-1353; eta_potential :1472-1475)
+__global__ __launch_bounds__(256) void b_real_kernel(int row0, int row1, const int *__restrict__ row_ptr,
+                                                     const int *__restrict__ ele_atom, const int *__restrict__ oth_atom,
+                                                     const double *__restrict__ x, const double *__restrict__ q,
+                                                     const int *__restrict__ type, RealParams rp,
+                                                     double *__restrict__ b_real) {
+#pragma clang fp contract(off)
+  const int row = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= row1) return;
+  const int lane = threadIdx.x & 63;
+  const int nt1 = rp.ntypes + 1;
+  double sum = 0.0;
+  for (int p = row_ptr[row] + lane; p < row_ptr[row + 1]; p += 64) {
+    const int ie = ele_atom[p], jo = oth_atom[p];
+    const double dx = x[3 * ie] - x[3 * jo], dy = x[3 * ie + 1] - x[3 * jo + 1], dz = x[3 * ie + 2] - x[3 * jo + 2];
+    const double rsq = dx * dx + dy * dy + dz * dz;
+    if (rsq < rp.cutsq[type[ie] * nt1 + type[jo]] && rsq < rp.cut_coulsq) {
+      double dudq = erfcr_sqrt_dev(rp.g_ewald * rp.g_ewald * rsq) * rp.g_ewald;
+      dudq += -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
+      sum -= q[jo] * dudq;
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) b_real[row] = sum;
+}
+
+void launch_b_real(hipStream_t s, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
+                   const double *x, const double *q, const int *type, RealParams rp, double *b_real) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(b_real_kernel, dim3((row1 - row0 + 3) / 4), dim3(256), 0, s, row0, row1, row_ptr, ele_atom,
+                     oth_atom, x, q, type, rp, b_real);
+}
+
+__global__ __launch_bounds__(256) void b_combine_kernel(int ne, int row0, int row1, int add_k,
+                                                        const double *__restrict__ bk, const double *__restrict__ b_real,
+                                                        int slab, const double *__restrict__ ele_z,
+                                                        const double *__restrict__ slab_part, int n_slab_part,
+                                                        double slab_pref, double *__restrict__ b_out,
+                                                        double *__restrict__ slab_out) {
+  __shared__ double sc;
+  if (slab) {
+    // every block re-derives the same scalar in the same order: sum_j 4 pi q_j z_j / V  (km_ewald.cpp:835-841)
+    if (threadIdx.x == 0) {
+      double sacc = 0.0;
+      for (int k = 0; k < n_slab_part; ++k) sacc += slab_part[k];
+      sc = slab_pref * sacc;
+      if (blockIdx.x == 0 && slab_out) *slab_out = sc;
+    }
+    __syncthreads();
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  double v = add_k ? bk[i] : 0.0;
+  if (slab) v -= ele_z[i] * sc;
+  if (i >= row0 && i < row1) v += b_real[i];
+  b_out[i] = v;
+}
+
+void launch_b_combine(hipStream_t s, int ne, int row0, int row1, int add_k, const double *bk, const double *b_real,
+                      int slab, const double *ele_z, const double *slab_part, int n_slab_part, double slab_pref,
+                      double *b_out, double *slab_out) {
+  hipLaunchKernelGGL(b_combine_kernel, dim3((ne + 255) / 256), dim3(256), 0, s, ne, row0, row1, add_k, bk, b_real, slab,
+                     ele_z, slab_part, n_slab_part, slab_pref, b_out, slab_out);
+}
+
+// ================================================================================================
+// 5. dense solve pieces.  GEMV: one wave per row, 16-byte loads (fix_conp.cpp:1135-1139 ddot_ per row)
+// ================================================================================================
+__global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row1, const double *__restrict__ S,
+                                                        const double *__restrict__ b, double *__restrict__ y) {
+  const int row = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= row1) return;
+  const int lane = threadIdx.x & 63;
+  const double *srow = S + (size_t)row * n;
+  double s0 = 0.0, s1 = 0.0;
+  if ((n & 1) == 0) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(srow);
+    const double2 *b2 = reinterpret_cast<const double2 *>(b);
+    for (int j = lane; j < n / 2; j += 64) {
+      const double2 a = s2[j], bb = b2[j];
+      s0 = fma(a.x, bb.x, s0);
+      s1 = fma(a.y, bb.y, s1);
+    }
+  } else {
+    for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
+  }
+  const double r = wave_sum(s0 + s1);
+  if (lane == 0) y[row] = r;
+}
+
+void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3((row1 - row0 + 3) / 4), dim3(256), 0, s, n, row0, row1, S, b, y);
+}
+
+// q_ele = eleallq + dV * elesetq (+ eleinitq)   (fix_conp.cpp:1153-1158)
+__global__ void charge_from_solution_kernel(int row0, int row1, const double *__restrict__ eleallq,
+                                            const double *__restrict__ elesetq, const double *__restrict__ eleinitq,
+                                            double potdiff, double *__restrict__ q_ele) {
+#pragma clang fp contract(off)
+  const int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row1) return;
+  double v = eleallq[i] + potdiff * elesetq[i];
+  if (eleinitq) v += eleinitq[i];
+  q_ele[i] = v;
+}
+
+void launch_charge_from_solution(hipStream_t s, int ne, int row0, int row1, const double *eleallq, const double *elesetq,
+                                 const double *eleinitq, double potdiff, double *q_ele) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(charge_from_solution_kernel, dim3((row1 - row0 + 255) / 256), dim3(256), 0, s, row0, row1, eleallq,
+                     elesetq, eleinitq, potdiff, q_ele);
+}
+
+__global__ void scatter_charge_kernel(int nall, const int *__restrict__ atom2eleall, const double *__restrict__ q_ele,
+                                      double *__restrict__ q_atoms) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nall) return;
+  const int e = atom2eleall[i];
+  if (e >= 0) q_atoms[i] = q_ele[e];
+}
+
+void launch_scatter_charge(hipStream_t s, int nall, const int *atom2eleall, const double *q_ele, double *q_atoms) {
+  hipLaunchKernelGGL(scatter_charge_kernel, dim3((nall + 255) / 256), dim3(256), 0, s, nall, atom2eleall, q_ele, q_atoms);
+}
+
+// sum of v over the group-1 ("left") electrode atoms (netcharge_left :1149-1151, totsetq :1098-1104); one workgroup
+__global__ __launch_bounds__(1024) void left_sum_kernel(int ne, const int *__restrict__ elecheck,
+                                                        const double *__restrict__ v, double *__restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < ne; i += 1024) if (elecheck[i] == 1) s += v[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    *out = tot;
+  }
+}
+
+void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out) {
+  hipLaunchKernelGGL(left_sum_kernel, dim3(1), dim3(1024), 0, s, ne, elecheck, v, out);
+}
+
+// ================================================================================================
+// 6. once-per-run: Ewald A matrix.
+//    k-space (km_ewald.cpp:584-645):  A_ij = sum_{r,t} w(r,t) Rp[r][i] Tz[t][i] Rp[r][j] Tz[t][j]   for i > j
+//    -- a SYRK over the (r,t) index on the FP64 matrix cores.  Workgroup = 4 waves = 128 x 128 tile, wave = 64 x 64
+//    (4 x 4 fragments); operands are formed in registers: A = w * Rp_i * Tz_i, B = Rp_j * Tz_j.
+//    Only tiles with (row block >= col block) run; the strict upper triangle is left for a_symmetrise.
+// ================================================================================================
+__global__ __launch_bounds__(256, 1) void a_kspace_kernel(int R_pad, int C_pad, int ne, int ne_pad,
+                                                          const double *__restrict__ wfull, const double *__restrict__ Rp,
+                                                          const double *__restrict__ Tz, double *__restrict__ A) {
+  // triangular tile index -> (bi >= bj)
+  int tidx = blockIdx.x, bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= tidx) ++bi;
+  const int bj = tidx - bi * (bi + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int ibase = bi * 128 + wi * 64 + fr, jbase = bj * 128 + wj * 64 + fr;
+  if (bi == bj && wj > wi) return;   // wave tile strictly above the diagonal
+  d4 acc[4][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int r = 0; r < R_pad; ++r) {
+    double ri[4], rj[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      ri[f] = Rp[(size_t)r * ne_pad + ibase + 16 * f];
+      rj[f] = Rp[(size_t)r * ne_pad + jbase + 16 * f];
+    }
+    const double *wrow = wfull + (size_t)r * C_pad + fk;
+    for (int ts = 0; ts < C_pad / 4; ++ts) {
+      const double ww = wrow[4 * ts];
+      const double *tzr = Tz + (size_t)(4 * ts + fk) * ne_pad;
+      double af[4], bf[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        af[f] = ww * ri[f] * tzr[ibase + 16 * f];
+        bf[f] = rj[f] * tzr[jbase + 16 * f];
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = bi * 128 + wi * 64 + 16 * f + fk + 4 * r;
+        const int j = bj * 128 + wj * 64 + 16 * g + fr;
+        if (i < ne && j < i) A[(size_t)i * ne + j] = acc[f][g][r];
+      }
+}
+
+void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A) {
+  const int nb = ne_pad / 128;
+  const int ntiles = nb * (nb + 1) / 2;
+  hipLaunchKernelGGL(a_kspace_kernel, dim3(ntiles), dim3(256), 0, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.wfull, Rp, Tz, A);
+}
+
+// diagonal ug_tot - 2g/sqrt(pi) + sqrt(2) eta/sqrt(pi) (km_ewald.cpp:631-634, fix_conp.cpp:796-801) and the slab
+// term 4 pi z_i z_j / V on j <= i (km_ewald.cpp:647-665)
+__global__ void a_diag_slab_kernel(int ne, double diag_k, double diag_self, int slab, double pref,
+                                   const double *__restrict__ ele_z, double *__restrict__ A) {
+#pragma clang fp contract(off)
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)ne * ne) return;
+  const int i = (int)(e / ne), j = (int)(e % ne);
+  if (j > i) return;
+  double v = A[e];
+  if (i == j) v = diag_k;
+  if (slab) v += pref * ele_z[i] * ele_z[j];
+  if (i == j) v += diag_self;
+  A[e] = v;
+}
+
+// one thread per electrode row, pairs in list order (deterministic): A[row][col] += [erfc(g r) - erfc(eta r / sqrt 2)] / r
+// (fix_conp.cpp:1242-1276, eta_potential_A :1467-1470)
+__global__ void a_real_kernel(int ne, const int *__restrict__ row_ptr, const int *__restrict__ ele_atom,
+                              const int *__restrict__ oth_atom, const int *__restrict__ col, const double *__restrict__ x,
+                              const int *__restrict__ type, RealParams rp, double *__restrict__ A) {
+#pragma clang fp contract(off)
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= ne) return;
+  const int nt1 = rp.ntypes + 1;
+  for (int p = row_ptr[row]; p < row_ptr[row + 1]; ++p) {
+    const int ie = ele_atom[p], jo = oth_atom[p];
+    const double dx = x[3 * ie] - x[3 * jo], dy = x[3 * ie + 1] - x[3 * jo + 1], dz = x[3 * ie + 2] - x[3 * jo + 2];
+    const double rsq = dx * dx + dy * dy + dz * dz;
+    if (rsq < rp.cutsq[type[ie] * nt1 + type[jo]] && rsq < rp.cut_coulsq) {
+      double dudq = erfcr_sqrt_dev(rp.g_ewald * rp.g_ewald * rsq) * rp.g_ewald;
+      const double etarij2 = rp.eta * rp.eta * rsq / 2;
+      dudq += -erfcr_sqrt_dev(etarij2) * rp.eta / sqrt(2.0);
+      A[(size_t)row * ne + col[p]] += dudq;
+    }
+  }
+}
+
+void launch_a_real(hipStream_t s, int ne, const int *row_ptr, const int *ele_atom, const int *oth_atom, const int *col,
+                   const double *x, const int *type, RealParams rp, double *A) {
+  hipLaunchKernelGGL(a_real_kernel, dim3((ne + 63) / 64), dim3(64), 0, s, ne, row_ptr, ele_atom, oth_atom, col, x, type, rp, A);
+}
+
+// a_ij += a_ji ; a_ji = a_ij  for i > j   (fix_conp.cpp:826-831)
+__global__ void a_symmetrise_kernel(int ne, double *__restrict__ A) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)ne * ne) return;
+  const int i = (int)(e / ne), j = (int)(e % ne);
+  if (j >= i) return;
+  const double v = A[(size_t)i * ne + j] + A[(size_t)j * ne + i];
+  A[(size_t)i * ne + j] = v;
+  A[(size_t)j * ne + i] = v;
+}
+
+void launch_a_symmetrise(hipStream_t s, int ne, double *A) {
+  const size_t n2 = (size_t)ne * ne;
+  hipLaunchKernelGGL(a_symmetrise_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, ne, A);
+}
+
+void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, int slab, double pref, const double *ele_z,
+                        double *A) {
+  const size_t n2 = (size_t)ne * ne;
+  hipLaunchKernelGGL(a_diag_slab_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, ne, diag_k, diag_self, slab,
+                     pref, ele_z, A);
+}
+
+// ================================================================================================
+// 7. electroneutrality projection, BIT-EXACT with the reference's operation order (fix_conp.cpp:996-1060):
+//    ainve_i = sum_j A_ij in j order (one thread per row, sequential), totinve = sum_i ainve_i in i order (one thread),
+//    A_ij -= ainve_i * ainve_j / totinve  evaluated as (ainve_i*ainve_j)/totinve, only if totinve^2 > 1e-8.
+//    mask != NULL: the zneutr variant (e restricted to atoms with z > zhalf).
+// ================================================================================================
+__global__ void inv_rowsum_kernel(int n, const double *__restrict__ A, const unsigned char *__restrict__ mask,
+                                  double *__restrict__ ainve) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double *row = A + (size_t)i * n;
+  double acc = 0;
+  if (mask) { for (int j = 0; j < n; ++j) if (mask[j]) acc += row[j]; }
+  else { for (int j = 0; j < n; ++j) acc += row[j]; }
+  ainve[i] = acc;
+}
+
+__global__ void inv_total_kernel(int n, const double *__restrict__ ainve, const unsigned char *__restrict__ mask,
+                                 double *__restrict__ totinve) {
+#pragma clang fp contract(off)
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double tot = 0;
+  for (int i = 0; i < n; ++i) if (!mask || mask[i]) tot += ainve[i];
+  *totinve = tot;
+}
+
+__global__ void inv_apply_kernel(int n, double *__restrict__ A, const double *__restrict__ ainve,
+                                 const double *__restrict__ totinve) {
+#pragma clang fp contract(off)
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n * n) return;
+  const double tot = *totinve;
+  if (!(tot * tot > 1e-8)) return;
+  const int i = (int)(e / n), j = (int)(e % n);
+  const double prod = ainve[i] * ainve[j];
+  const double quot = prod / tot;
+  A[e] = A[e] - quot;
+}
+
+void launch_inv_project(hipStream_t s, int n, double *A, int use_mask, const unsigned char *mask, double *ainve,
+                        double *totinve, int apply) {
+  const unsigned char *m = use_mask ? mask : nullptr;
+  hipLaunchKernelGGL(inv_rowsum_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, A, m, ainve);
+  hipLaunchKernelGGL(inv_total_kernel, dim3(1), dim3(64), 0, s, n, ainve, m, totinve);
+  if (apply) launch_inv_project_apply(s, n, A, ainve, totinve);
+}
+
+void launch_inv_project_apply(hipStream_t s, int n, double *A, const double *ainve, const double *totinve) {
+  const size_t n2 = (size_t)n * n;
+  hipLaunchKernelGGL(inv_apply_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, n, A, ainve, totinve);
+}
+
+// ================================================================================================
+// 8. conjugate gradient with the neutrality constraint (fix_conp.cpp:864-930).  The matvec is gemv_rows; the
+//    vector updates + scalars run in ONE workgroup so that every reduction has a fixed order.
+//    scal: [0] lresnorm [1] lgamma [2] netr [3] ptap [4] alpha [5] beta [6] converged-iteration
+// ================================================================================================
+__device__ double block_sum_1024(double v, double *red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double tot = 0.0;
+  for (int k = 0; k < 16; ++k) tot += red[k];
+  return tot;
+}
+
+__global__ __launch_bounds__(1024) void cg_init_kernel(int n, const double *__restrict__ b, double *__restrict__ q,
+                                                       double *__restrict__ res, double *__restrict__ p,
+                                                       double *__restrict__ scal) {
+  __shared__ double red[16];
+  double netr = 0, l2 = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) { q[i] = 0.0; const double r = b[i]; res[i] = r; netr += r; l2 += r * r; }
+  netr = block_sum_1024(netr, red);
+  l2 = block_sum_1024(l2, red);
+  const double ave = netr / n;
+  for (int i = threadIdx.x; i < n; i += 1024) p[i] = res[i] - ave;
+  if (threadIdx.x == 0) { const double lres = l2 - netr * ave; scal[0] = lres; scal[1] = lres; scal[2] = netr; scal[6] = 0.0; }
+}
+
+void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, double *q, double *res, double *p, double *scal) {
+  (void)A;
+  hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(1024), 0, s, n, b, q, res, p, scal);
+}
+
+__global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restrict__ q, double *__restrict__ res,
+                                                         double *__restrict__ p, const double *__restrict__ ap,
+                                                         double *__restrict__ scal, double tolerance, int *__restrict__ done,
+                                                         int iter) {
+  __shared__ double red[16];
+  if (*done) return;
+  double ptap = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) ptap += p[i] * ap[i];
+  ptap = block_sum_1024(ptap, red);
+  const double lresnorm = scal[0], gamma = scal[1];
+  const double alpha = lresnorm / ptap;
+  double lg = 0, netr = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    q[i] = q[i] + alpha * p[i];
+    const double r = res[i] - alpha * ap[i];
+    res[i] = r; lg += r * r; netr += r;
+  }
+  lg = block_sum_1024(lg, red);
+  netr = block_sum_1024(netr, red);
+  const double ave = netr / n;
+  lg -= netr * ave;
+  const double beta = lg / gamma;
+  double lr = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) { const double pn = beta * p[i] + res[i] - ave; p[i] = pn; lr += res[i] * pn; }
+  lr = block_sum_1024(lr, red);
+  if (threadIdx.x == 0) {
+    scal[0] = lr; scal[1] = lg; scal[2] = netr; scal[3] = ptap; scal[4] = alpha; scal[5] = beta;
+    if (lr / n < tolerance) { *done = 1; scal[6] = (double)iter; }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemv_rows_guarded_kernel(int n, const double *__restrict__ S, const double *__restrict__ b,
+                                                                double *__restrict__ y, const int *__restrict__ done) {
+  if (*done) return;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const double *srow = S + (size_t)row * n;
+  double s0 = 0.0;
+  for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
+  s0 = wave_sum(s0);
+  if (lane == 0) y[row] = s0;
+}
+
+void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *res, double *p, double *ap, double *scal,
+                    double tolerance, int *done, int iter) {
+  hipLaunchKernelGGL(gemv_rows_guarded_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, A, p, ap, done);
+  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, s, n, q, res, p, ap, scal, tolerance, done, iter);
+}
+
+}  // namespace conp

@@ -1,0 +1,58 @@
+"""no GPU needed: the C-ABI library loads, exports every symbol include/conp_hip.h declares, parses the fix command
+like the reference constructor, and refuses to compute without a device (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+from conp_amd import capi, systems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "conp_hip.h")).read()
+    declared = set(re.findall(r"\b(conp_[a-z_0-9]+)\s*\(", hdr))
+    lib = capi.load_library()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(capi.SYMBOLS)
+    assert lib.conp_abi_version() == 1
+
+
+def test_fix_command_parser_matches_reference_syntax():
+    a = capi.parse_fix_command("e eleleft conp 5 eleright 1.979 v_v log etypes 2 5 3 ffield zneutr".split(), 5)
+    assert (a.everynum, a.eta, a.potdiff_is_variable, a.ff_flag, a.zneutr) == (5, 1.979, 1, 1, 1)
+    assert a.smartlist == 1 and a.eletypenum == 2 and list(a.eletypes)[:2] == [5, 3]
+    assert (a.minimizer, a.maxiter, a.tolerance) == (1, 100, 1e-6)       # fix_conp.cpp:88-90 defaults
+    a = capi.parse_fix_command("e l conp 1 r 1.979 2.0 log noslab zneutr matout qinit himem nonneutral".split(), 5)
+    assert (a.ff_flag, a.zneutr, a.matout, a.qinit, a.lowmem, a.nullneutral) == (2, 1, 1, 1, 0, 0)
+    a = capi.parse_fix_command("e l conp 1 r 1.979 2.0 log cg maxiter 50 tol 1e-8".split(), 5)
+    assert (a.minimizer, a.maxiter, a.tolerance) == (0, 50, 1e-8)
+    a = capi.parse_fix_command("e l conp 1 r 1.979 2.0 log org amatrix".split(), 5)
+    assert a.a_matrix_f == 1 and a.a_matrix_file == b"amatrix"
+
+
+@pytest.mark.parametrize("cmd,msg", [
+    ("e l conp 1 r 1.979 2.0", "too few input parameters"),                                  # fix_conp.cpp:86
+    ("e l conp 1 r 1.979 2.0 log ffield noslab", "ffield and noslab cannot both be chosen"),  # :127
+    ("e l conp 1 r 1.979 2.0 log noslab ffield", "ffield and noslab cannot both be chosen"),  # :131
+    ("e l conp 1 r 1.979 2.0 log org a inv b", "A matrix file specified more than once"),     # :135
+    ("e l conp 1 r 1.979 2.0 log org", "No A matrix filename given"),                         # :139
+    ("e l conp 1 r 1.979 2.0 log etypes 1 9", "Invalid atom type in etypes"),                 # :156
+    ("e l conp 1 r 1.979 2.0 log etypes", "Insufficient input entries for etypes"),           # :148
+    ("e l conp 1 r 1.979 2.0 log frobnicate", "unknown option: frobnicate"),                  # :171-174
+])
+def test_fix_command_errors(cmd, msg):
+    with pytest.raises(capi.ConpError) as e:
+        capi.parse_fix_command(cmd.split(), 5)
+    assert msg in str(e.value)
+
+
+def test_no_cpu_fallback():
+    from helpers import has_gpu
+    if has_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.ConpError) as e:
+        capi.FixConp(systems.deck("dilute"))
+    assert e.value.code == -3
