@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- charge-solve updates/s of the MI355X constant-potential solver (BASELINE.json metric).
+
+One "step" = one charge update of `fix conp` = b-vector assembly (Ewald structure factors of the electrolyte on the
+FP64 matrix cores, projection on the electrode atoms, real-space electrode-electrolyte pairs) + q = S b (projected
+inverse GEMV) + charge write, with atoms, neighbour rows and S resident in HBM.  Workload at every N: the synthetic
+graphene-electrode / ionic-liquid box the metric is quoted on (4096 electrode / 32768 electrolyte atoms).
+N > 1: k-vectors (planar row tiles) and electrode rows are sharded over the ranks; one all-reduce of b (Ne doubles) and
+one all-gather of q (Ne doubles) per update over RCCL -> "strong" scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|big|il_onelayer] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lammps-user-conp2_amd"))
+
+import numpy as np  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (AMD spec); 77.8 measured with tools/microbench/mfma_f64_bench.hip
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md
+
+
+def make_workload(name):
+    from conp_amd import systems
+    if name == "headline":
+        return systems.synthetic_fast(n_cells_x=32, n_cells_y=16, lz=600.0, n_elyte=32768, cutoff=16.0,
+                                      accuracy_relative=1e-7, g_ewald=0.21218, mode="ffield", seed=12345,
+                                      name="synthetic graphene/IL 4096 electrode + 32768 electrolyte, ffield")
+    if name == "big":
+        return systems.synthetic_fast(n_cells_x=64, n_cells_y=32, lz=1200.0, n_elyte=262144, cutoff=12.0,
+                                      accuracy_relative=1e-6, g_ewald=0.2554, mode="ffield", seed=12345,
+                                      name="synthetic graphene/IL 16384 electrode + 262144 electrolyte, ffield")
+    if name == "il_onelayer":
+        return systems.deck("il_onelayer", "ffield")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(s, at, alist, blist, S_matrix, threads):
+    """the oracle (scalar port of km_ewald.cpp sincos_b + bbb_from_sincos_b, fix_conp.cpp blist_coul_cal + the ddot GEMV)
+    timed on this host on ONE full charge update of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    lib = oracle_py.load(fast=True)
+    threads = lib.orc_set_threads(threads)
+    ks = oracle_py.KSpace.from_system(lib, s)
+    fo = oracle_py.Fix(lib, s)
+    q = at.q.copy()
+    from conp_amd import neighbor
+    at_o = neighbor.Atoms(nlocal=at.nlocal, nghost=at.nghost, x=at.x, q=q, type=at.type, tag=at.tag, echeck=at.echeck,
+                          owner=at.owner)
+    fo.set_atoms(at_o); fo.set_lists(alist, blist); fo.post_neighbor()
+    m = fo.maps()
+    xele = np.zeros((len(m["eleall2tag"]), 3))
+    loc = {int(t): i for i, t in enumerate(at.tag[:at.nlocal])}
+    for ia, t in enumerate(m["eleall2tag"]):
+        xele[ia] = at.x[loc[int(t)]]
+    csk, snk = ks.ele_trig(xele)       # setup, not timed (reference: a_read, once per run)
+    t0 = time.perf_counter()
+    sr, si = ks.sincos_b(at.x, q, at.echeck, at.nlocal)
+    t1 = time.perf_counter()
+    b = ks.bbb(csk, snk, sr, si)
+    t2 = time.perf_counter()
+    breal = fo.blist_only()
+    t3 = time.perf_counter()
+    y = np.zeros(len(b))
+    lib.orc_gemv_rows(len(b), np.ascontiguousarray(S_matrix), b, y)
+    t4 = time.perf_counter()
+    total = t4 - t0
+    fo.close()
+    return dict(value=1.0 / total, unit="updates/s", cores=threads, kind="port",
+                sample=f"1 full charge update of the same workload ({total:.2f} s: S(k) {t1 - t0:.2f}, k-space b {t2 - t1:.2f}, "
+                       f"real-space b {t3 - t2:.3f}, GEMV {t4 - t3:.3f}); oracle/conp_oracle.c -O3 -mavx2 -mfma")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="headline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from conp_amd import FixConp, neighbor
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    t_setup0 = time.perf_counter()
+    s = make_workload(args.workload)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s, device=local_rank, rank=rank, nranks=world)
+    fx.set_stream(torch.cuda.current_stream().cuda_stream)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    t_a0 = time.perf_counter()
+    fx.linalg_setup(at)                     # A build (MFMA SYRK + real space) + LU inverse + projection + setq: once per run
+    torch.cuda.synchronize()
+    t_a1 = time.perf_counter()
+    info = fx.info()
+    ne = info.elenum_all
+
+    d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda()
+    d_q = torch.from_numpy(at.q.copy()).cuda()
+    d_b = torch.zeros(ne, dtype=torch.float64, device="cuda")
+    d_sol = torch.zeros(ne, dtype=torch.float64, device="cuda")
+    fx.bind_device_buffers(d_b.data_ptr(), d_sol.data_ptr())
+    row0, row1 = fx.row_range()
+    potdiff = s.potdiff
+    if world > 1:
+        counts = [0] * world
+        gathered = [torch.zeros(1)]  # placeholder; sizes fixed below
+        r0s = [int(ne * r // world) for r in range(world + 1)]
+        even = all((r0s[r + 1] - r0s[r]) == (r0s[1] - r0s[0]) for r in range(world))
+
+    def step():
+        if world == 1:
+            fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), potdiff)
+        else:
+            fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())
+            dist.all_reduce(d_b)                                  # b rows + k-shards (Ne doubles)
+            fx.solve_device(potdiff)
+            if even:
+                dist.all_gather_into_tensor(d_sol, d_sol[row0:row1].clone())
+            else:
+                parts = [torch.empty(r0s[r + 1] - r0s[r], dtype=torch.float64, device="cuda") for r in range(world)]
+                dist.all_gather(parts, d_sol[row0:row1].clone())
+                d_sol.copy_(torch.cat(parts))
+            fx.scatter_device(d_q.data_ptr(), potdiff)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # ---- the timed region: exactly K updates, no per-kernel instrumentation
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = args.steps / dt
+
+    # ---- the same K updates again with a HIP-event pair around every kernel on the library's stream: per-kernel
+    #      average launch durations for the roofline (the event records cost host time, so this pass is not `value`)
+    prof = {}
+    dt_prof = float("nan")
+    if not args.no_profile:
+        fx.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_prof = time.perf_counter() - t0
+        prof = fx.profile_read()
+        fx.profile(False)
+
+    if rank == 0:
+        K, nl = info.kcount, info.n_elyte_charged
+        # dominant kernel: the structure-factor contraction.  Algorithmic work per launch (DESIGN.md "roofline"):
+        # one complex MAC per (half-space k, atom) with the +-kz pair sharing its products = 4 real FMA per (kxy,kz)
+        # pair = 4 flop per k per atom.  (SURVEY 8d counts the reference loop's 16 flop per pair = 8 per k.)
+        shard = 1.0 / world
+        flops = 4.0 * nl * K * shard
+        roofline = None
+        if "sk_gemm" in prof:
+            t_ms = prof["sk_gemm"][0]
+            ach = flops / (t_ms * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel="sk_gemm_kernel (v_mfma_f64_16x16x4_f64)", achieved=ach, peak=FP64_PEAK_TFLOPS,
+                            unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=None, avg_launch_ms=t_ms,
+                            algorithmic_flops_per_launch=flops, survey_count_tflops=2 * ach,
+                            note="achieved uses 4 flop per (k, atom); SURVEY 8d's reference-loop count (8 per k) would double it")
+        out = dict(metric="charge-solve updates/sec + ns/day, 4096-atom electrode / 32k electrolyte", value=value,
+                   unit="updates/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+                   higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+                   config=dict(workload=s.name, Ne=int(ne), Nl=int(nl), K=int(K), kflat=int(info.kcount_flat),
+                               box=[float(v) for v in s.prd], cutoff=s.cutoff, g_ewald=s.g_ewald,
+                               accuracy_relative=s.accuracy_relative, mode="ffield" if s.ff_flag == 1 else "slab",
+                               solver="inv", blist_pairs=int(info.n_blist_pairs),
+                               parallelism=f"k-shard+row-shard x{world}"),
+                   ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
+                   setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),
+                   kernels_ms={k: round(v[0], 5) for k, v in prof.items()},
+                   ms_per_step_profiled_pass=dt_prof / args.steps * 1e3,
+                   roofline=roofline)
+        if not args.no_cpu_baseline and world == 1:
+            S = fx.matrix()
+            base = cpu_baseline(s, at, alist, blist, S, args.cpu_threads)
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu_baseline"] = value / base["value"]
+        print(json.dumps(out))
+    fx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

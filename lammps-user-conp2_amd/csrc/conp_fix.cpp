@@ -129,8 +129,11 @@ struct conp_fix {
   ListView alist, blist;
   bool have_alist = false, have_blist = false, kspace_ready = false;
   int runstage = 0;          // fix_conp.cpp:181-183
-  int ne_pad = 0, nl = 0, nl_pad = 0, nall = 0, nsplit = 1;
-  int rt0 = 0, rt1 = 0, row0 = 0, row1 = 0;
+  int ne_pad = 0, nl = 0, nl_pad = 0, nall = 0;
+  int row0 = 0, row1 = 0, num_cus = 256;
+  std::vector<SkItem> items_h;   // sk_gemm work items of this rank
+  std::vector<SkTile> tiles_h;   // (row tile, col tile) pairs of this rank, sorted by col tile
+  std::vector<int> ct_ptr_h;
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
   std::vector<double> csk_h, snk_h, xele_h, d_vec_h;
@@ -143,8 +146,10 @@ struct conp_fix {
       d_cg_ap, d_cg_scal;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_nb_act, d_ct_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
+  DevBuf<SkItem> d_items;
+  DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   int n_slab_part = 0;
   DevPlan dplan{};
@@ -179,6 +184,7 @@ struct conp_fix {
     HIP_TRY(hipGetDeviceProperties(&prop, env.device));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
       throw ConpError(CONP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    num_cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreate(&stream));
     own_stream = true;
     d_cutsq.upload(cutsq_h, stream);
@@ -197,15 +203,20 @@ struct conp_fix {
     d_wfull.upload(plan.wfull, stream);
     d_sf_row_a.upload(plan.sf_row_a, stream); d_sf_col_c.upload(plan.sf_col_c, stream);
     d_k_sign.upload(plan.k_sign, stream); d_k_p.upload(plan.k_p, stream); d_k_m.upload(plan.k_m, stream);
-    dplan = DevPlan{plan.np, plan.nz, plan.NB, plan.MT, plan.n_row_tiles, plan.n_col_tiles, plan.R_pad, plan.C_pad,
-                    plan.kxmax, plan.kymax, d_p_ikx.p, d_p_iky.p, d_p_sgn.p, d_wfull.p};
+    d_nb_act.upload(plan.nb_act, stream);
+    dplan = DevPlan{plan.np, plan.nz, plan.n_row_tiles, plan.n_col_tiles, plan.R_pad, plan.C_pad,
+                    plan.kxmax, plan.kymax, d_p_ikx.p, d_p_iky.p, d_p_sgn.p, d_nb_act.p, d_wfull.p};
     d_G.reserve((size_t)plan.R_pad * plan.C_pad); d_Gw.reserve((size_t)plan.R_pad * plan.C_pad);
     d_G.zero(stream); d_Gw.zero(stream);
-    // k-shard: contiguous row tiles per rank
-    rt0 = (int)((long long)plan.n_row_tiles * env.rank / env.nranks);
-    rt1 = (int)((long long)plan.n_row_tiles * (env.rank + 1) / env.nranks);
-    if ((size_t)plan.C_pad * 16 * 8 + 512 > 160 * 1024)
-      throw ConpError(CONP_ERR_ARG, "kz table too long for the b-projection kernel's LDS slice (C_pad > 1276)");
+    // k-shard: row tiles are rings of increasing |k_p| with decreasing kz range; dealing them round-robin balances ranks
+    tiles_h.clear();
+    ct_ptr_h.assign(plan.n_col_tiles + 1, 0);
+    for (int ct = 0; ct < plan.n_col_tiles; ++ct) {
+      for (int rt = env.rank; rt < plan.n_row_tiles; rt += env.nranks)
+        if (plan.nba(rt, ct) > 0) tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0});
+      ct_ptr_h[ct + 1] = (int)tiles_h.size();
+    }
+    d_ct_ptr.upload(ct_ptr_h, stream);
     sync();
     kspace_ready = true;
   }
@@ -241,7 +252,7 @@ struct conp_fix {
     if (grew) {
       ne_pad = (ne + 127) / 128 * 128;
       d_A.reserve((size_t)ne * ne);
-      d_bk.reserve(ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(ne_pad); d_eleallq_own.reserve(ne_pad); d_qele.reserve(ne_pad);
+      d_bk.reserve(2 * (size_t)ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(ne_pad); d_eleallq_own.reserve(ne_pad); d_qele.reserve(ne_pad);
       d_elesetq.reserve(ne_pad); d_eleinitq.reserve(ne_pad); d_ele_z.reserve(ne_pad); d_elecheck.reserve(ne_pad);
       d_ainve.reserve(ne_pad);
       d_bk.zero(stream); d_breal.zero(stream); d_b_own.zero(stream); d_eleallq_own.zero(stream); d_qele.zero(stream);
@@ -259,16 +270,45 @@ struct conp_fix {
     // atoms are consumed in chunks of 32; the splits want an even share of chunks
     nl_pad = std::max(32, (nl + 31) / 32 * 32);
     d_elyte_idx.upload(elyte_idx_h, stream);
-    const int rows_tiles = std::max(1, (rt1 - rt0) * plan.n_col_tiles);
-    const int nchunks = nl_pad / 32;
-    nsplit = std::max(1, std::min(nchunks, (512 + rows_tiles - 1) / rows_tiles));
+    build_items();
     d_Xt.reserve((size_t)(plan.kxmax + 1) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
-    d_Zt.reserve((size_t)plan.nz * nl_pad); d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 255) / 256 + 1);
-    d_Gpart.reserve((size_t)nsplit * plan.R_pad * plan.C_pad);
+    d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
+    d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 255) / 256 + 1);
+    d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
     // real-space rows of b
     build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
     d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
     sync();
+  }
+
+  // sk_gemm work items: every (row tile, col tile) of this rank is split over the atoms so that all items cost about
+  // the same (cost ~ active kz blocks x atoms) and there are ~2 waves of workgroups on the 256 CUs
+  void build_items() {
+    const int nchunks = nl_pad / 16;
+    long total = 0;
+    for (const auto &tl : tiles_h) total += tl.nba;
+    // one workgroup per CU (129 KB of LDS each): exactly one round of equally expensive items
+    const int target = std::max(num_cus, (int)tiles_h.size());
+    std::vector<int> nsv(tiles_h.size(), 1);
+    int used = 0;
+    for (size_t i = 0; i < tiles_h.size(); ++i) {
+      nsv[i] = std::max(1, std::min(nchunks, (int)((long long)target * tiles_h[i].nba / std::max<long>(total, 1))));
+      used += nsv[i];
+    }
+    for (size_t i = 0; used < target && !tiles_h.empty(); i = (i + 1) % tiles_h.size())   // hand out the remainder
+      if (nsv[i] < nchunks) { ++nsv[i]; ++used; } else if (std::all_of(nsv.begin(), nsv.end(), [&](int v) { return v >= nchunks; })) break;
+    items_h.clear();
+    size_t ti = 0;
+    for (auto &tl : tiles_h) {
+      const int ns = nsv[ti++];
+      tl.item0 = (int)items_h.size();
+      tl.nsplit = ns;
+      for (int sp = 0; sp < ns; ++sp)
+        items_h.push_back(SkItem{tl.rt, tl.ct, tl.nba, (int)((long long)nchunks * sp / ns),
+                                 (int)((long long)nchunks * (sp + 1) / ns)});
+    }
+    d_items.upload(items_h, stream);
+    d_tiles.upload(tiles_h, stream);
   }
 
   void gather_xele(const conp_atoms *at) {
@@ -465,16 +505,16 @@ struct conp_fix {
     const int ne = idx.elenum_all;
     prof.begin("elyte_phase", stream);
     launch_elyte_phase(stream, nl, nl_pad, d_elyte_idx.p, dx, dq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
-                       plan.kymax, plan.nz, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
+                       plan.kymax, plan.nz, KPlan::ZSTRIDE, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
     prof.end(stream);
     prof.begin("sk_gemm", stream);
-    launch_sk_gemm(stream, dplan, nl_pad, nsplit, rt0, rt1, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_Gpart.p);
+    launch_sk_gemm(stream, dplan, d_items.p, (int)items_h.size(), nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_Gpart.p);
     prof.end(stream);
     prof.begin("sk_reduce", stream);
-    launch_sk_reduce(stream, dplan, nsplit, rt0, rt1, d_Gpart.p, d_G.p, d_Gw.p);
+    launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), d_Gpart.p, d_G.p, d_Gw.p);
     prof.end(stream);
     prof.begin("b_project", stream);
-    launch_b_project(stream, dplan, ne, ne_pad, rt0 * 8, rt1 * 8, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
+    launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
     prof.end(stream);
     if (coulyes) {
       prof.begin("b_real", stream);
@@ -483,7 +523,7 @@ struct conp_fix {
     }
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     prof.begin("b_combine", stream);
-    launch_b_combine(stream, ne, coulyes ? row0 : 0, coulyes ? row1 : 0, 1, d_bk.p, d_breal.p, slab, d_ele_z.p,
+    launch_b_combine(stream, ne, ne_pad, coulyes ? row0 : 0, coulyes ? row1 : 0, 1, d_bk.p, d_breal.p, slab, d_ele_z.p,
                      d_slab_part.p, n_slab_part, 4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
     prof.end(stream);
   }
@@ -829,8 +869,8 @@ int conp_fix_get_sfac(conp_fix *f, double *sr, double *si) {
   CONP_GUARD_BEGIN
   const int K = f->kt.kcount;
   f->d_sfr.reserve(K); f->d_sfi.reserve(K);
-  launch_sfac_gather(f->stream, K, f->plan.C_pad, KPlan::PT, f->plan.MT, f->d_sf_row_a.p, f->d_sf_col_c.p, f->d_k_sign.p,
-                     f->d_k_p.p, f->d_k_m.p, f->d_G.p, f->d_sfr.p, f->d_sfi.p);
+  launch_sfac_gather(f->stream, K, f->plan.C_pad, KPlan::PT, f->d_sf_row_a.p, f->d_sf_col_c.p, f->d_k_sign.p, f->d_G.p,
+                     f->d_sfr.p, f->d_sfi.p);
   HIP_TRY(hipMemcpyAsync(sr, f->d_sfr.p, K * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   HIP_TRY(hipMemcpyAsync(si, f->d_sfi.p, K * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();

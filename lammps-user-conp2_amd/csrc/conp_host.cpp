@@ -129,18 +129,26 @@ void KPlan::build(const KTables &kt) {
   kxmax = kt.kcount_dims[0];
   kymax = kt.kcount_dims[1];
   nz = kt.kcount_dims[2] + 1;
-  const int d0 = kt.kcount_dims[0], d1 = kt.kcount_dims[1], d2 = kt.kcount_dims[2], d3 = kt.kcount_dims[3];
-  // planar list: origin, x axis, y axis, (k,+-l) in the reference's flat order
-  p_ikx.assign(1, 0); p_iky.assign(1, 0); p_sgn.assign(1, 1);
-  flat2p.assign(kt.kcount_flat, -1);
+  const int d0 = kt.kcount_dims[0], d1 = kt.kcount_dims[1], d2 = kt.kcount_dims[2];
+  // planar vectors: origin + every non-z flat entry, sorted by |k_p|^2 so that a row tile is a ring of similar
+  // radius and shares one kz cut-off (the listed k's fill a sphere: km_ewald.cpp:120-126)
+  struct Pv { int ikx, iky, sgn, flat; double k2; };
+  std::vector<Pv> pv;
+  pv.push_back({0, 0, 1, -1, 0.0});
   for (int f = 0; f < kt.kcount_flat; ++f) {
     if (f >= d0 + d1 && f < d0 + d1 + d2) continue;  // z axis
-    flat2p[f] = (int)p_ikx.size();
-    p_ikx.push_back(std::abs(kt.kxvecs[f]));
-    p_iky.push_back(std::abs(kt.kyvecs[f]));
-    p_sgn.push_back(kt.kyvecs[f] < 0 ? -1 : 1);
+    const int ax = std::abs(kt.kxvecs[f]), ay = std::abs(kt.kyvecs[f]);
+    pv.push_back({ax, ay, kt.kyvecs[f] < 0 ? -1 : 1, f,
+                  ax * ax * kt.unitk[0] * kt.unitk[0] + ay * ay * kt.unitk[1] * kt.unitk[1]});
   }
-  np = (int)p_ikx.size();
+  std::stable_sort(pv.begin() + 1, pv.end(), [](const Pv &a, const Pv &b) { return a.k2 < b.k2; });
+  np = (int)pv.size();
+  p_ikx.resize(np); p_iky.resize(np); p_sgn.resize(np);
+  flat2p.assign(kt.kcount_flat, -1);
+  for (int p = 0; p < np; ++p) {
+    p_ikx[p] = pv[p].ikx; p_iky[p] = pv[p].iky; p_sgn[p] = pv[p].sgn;
+    if (pv[p].flat >= 0) flat2p[pv[p].flat] = p;
+  }
   // reference k index -> (p, m, sign)
   k_p.assign(kt.kcount, 0); k_m.assign(kt.kcount, 0); k_sign.assign(kt.kcount, 1);
   for (int f = 0; f < kt.kcount_flat; ++f) {
@@ -154,31 +162,25 @@ void KPlan::build(const KTables &kt) {
     k_p[k0] = p; k_m[k0] = m; k_sign[k0] = 1;
     k_p[k0 + 1] = p; k_m[k0 + 1] = m; k_sign[k0 + 1] = -1;
   }
-  (void)d3;
-  // tile geometry: choose NB (16-col fragments per wave, 4 col groups per workgroup) to minimise padded columns
-  int best_nb = 1; long best_pad = -1;
-  for (int nb = 1; nb <= 5; ++nb) {
-    const int mt = 32 * nb;
-    const long tiles = (nz + mt - 1) / mt;
-    const long pad = tiles * mt;
-    if (best_pad < 0 || pad < best_pad || (pad == best_pad && nb > best_nb)) { best_pad = pad; best_nb = nb; }
-  }
-  NB = best_nb; MT = 32 * NB;
-  n_col_tiles = (nz + MT - 1) / MT;
+  nblk = (nz + 15) / 16;
+  n_col_tiles = (nblk + CT_BLK - 1) / CT_BLK;
   n_row_tiles = (np + PT - 1) / PT;
   R_pad = n_row_tiles * 2 * PT;
-  C_pad = n_col_tiles * 2 * MT;
+  C_pad = n_col_tiles * CT_COLS;
   // weights w(p,m) = sum over listed signs of 2 ug
   w.assign((size_t)np * nz, 0.0);
   for (int k = 0; k < kt.kcount; ++k) w[(size_t)k_p[k] * nz + k_m[k]] += 2.0 * kt.ug[k];
   wfull.assign((size_t)R_pad * C_pad, 0.0);
+  nb_act.assign(n_row_tiles, 0);
   for (int p = 0; p < np; ++p)
     for (int m = 0; m < nz; ++m) {
       const double ww = w[(size_t)p * nz + m];
+      if (ww == 0.0) continue;
       wfull[(size_t)row_a(p) * C_pad + col_c(m)] = ww;
       wfull[(size_t)row_a(p) * C_pad + col_s(m)] = ww;
       wfull[(size_t)row_b(p) * C_pad + col_c(m)] = ww;
       wfull[(size_t)row_b(p) * C_pad + col_s(m)] = ww;
+      nb_act[p / PT] = std::max(nb_act[p / PT], (m >> 4) + 1);
     }
   sf_row_a.assign(kt.kcount, 0); sf_col_c.assign(kt.kcount, 0);
   for (int k = 0; k < kt.kcount; ++k) { sf_row_a[k] = row_a(k_p[k]); sf_col_c[k] = col_c(k_m[k]); }

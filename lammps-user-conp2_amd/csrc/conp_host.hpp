@@ -5,6 +5,7 @@
 //   PairRows  : LAMMPS half lists -> electrode-row CSR for the real-space kernels
 // Pure C++17, no HIP.  Reference citations are file:line in /root/reference.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -39,23 +40,28 @@ struct KTables {
 // weighted by w(p,m) = sum over the signs present of 2 ug.  Rows/cols are laid out for the MFMA tiles.
 // ------------------------------------------------------------------------------------------------
 struct KPlan {
-  static constexpr int PT = 64;   // planar vectors per row tile (128 G rows: 64 'a' rows then 64 'b' rows)
-  int kxmax = 0, kymax = 0, nz = 0;  // nz = kzmax + 1 (m = 0 .. kzmax)
-  int np = 0;                        // planar vectors incl. the origin (index 0)
+  static constexpr int PT = 64;       // planar vectors per row tile (128 G rows: 64 'a' rows then 64 'b' rows)
+  static constexpr int CT_BLK = 10;   // 16-kz blocks per column tile (160 kz values = 320 G columns)
+  static constexpr int CT_COLS = 32 * CT_BLK;
+  static constexpr int ZSTRIDE = 5;   // the phase kernel stores a z-phase seed every 5th kz
+  int kxmax = 0, kymax = 0, nz = 0;   // nz = kzmax + 1 (m = 0 .. kzmax)
+  int np = 0;                         // planar vectors incl. the origin; sorted by |k_p|^2 (origin first)
   std::vector<int> p_ikx, p_iky, p_sgn;   // per p: |kx|, |ky|, sign of ky (+1/-1); origin = (0,0,+1)
   std::vector<int> flat2p;                // reference flat index (x axis, y axis, (k,+-l,0)) -> p ; z-axis entries -> -1
   std::vector<int> k_p, k_m, k_sign;      // per reference k index
-  int NB = 1;                             // 16-col fragments per wave (cols per col tile = 64*NB = MT 'c' cols + MT 's' cols)
-  int MT = 32;                            // kz values per col tile (= 32*NB)
+  int nblk = 0;                           // ceil(nz / 16)
   int n_row_tiles = 0, n_col_tiles = 0, R_pad = 0, C_pad = 0;
+  std::vector<int> nb_act;                // per row tile: number of leading 16-kz blocks that hold a listed k (sphere cut)
   std::vector<double> w;                  // [np][nz] weights
   std::vector<double> wfull;              // [R_pad][C_pad] weights expanded to G's layout (0 in padding)
-  std::vector<int> sf_row_a, sf_col_c;    // per reference k: G row of (p,'a') and col of (m,'c') (b row = +PT, s col = +MT)
+  std::vector<int> sf_row_a, sf_col_c;    // per reference k: G row of (p,'a') and col of (m,'c') (b row = +PT, s col = +16)
 
+  // G column layout: kz block b = m >> 4 occupies 32 columns: 16 'c' (cos) then 16 's' (sin)
   int row_a(int p) const { return (p / PT) * (2 * PT) + (p % PT); }
   int row_b(int p) const { return row_a(p) + PT; }
-  int col_c(int m) const { return (m / MT) * (2 * MT) + (m % MT); }
-  int col_s(int m) const { return col_c(m) + MT; }
+  int col_c(int m) const { return 32 * (m >> 4) + (m & 15); }
+  int col_s(int m) const { return col_c(m) + 16; }
+  int nba(int rt, int ct) const { return std::max(0, std::min(CT_BLK, nb_act[rt] - CT_BLK * ct)); }
 
   void build(const KTables &kt);
 };

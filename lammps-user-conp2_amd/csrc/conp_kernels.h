@@ -6,10 +6,14 @@
 namespace conp {
 
 struct DevPlan {              // device copy of KPlan geometry
-  int np, nz, NB, MT, n_row_tiles, n_col_tiles, R_pad, C_pad, kxmax, kymax;
+  int np, nz, n_row_tiles, n_col_tiles, R_pad, C_pad, kxmax, kymax;
   const int *p_ikx, *p_iky, *p_sgn;   // [n_row_tiles*64] padded (padding: 0,0,0 -> sgn 0 marks "no vector")
+  const int *nb_act;                  // [n_row_tiles] active kz blocks per row tile
   const double *wfull;                // [R_pad][C_pad]
 };
+
+struct SkItem { int rt, ct, nba, c0, c1; };            // one sk_gemm workgroup: tile + chunk range [c0, c1) of 16 atoms
+struct SkTile { int rt, ct, nba, item0, nsplit; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
   double g_ewald, eta, cut_coulsq;    // cut_coulsq already min(cut_coul^2, (5.8/g)^2)  fix_conp.cpp:1237-1240
@@ -19,20 +23,20 @@ struct RealParams {           // real-space pair kernels
 
 // ---- per-step electrolyte path -----------------------------------------------------------------
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
-                        double ux, double uy, double uz, int kxmax, int kymax, int nz, double2 *Xt, double2 *Yt,
-                        double2 *Zt, double *qc, double *slab_part, int *n_slab_part);
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, int nl_pad, int nsplit, int rt0, int rt1, const double2 *Xt,
-                    const double2 *Yt, const double2 *Zt, const double *qc, double *Gpart);
-void launch_sk_reduce(hipStream_t s, const DevPlan &pl, int nsplit, int rt0, int rt1, const double *Gpart, double *G,
-                      double *Gw);
-void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, int MT, const int *sf_row_a, const int *sf_col_c,
-                        const int *k_sign, const int *k_p, const int *k_m, const double *G, double *sfacrl, double *sfacim);
-void launch_b_project(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, int rf0, int rf1, const double *Gw,
-                      const double *Rp, const double *Tz, double *bk /*[ne_pad] overwritten*/);
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,
+                        double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part);
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, int nitems, int nl_pad, const double2 *Xt,
+                    const double2 *Yt, const double2 *Zs, const double *qc, double *part);
+void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, const double *part, double *G,
+                      double *Gwf);
+void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,
+                        const int *k_sign, const double *G, double *sfacrl, double *sfacim);
+void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr /*[n_col_tiles+1]*/, const SkTile *tiles,
+                      const double *Gwf, const double *Rp, const double *Tz, double *bk_part /*[2][ne_pad] overwritten*/);
 void launch_b_real(hipStream_t s, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
                    const double *x, const double *q, const int *type, RealParams rp, double *b_real /*[ne] rows row0..row1 written*/);
 // b = bk (if add_k) + b_real (rows row0..row1) - z*slab (if slab); everything else 0: the shard's contribution
-void launch_b_combine(hipStream_t s, int ne, int row0, int row1, int add_k, const double *bk, const double *b_real,
+void launch_b_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, int add_k, const double *bk, const double *b_real,
                       int slab, const double *ele_z, const double *slab_part, int n_slab_part, double slab_pref,
                       double *b_out, double *slab_out);
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);

@@ -31,8 +31,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double ux, double uy, double uz, int kxmax, int kymax, int nz,
-                                                          double2 *__restrict__ Xt, double2 *__restrict__ Yt,
-                                                          double2 *__restrict__ Zt, double *__restrict__ qc,
+                                                          int zstride, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
+                                                          double2 *__restrict__ Zs, double *__restrict__ qc,
                                                           double *__restrict__ slab_part) {
 #pragma clang fp contract(off)
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,20 +47,25 @@ __global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, co
     qz = qq * zz;
     const double ang[3] = {ux * xx, uy * yy, uz * zz};
     const int nrow[3] = {kxmax + 1, kymax + 1, nz};
-    double2 *tab[3] = {Xt, Yt, Zt};
+    double2 *tab[3] = {Xt, Yt, Zs};
+    // X and Y: every row.  Z: row 0 of Zs is the unit step (cos, sin)(uz z); row 1 + s is the seed for m = s*zstride --
+    // sk_gemm regenerates the m's in between with the same recurrence, so the values equal the full table's.
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       double c1, s1;
       sincos(ang[c], &s1, &c1);
       double2 *t = tab[c] + j;
-      t[0] = make_double2(1.0, 0.0);
+      const int stride = (c == 2) ? zstride : 1;
+      const int off = (c == 2) ? 1 : 0;
+      if (c == 2) t[0] = make_double2(c1, s1);
+      t[(size_t)off * nl_pad] = make_double2(1.0, 0.0);
       double cm = c1, sm = s1;
-      if (nrow[c] > 1) t[(size_t)nl_pad] = make_double2(c1, s1);
+      if (nrow[c] > 1 && stride == 1) t[(size_t)(off + 1) * nl_pad] = make_double2(c1, s1);
       for (int m = 2; m < nrow[c]; ++m) {
         const double cn = cm * c1 - sm * s1;
         const double sn = sm * c1 + cm * s1;
         cm = cn; sm = sn;
-        t[(size_t)m * nl_pad] = make_double2(cm, sm);
+        if (m % stride == 0) t[(size_t)(off + m / stride) * nl_pad] = make_double2(cm, sm);
       }
     }
   }
@@ -73,180 +78,216 @@ __global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, co
 }
 
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
-                        double ux, double uy, double uz, int kxmax, int kymax, int nz, double2 *Xt, double2 *Yt,
-                        double2 *Zt, double *qc, double *slab_part, int *n_slab_part) {
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,
+                        double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part) {
   const int nb = (nl_pad + 255) / 256;
   *n_slab_part = nb;
   hipLaunchKernelGGL(elyte_phase_kernel, dim3(nb), dim3(256), 0, s, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
-                     kymax, nz, Xt, Yt, Zt, qc, slab_part);
+                     kymax, nz, zstride, Xt, Yt, Zs, qc, slab_part);
 }
 
 // ================================================================================================
 // 2. structure-factor contraction on the FP64 matrix cores.
-//    Workgroup = 512 threads = 8 waves = 2 row halves x 4 column groups; macro tile = 128 G rows (64 planar
-//    vectors: 64 'a' rows then 64 'b' rows) x 64*NB G cols (MT = 32*NB kz values: MT 'c' cols then MT 's' cols).
-//    The atoms are split over `nsplit` workgroups per tile; each walks its atoms in chunks of J = 32:
-//      (i)  all threads build the operand panel in LDS, panel[feature][atom]:
-//             features 0..127      : a_pj / b_pj from the X/Y phase tables (one complex product + q)
-//             features 128..128+2MT: c_mj / s_mj copied from the Z table
-//           row stride J+2 doubles -> conflict-free ds_read_b64 of MFMA fragments (16 rows x 2 atoms per 32 lanes);
-//      (ii) 8 k-steps of 4 atoms: per wave 4 A fragments x NB B fragments -> 4*NB MFMAs.
-//    Partial tiles go to Gpart[split][R_pad][C_pad]; sk_reduce sums them in a fixed order (deterministic).
+//    Work item = (row tile rt: 64 planar vectors = 128 G rows, col tile ct: up to 10 kz blocks = 320 G cols,
+//    atom split).  Only the leading `nba` kz blocks of a row tile hold listed k vectors (sphere cut-off), so only
+//    2*nba column fragments are computed; they are dealt round-robin to the 4 column groups of the workgroup.
+//    Workgroup = 512 threads = 8 waves = 2 row halves x 4 column groups; wave tile = 4 x (<=5) fragments.
+//    Atoms are walked in chunks of J = 16 through a double-buffered LDS operand panel, panel[feature][atom]:
+//      features   0..127 : a_pj / b_pj  = q_j (cos,sin)(theta_pj)  from the X / Y phase tables (one complex product)
+//      features 128..447 : c_mj / s_mj  regenerated from a z-phase seed (every 5th kz) with the reference's
+//                          angle-addition recurrence (km_ewald.cpp:709-719)
+//    Row stride J+2 doubles makes every MFMA-fragment ds_read_b64 conflict-free (16 rows x 2 atoms per 32 lanes).
+//    Software pipeline per chunk: issue global loads for chunk c+1 -> MFMA on chunk c -> build panel c+1 -> barrier.
+//    Partial tiles go to part[item][128][320]; sk_reduce sums a tile's splits in a fixed order (deterministic).
 // ================================================================================================
-constexpr int SK_J = 32;
+constexpr int SK_J = 16;
 constexpr int SK_LD = SK_J + 2;
+constexpr int SK_NF = 128 + 320;
+constexpr int SK_PANEL = SK_NF * SK_LD;   // doubles per buffer
 
-template <int NB>
-__global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, int nl_pad, int nsplit, int rt0,
+// one step of the angle-addition recurrence without FMA contraction (same arithmetic as elyte_phase_kernel)
+__device__ __forceinline__ double2 zstep(double2 z, double2 st) {
+#pragma clang fp contract(off)
+  double2 r;
+  r.x = z.x * st.x - z.y * st.y;
+  r.y = z.y * st.x + z.x * st.y;
+  return r;
+}
+
+struct SkRaw {        // raw inputs of one thread for one chunk
+  double2 X0, Y0, X1, Y1, Zseed, Zst;
+  double q;
+};
+
+__global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkItem *__restrict__ items, int nl_pad,
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
-                                                         const double2 *__restrict__ Zt, const double *__restrict__ qc,
-                                                         double *__restrict__ Gpart) {
-  constexpr int MT = 32 * NB;
-  constexpr int NF = 128 + 2 * MT;
+                                                         const double2 *__restrict__ Zs, const double *__restrict__ qc,
+                                                         double *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *panel = reinterpret_cast<double *>(smem);   // [NF][SK_LD]
+  double *panel = reinterpret_cast<double *>(smem);   // [2][SK_NF][SK_LD]
 
+  const SkItem it = items[blockIdx.x];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int rh = wave & 1, cg = wave >> 1;
-  int work = blockIdx.x;
-  const int split = work % nsplit; work /= nsplit;
-  const int ct = work % pl.n_col_tiles;
-  const int rt = rt0 + work / pl.n_col_tiles;
+  const int nfrag = 2 * it.nba;                       // active column fragments of this item
+  const int nfw = (nfrag - cg + 3) >> 2;              // fragments of this wave: fi = 4 g + cg < nfrag
 
-  const int nchunks = nl_pad / SK_J;
-  const int c0 = (int)((long long)nchunks * split / nsplit), c1 = (int)((long long)nchunks * (split + 1) / nsplit);
+  // generation roles: atom gj of the chunk, sub-index gs 0..31
+  const int gj = t & 15, gs = t >> 4;
+  const int p0 = it.rt * 64 + gs, p1 = p0 + 32;
+  const size_t xoff0 = (size_t)pl.p_ikx[p0] * nl_pad, yoff0 = (size_t)pl.p_iky[p0] * nl_pad;
+  const size_t xoff1 = (size_t)pl.p_ikx[p1] * nl_pad, yoff1 = (size_t)pl.p_iky[p1] * nl_pad;
+  const double sg0 = (double)pl.p_sgn[p0], sg1 = (double)pl.p_sgn[p1];     // 0 marks a padding row
+  const bool zact = 5 * gs < 16 * it.nba;             // this thread's 5 kz values lie in an active block
+  const size_t zoff = (size_t)(1 + it.ct * 32 + gs) * nl_pad;
 
-  // per-thread constants of the generation phase
-  const int gj = t & 31, gs = t >> 5;   // atom within chunk, sub-index 0..15
-  int g_xoff[4], g_yoff[4];
-  double g_sgn[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int p = rt * 64 + r * 16 + gs;
-    g_xoff[r] = pl.p_ikx[p];
-    g_yoff[r] = pl.p_iky[p];
-    g_sgn[r] = (double)pl.p_sgn[p];   // 0 for padding rows
-  }
-
-  d4 acc[4][NB];
+  d4 acc[4][5];
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int g = 0; g < NB; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < 5; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
 
   const int fr = lane & 15, fk = lane >> 4;
-  const double *a_base = panel + (64 * rh + fr) * SK_LD + fk;
-  const double *b_base = panel + (128 + 16 * NB * cg + fr) * SK_LD + fk;
+  const int a_off = (64 * rh + fr) * SK_LD + fk;
+  const int b_off = (128 + 16 * cg + fr) * SK_LD + fk;
 
-  for (int ch = c0; ch < c1; ++ch) {
+  auto load_raw = [&](int ch, SkRaw &r) {
     const size_t jg = (size_t)ch * SK_J + gj;
-    // ---- (i) operand panel ----
+    r.q = qc[jg];
+    r.X0 = Xt[xoff0 + jg]; r.Y0 = Yt[yoff0 + jg];
+    r.X1 = Xt[xoff1 + jg]; r.Y1 = Yt[yoff1 + jg];
+    if (zact) { r.Zst = Zs[jg]; r.Zseed = Zs[zoff + jg]; }
+  };
+  auto build_panel = [&](const SkRaw &r, double *pn) {
+    // (kx, sg*ky): cos = cx cy - sg sx sy ; sin = sg cx sy + sx cy   (km_ewald.cpp:739-747)
     {
-      const double qq = qc[jg];
+      const double cth = r.X0.x * r.Y0.x - sg0 * (r.X0.y * r.Y0.y);
+      const double sth = sg0 * (r.X0.x * r.Y0.y) + r.X0.y * r.Y0.x;
+      const double live = sg0 * sg0;
+      pn[gs * SK_LD + gj] = live * (r.q * cth);
+      pn[(64 + gs) * SK_LD + gj] = live * (r.q * sth);
+    }
+    {
+      const double cth = r.X1.x * r.Y1.x - sg1 * (r.X1.y * r.Y1.y);
+      const double sth = sg1 * (r.X1.x * r.Y1.y) + r.X1.y * r.Y1.x;
+      const double live = sg1 * sg1;
+      pn[(32 + gs) * SK_LD + gj] = live * (r.q * cth);
+      pn[(96 + gs) * SK_LD + gj] = live * (r.q * sth);
+    }
+    if (zact) {
+      double2 Z = r.Zseed;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double2 X = Xt[(size_t)g_xoff[r] * nl_pad + jg];
-        const double2 Y = Yt[(size_t)g_yoff[r] * nl_pad + jg];
-        const double sg = g_sgn[r];
-        // (kx, sg*ky): cos = cx cy - sg sx sy ; sin = sg cx sy + sx cy   (km_ewald.cpp:739-747)
-        const double cth = X.x * Y.x - sg * (X.y * Y.y);
-        const double sth = sg * (X.x * Y.y) + X.y * Y.x;
-        const double live = sg * sg;   // 1 for real vectors, 0 for padding
-        const int pl_ = r * 16 + gs;
-        panel[pl_ * SK_LD + gj] = live * (qq * cth);
-        panel[(64 + pl_) * SK_LD + gj] = live * (qq * sth);
-      }
-#pragma unroll
-      for (int r = 0; r < 2 * NB; ++r) {
-        const int ml = r * 16 + gs;
-        const int m = ct * MT + ml;
-        double2 Z = make_double2(0.0, 0.0);
-        if (m < pl.nz) Z = Zt[(size_t)m * nl_pad + jg];
-        panel[(128 + ml) * SK_LD + gj] = Z.x;
-        panel[(128 + MT + ml) * SK_LD + gj] = Z.y;
+      for (int u = 0; u < 5; ++u) {
+        const int ml = 5 * gs + u;                        // kz index inside the col tile
+        const int feat = 128 + 32 * (ml >> 4) + (ml & 15);
+        const bool ok = it.ct * 160 + ml < pl.nz;
+        pn[feat * SK_LD + gj] = ok ? Z.x : 0.0;
+        pn[(feat + 16) * SK_LD + gj] = ok ? Z.y : 0.0;
+        Z = zstep(Z, r.Zst);
       }
     }
-    __syncthreads();
-    // ---- (ii) MFMA over the chunk ----
+  };
+
+  SkRaw raw;
+  if (it.c0 < it.c1) {
+    load_raw(it.c0, raw);
+    build_panel(raw, panel);
+  }
+  __syncthreads();
+  for (int ch = it.c0; ch < it.c1; ++ch) {
+    const double *cur = panel + ((ch - it.c0) & 1) * SK_PANEL;
+    double *nxt = panel + (((ch - it.c0) & 1) ^ 1) * SK_PANEL;
+    const bool more = ch + 1 < it.c1;
+    if (more) load_raw(ch + 1, raw);
 #pragma unroll
     for (int ks = 0; ks < SK_J / 4; ++ks) {
-      double af[4], bf[NB];
+      double af[4], bf[5];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) af[f] = a_base[(16 * f) * SK_LD + 4 * ks];
+      for (int f = 0; f < 4; ++f) af[f] = cur[a_off + (16 * f) * SK_LD + 4 * ks];
 #pragma unroll
-      for (int g = 0; g < NB; ++g) bf[g] = b_base[(16 * g) * SK_LD + 4 * ks];
+      for (int g = 0; g < 5; ++g) bf[g] = (g < nfw) ? cur[b_off + (64 * g) * SK_LD + 4 * ks] : 0.0;
+#pragma unroll
+      for (int g = 0; g < 5; ++g)
+        if (g < nfw) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+        }
+    }
+    if (more) build_panel(raw, nxt);
+    __syncthreads();
+  }
+  // ---- partial tile out: part[item][128][320] (only the active fragments)
+  double *out = part + (size_t)blockIdx.x * (128 * 320);
+#pragma unroll
+  for (int g = 0; g < 5; ++g)
+    if (g < nfw) {
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int g = 0; g < NB; ++g) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+        for (int r = 0; r < 4; ++r) {
+          const int row = 64 * rh + 16 * f + fk + 4 * r;
+          const int col = 16 * (4 * g + cg) + fr;
+          out[row * 320 + col] = acc[f][g][r];
+        }
     }
-    __syncthreads();
-  }
-  // ---- partial tile out ----
-  double *out = Gpart + (size_t)split * pl.R_pad * pl.C_pad;
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int g = 0; g < NB; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 128 + 64 * rh + 16 * f + fk + 4 * r;
-        const int col = ct * (2 * MT) + 16 * NB * cg + 16 * g + fr;
-        out[(size_t)row * pl.C_pad + col] = acc[f][g][r];
-      }
 }
 
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, int nl_pad, int nsplit, int rt0, int rt1, const double2 *Xt,
-                    const double2 *Yt, const double2 *Zt, const double *qc, double *Gpart) {
-  const int nblk = (rt1 - rt0) * pl.n_col_tiles * nsplit;
-  if (nblk <= 0) return;
-  const size_t lds = (size_t)(128 + 64 * pl.NB) * SK_LD * sizeof(double);
-#define SK_CASE(N)                                                                                              \
-  case N:                                                                                                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_gemm_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        (int)lds);                                                                              \
-    hipLaunchKernelGGL(sk_gemm_kernel<N>, dim3(nblk), dim3(512), lds, s, pl, nl_pad, nsplit, rt0, Xt, Yt, Zt, qc, \
-                       Gpart);                                                                                  \
-    break;
-  switch (pl.NB) {
-    SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5)
-    default: break;
-  }
-#undef SK_CASE
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, int nitems, int nl_pad, const double2 *Xt,
+                    const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
+  if (nitems <= 0) return;
+  const size_t lds = (size_t)2 * SK_PANEL * sizeof(double);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nitems), dim3(512), lds, s, pl, items, nl_pad, Xt, Yt, Zs, qc, part);
 }
 
-// G = sum over splits (fixed order), Gw = w * G.  Only rows of tiles [rt0, rt1) are touched.
-__global__ __launch_bounds__(256) void sk_reduce_kernel(int C_pad, size_t plane, int nsplit, size_t e0, size_t e1,
-                                                        const double *__restrict__ Gpart, const double *__restrict__ wfull,
-                                                        double *__restrict__ G, double *__restrict__ Gw) {
-  for (size_t e = e0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (size_t)gridDim.x * blockDim.x) {
+// G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:
+//   Gwf[((rf * (C_pad/4)) + ts) * 64 + fk * 16 + fr]  = (w G)[16 rf + fr][4 ts + fk]
+// One block per (tile, 16-row fragment, 80-column quarter): its Gwf output is one contiguous run of 1280 doubles,
+// transposed through LDS so that partial reads, G writes and Gwf writes are all coalesced.
+__global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
+                                                        const double *__restrict__ part, const double *__restrict__ wfull,
+                                                        double *__restrict__ G, double *__restrict__ Gwf) {
+  __shared__ double tr[1280];
+  const SkTile tl = tiles[blockIdx.x >> 5];
+  const int f16 = (blockIdx.x >> 2) & 7;       // 16-row fragment inside the 128-row tile
+  const int q = blockIdx.x & 3;                // 80-column quarter of the 320-column tile
+  const size_t plane = 128 * 320;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = threadIdx.x + 320 * k;
+    const int row = e / 80, cl = e % 80;
+    const int rowl = 16 * f16 + row, col = 80 * q + cl;
     double sum = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) sum += Gpart[(size_t)sp * plane + e];
-    G[e] = sum;
-    Gw[e] = wfull[e] * sum;
+    if (col < 32 * tl.nba) {
+      const double *src = part + (size_t)tl.item0 * plane + rowl * 320 + col;
+      for (int sp = 0; sp < tl.nsplit; ++sp) sum += src[(size_t)sp * plane];
+    }
+    const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
+    G[grow * C_pad + gcol] = sum;
+    tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sum;
   }
+  __syncthreads();
+  const size_t rf = (size_t)tl.rt * 8 + f16;
+  double *dst = Gwf + (rf * (C_pad / 4) + (size_t)tl.ct * 80 + 20 * q) * 64;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dst[threadIdx.x + 320 * k] = tr[threadIdx.x + 320 * k];
 }
 
-void launch_sk_reduce(hipStream_t s, const DevPlan &pl, int nsplit, int rt0, int rt1, const double *Gpart, double *G,
-                      double *Gw) {
-  const size_t plane = (size_t)pl.R_pad * pl.C_pad;
-  const size_t e0 = (size_t)rt0 * 128 * pl.C_pad, e1 = (size_t)rt1 * 128 * pl.C_pad;
-  if (e1 <= e0) return;
-  int nb = (int)((e1 - e0 + 255) / 256);
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(sk_reduce_kernel, dim3(nb), dim3(256), 0, s, pl.C_pad, plane, nsplit, e0, e1, Gpart, pl.wfull, G, Gw);
+void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, const double *part, double *G,
+                      double *Gwf) {
+  if (ntiles <= 0) return;
+  hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf);
 }
 
 // structure factors in the reference's k order (parity read-back; km_ewald.cpp sfacrl_all / sfacim_all)
-__global__ void sfac_gather_kernel(int kcount, int C_pad, int PT, int MT, const int *__restrict__ row_a,
+__global__ void sfac_gather_kernel(int kcount, int C_pad, int PT, const int *__restrict__ row_a,
                                    const int *__restrict__ col_c, const int *__restrict__ k_sign,
-                                   const int *__restrict__ k_p, const int *__restrict__ k_m, const double *__restrict__ G,
-                                   double *__restrict__ sr, double *__restrict__ si) {
+                                   const double *__restrict__ G, double *__restrict__ sr, double *__restrict__ si) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= kcount) return;
   const size_t ra = (size_t)row_a[k] * C_pad, rb = (size_t)(row_a[k] + PT) * C_pad;
-  const int cc = col_c[k], cs = col_c[k] + MT;
+  const int cc = col_c[k], cs = col_c[k] + 16;
   const double CC = G[ra + cc], CS = G[ra + cs], SC = G[rb + cc], SS = G[rb + cs];
   const double sg = (double)k_sign[k];
   // (p,+m): Sr = CC - SS, Si = CS + SC ; (p,-m): Sr = CC + SS, Si = SC - CS   (km_ewald.cpp:768-773)
@@ -254,50 +295,84 @@ __global__ void sfac_gather_kernel(int kcount, int C_pad, int PT, int MT, const 
   si[k] = SC + sg * CS;
 }
 
-void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, int MT, const int *sf_row_a, const int *sf_col_c,
-                        const int *k_sign, const int *k_p, const int *k_m, const double *G, double *sfacrl, double *sfacim) {
-  hipLaunchKernelGGL(sfac_gather_kernel, dim3((kcount + 255) / 256), dim3(256), 0, s, kcount, C_pad, PT, MT, sf_row_a,
-                     sf_col_c, k_sign, k_p, k_m, G, sfacrl, sfacim);
+void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,
+                        const int *k_sign, const double *G, double *sfacrl, double *sfacim) {
+  hipLaunchKernelGGL(sfac_gather_kernel, dim3((kcount + 255) / 256), dim3(256), 0, s, kcount, C_pad, PT, sf_row_a,
+                     sf_col_c, k_sign, G, sfacrl, sfacim);
 }
 
 // ================================================================================================
-// 3. k-space b vector (km_ewald.cpp:789-825):  b_i = - sum_{r,t} Rp[r][i] * Gw[r][t] * Tz[t][i]
-//    One workgroup (4 waves) per 16 electrode atoms: H = Gw(16-row fragment) x Tz(slice in LDS) on MFMA, then
-//    the Hadamard with Rp and the column sum in the epilogue.  Row fragments [rf0, rf1) only (k-shard).
+// 3. k-space b vector (km_ewald.cpp:789-825):  b_i = - sum_{r,t} Rp[r][i] * (w G)[r][t] * Tz[t][i]
+//    Workgroup = 16 waves, 32 electrode atoms (2 column fragments) x the row tiles of one `half`
+//    (row tiles alternate between the two halves; the halves' sums are added by b_combine -- two terms, so the
+//    result does not depend on arrival order).  H = (w G)(16-row fragment) x Tz(slice in LDS) on MFMA, Hadamard
+//    with Rp and column sum in the epilogue.  (w G) arrives fragment-major: every A operand is one contiguous
+//    512-byte load.  Only the leading 8*nba k-steps of a row tile carry weight.
 // ================================================================================================
-__global__ __launch_bounds__(256) void b_project_kernel(int C_pad, int ne_pad, int rf0, int rf1,
-                                                        const double *__restrict__ Gw, const double *__restrict__ Rp,
-                                                        const double *__restrict__ Tz, double *__restrict__ bk) {
+__global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, int n_col_tiles, const int *__restrict__ ct_ptr,
+                                                         const SkTile *__restrict__ tiles, const double *__restrict__ Gwf,
+                                                         const double *__restrict__ Rp, const double *__restrict__ Tz,
+                                                         double *__restrict__ bk_part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *tz = reinterpret_cast<double *>(smem);          // [C_pad][16]
-  double *red = tz + (size_t)C_pad * 16;                   // [4 waves][16]
-  const int i0 = blockIdx.x * 16;
+  double *tz0 = reinterpret_cast<double *>(smem);         // [320][16]  atoms i0 .. i0+15
+  double *tz1 = tz0 + 320 * 16;                            // [320][16]  atoms i0+16 .. i0+31
+  double *red = tz1 + 320 * 16;                            // [16 waves][32]
+  const int half = blockIdx.y;
+  const int i0 = blockIdx.x * 32;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int e = t; e < C_pad * 16; e += 256) tz[e] = Tz[(size_t)(e >> 4) * ne_pad + i0 + (e & 15)];
-  __syncthreads();
   const int fr = lane & 15, fk = lane >> 4;
-  double part = 0.0;
-  for (int rf = rf0 + wave; rf < rf1; rf += 4) {
-    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-    const double *arow = Gw + (size_t)(16 * rf + fr) * C_pad + fk;
-    const double *brow = tz + fk * 16 + fr;
-#pragma unroll 8
-    for (int ts = 0; ts < C_pad / 4; ++ts) acc = MFMA_F64(arow[4 * ts], brow[64 * ts], acc);
+  double part0 = 0.0, part1 = 0.0;
+  for (int ct = 0; ct < n_col_tiles; ++ct) {
+    const int tb = ct_ptr[ct], te = ct_ptr[ct + 1];
+    if (te <= tb) continue;
+    __syncthreads();
+    for (int e = t; e < 320 * 32; e += 1024) {
+      const int col = e >> 5, a = e & 31;
+      const double v = Tz[(size_t)(ct * 320 + col) * ne_pad + i0 + a];
+      if (a < 16) tz0[col * 16 + a] = v; else tz1[col * 16 + a - 16] = v;
+    }
+    __syncthreads();
+    // units of this half: tiles tb + half, tb + half + 2, ... x 8 row fragments; dealt round-robin to the 16 waves
+    const int nth = (te - tb - half + 1) / 2;
+    for (int u = wave; u < 8 * nth; u += 16) {
+      const SkTile tl = tiles[tb + half + 2 * (u >> 3)];
+      const int rf = tl.rt * 8 + (u & 7);
+      d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+      const double *ap = Gwf + ((size_t)rf * (C_pad / 4) + (size_t)ct * 80) * 64 + lane;
+      const double *bp0 = tz0 + fk * 16 + fr, *bp1 = tz1 + fk * 16 + fr;
+      const int nks = 8 * tl.nba;
+#pragma unroll 4
+      for (int ts = 0; ts < nks; ++ts) {
+        const double a = ap[(size_t)ts * 64];
+        acc0 = MFMA_F64(a, bp0[64 * ts], acc0);
+        acc1 = MFMA_F64(a, bp1[64 * ts], acc1);
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part += Rp[(size_t)(16 * rf + fk + 4 * r) * ne_pad + i0 + fr] * acc[r];
+      for (int r = 0; r < 4; ++r) {
+        const double *rp = Rp + (size_t)(16 * rf + fk + 4 * r) * ne_pad + i0 + fr;
+        part0 += rp[0] * acc0[r];
+        part1 += rp[16] * acc1[r];
+      }
+    }
   }
-  part += __shfl_xor(part, 16, 64);
-  part += __shfl_xor(part, 32, 64);
-  if (lane < 16) red[wave * 16 + lane] = part;
+  part0 += __shfl_xor(part0, 16, 64); part0 += __shfl_xor(part0, 32, 64);
+  part1 += __shfl_xor(part1, 16, 64); part1 += __shfl_xor(part1, 32, 64);
   __syncthreads();
-  if (t < 16) bk[i0 + t] = -((red[t] + red[16 + t]) + (red[32 + t] + red[48 + t]));
+  if (lane < 16) { red[wave * 32 + lane] = part0; red[wave * 32 + 16 + lane] = part1; }
+  __syncthreads();
+  if (t < 32) {
+    double sum = 0.0;
+    for (int w = 0; w < 16; ++w) sum += red[w * 32 + t];
+    bk_part[(size_t)half * ne_pad + i0 + t] = -sum;
+  }
 }
 
-void launch_b_project(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, int rf0, int rf1, const double *Gw,
-                      const double *Rp, const double *Tz, double *bk) {
-  const size_t lds = ((size_t)pl.C_pad * 16 + 64) * sizeof(double);
+void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr, const SkTile *tiles, const double *Gwf,
+                      const double *Rp, const double *Tz, double *bk_part) {
+  const size_t lds = ((size_t)320 * 32 + 16 * 32) * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(b_project_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 16), dim3(256), lds, s, pl.C_pad, ne_pad, rf0, rf1, Gw, Rp, Tz, bk);
+  hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 32, 2), dim3(1024), lds, s, pl.C_pad, ne_pad, pl.n_col_tiles, ct_ptr, tiles,
+                     Gwf, Rp, Tz, bk_part);
 }
 
 // ================================================================================================
@@ -348,7 +423,7 @@ void launch_b_real(hipStream_t s, int row0, int row1, const int *row_ptr, const 
                      oth_atom, x, q, type, rp, b_real);
 }
 
-__global__ __launch_bounds__(256) void b_combine_kernel(int ne, int row0, int row1, int add_k,
+__global__ __launch_bounds__(256) void b_combine_kernel(int ne, int ne_pad, int row0, int row1, int add_k,
                                                         const double *__restrict__ bk, const double *__restrict__ b_real,
                                                         int slab, const double *__restrict__ ele_z,
                                                         const double *__restrict__ slab_part, int n_slab_part,
@@ -367,16 +442,16 @@ __global__ __launch_bounds__(256) void b_combine_kernel(int ne, int row0, int ro
   }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ne) return;
-  double v = add_k ? bk[i] : 0.0;
+  double v = add_k ? bk[i] + bk[ne_pad + i] : 0.0;
   if (slab) v -= ele_z[i] * sc;
   if (i >= row0 && i < row1) v += b_real[i];
   b_out[i] = v;
 }
 
-void launch_b_combine(hipStream_t s, int ne, int row0, int row1, int add_k, const double *bk, const double *b_real,
+void launch_b_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, int add_k, const double *bk, const double *b_real,
                       int slab, const double *ele_z, const double *slab_part, int n_slab_part, double slab_pref,
                       double *b_out, double *slab_out) {
-  hipLaunchKernelGGL(b_combine_kernel, dim3((ne + 255) / 256), dim3(256), 0, s, ne, row0, row1, add_k, bk, b_real, slab,
+  hipLaunchKernelGGL(b_combine_kernel, dim3((ne + 255) / 256), dim3(256), 0, s, ne, ne_pad, row0, row1, add_k, bk, b_real, slab,
                      ele_z, slab_part, n_slab_part, slab_pref, b_out, slab_out);
 }
 
@@ -469,7 +544,7 @@ void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v
 //    Only tiles with (row block >= col block) run; the strict upper triangle is left for a_symmetrise.
 // ================================================================================================
 __global__ __launch_bounds__(256, 1) void a_kspace_kernel(int R_pad, int C_pad, int ne, int ne_pad,
-                                                          const double *__restrict__ wfull, const double *__restrict__ Rp,
+                                                          const int *__restrict__ nb_act, const double *__restrict__ wfull, const double *__restrict__ Rp,
                                                           const double *__restrict__ Tz, double *__restrict__ A) {
   // triangular tile index -> (bi >= bj)
   int tidx = blockIdx.x, bi = 0;
@@ -493,7 +568,8 @@ __global__ __launch_bounds__(256, 1) void a_kspace_kernel(int R_pad, int C_pad, 
       rj[f] = Rp[(size_t)r * ne_pad + jbase + 16 * f];
     }
     const double *wrow = wfull + (size_t)r * C_pad + fk;
-    for (int ts = 0; ts < C_pad / 4; ++ts) {
+    const int nks = 8 * nb_act[r >> 7];           // only the leading kz blocks of this row tile carry weight
+    for (int ts = 0; ts < nks; ++ts) {
       const double ww = wrow[4 * ts];
       const double *tzr = Tz + (size_t)(4 * ts + fk) * ne_pad;
       double af[4], bf[4];
@@ -523,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void a_kspace_kernel(int R_pad, int C_pad, 
 void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A) {
   const int nb = ne_pad / 128;
   const int ntiles = nb * (nb + 1) / 2;
-  hipLaunchKernelGGL(a_kspace_kernel, dim3(ntiles), dim3(256), 0, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.wfull, Rp, Tz, A);
+  hipLaunchKernelGGL(a_kspace_kernel, dim3(ntiles), dim3(256), 0, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.nb_act, pl.wfull, Rp, Tz, A);
 }
 
 // diagonal ug_tot - 2g/sqrt(pi) + sqrt(2) eta/sqrt(pi) (km_ewald.cpp:631-634, fix_conp.cpp:796-801) and the slab

@@ -24,6 +24,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef ORC_OPENMP
+#include <omp.h>
+#endif
 
 /* LAMMPS math_const.h values (used at km_ewald.cpp:85-89, fix_conp.cpp:783) */
 #define ORC_PI   3.14159265358979323846
@@ -221,6 +224,17 @@ orc_kspace *orc_kspace_create(double g_ewald, double accuracy, double slab_volfa
   return ks;
 }
 
+/* thread count of the OpenMP build (bench.py cpu_baseline); no-op in the exact build */
+int orc_set_threads(int n) {
+#ifdef ORC_OPENMP
+  omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
 /* getters (ctypes-friendly) */
 void orc_kspace_info(const orc_kspace *ks, int *iout /*[16]*/, double *dout /*[8]*/) {
   int i;
@@ -315,7 +329,11 @@ int orc_sincos_b(const orc_kspace *ks, int nlocal, const double *x, const double
     sfacrl[kf] = tr0; sfacim[kf] = ti0; sfacrl[kf + 1] = tr1; sfacim[kf + 1] = ti1;
     kf += 2;
   }
+#ifdef ORC_OPENMP
+#pragma omp parallel for schedule(static) private(j)
+#endif
   for (m = 0; m < ks->kcount_expand; ++m) {           /* :761-779 (..,+-m) pairs */
+    const int kf = ks->kcount_flat + 2 * m;
     const double *cxy = &CS(ks->kxy_list[m], 0), *sxy = &SN(ks->kxy_list[m], 0);
     const double *cz = &CS(ks->kz_list[m], 0), *sz = &SN(ks->kz_list[m], 0);
     double tr0 = 0, ti0 = 0, tr1 = 0, ti1 = 0;
@@ -326,7 +344,6 @@ int orc_sincos_b(const orc_kspace *ks, int nlocal, const double *x, const double
       ti1 += qj[j] * (-cxy[j] * sz[j] + sxy[j] * cz[j]);
     }
     sfacrl[kf] = tr0; sfacim[kf] = ti0; sfacrl[kf + 1] = tr1; sfacim[kf + 1] = ti1;
-    kf += 2;
   }
 #undef CS
 #undef SN
@@ -388,9 +405,16 @@ static void orc_kz_expand(const orc_kspace *ks, const double *c, const double *s
 void orc_bbb_from_sincos_b(const orc_kspace *ks, int ne, const double *csk, const double *snk,
                            const double *sfacrl, const double *sfacim, double *bbb) {
   const int kflat = ks->kcount_flat, kexp = ks->kcount_expand;
+  int i, k;
+#ifdef ORC_OPENMP
+#pragma omp parallel private(i, k)
+#endif
+  {
   double *ce = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
   double *se = (double *)malloc(sizeof(double) * 2 * (kexp + 1));
-  int i, k;
+#ifdef ORC_OPENMP
+#pragma omp for schedule(static)
+#endif
   for (i = 0; i < ne; ++i) {
     const double *c = csk + (size_t)i * kflat, *s = snk + (size_t)i * kflat;
     double bbbtmp = 0;
@@ -401,6 +425,7 @@ void orc_bbb_from_sincos_b(const orc_kspace *ks, int ne, const double *csk, cons
     bbb[i] = bbbtmp;
   }
   free(ce); free(se);
+  }
 }
 
 /* km_ewald.cpp:827-847 slabcorr: bbb[i] -= z_i * sum_{j not electrode} 4 pi q_j z_j / V */
@@ -934,6 +959,15 @@ static double orc_ddot(int n, const double *a, const double *b) {
   int i;
   for (i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
+}
+
+/* the row-dot GEMV of update_charge in isolation (fix_conp.cpp:1135-1139), for bench.py's cpu_baseline leg */
+void orc_gemv_rows(int n, const double *aaa, const double *b, double *y) {
+  int i;
+#ifdef ORC_OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (i = 0; i < n; ++i) y[i] = orc_ddot(n, aaa + (size_t)i * n, b);
 }
 
 /* fix_conp.cpp:1071-1116 get_setq */

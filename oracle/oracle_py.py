@@ -69,6 +69,9 @@ def load(fast: bool = False):
     lib.orc_fix_get_trig.argtypes = [vp, _dp, _dp]
     lib.orc_fix_blist_only.argtypes = [vp, _dp]
     lib.orc_fix_alist_only.argtypes = [vp, _dp]
+    lib.orc_set_threads.argtypes = [C.c_int]
+    lib.orc_set_threads.restype = C.c_int
+    lib.orc_gemv_rows.argtypes = [C.c_int, _dp, _dp, _dp]
     lib.orc_multirank_maps.argtypes = [C.c_int, _ip, _ip, _ip, _ip, C.c_int, _ip, _ip, _ip, _ip]
     return lib
 
