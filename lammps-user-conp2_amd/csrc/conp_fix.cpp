@@ -133,7 +133,7 @@ struct conp_fix {
   int row0 = 0, row1 = 0, num_cus = 256;
   std::vector<SkItem> items_h;   // sk_gemm work items of this rank
   std::vector<SkTile> tiles_h;   // (row tile, col tile) pairs of this rank, sorted by col tile
-  std::vector<int> ct_ptr_h;
+  std::vector<int> ct_ptr_h, seg_ptr_h;
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
   std::vector<double> csk_h, snk_h, xele_h, d_vec_h;
@@ -146,7 +146,7 @@ struct conp_fix {
       d_cg_ap, d_cg_scal;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_nb_act, d_ct_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -281,33 +281,51 @@ struct conp_fix {
     sync();
   }
 
-  // sk_gemm work items: every (row tile, col tile) of this rank is split over the atoms so that all items cost about
-  // the same (cost ~ active kz blocks x atoms) and there are ~2 waves of workgroups on the 256 CUs
+  // sk_gemm schedule ("stream-K" over the atom chunks): the work of all tiles of this rank is laid out on one axis,
+  // tile after tile, chunk after chunk, with cost (nba + SK_C0) per chunk of 16 atoms (MFMA work ~ nba, operand
+  // generation + barrier ~ SK_C0), and cut into num_cus equal shares.  A share is a list of segments (tile, chunk
+  // range); every segment writes one partial tile, sk_reduce adds a tile's segments in order.
+  static constexpr double SK_C0 = 2.0;
   void build_items() {
     const int nchunks = nl_pad / 16;
-    long total = 0;
-    for (const auto &tl : tiles_h) total += tl.nba;
-    // one workgroup per CU (129 KB of LDS each): exactly one round of equally expensive items
-    const int target = std::max(num_cus, (int)tiles_h.size());
-    std::vector<int> nsv(tiles_h.size(), 1);
-    int used = 0;
-    for (size_t i = 0; i < tiles_h.size(); ++i) {
-      nsv[i] = std::max(1, std::min(nchunks, (int)((long long)target * tiles_h[i].nba / std::max<long>(total, 1))));
-      used += nsv[i];
-    }
-    for (size_t i = 0; used < target && !tiles_h.empty(); i = (i + 1) % tiles_h.size())   // hand out the remainder
-      if (nsv[i] < nchunks) { ++nsv[i]; ++used; } else if (std::all_of(nsv.begin(), nsv.end(), [&](int v) { return v >= nchunks; })) break;
+    const int nwg = std::max(1, num_cus);
+    const size_t nt = tiles_h.size();
+    std::vector<double> start(nt + 1, 0.0);
+    for (size_t i = 0; i < nt; ++i) start[i + 1] = start[i] + nchunks * (tiles_h[i].nba + SK_C0);
+    const double W = start.back();
+    auto locate = [&](double pos, size_t &ti, int &ch) {
+      ti = 0;
+      while (ti + 1 < nt && pos >= start[ti + 1]) ++ti;
+      ch = (int)std::lround((pos - start[ti]) / (tiles_h[ti].nba + SK_C0));
+      ch = std::max(0, std::min(nchunks, ch));
+    };
     items_h.clear();
+    seg_ptr_h.assign(nwg + 1, 0);
     size_t ti = 0;
+    int ch = 0;
+    for (int w = 0; w < nwg && nt > 0; ++w) {
+      seg_ptr_h[w] = (int)items_h.size();
+      size_t te = nt - 1;
+      int ce = nchunks;
+      if (w + 1 < nwg) locate(W * (w + 1) / nwg, te, ce);
+      while (ti < te) {
+        if (ch < nchunks) items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, nchunks});
+        ++ti; ch = 0;
+      }
+      if (ti == te && ch < ce) {
+        items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, ce});
+        ch = ce;
+      }
+    }
+    for (int w = 0; w <= nwg; ++w) if (w == nwg || nt == 0) seg_ptr_h[w] = (int)items_h.size();
+    // tiles -> their segments (contiguous in items_h)
+    size_t it = 0;
     for (auto &tl : tiles_h) {
-      const int ns = nsv[ti++];
-      tl.item0 = (int)items_h.size();
-      tl.nsplit = ns;
-      for (int sp = 0; sp < ns; ++sp)
-        items_h.push_back(SkItem{tl.rt, tl.ct, tl.nba, (int)((long long)nchunks * sp / ns),
-                                 (int)((long long)nchunks * (sp + 1) / ns)});
+      tl.item0 = (int)it; tl.nsplit = 0;
+      while (it < items_h.size() && items_h[it].rt == tl.rt && items_h[it].ct == tl.ct) { ++it; ++tl.nsplit; }
     }
     d_items.upload(items_h, stream);
+    d_seg_ptr.upload(seg_ptr_h, stream);
     d_tiles.upload(tiles_h, stream);
   }
 
@@ -508,7 +526,8 @@ struct conp_fix {
                        plan.kymax, plan.nz, KPlan::ZSTRIDE, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
     prof.end(stream);
     prof.begin("sk_gemm", stream);
-    launch_sk_gemm(stream, dplan, d_items.p, (int)items_h.size(), nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_Gpart.p);
+    launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
+                   d_Gpart.p);
     prof.end(stream);
     prof.begin("sk_reduce", stream);
     launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), d_Gpart.p, d_G.p, d_Gw.p);

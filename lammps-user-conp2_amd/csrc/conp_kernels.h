@@ -12,7 +12,7 @@ struct DevPlan {              // device copy of KPlan geometry
   const double *wfull;                // [R_pad][C_pad]
 };
 
-struct SkItem { int rt, ct, nba, c0, c1; };            // one sk_gemm workgroup: tile + chunk range [c0, c1) of 16 atoms
+struct SkItem { int rt, ct, nba, c0, c1; };            // one sk_gemm segment: tile + chunk range [c0, c1) of 16 atoms
 struct SkTile { int rt, ct, nba, item0, nsplit; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
@@ -25,8 +25,8 @@ struct RealParams {           // real-space pair kernels
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part);
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, int nitems, int nl_pad, const double2 *Xt,
-                    const double2 *Yt, const double2 *Zs, const double *qc, double *part);
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
+                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, const double *part, double *G,
                       double *Gwf);
 void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,

@@ -101,7 +101,7 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
 //    Partial tiles go to part[item][128][320]; sk_reduce sums a tile's splits in a fixed order (deterministic).
 // ================================================================================================
 constexpr int SK_J = 16;
-constexpr int SK_LD = SK_J + 2;
+constexpr int SK_LD = SK_J + 1;   // 17 doubles: conflict-free for ds_read2st64_b64 / ds_write_b64 (banks mod 32, 16-lane groups)
 constexpr int SK_NF = 128 + 320;
 constexpr int SK_PANEL = SK_NF * SK_LD;   // doubles per buffer
 
@@ -119,126 +119,179 @@ struct SkRaw {        // raw inputs of one thread for one chunk
   double q;
 };
 
-__global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkItem *__restrict__ items, int nl_pad,
+struct SkCtx {        // per-thread constants of one work item
+  SkItem it;
+  int nl_pad, nz;
+  int gj, gs;                       // generation role: atom gj of the chunk, sub-index gs 0..31
+  size_t xoff0, yoff0, xoff1, yoff1, zoff;
+  double sg0, sg1;
+  bool zact;
+  int a_off, b_off, fr, fk, rh, cg;
+  const double2 *Xt, *Yt, *Zs;
+  const double *qc;
+};
+
+__device__ __forceinline__ void sk_load_raw(const SkCtx &c, int ch, SkRaw &r) {
+  const size_t jg = (size_t)ch * SK_J + c.gj;
+  r.q = c.qc[jg];
+  r.X0 = c.Xt[c.xoff0 + jg]; r.Y0 = c.Yt[c.yoff0 + jg];
+  r.X1 = c.Xt[c.xoff1 + jg]; r.Y1 = c.Yt[c.yoff1 + jg];
+  if (c.zact) { r.Zst = c.Zs[jg]; r.Zseed = c.Zs[c.zoff + jg]; }
+}
+
+__device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, double *pn) {
+  // (kx, sg*ky): cos = cx cy - sg sx sy ; sin = sg cx sy + sx cy   (km_ewald.cpp:739-747)
+  {
+    const double cth = r.X0.x * r.Y0.x - c.sg0 * (r.X0.y * r.Y0.y);
+    const double sth = c.sg0 * (r.X0.x * r.Y0.y) + r.X0.y * r.Y0.x;
+    const double live = c.sg0 * c.sg0;
+    pn[c.gs * SK_LD + c.gj] = live * (r.q * cth);
+    pn[(64 + c.gs) * SK_LD + c.gj] = live * (r.q * sth);
+  }
+  {
+    const double cth = r.X1.x * r.Y1.x - c.sg1 * (r.X1.y * r.Y1.y);
+    const double sth = c.sg1 * (r.X1.x * r.Y1.y) + r.X1.y * r.Y1.x;
+    const double live = c.sg1 * c.sg1;
+    pn[(32 + c.gs) * SK_LD + c.gj] = live * (r.q * cth);
+    pn[(96 + c.gs) * SK_LD + c.gj] = live * (r.q * sth);
+  }
+  if (c.zact) {
+    double2 Z = r.Zseed;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int ml = 5 * c.gs + u;                        // kz index inside the col tile
+      const int feat = 128 + 32 * (ml >> 4) + (ml & 15);
+      const bool ok = c.it.ct * 160 + ml < c.nz;
+      pn[feat * SK_LD + c.gj] = ok ? Z.x : 0.0;
+      pn[(feat + 16) * SK_LD + c.gj] = ok ? Z.y : 0.0;
+      Z = zstep(Z, r.Zst);
+    }
+  }
+}
+
+// MFMA phase of one chunk for a wave that owns NFW column fragments (fi = 4 g + cg, g < NFW)
+template <int NFW>
+__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const double *cur, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
+  if (NFW > 0) {
+    const double *ap = cur + c.a_off, *bp = cur + c.b_off;
+#pragma unroll 1
+    for (int ks = 0; ks < SK_J / 4; ++ks) {
+      double af[4], bf[NFW > 0 ? NFW : 1];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) af[f] = ap[(16 * f) * SK_LD + 4 * ks];
+#pragma unroll
+      for (int g = 0; g < NFW; ++g) bf[g] = bp[(64 * g) * SK_LD + 4 * ks];
+#pragma unroll
+      for (int g = 0; g < NFW; ++g)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+    }
+  }
+}
+
+// One segment = (tile, chunk range).  Between two barriers the workgroup multiplies chunk c (panel buffer c&1) and
+// builds chunk c+1 (other buffer).  The two waves of a SIMD (w and w+4) do this in OPPOSITE order -- waves 0-3
+// multiply first, waves 4-7 build first -- so one wave's operand generation overlaps its partner's MFMAs.
+template <int NFW, bool late>
+__device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *out) {
+  d4 acc[4][NFW > 0 ? NFW : 1];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < (NFW > 0 ? NFW : 1); ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
+  SkRaw raw;
+  sk_load_raw(c, c.it.c0, raw);
+  sk_build_panel(c, raw, panel);
+  if (late && c.it.c0 + 1 < c.it.c1) sk_load_raw(c, c.it.c0 + 1, raw);
+  __syncthreads();
+  for (int ch = c.it.c0; ch < c.it.c1; ++ch) {
+    const double *cur = panel + ((ch - c.it.c0) & 1) * SK_PANEL;
+    double *nxt = panel + (((ch - c.it.c0) & 1) ^ 1) * SK_PANEL;
+    const bool more = ch + 1 < c.it.c1;
+    if (!late) {
+      if (more) sk_load_raw(c, ch + 1, raw);
+      sk_mfma_chunk<NFW>(c, cur, acc);
+      if (more) sk_build_panel(c, raw, nxt);
+    } else {
+      if (more) sk_build_panel(c, raw, nxt);
+      if (ch + 2 < c.it.c1) sk_load_raw(c, ch + 2, raw);
+      sk_mfma_chunk<NFW>(c, cur, acc);
+    }
+    __syncthreads();
+  }
+  // ---- partial tile out: part[segment][128][320] (only the active fragments)
+#pragma unroll
+  for (int g = 0; g < NFW; ++g)
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 64 * c.rh + 16 * f + c.fk + 4 * r;
+        const int col = 16 * (4 * g + c.cg) + c.fr;
+        out[row * 320 + col] = acc[f][g][r];
+      }
+}
+
+// Persistent-style launch: workgroup w runs the segments seg_ptr[w] .. seg_ptr[w+1]-1 (host: equal cost per workgroup,
+// a segment boundary may fall inside a tile -- "stream-K" over the atom chunks).
+__global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkItem *__restrict__ items,
+                                                         const int *__restrict__ seg_ptr, int nl_pad,
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
                                                          double *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *panel = reinterpret_cast<double *>(smem);   // [2][SK_NF][SK_LD]
-
-  const SkItem it = items[blockIdx.x];
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int rh = wave & 1, cg = wave >> 1;
-  const int nfrag = 2 * it.nba;                       // active column fragments of this item
-  const int nfw = (nfrag - cg + 3) >> 2;              // fragments of this wave: fi = 4 g + cg < nfrag
-
-  // generation roles: atom gj of the chunk, sub-index gs 0..31
-  const int gj = t & 15, gs = t >> 4;
-  const int p0 = it.rt * 64 + gs, p1 = p0 + 32;
-  const size_t xoff0 = (size_t)pl.p_ikx[p0] * nl_pad, yoff0 = (size_t)pl.p_iky[p0] * nl_pad;
-  const size_t xoff1 = (size_t)pl.p_ikx[p1] * nl_pad, yoff1 = (size_t)pl.p_iky[p1] * nl_pad;
-  const double sg0 = (double)pl.p_sgn[p0], sg1 = (double)pl.p_sgn[p1];     // 0 marks a padding row
-  const bool zact = 5 * gs < 16 * it.nba;             // this thread's 5 kz values lie in an active block
-  const size_t zoff = (size_t)(1 + it.ct * 32 + gs) * nl_pad;
-
-  d4 acc[4][5];
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int g = 0; g < 5; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  const int fr = lane & 15, fk = lane >> 4;
-  const int a_off = (64 * rh + fr) * SK_LD + fk;
-  const int b_off = (128 + 16 * cg + fr) * SK_LD + fk;
-
-  auto load_raw = [&](int ch, SkRaw &r) {
-    const size_t jg = (size_t)ch * SK_J + gj;
-    r.q = qc[jg];
-    r.X0 = Xt[xoff0 + jg]; r.Y0 = Yt[yoff0 + jg];
-    r.X1 = Xt[xoff1 + jg]; r.Y1 = Yt[yoff1 + jg];
-    if (zact) { r.Zst = Zs[jg]; r.Zseed = Zs[zoff + jg]; }
-  };
-  auto build_panel = [&](const SkRaw &r, double *pn) {
-    // (kx, sg*ky): cos = cx cy - sg sx sy ; sin = sg cx sy + sx cy   (km_ewald.cpp:739-747)
-    {
-      const double cth = r.X0.x * r.Y0.x - sg0 * (r.X0.y * r.Y0.y);
-      const double sth = sg0 * (r.X0.x * r.Y0.y) + r.X0.y * r.Y0.x;
-      const double live = sg0 * sg0;
-      pn[gs * SK_LD + gj] = live * (r.q * cth);
-      pn[(64 + gs) * SK_LD + gj] = live * (r.q * sth);
-    }
-    {
-      const double cth = r.X1.x * r.Y1.x - sg1 * (r.X1.y * r.Y1.y);
-      const double sth = sg1 * (r.X1.x * r.Y1.y) + r.X1.y * r.Y1.x;
-      const double live = sg1 * sg1;
-      pn[(32 + gs) * SK_LD + gj] = live * (r.q * cth);
-      pn[(96 + gs) * SK_LD + gj] = live * (r.q * sth);
-    }
-    if (zact) {
-      double2 Z = r.Zseed;
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        const int ml = 5 * gs + u;                        // kz index inside the col tile
-        const int feat = 128 + 32 * (ml >> 4) + (ml & 15);
-        const bool ok = it.ct * 160 + ml < pl.nz;
-        pn[feat * SK_LD + gj] = ok ? Z.x : 0.0;
-        pn[(feat + 16) * SK_LD + gj] = ok ? Z.y : 0.0;
-        Z = zstep(Z, r.Zst);
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  SkCtx c;
+  c.nl_pad = nl_pad; c.nz = pl.nz;
+  c.rh = wave & 1; c.cg = wave >> 1;
+  c.gj = t & 15; c.gs = t >> 4;
+  c.fr = lane & 15; c.fk = lane >> 4;
+  c.a_off = (64 * c.rh + c.fr) * SK_LD + c.fk;
+  c.b_off = (128 + 16 * c.cg + c.fr) * SK_LD + c.fk;
+  c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
+  const bool late = wave >= 4;
+  const int s0 = seg_ptr[blockIdx.x], s1 = seg_ptr[blockIdx.x + 1];
+  for (int sg = s0; sg < s1; ++sg) {
+    c.it = items[sg];
+    const int nfrag = 2 * c.it.nba;                     // active column fragments of this tile
+    const int nfw = (nfrag - c.cg + 3) >> 2;            // fragments of this wave: fi = 4 g + cg < nfrag   (wave-uniform)
+    const int p0 = c.it.rt * 64 + c.gs, p1 = p0 + 32;
+    c.xoff0 = (size_t)pl.p_ikx[p0] * nl_pad; c.yoff0 = (size_t)pl.p_iky[p0] * nl_pad;
+    c.xoff1 = (size_t)pl.p_ikx[p1] * nl_pad; c.yoff1 = (size_t)pl.p_iky[p1] * nl_pad;
+    c.sg0 = (double)pl.p_sgn[p0]; c.sg1 = (double)pl.p_sgn[p1];       // 0 marks a padding row
+    c.zact = 5 * c.gs < 16 * c.it.nba;                  // this thread's 5 kz values lie in an active block
+    c.zoff = (size_t)(1 + c.it.ct * 32 + c.gs) * nl_pad;
+    double *out = part + (size_t)sg * (128 * 320);
+    if (late) {
+      switch (nfw) {
+        case 5: sk_body<5, true>(c, panel, out); break;
+        case 4: sk_body<4, true>(c, panel, out); break;
+        case 3: sk_body<3, true>(c, panel, out); break;
+        case 2: sk_body<2, true>(c, panel, out); break;
+        case 1: sk_body<1, true>(c, panel, out); break;
+        default: sk_body<0, true>(c, panel, out); break;
+      }
+    } else {
+      switch (nfw) {
+        case 5: sk_body<5, false>(c, panel, out); break;
+        case 4: sk_body<4, false>(c, panel, out); break;
+        case 3: sk_body<3, false>(c, panel, out); break;
+        case 2: sk_body<2, false>(c, panel, out); break;
+        case 1: sk_body<1, false>(c, panel, out); break;
+        default: sk_body<0, false>(c, panel, out); break;
       }
     }
-  };
-
-  SkRaw raw;
-  if (it.c0 < it.c1) {
-    load_raw(it.c0, raw);
-    build_panel(raw, panel);
   }
-  __syncthreads();
-  for (int ch = it.c0; ch < it.c1; ++ch) {
-    const double *cur = panel + ((ch - it.c0) & 1) * SK_PANEL;
-    double *nxt = panel + (((ch - it.c0) & 1) ^ 1) * SK_PANEL;
-    const bool more = ch + 1 < it.c1;
-    if (more) load_raw(ch + 1, raw);
-#pragma unroll
-    for (int ks = 0; ks < SK_J / 4; ++ks) {
-      double af[4], bf[5];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) af[f] = cur[a_off + (16 * f) * SK_LD + 4 * ks];
-#pragma unroll
-      for (int g = 0; g < 5; ++g) bf[g] = (g < nfw) ? cur[b_off + (64 * g) * SK_LD + 4 * ks] : 0.0;
-#pragma unroll
-      for (int g = 0; g < 5; ++g)
-        if (g < nfw) {
-#pragma unroll
-          for (int f = 0; f < 4; ++f) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
-        }
-    }
-    if (more) build_panel(raw, nxt);
-    __syncthreads();
-  }
-  // ---- partial tile out: part[item][128][320] (only the active fragments)
-  double *out = part + (size_t)blockIdx.x * (128 * 320);
-#pragma unroll
-  for (int g = 0; g < 5; ++g)
-    if (g < nfw) {
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 64 * rh + 16 * f + fk + 4 * r;
-          const int col = 16 * (4 * g + cg) + fr;
-          out[row * 320 + col] = acc[f][g][r];
-        }
-    }
 }
 
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, int nitems, int nl_pad, const double2 *Xt,
-                    const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
-  if (nitems <= 0) return;
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
+                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
+  if (nwg <= 0) return;
   const size_t lds = (size_t)2 * SK_PANEL * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nitems), dim3(512), lds, s, pl, items, nl_pad, Xt, Yt, Zs, qc, part);
+  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, nl_pad, Xt, Yt, Zs, qc, part);
 }
 
 // G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:

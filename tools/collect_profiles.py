@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel trace stats + PMC passes) into small text/JSON files.
+usage: collect_profiles.py <dir with trace/ pmc_*/ subdirs> [out.json]"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.split("(")[0]
+    for pre in ("void conp::", "conp::"):
+        if n.startswith(pre):
+            n = n[len(pre):]
+    return n.split("<")[0][:60]
+
+
+def main():
+    root = sys.argv[1]
+    out = {}
+    # kernel stats
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        ks = []
+        for r in rows:
+            ks.append(dict(kernel=short(r.get("Name", "")), calls=int(r.get("Calls", 0)),
+                           total_ns=float(r.get("TotalDurationNs", 0)), avg_ns=float(r.get("AverageNs", 0)),
+                           pct=float(r.get("Percentage", 0))))
+        ks.sort(key=lambda k: -k["total_ns"])
+        out["kernel_stats"] = ks
+        print("== kernel trace stats (%s)" % os.path.relpath(f, root))
+        for k in ks[:20]:
+            print("%-44s calls %6d  avg %10.1f us  total %10.3f ms  %5.1f%%" % (k["kernel"], k["calls"], k["avg_ns"] / 1e3,
+                                                                            k["total_ns"] / 1e6, k["pct"]))
+    # PMC
+    pmc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out["pmc"] = {}
+    print("== PMC averages per dispatch")
+    for k, cs in pmc.items():
+        if not any(x in k for x in ("sk_gemm", "b_project", "sk_reduce", "gemv", "elyte", "b_real", "a_kspace")):
+            continue
+        d = {c: sum(v) / len(v) for c, v in cs.items()}
+        out["pmc"][k] = d
+        print(k)
+        for c, v in sorted(d.items()):
+            print("    %-28s %16.1f" % (c, v))
+    if len(sys.argv) > 2:
+        json.dump(out, open(sys.argv[2], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
