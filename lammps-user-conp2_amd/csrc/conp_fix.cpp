@@ -285,7 +285,7 @@ struct conp_fix {
   // tile after tile, chunk after chunk, with cost (nba + SK_C0) per chunk of 16 atoms (MFMA work ~ nba, operand
   // generation + barrier ~ SK_C0), and cut into num_cus equal shares.  A share is a list of segments (tile, chunk
   // range); every segment writes one partial tile, sk_reduce adds a tile's segments in order.
-  static constexpr double SK_C0 = 2.0;
+  double SK_C0 = getenv("CONP_SK_C0") ? atof(getenv("CONP_SK_C0")) : 2.0;
   void build_items() {
     const int nchunks = nl_pad / 16;
     const int nwg = std::max(1, num_cus);
@@ -535,15 +535,11 @@ struct conp_fix {
     prof.begin("b_project", stream);
     launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
     prof.end(stream);
-    if (coulyes) {
-      prof.begin("b_real", stream);
-      launch_b_real(stream, row0, row1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), d_breal.p);
-      prof.end(stream);
-    }
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
-    prof.begin("b_combine", stream);
-    launch_b_combine(stream, ne, ne_pad, coulyes ? row0 : 0, coulyes ? row1 : 0, 1, d_bk.p, d_breal.p, slab, d_ele_z.p,
-                     d_slab_part.p, n_slab_part, 4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
+    prof.begin("b_real_combine", stream);
+    launch_b_real_combine(stream, ne, ne_pad, coulyes ? row0 : 0, coulyes ? row1 : 0, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
+                          d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
+                          4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
     prof.end(stream);
   }
 
@@ -564,10 +560,8 @@ struct conp_fix {
   void scatter_device(double *d_q_atoms, double potdiff) {
     const int ne = idx.elenum_all;
     prof.begin("charge_write", stream);
-    launch_charge_from_solution(stream, ne, 0, ne, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr, potdiff,
-                                d_qele.p);
-    launch_left_sum(stream, ne, d_elecheck.p, d_eleallq, d_scalars.p + 1);
-    if (d_q_atoms) launch_scatter_charge(stream, nall, d_atom2eleall.p, d_qele.p, d_q_atoms);
+    launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
+                         args.qinit ? d_eleinitq.p : nullptr, potdiff, d_qele.p, d_q_atoms, d_scalars.p + 1);
     prof.end(stream);
   }
 

@@ -33,16 +33,15 @@ void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int 
                         const int *k_sign, const double *G, double *sfacrl, double *sfacim);
 void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr /*[n_col_tiles+1]*/, const SkTile *tiles,
                       const double *Gwf, const double *Rp, const double *Tz, double *bk_part /*[2][ne_pad] overwritten*/);
-void launch_b_real(hipStream_t s, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
-                   const double *x, const double *q, const int *type, RealParams rp, double *b_real /*[ne] rows row0..row1 written*/);
-// b = bk (if add_k) + b_real (rows row0..row1) - z*slab (if slab); everything else 0: the shard's contribution
-void launch_b_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, int add_k, const double *bk, const double *b_real,
-                      int slab, const double *ele_z, const double *slab_part, int n_slab_part, double slab_pref,
-                      double *b_out, double *slab_out);
+// this rank's contribution to b in one launch: k-space halves + slab (rank 0) + real-space rows row0..row1
+void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
+                           const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,
+                           const double *bk, int slab, const double *ele_z, const double *slab_part, int n_slab_part,
+                           double slab_pref, double *b_out, double *slab_out);
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);
-void launch_charge_from_solution(hipStream_t s, int ne, int row0, int row1, const double *eleallq, const double *elesetq,
-                                 const double *eleinitq, double potdiff, double *q_ele);
-void launch_scatter_charge(hipStream_t s, int nall, const int *atom2eleall, const double *q_ele, double *q_atoms);
+void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleall, const int *elecheck, const double *eleallq,
+                          const double *elesetq, const double *eleinitq, double potdiff, double *q_ele, double *q_atoms,
+                          double *left_out);
 void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);
 
 // ---- once-per-run matrix work ------------------------------------------------------------------

@@ -11,6 +11,8 @@
 //   C/D: register r of lane l is C[row = (l >> 4) + 4 r][col = l & 15].
 #include "conp_kernels.h"
 
+#include <cstdlib>
+
 namespace conp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -123,16 +125,17 @@ struct SkCtx {        // per-thread constants of one work item
   SkItem it;
   int nl_pad, nz;
   int gj, gs;                       // generation role: atom gj of the chunk, sub-index gs 0..31
-  size_t xoff0, yoff0, xoff1, yoff1, zoff;
+  unsigned xoff0, yoff0, xoff1, yoff1, zoff;   // element offsets into the phase tables (< 2^32)
   double sg0, sg1;
   bool zact;
   int a_off, b_off, fr, fk, rh, cg;
   const double2 *Xt, *Yt, *Zs;
   const double *qc;
+  int dbg;
 };
 
 __device__ __forceinline__ void sk_load_raw(const SkCtx &c, int ch, SkRaw &r) {
-  const size_t jg = (size_t)ch * SK_J + c.gj;
+  const unsigned jg = (unsigned)ch * SK_J + c.gj;
   r.q = c.qc[jg];
   r.X0 = c.Xt[c.xoff0 + jg]; r.Y0 = c.Yt[c.yoff0 + jg];
   r.X1 = c.Xt[c.xoff1 + jg]; r.Y1 = c.Yt[c.yoff1 + jg];
@@ -174,6 +177,8 @@ template <int NFW>
 __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const double *cur, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
   if (NFW > 0) {
     const double *ap = cur + c.a_off, *bp = cur + c.b_off;
+    // not unrolled on purpose: 160 of the 256 VGPRs are accumulators; hoisting the LDS reads of several k-steps spills,
+    // and the SIMD partner wave covers the LDS latency (measured: explicit double-buffering of the fragments gave nothing)
 #pragma unroll 1
     for (int ks = 0; ks < SK_J / 4; ++ks) {
       double af[4], bf[NFW > 0 ? NFW : 1];
@@ -209,17 +214,18 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *o
     double *nxt = panel + (((ch - c.it.c0) & 1) ^ 1) * SK_PANEL;
     const bool more = ch + 1 < c.it.c1;
     if (!late) {
-      if (more) sk_load_raw(c, ch + 1, raw);
-      sk_mfma_chunk<NFW>(c, cur, acc);
-      if (more) sk_build_panel(c, raw, nxt);
+      if (more && !(c.dbg & 4)) sk_load_raw(c, ch + 1, raw);
+      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
+      if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
     } else {
-      if (more) sk_build_panel(c, raw, nxt);
-      if (ch + 2 < c.it.c1) sk_load_raw(c, ch + 2, raw);
-      sk_mfma_chunk<NFW>(c, cur, acc);
+      if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
+      if (ch + 2 < c.it.c1 && !(c.dbg & 4)) sk_load_raw(c, ch + 2, raw);
+      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
     }
     __syncthreads();
   }
   // ---- partial tile out: part[segment][128][320] (only the active fragments)
+  if (c.dbg & 16) return;
 #pragma unroll
   for (int g = 0; g < NFW; ++g)
 #pragma unroll
@@ -238,12 +244,13 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
                                                          const int *__restrict__ seg_ptr, int nl_pad,
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
-                                                         double *__restrict__ part) {
+                                                         double *__restrict__ part, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *panel = reinterpret_cast<double *>(smem);   // [2][SK_NF][SK_LD]
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   SkCtx c;
+  c.dbg = dbg;
   c.nl_pad = nl_pad; c.nz = pl.nz;
   c.rh = wave & 1; c.cg = wave >> 1;
   c.gj = t & 15; c.gs = t >> 4;
@@ -251,18 +258,18 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   c.a_off = (64 * c.rh + c.fr) * SK_LD + c.fk;
   c.b_off = (128 + 16 * c.cg + c.fr) * SK_LD + c.fk;
   c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
-  const bool late = wave >= 4;
+  const bool late = wave >= 4 && !(dbg & 8);
   const int s0 = seg_ptr[blockIdx.x], s1 = seg_ptr[blockIdx.x + 1];
   for (int sg = s0; sg < s1; ++sg) {
     c.it = items[sg];
     const int nfrag = 2 * c.it.nba;                     // active column fragments of this tile
     const int nfw = (nfrag - c.cg + 3) >> 2;            // fragments of this wave: fi = 4 g + cg < nfrag   (wave-uniform)
     const int p0 = c.it.rt * 64 + c.gs, p1 = p0 + 32;
-    c.xoff0 = (size_t)pl.p_ikx[p0] * nl_pad; c.yoff0 = (size_t)pl.p_iky[p0] * nl_pad;
-    c.xoff1 = (size_t)pl.p_ikx[p1] * nl_pad; c.yoff1 = (size_t)pl.p_iky[p1] * nl_pad;
+    c.xoff0 = (unsigned)pl.p_ikx[p0] * nl_pad; c.yoff0 = (unsigned)pl.p_iky[p0] * nl_pad;
+    c.xoff1 = (unsigned)pl.p_ikx[p1] * nl_pad; c.yoff1 = (unsigned)pl.p_iky[p1] * nl_pad;
     c.sg0 = (double)pl.p_sgn[p0]; c.sg1 = (double)pl.p_sgn[p1];       // 0 marks a padding row
     c.zact = 5 * c.gs < 16 * c.it.nba;                  // this thread's 5 kz values lie in an active block
-    c.zoff = (size_t)(1 + c.it.ct * 32 + c.gs) * nl_pad;
+    c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * nl_pad;
     double *out = part + (size_t)sg * (128 * 320);
     if (late) {
       switch (nfw) {
@@ -291,7 +298,8 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
   if (nwg <= 0) return;
   const size_t lds = (size_t)2 * SK_PANEL * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, nl_pad, Xt, Yt, Zs, qc, part);
+  static const int dbg = getenv("CONP_SK_DBG") ? atoi(getenv("CONP_SK_DBG")) : 0;   // ablation switches for experiments
+  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, nl_pad, Xt, Yt, Zs, qc, part, dbg);
 }
 
 // G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:
@@ -314,7 +322,15 @@ __global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile 
     double sum = 0.0;
     if (col < 32 * tl.nba) {
       const double *src = part + (size_t)tl.item0 * plane + rowl * 320 + col;
-      for (int sp = 0; sp < tl.nsplit; ++sp) sum += src[(size_t)sp * plane];
+      // 8 loads in flight; the association ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)) is fixed -> bitwise reproducible
+      double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int sp = 0;
+      for (; sp + 8 <= tl.nsplit; sp += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * plane];
+      }
+      for (int u = 0; sp < tl.nsplit; ++sp, ++u) s8[u] += src[(size_t)sp * plane];
+      sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
     const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
     G[grow * C_pad + gcol] = sum;
@@ -357,7 +373,7 @@ void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int 
 // ================================================================================================
 // 3. k-space b vector (km_ewald.cpp:789-825):  b_i = - sum_{r,t} Rp[r][i] * (w G)[r][t] * Tz[t][i]
 //    Workgroup = 16 waves, 32 electrode atoms (2 column fragments) x the row tiles of one `half`
-//    (row tiles alternate between the two halves; the halves' sums are added by b_combine -- two terms, so the
+//    (row tiles alternate between the two halves; the halves' sums are added by b_real_combine -- two terms, so the
 //    result does not depend on arrival order).  H = (w G)(16-row fragment) x Tz(slice in LDS) on MFMA, Hadamard
 //    with Rp and column sum in the epilogue.  (w G) arrives fragment-major: every A operand is one contiguous
 //    512-byte load.  Only the leading 8*nba k-steps of a row tile carry weight.
@@ -442,70 +458,60 @@ __device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
   return 0.0;
 }
 
-// one wave per electrode row (global eleall index): b_real[row] = - sum_pairs q_j [erfc(g r) - erfc(eta r)] / r
-// (fix_conp.cpp:1313-1353; eta_potential :1472-1475)
-__global__ __launch_bounds__(256) void b_real_kernel(int row0, int row1, const int *__restrict__ row_ptr,
-                                                     const int *__restrict__ ele_atom, const int *__restrict__ oth_atom,
-                                                     const double *__restrict__ x, const double *__restrict__ q,
-                                                     const int *__restrict__ type, RealParams rp,
-                                                     double *__restrict__ b_real) {
+// one wave per electrode row (global eleall index), fused with the assembly of this rank's b contribution:
+//   b[row] = bk_half0[row] + bk_half1[row]                       (k-space shard, km_ewald.cpp:789-825)
+//          - z_row * sum_j 4 pi q_j z_j / V                      (slab, km_ewald.cpp:827-847; rank 0 only)
+//          - sum_pairs q_j [erfc(g r) - erfc(eta r)] / r         (rows row0..row1 only; fix_conp.cpp:1313-1353)
+__global__ __launch_bounds__(256) void b_real_combine_kernel(int ne, int ne_pad, int row0, int row1,
+                                                             const int *__restrict__ row_ptr, const int *__restrict__ ele_atom,
+                                                             const int *__restrict__ oth_atom, const double *__restrict__ x,
+                                                             const double *__restrict__ q, const int *__restrict__ type,
+                                                             RealParams rp, int add_k, const double *__restrict__ bk, int slab,
+                                                             const double *__restrict__ ele_z,
+                                                             const double *__restrict__ slab_part, int n_slab_part,
+                                                             double slab_pref, double *__restrict__ b_out,
+                                                             double *__restrict__ slab_out) {
 #pragma clang fp contract(off)
-  const int row = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= row1) return;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= ne) return;
   const int lane = threadIdx.x & 63;
   const int nt1 = rp.ntypes + 1;
   double sum = 0.0;
-  for (int p = row_ptr[row] + lane; p < row_ptr[row + 1]; p += 64) {
-    const int ie = ele_atom[p], jo = oth_atom[p];
-    const double dx = x[3 * ie] - x[3 * jo], dy = x[3 * ie + 1] - x[3 * jo + 1], dz = x[3 * ie + 2] - x[3 * jo + 2];
-    const double rsq = dx * dx + dy * dy + dz * dz;
-    if (rsq < rp.cutsq[type[ie] * nt1 + type[jo]] && rsq < rp.cut_coulsq) {
-      double dudq = erfcr_sqrt_dev(rp.g_ewald * rp.g_ewald * rsq) * rp.g_ewald;
-      dudq += -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
-      sum -= q[jo] * dudq;
+  if (row >= row0 && row < row1) {
+    for (int p = row_ptr[row] + lane; p < row_ptr[row + 1]; p += 64) {
+      const int ie = ele_atom[p], jo = oth_atom[p];
+      const double dx = x[3 * ie] - x[3 * jo], dy = x[3 * ie + 1] - x[3 * jo + 1], dz = x[3 * ie + 2] - x[3 * jo + 2];
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq < rp.cutsq[type[ie] * nt1 + type[jo]] && rsq < rp.cut_coulsq) {
+        double dudq = erfcr_sqrt_dev(rp.g_ewald * rp.g_ewald * rsq) * rp.g_ewald;
+        dudq += -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
+        sum -= q[jo] * dudq;
+      }
     }
   }
   sum = wave_sum(sum);
-  if (lane == 0) b_real[row] = sum;
-}
-
-void launch_b_real(hipStream_t s, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
-                   const double *x, const double *q, const int *type, RealParams rp, double *b_real) {
-  if (row1 <= row0) return;
-  hipLaunchKernelGGL(b_real_kernel, dim3((row1 - row0 + 3) / 4), dim3(256), 0, s, row0, row1, row_ptr, ele_atom,
-                     oth_atom, x, q, type, rp, b_real);
-}
-
-__global__ __launch_bounds__(256) void b_combine_kernel(int ne, int ne_pad, int row0, int row1, int add_k,
-                                                        const double *__restrict__ bk, const double *__restrict__ b_real,
-                                                        int slab, const double *__restrict__ ele_z,
-                                                        const double *__restrict__ slab_part, int n_slab_part,
-                                                        double slab_pref, double *__restrict__ b_out,
-                                                        double *__restrict__ slab_out) {
-  __shared__ double sc;
-  if (slab) {
-    // every block re-derives the same scalar in the same order: sum_j 4 pi q_j z_j / V  (km_ewald.cpp:835-841)
-    if (threadIdx.x == 0) {
-      double sacc = 0.0;
-      for (int k = 0; k < n_slab_part; ++k) sacc += slab_part[k];
-      sc = slab_pref * sacc;
-      if (blockIdx.x == 0 && slab_out) *slab_out = sc;
-    }
-    __syncthreads();
+  double sc = 0.0;
+  if (slab) {   // every wave derives the same scalar with the same summation tree
+    double sp = 0.0;
+    for (int k = lane; k < n_slab_part; k += 64) sp += slab_part[k];
+    sp = wave_sum(sp);
+    sc = slab_pref * __shfl(sp, 0, 64);
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne) return;
-  double v = add_k ? bk[i] + bk[ne_pad + i] : 0.0;
-  if (slab) v -= ele_z[i] * sc;
-  if (i >= row0 && i < row1) v += b_real[i];
-  b_out[i] = v;
+  if (lane == 0) {
+    double v = add_k ? bk[row] + bk[ne_pad + row] : 0.0;
+    if (slab) v -= ele_z[row] * sc;
+    v += sum;
+    b_out[row] = v;
+    if (slab && row == 0 && slab_out) *slab_out = sc;
+  }
 }
 
-void launch_b_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, int add_k, const double *bk, const double *b_real,
-                      int slab, const double *ele_z, const double *slab_part, int n_slab_part, double slab_pref,
-                      double *b_out, double *slab_out) {
-  hipLaunchKernelGGL(b_combine_kernel, dim3((ne + 255) / 256), dim3(256), 0, s, ne, ne_pad, row0, row1, add_k, bk, b_real, slab,
-                     ele_z, slab_part, n_slab_part, slab_pref, b_out, slab_out);
+void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
+                           const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,
+                           const double *bk, int slab, const double *ele_z, const double *slab_part, int n_slab_part,
+                           double slab_pref, double *b_out, double *slab_out) {
+  hipLaunchKernelGGL(b_real_combine_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, ne, ne_pad, row0, row1, row_ptr, ele_atom,
+                     oth_atom, x, q, type, rp, add_k, bk, slab, ele_z, slab_part, n_slab_part, slab_pref, b_out, slab_out);
 }
 
 // ================================================================================================
@@ -538,38 +544,51 @@ void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S,
   hipLaunchKernelGGL(gemv_rows_kernel, dim3((row1 - row0 + 3) / 4), dim3(256), 0, s, n, row0, row1, S, b, y);
 }
 
-// q_ele = eleallq + dV * elesetq (+ eleinitq)   (fix_conp.cpp:1153-1158)
-__global__ void charge_from_solution_kernel(int row0, int row1, const double *__restrict__ eleallq,
-                                            const double *__restrict__ elesetq, const double *__restrict__ eleinitq,
-                                            double potdiff, double *__restrict__ q_ele) {
+// fix_conp.cpp:1149-1159 in one launch:
+//   blocks 0 .. nb-2 : q_ele[e] = eleallq[e] + dV * elesetq[e] (+ eleinitq[e]) for e < ne, and the same value written to
+//                      every owned or ghost electrode atom i < nall (atom2eleall[i] >= 0)
+//   last block       : netcharge_left = sum of eleallq over the group-1 atoms (fixed tree)
+__global__ __launch_bounds__(256) void charge_finish_kernel(int ne, int nall, const int *__restrict__ atom2eleall,
+                                                            const int *__restrict__ elecheck, const double *__restrict__ eleallq,
+                                                            const double *__restrict__ elesetq, const double *__restrict__ eleinitq,
+                                                            double potdiff, double *__restrict__ q_ele,
+                                                            double *__restrict__ q_atoms, double *__restrict__ left_out) {
 #pragma clang fp contract(off)
-  const int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= row1) return;
-  double v = eleallq[i] + potdiff * elesetq[i];
-  if (eleinitq) v += eleinitq[i];
-  q_ele[i] = v;
+  if (blockIdx.x == gridDim.x - 1) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < ne; i += 256) if (elecheck[i] == 1) s += eleallq[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *left_out = (red[0] + red[1]) + (red[2] + red[3]);
+    return;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ne) {
+    double v = eleallq[i] + potdiff * elesetq[i];
+    if (eleinitq) v += eleinitq[i];
+    q_ele[i] = v;
+  }
+  if (q_atoms && i < nall) {
+    const int e = atom2eleall[i];
+    if (e >= 0) {
+      double v = eleallq[e] + potdiff * elesetq[e];
+      if (eleinitq) v += eleinitq[e];
+      q_atoms[i] = v;
+    }
+  }
 }
 
-void launch_charge_from_solution(hipStream_t s, int ne, int row0, int row1, const double *eleallq, const double *elesetq,
-                                 const double *eleinitq, double potdiff, double *q_ele) {
-  if (row1 <= row0) return;
-  hipLaunchKernelGGL(charge_from_solution_kernel, dim3((row1 - row0 + 255) / 256), dim3(256), 0, s, row0, row1, eleallq,
-                     elesetq, eleinitq, potdiff, q_ele);
+void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleall, const int *elecheck, const double *eleallq,
+                          const double *elesetq, const double *eleinitq, double potdiff, double *q_ele, double *q_atoms,
+                          double *left_out) {
+  const int n = q_atoms ? (nall > ne ? nall : ne) : ne;
+  hipLaunchKernelGGL(charge_finish_kernel, dim3((n + 255) / 256 + 1), dim3(256), 0, s, ne, nall, atom2eleall, elecheck, eleallq,
+                     elesetq, eleinitq, potdiff, q_ele, q_atoms, left_out);
 }
 
-__global__ void scatter_charge_kernel(int nall, const int *__restrict__ atom2eleall, const double *__restrict__ q_ele,
-                                      double *__restrict__ q_atoms) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nall) return;
-  const int e = atom2eleall[i];
-  if (e >= 0) q_atoms[i] = q_ele[e];
-}
-
-void launch_scatter_charge(hipStream_t s, int nall, const int *atom2eleall, const double *q_ele, double *q_atoms) {
-  hipLaunchKernelGGL(scatter_charge_kernel, dim3((nall + 255) / 256), dim3(256), 0, s, nall, atom2eleall, q_ele, q_atoms);
-}
-
-// sum of v over the group-1 ("left") electrode atoms (netcharge_left :1149-1151, totsetq :1098-1104); one workgroup
+// sum of v over the group-1 ("left") electrode atoms (totsetq :1098-1104); one workgroup
 __global__ __launch_bounds__(1024) void left_sum_kernel(int ne, const int *__restrict__ elecheck,
                                                         const double *__restrict__ v, double *__restrict__ out) {
   __shared__ double red[16];
