@@ -151,6 +151,10 @@ int conp_fix_get_ele_trig(conp_fix *fix, double *csk, double *snk);    /* [Ne][k
 int conp_inv_project(conp_fix *fix, int n, double *aaa, int nullneutral, int zneutr, const double *eleallz, double zhalf,
                      double *totinve_out);
 
+/* the LU-quality inverse that stands where the reference calls dgetrf_/dgetri_ (fix_conp.cpp:947-949), on a caller-supplied
+ * row-major n x n matrix (host pointer, overwritten).  CONP_ERR_NUMERIC ("Inversion failed!") on a singular matrix. */
+int conp_invert(conp_fix *fix, int n, double *aaa);
+
 /* ---- device-resident operation (bench, GPU-resident MD engines, multi-GPU) -------------------------------------
  * x/q are DEVICE pointers with the same layout as conp_atoms.x/q; nothing crosses PCIe.  One charge update =
  *   conp_fix_b_cal_device  (this rank's shard of b into the bound b buffer: its k-shard for ALL rows + its rows of

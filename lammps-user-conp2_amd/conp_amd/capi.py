@@ -69,7 +69,7 @@ SYMBOLS = [
     "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
     "conp_fix_equation_solve", "conp_fix_update_charge", "conp_km_conp_setup", "conp_km_a_cal", "conp_km_b_cal",
     "conp_fix_info", "conp_fix_get_ktables", "conp_fix_get_maps", "conp_fix_get_matrix", "conp_fix_set_matrix",
-    "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_fix_set_stream",
+    "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_invert", "conp_fix_set_stream",
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
 ]
@@ -112,6 +112,7 @@ def load_library():
     lib.conp_fix_get_sfac.argtypes = [vp, dp, dp]
     lib.conp_fix_get_ele_trig.argtypes = [vp, dp, dp]
     lib.conp_inv_project.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, dp, C.c_double, dp]
+    lib.conp_invert.argtypes = [vp, C.c_int, dp]
     lib.conp_fix_set_stream.argtypes = [vp, vp]
     lib.conp_fix_bind_device_buffers.argtypes = [vp, vp, vp]
     lib.conp_fix_row_range.argtypes = [vp, ip, ip]
@@ -310,6 +311,11 @@ class FixConp:
         tot = C.c_double()
         self._check(self.lib.conp_inv_project(self.h, n, _dptr(a), int(nullneutral), int(zneutr), _dptr(z), zhalf, C.byref(tot)))
         return a, tot.value
+
+    def invert(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).copy()
+        self._check(self.lib.conp_invert(self.h, a.shape[0], _dptr(a)))
+        return a
 
     # -- device-resident path --------------------------------------------------------------------
     def set_stream(self, stream_ptr: int):

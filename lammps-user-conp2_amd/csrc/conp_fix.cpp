@@ -1,7 +1,6 @@
 // Host orchestration of one `fix conp` instance on one MI355X and the C ABI of include/conp_hip.h.
 // Method names mirror FixConp / KSpaceModuleEwald (fix_conp.h:37-74, kspacemodule.h:30-40); citations are
 // file:line in /root/reference.  There is no CPU fallback: every compute entry point needs the HIP device.
-#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -86,33 +85,6 @@ struct Profiler {
   void reset() { collect(); acc.clear(); order.clear(); }
 };
 
-// rocSOLVER is loaded lazily: the once-per-run LU inverse stands where the reference calls LAPACK dgetrf_/dgetri_
-// (fix_conp.cpp:947-949); nothing on the per-step path touches it.
-struct RocSolver {
-  void *h_solver = nullptr, *h_blas = nullptr, *handle = nullptr;
-  int (*create)(void **) = nullptr;
-  int (*destroy)(void *) = nullptr;
-  int (*set_stream)(void *, hipStream_t) = nullptr;
-  int (*dgetrf)(void *, int, int, double *, int, int *, int *) = nullptr;
-  int (*dgetri)(void *, int, double *, int, int *, int *) = nullptr;
-  void load() {
-    if (handle) return;
-    h_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h_blas) h_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    h_solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h_solver) h_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h_blas || !h_solver) throw ConpError(CONP_ERR_NO_DEVICE, std::string("cannot load rocsolver/rocblas: ") + dlerror());
-    create = reinterpret_cast<int (*)(void **)>(dlsym(h_blas, "rocblas_create_handle"));
-    destroy = reinterpret_cast<int (*)(void *)>(dlsym(h_blas, "rocblas_destroy_handle"));
-    set_stream = reinterpret_cast<int (*)(void *, hipStream_t)>(dlsym(h_blas, "rocblas_set_stream"));
-    dgetrf = reinterpret_cast<int (*)(void *, int, int, double *, int, int *, int *)>(dlsym(h_solver, "rocsolver_dgetrf"));
-    dgetri = reinterpret_cast<int (*)(void *, int, double *, int, int *, int *)>(dlsym(h_solver, "rocsolver_dgetri"));
-    if (!create || !set_stream || !dgetrf || !dgetri) throw ConpError(CONP_ERR_NO_DEVICE, "rocsolver symbols missing");
-    if (create(&handle) != 0) throw ConpError(CONP_ERR_NO_DEVICE, "rocblas_create_handle failed");
-  }
-  ~RocSolver() { if (handle && destroy) destroy(handle); }
-};
-
 }  // namespace
 
 using namespace conp;
@@ -143,7 +115,7 @@ struct conp_fix {
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
-      d_cg_ap, d_cg_scal;
+      d_cg_ap, d_cg_scal, d_inv_work;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
       d_elecheck, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
@@ -154,7 +126,6 @@ struct conp_fix {
   int n_slab_part = 0;
   DevPlan dplan{};
   Profiler prof;
-  RocSolver solver;
 
   ~conp_fix() {
     prof.collect();
@@ -439,21 +410,24 @@ struct conp_fix {
     inv_project_device(ne, d_A.p, &z, 0.5 * env.zprd + env.boxlo_z);
   }
 
+  // LU-quality inverse in place of dgetrf_/dgetri_ (fix_conp.cpp:947-949): blocked Gauss-Jordan, partial pivoting
+  void invert_device(int n, double *A) {
+    d_inv_work.reserve(inverse_workspace_doubles(n));
+    d_ipiv.reserve(n + 1); d_info.reserve(2);
+    prof.begin("inverse", stream);
+    launch_inverse(stream, n, A, d_inv_work.p, d_ipiv.p, d_info.p);
+    prof.end(stream);
+    int info = 0;
+    HIP_TRY(hipMemcpyAsync(&info, d_info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    sync();
+    if (info != 0) throw ConpError(CONP_ERR_NUMERIC, "Inversion failed!");   // fix_conp.cpp:956
+  }
+
   // fix_conp.cpp:932-980 inv
   void inv() {
     if (runstage == 2 && args.a_matrix_f < 2) {
       const int ne = idx.elenum_all;
-      solver.load();
-      solver.set_stream(solver.handle, stream);
-      d_ipiv.reserve(ne + 1); d_info.reserve(2);
-      prof.begin("lu_inverse", stream);
-      int rc = solver.dgetrf(solver.handle, ne, ne, d_A.p, ne, d_ipiv.p, d_info.p);
-      rc |= solver.dgetri(solver.handle, ne, d_A.p, ne, d_ipiv.p, d_info.p + 1);
-      prof.end(stream);
-      int info[2] = {0, 0};
-      HIP_TRY(hipMemcpyAsync(info, d_info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
-      sync();
-      if (rc != 0 || info[0] != 0 || info[1] != 0) throw ConpError(CONP_ERR_NUMERIC, "Inversion failed!");
+      invert_device(ne, d_A.p);
       if (!env.one_electrode) inv_project();
     }
     if (runstage == 2) runstage = 3;
@@ -911,6 +885,16 @@ int conp_inv_project(conp_fix *f, int n, double *aaa, int nullneutral, int zneut
   HIP_TRY(hipMemcpyAsync(aaa, dA.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();
   if (totinve_out) *totinve_out = f->totinve;
+  CONP_GUARD_END
+}
+
+int conp_invert(conp_fix *f, int n, double *aaa) {
+  CONP_GUARD_BEGIN
+  DevBuf<double> dA;
+  dA.upload(aaa, (size_t)n * n, f->stream);
+  f->invert_device(n, dA.p);
+  HIP_TRY(hipMemcpyAsync(aaa, dA.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
   CONP_GUARD_END
 }
 

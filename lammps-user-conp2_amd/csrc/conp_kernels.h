@@ -54,6 +54,9 @@ void launch_a_symmetrise(hipStream_t s, int ne, double *A);
 void launch_inv_project(hipStream_t s, int n, double *A, int use_mask, const unsigned char *mask, double *ainve,
                         double *totinve /*device scalar*/, int apply);
 void launch_inv_project_apply(hipStream_t s, int n, double *A, const double *ainve, const double *totinve);
+// in-place inverse (conp_inverse.hip): blocked Gauss-Jordan with partial pivoting; *info != 0 -> singular
+size_t inverse_workspace_doubles(int n);
+void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/);
 // CG (fix_conp.cpp:864-930): state vectors on device; returns via *d_done
 void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, double *q, double *res, double *p,
                     double *scal /*[8]*/);

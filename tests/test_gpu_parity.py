@@ -145,6 +145,32 @@ def test_inv_project_bit_exact(oracle):
     fx.close()
 
 
+def test_inverse_matches_numpy():
+    """the in-place blocked Gauss-Jordan inverse (stands for dgetrf_/dgetri_): general matrices that need row
+    pivoting, sizes that are not multiples of the 64-column block, and a singular matrix -> the reference's "Inversion failed!" error"""
+    from conp_amd import ConpError
+    rng = np.random.default_rng(3)
+    s = systems.small_random()
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    for n in (5, 64, 130, 257, 700):
+        a = rng.normal(size=(n, n))                      # no diagonal dominance: pivoting is exercised
+        inv = fx.invert(a)
+        ref = np.linalg.inv(a)
+        assert np.abs(inv - ref).max() / np.abs(ref).max() < 1e-9 * max(1.0, np.linalg.cond(a) / 1e4), n
+        assert np.abs(inv @ a - np.eye(n)).max() < 1e-8 * max(1.0, np.linalg.cond(a) / 1e4), n
+    m = rng.normal(size=(300, 300)); spd = m @ m.T / 300 + np.eye(300)
+    inv = fx.invert(spd)
+    assert np.abs(inv - np.linalg.inv(spd)).max() / np.abs(inv).max() < 1e-12
+    sing = rng.normal(size=(80, 80)); sing[17] = 0.0
+    with pytest.raises(ConpError) as e:
+        fx.invert(sing)
+    assert "Inversion failed" in str(e.value) and e.value.code == -4
+    fx.close()
+
+
 def test_cg_solver_matches_oracle(oracle):
     s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
     at, alist, blist = neighbor.build_lists(s)
