@@ -56,6 +56,7 @@ typedef struct {
   double tolerance;        /* default 1e-6 (:89) */
   char logfile[512];       /* arg[7] :119 */
   char group2[128];        /* arg[4] :104 */
+  char potdiff_var[128];   /* name after "v_" when potdiff_is_variable (potdiffstr :113) */
 } conp_fix_args;
 
 /* Parses arg[3..narg-1] of the fix command exactly like the reference constructor (same keywords, same

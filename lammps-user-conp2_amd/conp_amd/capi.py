@@ -30,7 +30,7 @@ class conp_fix_args(C.Structure):
                 ("qinit", C.c_int), ("lowmem", C.c_int), ("nullneutral", C.c_int), ("ehgo", C.c_int),
                 ("a_matrix_f", C.c_int), ("a_matrix_file", C.c_char * 512), ("smartlist", C.c_int),
                 ("eletypenum", C.c_int), ("eletypes", C.c_int * 32), ("minimizer", C.c_int), ("maxiter", C.c_int),
-                ("tolerance", C.c_double), ("logfile", C.c_char * 512), ("group2", C.c_char * 128)]
+                ("tolerance", C.c_double), ("logfile", C.c_char * 512), ("group2", C.c_char * 128), ("potdiff_var", C.c_char * 128)]
 
 
 class conp_env(C.Structure):

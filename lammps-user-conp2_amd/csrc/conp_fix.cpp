@@ -618,7 +618,10 @@ int conp_parse_fix_args(int narg, const char *const *arg, int ntypes, conp_fix_a
   if (out->everynum <= 0) throw ConpError(CONP_ERR_ARG, "Illegal fix conp command (Nevery must be positive)");
   std::snprintf(out->group2, sizeof(out->group2), "%s", arg[4]);
   out->eta = numeric(arg[5], "fix conp eta");
-  if (std::strncmp(arg[6], "v_", 2) == 0) out->potdiff_is_variable = 1;
+  if (std::strncmp(arg[6], "v_", 2) == 0) {
+    out->potdiff_is_variable = 1;
+    std::snprintf(out->potdiff_var, sizeof(out->potdiff_var), "%s", arg[6] + 2);
+  }
   else out->potdiff = numeric(arg[6], "fix conp DV");
   std::snprintf(out->logfile, sizeof(out->logfile), "%s", arg[7]);
   for (int iarg = 8; iarg < narg; ++iarg) {

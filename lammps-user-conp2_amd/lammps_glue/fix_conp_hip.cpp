@@ -1,0 +1,179 @@
+// FixConpHip: LAMMPS-facing glue.  Everything numerical happens behind the C ABI of include/conp_hip.h.
+#include "fix_conp_hip.h"
+
+#include <cstring>
+
+#ifndef CONP_GLUE_MOCK
+#include "atom.h"
+#include "comm.h"
+#include "domain.h"
+#include "error.h"
+#include "force.h"
+#include "group.h"
+#include "input.h"
+#include "kspace.h"
+#include "modify.h"
+#include "neigh_list.h"
+#include "neigh_request.h"
+#include "neighbor.h"
+#include "pair.h"
+#include "update.h"
+#include "variable.h"
+#endif
+
+using namespace LAMMPS_NS;
+using namespace FixConst;
+
+void FixConpHip::fail_if(int status) {
+  if (status != CONP_OK) error->all(FLERR, conp_last_error());
+}
+
+FixConpHip::FixConpHip(LAMMPS *lmp, int narg, char **arg)
+    : Fix(lmp, narg, arg), h(nullptr), potdiffvar(-1), arequest(-1), brequest(-1), alist(nullptr), blist(nullptr),
+      coulpair(nullptr), outf(nullptr) {
+  fail_if(conp_parse_fix_args(narg, arg, atom->ntypes, &args));           // fix_conp.cpp:79-176, same syntax and errors
+  jgroup = group->find(args.group2);
+  if (jgroup == -1) error->all(FLERR, "Fix conp group ID does not exist");  // :106-107
+  jgroupbit = group->bitmask[jgroup];
+  outf = fopen(args.logfile, "w");                                         // :119
+  if (comm->nprocs > 1)
+    error->all(FLERR, "fix conp/hip: one MPI rank per fix in this release (multi-GPU runs shard inside the library)");
+  scalar_flag = 1; extscalar = 0; global_freq = 1;                         // :177-179
+}
+
+FixConpHip::~FixConpHip() {
+  conp_fix_destroy(h);
+  if (outf) fclose(outf);
+}
+
+int FixConpHip::setmask() { return POST_NEIGHBOR | PRE_FORCE | POST_FORCE | END_OF_STEP; }   // :233-241
+
+void FixConpHip::init() {
+  coulpair = force->pair_match("coul", 0);                                 // :252-258
+  if (coulpair == nullptr) coulpair = force->pair_match("coul", 0, 1);
+  if (coulpair == nullptr) error->all(FLERR, "Fix conp couldn't detect a Coulombic pair style");
+  if (args.potdiff_is_variable) {                                          // :266-272
+    potdiffvar = input->variable->find(args.potdiff_var);
+    if (potdiffvar < 0) error->all(FLERR, "Fix conp potential difference variable does not exist");
+    if (!input->variable->equalstyle(potdiffvar)) error->all(FLERR, "Fix conp potential difference variable is invalid style");
+  }
+  if (alist == nullptr || blist == nullptr) {                              // :279-291
+    if (args.smartlist) request_smartlist();
+    else {
+      int irequest = neighbor->request(this, instance_me);
+      neighbor->requests[irequest]->pair = 0;
+      neighbor->requests[irequest]->fix = 1;
+    }
+  }
+  if (h == nullptr) {
+    const int nt1 = atom->ntypes + 1;
+    cutsq_flat.resize((size_t)nt1 * nt1);
+    for (int i = 0; i < nt1; ++i)
+      for (int j = 0; j < nt1; ++j) cutsq_flat[(size_t)i * nt1 + j] = (i && j) ? coulpair->cutsq[i][j] : 0.0;
+    int itmp;
+    conp_env env;
+    std::memset(&env, 0, sizeof(env));
+    env.qqrd2e = force->qqrd2e; env.qqr2e = force->qqr2e; env.qe2f = force->qe2f; env.dielectric = force->dielectric;
+    env.newton_pair = force->newton_pair;
+    env.g_ewald = force->kspace->g_ewald; env.accuracy = force->kspace->accuracy;
+    env.slab_volfactor = force->kspace->slab_volfactor; env.slabflag = force->kspace->slabflag;
+    env.xprd = domain->xprd; env.yprd = domain->yprd; env.zprd = domain->zprd; env.boxlo_z = domain->boxlo[2];
+    env.ntypes = atom->ntypes; env.cutsq = cutsq_flat.data();
+    env.cut_coul = *(double *)coulpair->extract("cut_coul", itmp);
+    env.one_electrode = (groupbit == jgroupbit);                           // :295
+    env.device = 0; env.rank = 0; env.nranks = 1;
+    fail_if(conp_fix_create(&args, &env, &h));
+  }
+}
+
+// etypes skip lists, same requests as fix_conp.cpp:304-361
+void FixConpHip::request_smartlist() {
+  const int ntypes = atom->ntypes;
+  int *iskip_a = new int[ntypes + 1], *iskip_b = new int[ntypes + 1];
+  int **ijskip_a = new int *[ntypes + 1], **ijskip_b = new int *[ntypes + 1];
+  for (int i = 0; i <= ntypes; ++i) {
+    ijskip_a[i] = new int[ntypes + 1]; ijskip_b[i] = new int[ntypes + 1];
+    iskip_a[i] = 1; iskip_b[i] = 0;
+    for (int j = 0; j <= ntypes; ++j) ijskip_a[i][j] = 1;
+  }
+  for (int e = 0; e < args.eletypenum; ++e) { iskip_a[args.eletypes[e]] = 0; ijskip_a[args.eletypes[e]][args.eletypes[e]] = 0; }
+  for (int i = 0; i <= ntypes; ++i)
+    for (int j = 0; j <= ntypes; ++j) ijskip_b[i][j] = ((!!iskip_a[i]) ^ (!!iskip_a[j])) ? 0 : 1;
+  if (args.a_matrix_f == 0) {
+    arequest = neighbor->request(this, instance_me);
+    NeighRequest *r = neighbor->requests[arequest];
+    r->pair = 0; r->fix = 1; r->half = 1; r->full = 0; r->occasional = 1; r->skip = 1; r->iskip = iskip_a; r->ijskip = ijskip_a;
+  }
+  brequest = neighbor->request(this, instance_me);
+  NeighRequest *r = neighbor->requests[brequest];
+  r->pair = 0; r->fix = 1; r->half = 1; r->full = 0; r->skip = 1; r->iskip = iskip_b; r->ijskip = ijskip_b;
+}
+
+void FixConpHip::init_list(int, NeighList *ptr) {                         // :365-378
+  if (args.smartlist) {
+    if (ptr->index == arequest) alist = ptr;
+    else if (ptr->index == brequest) blist = ptr;
+  } else { alist = ptr; blist = ptr; }
+}
+
+conp_atoms FixConpHip::view() {
+  const int nall = atom->nlocal + atom->nghost;
+  xbuf.resize(3 * (size_t)nall);
+  echeck.resize(nall);
+  for (int i = 0; i < nall; ++i) {
+    for (int c = 0; c < 3; ++c) xbuf[3 * (size_t)i + c] = atom->x[i][c];
+    echeck[i] = (atom->mask[i] & groupbit) ? 1 : ((atom->mask[i] & jgroupbit) ? -1 : 0);   // electrode_check :599-605
+  }
+  conp_atoms a;
+  a.nlocal = atom->nlocal; a.nghost = atom->nghost; a.x = xbuf.data(); a.q = atom->q; a.type = atom->type; a.tag = atom->tag;
+  a.echeck = echeck.data();
+  return a;
+}
+
+// LAMMPS pages firstneigh; the library wants it flat (once per re-neighbour, not per step)
+void FixConpHip::push_list(int which, NeighList *l, std::vector<int> &first, std::vector<int> &neigh) {
+  const int nall = atom->nlocal + atom->nghost;
+  first.assign(nall, 0);
+  neigh.clear();
+  for (int ii = 0; ii < l->inum; ++ii) {
+    const int i = l->ilist[ii];
+    first[i] = (int)neigh.size();
+    neigh.insert(neigh.end(), l->firstneigh[i], l->firstneigh[i] + l->numneigh[i]);
+  }
+  if (neigh.empty()) neigh.push_back(0);
+  conp_neighlist v;
+  v.inum = l->inum; v.ilist = l->ilist; v.numneigh = l->numneigh; v.first = first.data(); v.neigh = neigh.data();
+  v.nneigh = (int64_t)neigh.size();
+  fail_if(conp_fix_init_list(h, which, &v));
+}
+
+double FixConpHip::potdiff_now() {                                         // :1143
+  return args.potdiff_is_variable ? input->variable->compute_equal(potdiffvar) : args.potdiff;
+}
+
+void FixConpHip::setup_post_neighbor() {                                   // :382-385
+  if (alist->occasional) { neighbor->build(0); neighbor->build_one(alist, 1); }   // :1212-1215 (a_cal needs it once)
+  if (alist == blist) push_list(2, blist, first_b, neigh_b);
+  else { push_list(0, alist, first_a, neigh_a); push_list(1, blist, first_b, neigh_b); }
+  conp_atoms a = view();
+  fail_if(conp_fix_setup_post_neighbor(h, &a));
+}
+
+void FixConpHip::setup_pre_force(int) {                                    // :387-391
+  force->kspace->setup();
+  conp_atoms a = view();
+  fail_if(conp_fix_setup_pre_force(h, &a, (int64_t)update->ntimestep, potdiff_now()));
+}
+
+void FixConpHip::post_neighbor() {                                         // :468-539
+  push_list(alist == blist ? 2 : 1, blist, first_b, neigh_b);
+  conp_atoms a = view();
+  fail_if(conp_fix_post_neighbor(h, &a));
+}
+
+void FixConpHip::pre_force(int) {                                          // :543-573
+  conp_atoms a = view();
+  fail_if(conp_fix_pre_force(h, &a, (int64_t)update->ntimestep, potdiff_now()));
+}
+
+double FixConpHip::compute_scalar() { return conp_fix_compute_scalar(h); }  // :592-595

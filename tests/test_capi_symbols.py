@@ -23,6 +23,7 @@ def test_every_declared_symbol_is_exported():
 def test_fix_command_parser_matches_reference_syntax():
     a = capi.parse_fix_command("e eleleft conp 5 eleright 1.979 v_v log etypes 2 5 3 ffield zneutr".split(), 5)
     assert (a.everynum, a.eta, a.potdiff_is_variable, a.ff_flag, a.zneutr) == (5, 1.979, 1, 1, 1)
+    assert a.potdiff_var == b"v" and a.group2 == b"eleright" and a.logfile == b"log"
     assert a.smartlist == 1 and a.eletypenum == 2 and list(a.eletypes)[:2] == [5, 3]
     assert (a.minimizer, a.maxiter, a.tolerance) == (1, 100, 1e-6)       # fix_conp.cpp:88-90 defaults
     a = capi.parse_fix_command("e l conp 1 r 1.979 2.0 log noslab zneutr matout qinit himem nonneutral".split(), 5)
