@@ -92,6 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
     from conp_amd import FixConp, neighbor
+    from conp_amd.distributed import sharded_update
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,26 +126,30 @@ def main():
     fx.bind_device_buffers(d_b.data_ptr(), d_sol.data_ptr())
     row0, row1 = fx.row_range()
     potdiff = s.potdiff
-    if world > 1:
-        counts = [0] * world
-        gathered = [torch.zeros(1)]  # placeholder; sizes fixed below
-        r0s = [int(ne * r // world) for r in range(world + 1)]
-        even = all((r0s[r + 1] - r0s[r]) == (r0s[1] - r0s[0]) for r in range(world))
+
+    class HipBackend:
+        """plugs the HIP library into conp_amd.distributed.sharded_update (device tensors, RCCL collectives)"""
+
+        def b_local(self):
+            fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())       # k-shard for all rows + own real-space rows -> d_b
+            return d_b
+
+        def solve_rows(self, b):
+            fx.solve_device(potdiff)                              # own rows of S b -> d_sol[row0:row1]
+            return d_sol[row0:row1]
+
+        def finish(self, q_all):
+            if q_all.data_ptr() != d_sol.data_ptr():
+                d_sol.copy_(q_all)
+            fx.scatter_device(d_q.data_ptr(), potdiff)
+
+    backend = HipBackend()
 
     def step():
         if world == 1:
             fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), potdiff)
         else:
-            fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())
-            dist.all_reduce(d_b)                                  # b rows + k-shards (Ne doubles)
-            fx.solve_device(potdiff)
-            if even:
-                dist.all_gather_into_tensor(d_sol, d_sol[row0:row1].clone())
-            else:
-                parts = [torch.empty(r0s[r + 1] - r0s[r], dtype=torch.float64, device="cuda") for r in range(world)]
-                dist.all_gather(parts, d_sol[row0:row1].clone())
-                d_sol.copy_(torch.cat(parts))
-            fx.scatter_device(d_q.data_ptr(), potdiff)
+            sharded_update(backend, ne, rank, world)
 
     def fence():
         if world > 1:
@@ -192,8 +197,17 @@ def main():
         if "sk_gemm" in prof:
             t_ms = prof["sk_gemm"][0]
             ach = flops / (t_ms * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            pj = os.path.join(ROOT, "profiles", "r01_bench_headline_summary.json")
+            if args.workload == "headline" and world == 1 and os.path.exists(pj):
+                pm = json.load(open(pj)).get("pmc", {}).get("sk_gemm_kernel", {})
+                if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                    # rocprofv3 reports KiB; FETCH_SIZE x2: gfx950 counts 16-B-per-lane streams at half (MI355X_MICROARCH.md, HBM)
+                    traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+                    traffic_src = "profiles/r01_bench_headline_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             roofline = dict(bound="mfma", kernel="sk_gemm_kernel (v_mfma_f64_16x16x4_f64)", achieved=ach, peak=FP64_PEAK_TFLOPS,
-                            unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=None, avg_launch_ms=t_ms,
+                            unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_src,
+                            avg_launch_ms=t_ms,
                             algorithmic_flops_per_launch=flops, survey_count_tflops=2 * ach,
                             note="achieved uses 4 flop per (k, atom); SURVEY 8d's reference-loop count (8 per k) would double it")
         out = dict(metric="charge-solve updates/sec + ns/day, 4096-atom electrode / 32k electrolyte", value=value,

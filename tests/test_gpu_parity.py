@@ -223,3 +223,65 @@ def test_pre_force_respects_nevery_and_reneighbor(oracle):
     ele = at2.echeck != 0
     assert rel_err(at2.q[ele], o.q[ele]) < TOL_Q
     fx.close(); o.fx.close()
+
+
+def _gpu_shard_worker(rank, world, port, out):
+    import os, sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "lammps-user-conp2_amd"))
+    from conp_amd import FixConp, neighbor, systems
+    from conp_amd.distributed import sharded_update
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks drive cuda:0; collectives over gloo
+    s = systems.deck("dilute", "slab", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s, device=0, rank=rank, nranks=world)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.linalg_setup(at)
+    ne = fx.info().elenum_all
+    d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda()
+    d_q = torch.from_numpy(at.q.copy()).cuda()
+    d_b = torch.zeros(ne, dtype=torch.float64, device="cuda")
+    d_sol = torch.zeros(ne, dtype=torch.float64, device="cuda")
+    fx.bind_device_buffers(d_b.data_ptr(), d_sol.data_ptr())
+    r0, r1 = fx.row_range()
+
+    class Backend:
+        def b_local(self):
+            fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr()); torch.cuda.synchronize()
+            return d_b.cpu()
+        def solve_rows(self, b):
+            d_b.copy_(b); fx.solve_device(s.potdiff); torch.cuda.synchronize()
+            return d_sol[r0:r1].cpu()
+        def finish(self, q_all):
+            d_sol.copy_(q_all); fx.scatter_device(d_q.data_ptr(), s.potdiff); torch.cuda.synchronize()
+
+    b, q_all = sharded_update(Backend(), ne, rank, world)
+    out[rank] = (b.numpy().copy(), q_all.numpy().copy(), d_q.cpu().numpy().copy(), (r0, r1))
+    fx.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_on_one_gpu_matches_single_rank():
+    """k-shard + row-shard device path (conp_fix_b_cal_device / solve_device / scatter_device) with world_size 2:
+    both ranks use cuda:0, the two collectives run over gloo; result == the unsharded update"""
+    import torch.multiprocessing as mp
+    s = systems.deck("dilute", "slab", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    b1, q1, _ = fx.vectors()
+    fx.close()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_gpu_shard_worker, args=(2, 29871, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        b, q_all, q_atoms, rr = out[rank]
+        assert rel_err(b, b1) < 1e-12 and rel_err(q_all, q1) < 1e-11
+        ele = at.echeck != 0
+        assert rel_err(q_atoms[ele], at.q[ele]) < 1e-11
+    assert out[0][3][1] == out[1][3][0]
