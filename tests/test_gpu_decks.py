@@ -1,0 +1,121 @@
+"""-m gpu: the reference's ionic-liquid decks (BASELINE configs[1], [2]) and the headline-size box.
+
+il_onelayer / il_twolayer: full parity against the CPU oracle (Ne = 832 / 1664 -- the oracle needs tens of seconds for
+its A matrix, so these share one oracle run per deck).  Headline size (4096 / 32768): the oracle's A build would take
+hours, so the checks are size-independent properties plus an oracle comparison of the per-step b vector."""
+import numpy as np
+import pytest
+
+from conp_amd import FixConp, neighbor, systems
+from helpers import OracleRun, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("deck,mode,extra", [
+    ("il_onelayer", "ffield", ()),
+    ("il_onelayer", "slab", ()),
+    ("il_twolayer", "ffield", ("cg",)),        # BASELINE configs[2]: CG solver + etypes split lists
+])
+def test_il_decks_match_oracle(oracle, deck, mode, extra):
+    s = systems.deck(deck, mode, etypes=True, shuffle_seed=11)
+    at, alist, blist = neighbor.build_lists(s)
+    cg = "cg" in extra
+    o = OracleRun(oracle, s, at, alist, blist, minimizer=0 if cg else 1)
+    o.setup()
+    fx = FixConp(s, extra_args=list(extra))
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    q0 = at.q.copy()
+    fx.setup_pre_force(at, 0, s.potdiff)
+    o.pre_force(s.potdiff)
+    info = fx.info()
+    assert info.elenum_all == (832 if deck == "il_onelayer" else 1664)
+    for name, v in o.fx.maps().items():
+        assert np.array_equal(v, fx.maps()[name]), name
+    kt = fx.ktables()
+    for name in ("kxvecs", "kyvecs", "kzvecs", "kxy_list", "kz_list", "ug"):
+        assert np.array_equal(kt[name], getattr(o.fx.ks, name)), name
+    sr_o, si_o = o.fx.ks.sincos_b(at.x, q0, at.echeck, at.nlocal)
+    sr_g, si_g = fx.sfac()
+    scale = max(np.abs(sr_o).max(), np.abs(si_o).max())
+    assert max(np.abs(sr_g - sr_o).max(), np.abs(si_g - si_o).max()) / scale < 1e-11
+    b_o, q_o, sq_o = o.fx.vectors()
+    b_g, q_g, sq_g = fx.vectors()
+    assert rel_err(b_g, b_o) < 1e-10
+    tol = 1e-6 if cg else 1e-8
+    assert rel_err(sq_g, sq_o) < tol and rel_err(q_g, q_o) < tol
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < tol
+    assert abs(at.q[:at.nlocal][at.echeck[:at.nlocal] != 0].sum()) < 1e-11
+    if not cg:
+        assert rel_err(fx.matrix(), o.fx.matrix()) < 1e-8
+    assert fx.compute_scalar() == pytest.approx(o.fx.scalars()["scalar_output"], rel=1e-6, abs=1e-10)
+    fx.close(); o.fx.close()
+
+
+@pytest.fixture(scope="module")
+def headline():
+    s = systems.synthetic_fast()          # 4096 electrode / 32768 electrolyte, ffield (bench.py's workload)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.linalg_setup(at)
+    yield s, at, alist, blist, fx
+    fx.close()
+
+
+def test_headline_b_vector_matches_oracle(oracle, headline):
+    """k-space + real-space b at the full benchmark size against the oracle's sincos_b / bbb / blist loops"""
+    import oracle_py
+    s, at, alist, blist, fx = headline
+    fx.b_cal(at)
+    b_g, _, _ = fx.vectors()
+    o = OracleRun(oracle, s, at, alist, blist)          # post_neighbor only: no A matrix needed for b
+    m = o.fx.maps()
+    loc = {int(t): i for i, t in enumerate(at.tag[:at.nlocal])}
+    xele = np.array([at.x[loc[int(t)]] for t in m["eleall2tag"]])
+    fast = oracle_py.load(fast=True); fast.orc_set_threads(16)    # same arithmetic, OpenMP over k rows
+    ks = oracle_py.KSpace.from_system(fast, s)
+    sr, si = ks.sincos_b(at.x, at.q, at.echeck, at.nlocal)
+    csk, snk = ks.ele_trig(xele)
+    b_o = ks.bbb(csk, snk, sr, si)
+    breal = np.zeros(len(b_o)); breal[m["ele2eleall"]] = o.fx.blist_only()
+    b_o += breal
+    sr_g, si_g = fx.sfac()
+    scale = max(np.abs(sr).max(), np.abs(si).max())
+    assert max(np.abs(sr_g - sr).max(), np.abs(si_g - si).max()) / scale < 1e-11
+    assert rel_err(b_g, b_o) < 1e-10
+    info = fx.info()
+    assert (info.elenum_all, info.n_elyte_charged) == (4096, 32768) and info.kcount == ks.kcount
+    ks.close(); o.fx.close()
+
+
+def test_headline_properties(headline):
+    s, at, alist, blist, fx = headline
+    S = fx.matrix()
+    n = S.shape[0]
+    # projected inverse: symmetric, S e = 0 (electroneutrality for any b), S A S = S
+    assert np.abs(S - S.T).max() / np.abs(S).max() < 1e-9
+    assert np.abs(S.sum(axis=1)).max() / np.abs(S).max() < 1e-9
+    # one update: charges neutral, scalar consistent, electrolyte untouched
+    q_before = at.q.copy()
+    fx.pre_force(at, 0, s.potdiff)
+    ele = at.echeck != 0
+    assert abs(at.q[:at.nlocal][ele[:at.nlocal]].sum()) < 1e-9
+    assert np.array_equal(at.q[~ele], q_before[~ele])
+    b, q, setq = fx.vectors()
+    assert rel_err(S @ b, q) < 1e-10                       # the GEMV really is S b
+    left = fx.maps()["elecheck_eleall"] == 1
+    assert fx.compute_scalar() == pytest.approx(s.potdiff * setq[left].sum() + q[left].sum(), rel=1e-9)
+    # linearity in the electrolyte charges: b(2 q) = 2 b(q)  (exact in binary floating point up to the last bits)
+    at2_q = at.q.copy(); at2_q[~ele] *= 2.0
+    at2 = neighbor.Atoms(nlocal=at.nlocal, nghost=at.nghost, x=at.x, q=at2_q, type=at.type, tag=at.tag, echeck=at.echeck, owner=at.owner)
+    fx.b_cal(at2)
+    b2, _, _ = fx.vectors()
+    assert rel_err(b2, 2.0 * b) < 1e-13
+    # idempotence: the same inputs give bitwise the same b (fixed summation trees, no atomics)
+    fx.b_cal(at2)
+    b3, _, _ = fx.vectors()
+    assert np.array_equal(b2, b3)
