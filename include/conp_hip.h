@@ -134,6 +134,7 @@ typedef struct {
   int kcount, kcount_flat, kcount_expand, kxmax, kymax, kzmax, kmax, kmax3d;
   int kcount_dims[7];
   int cg_iterations;
+  int n_zclasses;          /* distinct electrode z values when the planar fast path of the projection is active, else 0 */
   double unitk[3], volume, gsqmx, ug_tot, totsetq, scalar_output, totinve, slabcorr;
   int64_t n_blist_pairs, n_alist_pairs, n_elyte_charged;
 } conp_info;

@@ -56,7 +56,7 @@ class conp_info(C.Structure):
     _fields_ = [("elenum", C.c_int), ("elenum_all", C.c_int), ("elytenum", C.c_int), ("maxtag_all", C.c_int),
                 ("runstage", C.c_int), ("kcount", C.c_int), ("kcount_flat", C.c_int), ("kcount_expand", C.c_int),
                 ("kxmax", C.c_int), ("kymax", C.c_int), ("kzmax", C.c_int), ("kmax", C.c_int), ("kmax3d", C.c_int),
-                ("kcount_dims", C.c_int * 7), ("cg_iterations", C.c_int), ("unitk", C.c_double * 3),
+                ("kcount_dims", C.c_int * 7), ("cg_iterations", C.c_int), ("n_zclasses", C.c_int), ("unitk", C.c_double * 3),
                 ("volume", C.c_double), ("gsqmx", C.c_double), ("ug_tot", C.c_double), ("totsetq", C.c_double),
                 ("scalar_output", C.c_double), ("totinve", C.c_double), ("slabcorr", C.c_double),
                 ("n_blist_pairs", C.c_int64), ("n_alist_pairs", C.c_int64), ("n_elyte_charged", C.c_int64)]

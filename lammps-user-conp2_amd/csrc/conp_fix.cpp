@@ -108,6 +108,7 @@ struct conp_fix {
   std::vector<int> ct_ptr_h, seg_ptr_h;
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
+  int nzc = 0;               // distinct electrode z values (<= 64: planar fast path of the projection), else 0
   std::vector<double> csk_h, snk_h, xele_h, d_vec_h;
   std::vector<int> atom2eleall_h, elyte_idx_h;
   // device state
@@ -115,10 +116,10 @@ struct conp_fix {
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
-      d_cg_ap, d_cg_scal, d_inv_work;
+      d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -223,7 +224,7 @@ struct conp_fix {
     if (grew) {
       ne_pad = (ne + 127) / 128 * 128;
       d_A.reserve((size_t)ne * ne);
-      d_bk.reserve(2 * (size_t)ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(ne_pad); d_eleallq_own.reserve(ne_pad); d_qele.reserve(ne_pad);
+      d_bk.reserve(4 * (size_t)ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(ne_pad); d_eleallq_own.reserve(ne_pad); d_qele.reserve(ne_pad);
       d_elesetq.reserve(ne_pad); d_eleinitq.reserve(ne_pad); d_ele_z.reserve(ne_pad); d_elecheck.reserve(ne_pad);
       d_ainve.reserve(ne_pad);
       d_bk.zero(stream); d_breal.zero(stream); d_b_own.zero(stream); d_eleallq_own.zero(stream); d_qele.zero(stream);
@@ -318,6 +319,25 @@ struct conp_fix {
     electrode_plan_tables(kt, plan, ne, ne_pad, csk_h, snk_h, Rp, Tz);
     for (int i = 0; i < ne; ++i) z[i] = xele_h[3 * (size_t)i + 2];
     d_Rp.upload(Rp, stream); d_Tz.upload(Tz, stream); d_ele_z.upload(z, stream);
+    // z classes: atoms with bitwise equal z share their Tz column
+    {
+      std::map<double, int> cls;
+      std::vector<int> zclass(ne_pad, 0), rep;
+      for (int i = 0; i < ne; ++i) {
+        auto it = cls.find(z[i]);
+        if (it == cls.end()) { it = cls.emplace(z[i], (int)cls.size()).first; rep.push_back(i); }
+        zclass[i] = it->second;
+      }
+      const bool off = getenv("CONP_NO_ZCLASS") != nullptr;
+      nzc = (!off && cls.size() <= 64 && 4 * cls.size() <= (size_t)ne) ? (int)cls.size() : 0;   // worthwhile only if it compresses
+      if (nzc > 0) {
+        std::vector<double> Tzc((size_t)plan.C_pad * 64, 0.0);
+        for (int t = 0; t < plan.C_pad; ++t)
+          for (int c = 0; c < nzc; ++c) Tzc[(size_t)t * 64 + c] = Tz[(size_t)t * ne_pad + rep[c]];
+        d_Tzc.upload(Tzc, stream); d_zclass.upload(zclass, stream);
+        d_Hc.reserve((size_t)4 * plan.R_pad * 64);
+      }
+    }
     sync();
   }
 
@@ -507,7 +527,11 @@ struct conp_fix {
     launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), d_Gpart.p, d_G.p, d_Gw.p);
     prof.end(stream);
     prof.begin("b_project", stream);
-    launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
+    if (nzc > 0)
+      launch_b_project_zclass(stream, dplan, ne_pad, env.rank, env.nranks, nzc, d_Gw.p, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p,
+                              d_bk.p);
+    else
+      launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
     prof.end(stream);
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     prof.begin("b_real_combine", stream);
@@ -797,6 +821,7 @@ int conp_fix_info(const conp_fix *f, conp_info *o) {
   o->kxmax = f->kt.kxmax; o->kymax = f->kt.kymax; o->kzmax = f->kt.kzmax; o->kmax = f->kt.kmax; o->kmax3d = f->kt.kmax3d;
   for (int i = 0; i < 7; ++i) o->kcount_dims[i] = f->kt.kcount_dims[i];
   o->cg_iterations = f->cg_iterations;
+  o->n_zclasses = f->nzc;
   for (int i = 0; i < 3; ++i) o->unitk[i] = f->kt.unitk[i];
   o->volume = f->kt.volume; o->gsqmx = f->kt.gsqmx; o->ug_tot = f->kt.ug_tot; o->totsetq = f->totsetq;
   o->scalar_output = f->scalar_output; o->totinve = f->totinve; o->slabcorr = f->slabcorr;

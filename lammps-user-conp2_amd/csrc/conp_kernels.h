@@ -32,7 +32,11 @@ void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int
 void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,
                         const int *k_sign, const double *G, double *sfacrl, double *sfacim);
 void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr /*[n_col_tiles+1]*/, const SkTile *tiles,
-                      const double *Gwf, const double *Rp, const double *Tz, double *bk_part /*[2][ne_pad] overwritten*/);
+                      const double *Gwf, const double *Rp, const double *Tz, double *bk_part /*[4][ne_pad] overwritten*/);
+// planar-electrode fast path of the projection (<= 64 distinct electrode z values)
+void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, int rank, int nranks, int nzc, const double *Gwf,
+                             const double *Tzc /*[C_pad][64]*/, const double *Rp, const int *zclass /*[ne_pad]*/,
+                             double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/);
 // this rank's contribution to b in one launch: k-space halves + slab (rank 0) + real-space rows row0..row1
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
                            const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,

@@ -433,6 +433,7 @@ __global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, 
     double sum = 0.0;
     for (int w = 0; w < 16; ++w) sum += red[w * 32 + t];
     bk_part[(size_t)half * ne_pad + i0 + t] = -sum;
+    bk_part[(size_t)(2 + half) * ne_pad + i0 + t] = 0.0;     // slots 2, 3 belong to the planar fast path
   }
 }
 
@@ -442,6 +443,76 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(b_project_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 32, 2), dim3(1024), lds, s, pl.C_pad, ne_pad, pl.n_col_tiles, ct_ptr, tiles,
                      Gwf, Rp, Tz, bk_part);
+}
+
+// ---- planar-electrode fast path ------------------------------------------------------------------------------------
+// Electrode atoms that share a z coordinate (graphene sheets: every atom of a layer) share their z-phase column Tz[:, i].
+// With at most 64 distinct z values ("z classes") the projection factorises:
+//     Hc[r][zc] = sum_t (w G)[r][t] * Tzc[t][zc]            R_pad x 64   (MFMA, 1/64 of the general work)
+//     b_i      = - sum_r Rp[r][i] * Hc[r][zclass(i)]        one 2*n_p-term dot product per atom
+// Same arithmetic per term as the general kernel; only the grouping of equal columns changes.
+// grid = (R_pad/16 row fragments, 4 k-quarters); one wave per (fragment, quarter, 16-class group)
+__global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, int rank, int nranks, int nzc16,
+                                                   const int *__restrict__ nb_act, const double *__restrict__ Gwf,
+                                                   const double *__restrict__ Tzc /*[C_pad][64]*/,
+                                                   double *__restrict__ Hc4 /*[4][R_pad][64]*/, int R_pad) {
+  const int rf = blockIdx.x, rt = rf >> 3, kq = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  if (wave >= nzc16) return;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  if (rt % nranks == rank) {
+    for (int ct = 0; ct < n_col_tiles; ++ct) {
+      int nba = nb_act[rt] - 10 * ct;
+      nba = nba < 0 ? 0 : (nba > 10 ? 10 : nba);
+      const int nks = 8 * nba, t0 = nks * kq / 4, t1 = nks * (kq + 1) / 4;
+      const double *ap = Gwf + ((size_t)rf * (C_pad / 4) + (size_t)ct * 80) * 64 + lane;
+      const double *bp = Tzc + (size_t)(ct * 320 + fk) * 64 + 16 * wave + fr;
+#pragma unroll 8
+      for (int ts = t0; ts < t1; ++ts) acc = MFMA_F64(ap[(size_t)ts * 64], bp[(size_t)ts * 256], acc);
+    }
+  }
+  double *out = Hc4 + (size_t)kq * R_pad * 64;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(size_t)(16 * rf + fk + 4 * r) * 64 + 16 * wave + fr] = acc[r];
+}
+
+// grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16
+__global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_row_tiles, int R_pad, int ne_pad, int rank, int nranks,
+                                                        const double *__restrict__ Rp, const double *__restrict__ Hc4,
+                                                        const int *__restrict__ zclass, double *__restrict__ bk) {
+  __shared__ double red[16][64];
+  const int a = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + a;
+  const int zc = zclass[i];
+  const size_t hp = (size_t)R_pad * 64;
+  double sum = 0.0;
+  for (int rt = rank; rt < n_row_tiles; rt += nranks) {
+    const int rbase = rt * 128 + blockIdx.y * 32;           // this quarter's 32 rows of the tile
+#pragma unroll
+    for (int rr = w; rr < 32; rr += 16) {
+      const size_t r = rbase + rr;
+      const double h = (Hc4[r * 64 + zc] + Hc4[hp + r * 64 + zc]) + (Hc4[2 * hp + r * 64 + zc] + Hc4[3 * hp + r * 64 + zc]);
+      sum += Rp[r * ne_pad + i] * h;
+    }
+  }
+  red[w][a] = sum;
+  __syncthreads();
+  if (w == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[k][a];
+    bk[(size_t)blockIdx.y * ne_pad + i] = -tot;
+  }
+}
+
+void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, int rank, int nranks, int nzc, const double *Gwf,
+                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part) {
+  const int nzc16 = (nzc + 15) / 16;
+  hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rank, nranks, nzc16,
+                     pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
+  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), 0, s, pl.n_row_tiles, pl.R_pad, ne_pad, rank, nranks, Rp, Hc,
+                     zclass, bk_part);
 }
 
 // ================================================================================================
@@ -498,7 +569,7 @@ __global__ __launch_bounds__(256) void b_real_combine_kernel(int ne, int ne_pad,
     sc = slab_pref * __shfl(sp, 0, 64);
   }
   if (lane == 0) {
-    double v = add_k ? bk[row] + bk[ne_pad + row] : 0.0;
+    double v = add_k ? (bk[row] + bk[ne_pad + row]) + (bk[2 * (size_t)ne_pad + row] + bk[3 * (size_t)ne_pad + row]) : 0.0;
     if (slab) v -= ele_z[row] * sc;
     v += sum;
     b_out[row] = v;

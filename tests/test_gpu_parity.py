@@ -27,7 +27,17 @@ CASES = {
     "dilute_slab_generic_list": lambda: systems.deck("dilute", "slab", etypes=False, shuffle_seed=5),
     "small_ffield": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0),
     "small_slab": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab"),
+    # rough electrodes: every atom has its own z -> the general (non z-class) projection kernel
+    "small_rough_ffield": lambda: rough(systems.small_random(ne_side=4, n_elyte=96, lz=60.0)),
+    "dilute_rough_slab": lambda: rough(systems.deck("dilute", "slab", etypes=True)),
 }
+
+
+def rough(s, amp=0.05, seed=4):
+    rng = np.random.default_rng(seed)
+    ele = s.echeck != 0
+    s.x[ele, 2] += rng.uniform(-amp, amp, size=int(ele.sum()))
+    return s
 
 
 def run_pair(oracle, s, extra=(), okw=None, special_frac=0.0):
@@ -95,6 +105,7 @@ def test_full_chain_matches_oracle(oracle, case):
     assert np.array_equal(at.q[~ele], q_before[~ele])       # electrolyte untouched
     assert abs(at.q[:at.nlocal][at.echeck[:at.nlocal] != 0].sum()) < 1e-12   # electroneutral
     assert np.array_equal(o.fx.maps()["elecheck_eleall"], fx.maps()["elecheck_eleall"])
+    assert (fx.info().n_zclasses == 0) == ("rough" in case)      # planar decks take the z-class fast path
     sc_o = o.fx.scalars()
     assert fx.compute_scalar() == pytest.approx(sc_o["scalar_output"], rel=1e-7, abs=1e-12)
     assert fx.info().totsetq == pytest.approx(sc_o["totsetq"], rel=1e-7)
