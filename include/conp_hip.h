@@ -57,6 +57,7 @@ typedef struct {
   char logfile[512];       /* arg[7] :119 */
   char group2[128];        /* arg[4] :104 */
   char potdiff_var[128];   /* name after "v_" when potdiff_is_variable (potdiffstr :113) */
+  int conq;                /* 1 when arg[2] names the conq style (fix_conq.h:21): DV is then the prescribed charge QR */
 } conp_fix_args;
 
 /* Parses arg[3..narg-1] of the fix command exactly like the reference constructor (same keywords, same
@@ -115,6 +116,12 @@ int conp_fix_setup_pre_force(conp_fix *fix, const conp_atoms *atoms, int64_t nti
 int conp_fix_post_neighbor(conp_fix *fix, const conp_atoms *atoms);       /* :468-539 */
 int conp_fix_pre_force(conp_fix *fix, const conp_atoms *atoms, int64_t ntimestep, double potdiff); /* :543-573 */
 double conp_fix_compute_scalar(const conp_fix *fix);                      /* :592-595 */
+/* FixConp::post_force -> force_cal (fix_conp.cpp:577-580, 1163-1201) + blist_coul_cal_post_force (:1368-1444), ETA pair mode:
+ * adds the real-space Gaussian-correction forces to f[nall][3] (host, accumulated like atom->f) and returns what the reference
+ * adds to force->kspace->energy (Gaussian self energy) and, through Pair::ev_tally, to eng_coul and the global virial
+ * (xx,yy,zz,xy,xz,yz).  The reference's arithmetic is kept as written, including `del*forcecoul` and the `eta^2 r^2 < 5.8` gate. */
+int conp_fix_post_force(conp_fix *fix, const conp_atoms *atoms, double *f, double *kspace_energy_add, double *eng_coul_add,
+                        double *virial_add /*[6]*/);
 
 /* finer-grained pieces of the same path (same names as the reference's methods) */
 int conp_fix_linalg_setup(conp_fix *fix, const conp_atoms *atoms);        /* :426-464 a_cal, b_setq_cal, equation_solve, get_setq */

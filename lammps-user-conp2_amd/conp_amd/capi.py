@@ -30,7 +30,7 @@ class conp_fix_args(C.Structure):
                 ("qinit", C.c_int), ("lowmem", C.c_int), ("nullneutral", C.c_int), ("ehgo", C.c_int),
                 ("a_matrix_f", C.c_int), ("a_matrix_file", C.c_char * 512), ("smartlist", C.c_int),
                 ("eletypenum", C.c_int), ("eletypes", C.c_int * 32), ("minimizer", C.c_int), ("maxiter", C.c_int),
-                ("tolerance", C.c_double), ("logfile", C.c_char * 512), ("group2", C.c_char * 128), ("potdiff_var", C.c_char * 128)]
+                ("tolerance", C.c_double), ("logfile", C.c_char * 512), ("group2", C.c_char * 128), ("potdiff_var", C.c_char * 128), ("conq", C.c_int)]
 
 
 class conp_env(C.Structure):
@@ -66,7 +66,7 @@ class conp_info(C.Structure):
 SYMBOLS = [
     "conp_parse_fix_args", "conp_fix_create", "conp_fix_destroy", "conp_last_error", "conp_abi_version",
     "conp_fix_init_list", "conp_fix_setup_post_neighbor", "conp_fix_setup_pre_force", "conp_fix_post_neighbor",
-    "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
+    "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_post_force", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
     "conp_fix_equation_solve", "conp_fix_update_charge", "conp_km_conp_setup", "conp_km_a_cal", "conp_km_b_cal",
     "conp_fix_info", "conp_fix_get_ktables", "conp_fix_get_maps", "conp_fix_get_matrix", "conp_fix_set_matrix",
     "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_invert", "conp_fix_set_stream",
@@ -98,6 +98,7 @@ def load_library():
         getattr(lib, n).argtypes = [vp, C.POINTER(conp_atoms), C.c_int64, C.c_double]
     lib.conp_fix_compute_scalar.argtypes = [vp]
     lib.conp_fix_compute_scalar.restype = C.c_double
+    lib.conp_fix_post_force.argtypes = [vp, C.POINTER(conp_atoms), dp, dp, dp, dp]
     lib.conp_fix_equation_solve.argtypes = [vp]
     lib.conp_fix_update_charge.argtypes = [vp, C.POINTER(conp_atoms), C.c_double]
     lib.conp_km_conp_setup.argtypes = [vp, C.c_double, C.c_int64]
@@ -145,9 +146,9 @@ def parse_fix_command(tokens: Sequence[str], ntypes: int) -> conp_fix_args:
     return out
 
 
-def fix_command_for(s: "_systems.System", extra: Sequence[str] = ()) -> list:
+def fix_command_for(s: "_systems.System", extra: Sequence[str] = (), style: str = "conp") -> list:
     """the fix command the reference's decks would use for this system"""
-    toks = ["e", "eleleft", "conp", "1", "eleright", repr(float(s.eta)), repr(float(s.potdiff)), "log_conp"]
+    toks = ["e", "eleleft", style, "1", "eleright", repr(float(s.eta)), repr(float(s.potdiff)), "log_conp"]
     if s.eletypes is not None:
         toks += ["etypes", str(len(s.eletypes))] + [str(t) for t in s.eletypes]
     if s.ff_flag == 1:
@@ -164,10 +165,10 @@ class FixConp:
     init_list -> setup_post_neighbor -> setup_pre_force -> [post_neighbor] -> pre_force ...."""
 
     def __init__(self, s: "_systems.System", extra_args: Sequence[str] = (), device: int = 0, rank: int = 0,
-                 nranks: int = 1, one_electrode: bool = False):
+                 nranks: int = 1, one_electrode: bool = False, style: str = "conp"):
         self.lib = load_library()
         self.s = s
-        self.args = parse_fix_command(fix_command_for(s, extra_args), s.ntypes)
+        self.args = parse_fix_command(fix_command_for(s, extra_args, style), s.ntypes)
         self._cutsq = np.ascontiguousarray(s.cutsq_table())
         env = conp_env(qqrd2e=_systems.QQRD2E, qqr2e=_systems.QQR2E, qe2f=_systems.QE2F, dielectric=1.0,
                        newton_pair=int(s.newton), g_ewald=s.g_ewald, accuracy=s.accuracy,
@@ -233,6 +234,11 @@ class FixConp:
     def update_charge(self, at, potdiff=None):
         pd = self.s.potdiff if potdiff is None else potdiff
         self._check(self.lib.conp_fix_update_charge(self.h, C.byref(self.atoms_view(at)), pd))
+
+    def post_force(self, at):
+        f = np.zeros((at.nlocal + at.nghost, 3)); ek = C.c_double(); ec = C.c_double(); vir = np.zeros(6)
+        self._check(self.lib.conp_fix_post_force(self.h, C.byref(self.atoms_view(at)), _dptr(f), C.byref(ek), C.byref(ec), _dptr(vir)))
+        return f, ek.value, ec.value, vir
 
     def compute_scalar(self):
         return float(self.lib.conp_fix_compute_scalar(self.h))

@@ -110,16 +110,17 @@ struct conp_fix {
   int cg_iterations = 0;
   int nzc = 0;               // distinct electrode z values (<= 64: planar fast path of the projection), else 0
   std::vector<double> csk_h, snk_h, xele_h, d_vec_h;
-  std::vector<int> atom2eleall_h, elyte_idx_h;
+  std::vector<int> atom2eleall_h, elyte_idx_h, pf_i_h, pf_j_h;
+  int nlocal_cur = 0;
   // device state
   hipStream_t stream = nullptr;
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
-      d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc;
+      d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc, d_f, d_pfacc;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -250,6 +251,9 @@ struct conp_fix {
     // real-space rows of b
     build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
     d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
+    build_pf_pairs(blist, at->echeck, pf_i_h, pf_j_h);
+    d_pf_i.upload(pf_i_h, stream); d_pf_j.upload(pf_j_h, stream);
+    nlocal_cur = at->nlocal;
     sync();
   }
 
@@ -558,16 +562,25 @@ struct conp_fix {
   void scatter_device(double *d_q_atoms, double potdiff) {
     const int ne = idx.elenum_all;
     prof.begin("charge_write", stream);
-    launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
-                         args.qinit ? d_eleinitq.p : nullptr, potdiff, d_qele.p, d_q_atoms, d_scalars.p + 1);
+    if (args.conq) {
+      // fix conq (fix_conq.cpp:41-90): `potdiff` carries the prescribed charge QR; the potential difference follows from
+      // the group-1 sum of S b, all on the device
+      launch_left_sum(stream, ne, d_elecheck.p, d_eleallq, d_scalars.p + 1);
+      launch_conq_potdiff(stream, d_scalars.p + 1, potdiff, totsetq, env.one_electrode, d_scalars.p + 3);
+      launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
+                           args.qinit ? d_eleinitq.p : nullptr, 0.0, d_scalars.p + 3, d_qele.p, d_q_atoms, nullptr);
+    } else {
+      launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
+                           args.qinit ? d_eleinitq.p : nullptr, potdiff, nullptr, d_qele.p, d_q_atoms, d_scalars.p + 1);
+    }
     prof.end(stream);
   }
 
   void finish_scalar(double potdiff) {
-    double h[3];
-    HIP_TRY(hipMemcpyAsync(h, d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    double h[4];
+    HIP_TRY(hipMemcpyAsync(h, d_scalars.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
-    scalar_output = potdiff * totsetq + h[1];   // :1159
+    scalar_output = args.conq ? h[3] : potdiff * totsetq + h[1];   // fix_conp.cpp:1159 / fix_conq.cpp:78-80
     slabcorr = h[2];
   }
 
@@ -584,6 +597,26 @@ struct conp_fix {
       if (!at->echeck[i]) continue;
       at->q[i] = qe[idx.tag2eleall[at->tag[i]]];
     }
+  }
+
+  // fix_conp.cpp:577-580 post_force -> :1163-1201 force_cal + :1368-1444 blist_coul_cal_post_force
+  void post_force(const conp_atoms *at, double *f, double *ek, double *ec, double *vir) {
+    if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
+    upload_xq(at);   // charges were just updated by pre_force on the host side
+    d_f.reserve((size_t)nall * 3); d_pfacc.reserve(8);
+    prof.begin("post_force", stream);
+    launch_post_force(stream, (int)pf_i_h.size(), d_pf_i.p, d_pf_j.p, at->nlocal, nall, env.newton_pair != 0, d_x.p, d_q.p, d_type.p,
+                      d_atom2eleall.p, real_params(), env.qqrd2e, d_f.p, d_pfacc.p);
+    prof.end(stream);
+    std::vector<double> fh((size_t)nall * 3);
+    double acc[8];
+    HIP_TRY(hipMemcpyAsync(fh.data(), d_f.p, fh.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(acc, d_pfacc.p, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    if (f) for (size_t k = 0; k < fh.size(); ++k) f[k] += fh[k];
+    if (ek) *ek = env.qqrd2e * 1.0 * args.eta * acc[7] / (std::sqrt(2.0) * 1.77245385090551602729);   // :1180
+    if (ec) *ec = acc[0];
+    if (vir) for (int k = 0; k < 6; ++k) vir[k] = acc[1 + k];
   }
 
   // fix_conp.cpp:677-695 b_cal / update_bk
@@ -638,6 +671,7 @@ int conp_parse_fix_args(int narg, const char *const *arg, int ntypes, conp_fix_a
   };
   out->maxiter = 100; out->tolerance = 0.000001; out->minimizer = CONP_SOLVER_INV;   // :88-90
   out->lowmem = 1; out->nullneutral = 1; out->ff_flag = CONP_FF_NORMAL;
+  out->conq = std::strncmp(arg[2], "conq", 4) == 0;   // FixStyle(conq,FixConq) fix_conq.h:21
   out->everynum = inumeric(arg[3], "fix conp Nevery");
   if (out->everynum <= 0) throw ConpError(CONP_ERR_ARG, "Illegal fix conp command (Nevery must be positive)");
   std::snprintf(out->group2, sizeof(out->group2), "%s", arg[4]);
@@ -756,6 +790,13 @@ int conp_fix_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimestep, dou
 }
 
 double conp_fix_compute_scalar(const conp_fix *f) { return f->scalar_output; }
+
+int conp_fix_post_force(conp_fix *f, const conp_atoms *at, double *fo, double *ek, double *ec, double *vir) {
+  CONP_GUARD_BEGIN
+  if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "post_force before setup");
+  f->post_force(at, fo, ek, ec, vir);
+  CONP_GUARD_END
+}
 
 int conp_fix_a_cal(conp_fix *f, const conp_atoms *at) {
   CONP_GUARD_BEGIN

@@ -337,6 +337,19 @@ void build_b_rows(const ListView &l, int nlocal, const int *tag, const int *eche
   finish_rows(raw, idx.elenum_all, false, out);
 }
 
+void build_pf_pairs(const ListView &l, const int *echeck, std::vector<int> &pi, std::vector<int> &pj) {
+  pi.clear(); pj.clear();
+  for (int ii = 0; ii < l.inum; ++ii) {
+    const int i = l.ilist[ii];
+    const bool ei = echeck[i] != 0;
+    const int *jlist = l.neigh + l.first[i];
+    for (int jj = 0; jj < l.numneigh[i]; ++jj) {
+      const int j = jlist[jj] & NEIGHMASK;
+      if (ei ^ (echeck[j] != 0)) { pi.push_back(i); pj.push_back(j); }
+    }
+  }
+}
+
 void build_a_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
                   PairRows &out) {
   std::vector<RawPair> raw;

@@ -108,6 +108,9 @@ struct ListView {
 
 void build_b_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
                   PairRows &out);
+// every listed pair with exactly one electrode member, as (owner i, neighbour j): the pair set of
+// blist_coul_cal_post_force (fix_conp.cpp:1411), which has no newton/ghost filter
+void build_pf_pairs(const ListView &l, const int *echeck, std::vector<int> &pi, std::vector<int> &pj);
 void build_a_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
                   PairRows &out);
 

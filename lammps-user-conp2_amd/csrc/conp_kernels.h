@@ -44,8 +44,12 @@ void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1
                            double slab_pref, double *b_out, double *slab_out);
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);
 void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleall, const int *elecheck, const double *eleallq,
-                          const double *elesetq, const double *eleinitq, double potdiff, double *q_ele, double *q_atoms,
-                          double *left_out);
+                          const double *elesetq, const double *eleinitq, double potdiff, const double *d_potdiff, double *q_ele,
+                          double *q_atoms, double *left_out);
+void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out);
+void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, int nlocal, int nall, int newton, const double *x,
+                       const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
+                       double *acc /*[8]: eng_coul, virial[6], sum q^2 of owned electrode atoms*/);
 void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);
 
 // ---- once-per-run matrix work ------------------------------------------------------------------

@@ -622,10 +622,13 @@ void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S,
 __global__ __launch_bounds__(256) void charge_finish_kernel(int ne, int nall, const int *__restrict__ atom2eleall,
                                                             const int *__restrict__ elecheck, const double *__restrict__ eleallq,
                                                             const double *__restrict__ elesetq, const double *__restrict__ eleinitq,
-                                                            double potdiff, double *__restrict__ q_ele,
+                                                            double potdiff, const double *__restrict__ d_potdiff,
+                                                            double *__restrict__ q_ele,
                                                             double *__restrict__ q_atoms, double *__restrict__ left_out) {
 #pragma clang fp contract(off)
+  if (d_potdiff) potdiff = *d_potdiff;      // fix conq: the potential difference was derived on the device
   if (blockIdx.x == gridDim.x - 1) {
+    if (!left_out) return;
     __shared__ double red[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < ne; i += 256) if (elecheck[i] == 1) s += eleallq[i];
@@ -652,11 +655,95 @@ __global__ __launch_bounds__(256) void charge_finish_kernel(int ne, int nall, co
 }
 
 void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleall, const int *elecheck, const double *eleallq,
-                          const double *elesetq, const double *eleinitq, double potdiff, double *q_ele, double *q_atoms,
-                          double *left_out) {
+                          const double *elesetq, const double *eleinitq, double potdiff, const double *d_potdiff, double *q_ele,
+                          double *q_atoms, double *left_out) {
   const int n = q_atoms ? (nall > ne ? nall : ne) : ne;
   hipLaunchKernelGGL(charge_finish_kernel, dim3((n + 255) / 256 + 1), dim3(256), 0, s, ne, nall, atom2eleall, elecheck, eleallq,
-                     elesetq, eleinitq, potdiff, q_ele, q_atoms, left_out);
+                     elesetq, eleinitq, potdiff, d_potdiff, q_ele, q_atoms, left_out);
+}
+
+// fix conq (fix_conq.cpp:74-80): potential difference that yields total charge -Q / +Q:  dV = -(Q + sum_left q) / totsetq
+__global__ void conq_potdiff_kernel(const double *__restrict__ left, double rightcharge, double totsetq, int one_electrode,
+                                    double *__restrict__ out) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double netcharge_right = -(*left);
+  double v = -(rightcharge - netcharge_right) / totsetq;
+  if (one_electrode) v += 2 * rightcharge / totsetq;
+  *out = v;
+}
+
+void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out) {
+  hipLaunchKernelGGL(conq_potdiff_kernel, dim3(1), dim3(64), 0, s, left, rightcharge, totsetq, one_electrode, out);
+}
+
+// ---- post-force real-space correction (fix_conp.cpp:1368-1444) ----------------------------------------------------
+__device__ __forceinline__ double ferfcr_sqrt_dev(double a2_r2) {
+#pragma clang fp contract(off)
+  if (a2_r2 < 5.8 * 5.8) {
+    const double a_r = sqrt(a2_r2);
+    const double expm2 = exp(-a2_r2);
+    const double t = 1.0 / (1.0 + 0.3275911 * a_r);
+    const double erfcr = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2 / a_r;
+    return erfcr + 1.12837917 * expm2;
+  }
+  return 0.0;
+}
+
+// one thread per listed (owner i, neighbour j) pair with exactly one electrode member; acc[0] eng_coul, acc[1..6] virial
+__global__ __launch_bounds__(256) void post_force_kernel(int npairs, const int *__restrict__ pi, const int *__restrict__ pj,
+                                                         int nlocal, int newton, const double *__restrict__ x,
+                                                         const double *__restrict__ q, const int *__restrict__ type,
+                                                         const int *__restrict__ atom2eleall, RealParams rp, double qqrd2e,
+                                                         double *__restrict__ f, double *__restrict__ acc) {
+#pragma clang fp contract(off)
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const int i = pi[p], j = pj[p];
+  const double delx = x[3 * i] - x[3 * j], dely = x[3 * i + 1] - x[3 * j + 1], delz = x[3 * i + 2] - x[3 * j + 2];
+  const double rsq = delx * delx + dely * dely + delz * delz;
+  if (!(rsq < rp.cutsq[type[i] * (rp.ntypes + 1) + type[j]])) return;
+  const double etarij2 = rp.eta * rp.eta * rsq;
+  if (!(etarij2 < 5.8)) return;                                  // :1419 (ERFC_MAX, not its square -- kept as written)
+  const bool eleilocal = atom2eleall[i] >= 0;
+  const double prefactor = qqrd2e * q[i] * q[j];
+  const double forcecoul = prefactor * (-ferfcr_sqrt_dev(etarij2) * rp.eta);
+  const double fpair = forcecoul / rsq;
+  if (!eleilocal) {
+    atomicAdd(&f[3 * i], delx * forcecoul); atomicAdd(&f[3 * i + 1], dely * forcecoul); atomicAdd(&f[3 * i + 2], delz * forcecoul);
+  } else if (newton || j < nlocal) {
+    atomicAdd(&f[3 * j], -(delx * forcecoul)); atomicAdd(&f[3 * j + 1], -(dely * forcecoul)); atomicAdd(&f[3 * j + 2], -(delz * forcecoul));
+  }
+  const double ecoul = prefactor * (-erfcr_sqrt_dev(etarij2) * rp.eta);
+  double w = 0.0;
+  if (newton) w = 1.0;
+  else { if (i < nlocal) w += 0.5; if (j < nlocal) w += 0.5; }
+  atomicAdd(&acc[0], w * ecoul);
+  atomicAdd(&acc[1], w * (delx * delx * fpair)); atomicAdd(&acc[2], w * (dely * dely * fpair)); atomicAdd(&acc[3], w * (delz * delz * fpair));
+  atomicAdd(&acc[4], w * (delx * dely * fpair)); atomicAdd(&acc[5], w * (delx * delz * fpair)); atomicAdd(&acc[6], w * (dely * delz * fpair));
+}
+
+// Gaussian self energy sum over owned electrode atoms of q^2 (fix_conp.cpp:1167-1181), one workgroup, fixed tree
+__global__ __launch_bounds__(1024) void ele_qsq_kernel(int nlocal, const int *__restrict__ atom2eleall, const double *__restrict__ q,
+                                                       double *__restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nlocal; i += 1024) if (atom2eleall[i] >= 0) s += q[i] * q[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < 16; ++k) t += red[k]; *out = t; }
+}
+
+void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, int nlocal, int nall, int newton, const double *x,
+                       const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
+                       double *acc /*[8]: eng_coul, virial[6], qsq*/) {
+  (void)hipMemsetAsync(f, 0, (size_t)nall * 3 * sizeof(double), s);
+  (void)hipMemsetAsync(acc, 0, 8 * sizeof(double), s);
+  if (npairs > 0)
+    hipLaunchKernelGGL(post_force_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, npairs, pi, pj, nlocal, newton, x, q, type,
+                       atom2eleall, rp, qqrd2e, f, acc);
+  hipLaunchKernelGGL(ele_qsq_kernel, dim3(1), dim3(1024), 0, s, nlocal, atom2eleall, q, acc + 7);
 }
 
 // sum of v over the group-1 ("left") electrode atoms (totsetq :1098-1104); one workgroup

@@ -30,7 +30,7 @@ void FixConpHip::fail_if(int status) {
 
 FixConpHip::FixConpHip(LAMMPS *lmp, int narg, char **arg)
     : Fix(lmp, narg, arg), h(nullptr), potdiffvar(-1), arequest(-1), brequest(-1), alist(nullptr), blist(nullptr),
-      coulpair(nullptr), outf(nullptr) {
+      coulpair(nullptr), outf(nullptr), postforceflag(false) {
   fail_if(conp_parse_fix_args(narg, arg, atom->ntypes, &args));           // fix_conp.cpp:79-176, same syntax and errors
   jgroup = group->find(args.group2);
   if (jgroup == -1) error->all(FLERR, "Fix conp group ID does not exist");  // :106-107
@@ -174,6 +174,26 @@ void FixConpHip::post_neighbor() {                                         // :4
 void FixConpHip::pre_force(int) {                                          // :543-573
   conp_atoms a = view();
   fail_if(conp_fix_pre_force(h, &a, (int64_t)update->ntimestep, potdiff_now()));
+}
+
+// fix_conp.cpp:577-588 post_force / end_of_step -> force_cal (:1163-1201)
+void FixConpHip::post_force(int) {
+  postforceflag = true;
+  conp_atoms a = view();
+  const int nall = atom->nlocal + atom->nghost;
+  fbuf.assign(3 * (size_t)nall, 0.0);
+  double ek = 0.0, ec = 0.0, vir[6];
+  fail_if(conp_fix_post_force(h, &a, fbuf.data(), &ek, &ec, vir));
+  for (int i = 0; i < nall; ++i)
+    for (int c = 0; c < 3; ++c) atom->f[i][c] += fbuf[3 * (size_t)i + c];
+  if (force->kspace->energy) force->kspace->energy += ek;       // :1165 (the reference adds only when kspace tallied energy)
+  force->pair->eng_coul += ec;                                   // what Pair::ev_tally accumulates (:1436)
+  for (int k = 0; k < 6; ++k) force->pair->virial[k] += vir[k];
+}
+
+void FixConpHip::end_of_step() {
+  if (!postforceflag) post_force(0);
+  postforceflag = false;
 }
 
 double FixConpHip::compute_scalar() { return conp_fix_compute_scalar(h); }  // :592-595

@@ -4,6 +4,7 @@
 #ifdef FIX_CLASS
 
 FixStyle(conp/hip,FixConpHip)
+FixStyle(conq/hip,FixConpHip)
 
 #else
 
@@ -32,6 +33,8 @@ class FixConpHip : public Fix {
   void setup_pre_force(int) override;
   void post_neighbor() override;
   void pre_force(int) override;
+  void post_force(int) override;
+  void end_of_step() override;
   double compute_scalar() override;
 
  private:
@@ -42,6 +45,8 @@ class FixConpHip : public Fix {
   class NeighList *alist, *blist;
   class Pair *coulpair;
   FILE *outf;
+  bool postforceflag;
+  std::vector<double> fbuf;
   std::vector<double> xbuf, cutsq_flat;
   std::vector<int> echeck, first_a, first_b, neigh_a, neigh_b;
   conp_atoms view();

@@ -17,7 +17,7 @@ class Error { public: [[noreturn]] void all(const char *, int, const std::string
 class Memory {};
 class Atom { public: int nlocal, nghost, ntypes; bigint natoms; double **x, **f, *q; int *type, *mask; tagint *tag; int map(tagint); };
 class KSpace { public: double g_ewald, accuracy, slab_volfactor, energy; int slabflag; virtual void setup(); };
-class Pair { public: double **cutsq; virtual void *extract(const char *, int &); void ev_tally(int, int, int, int, double, double, double, double, double, double); };
+class Pair { public: double **cutsq; double eng_coul, virial[6]; virtual void *extract(const char *, int &); void ev_tally(int, int, int, int, double, double, double, double, double, double); };
 class Force { public: double qqrd2e, qqr2e, qe2f, dielectric; int newton_pair; KSpace *kspace; Pair *pair; Pair *pair_match(const std::string &, int, int nsub = 0); };
 class Domain { public: double xprd, yprd, zprd, zprd_half, boxlo[3]; };
 class Update { public: bigint ntimestep, laststep; char *integrate_style; };

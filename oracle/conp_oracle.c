@@ -1045,6 +1045,103 @@ void orc_fix_update_charge(orc_fix *f, double potdiff) {
   f->scalar_output = potdiff * f->totsetq + netcharge_left;
 }
 
+/* fix_conq.cpp:41-90 FixConq::update_charge: potential difference that puts total charge -Q / +Q on group1 / group2.
+ * rightcharge = the DV argument of `fix conq`.  Returns the potential difference used (= the fix scalar). */
+double orc_fix_update_charge_conq(orc_fix *f, double rightcharge) {
+  const orc_atoms *at = &f->at;
+  int i, iall, iloc;
+  const int nall = at->nlocal + at->nghost;
+  double netcharge_right = 0, potdiff_conq;
+  if (f->minimizer == 1) {
+    for (iloc = 0; iloc < f->elenum; ++iloc) {
+      iall = f->ele2eleall[iloc];
+      f->bbb[iloc] = orc_ddot(f->elenum_all, f->aaa_all + (size_t)iall * f->elenum_all, f->bbb_all);
+    }
+    orc_b_comm(f, f->bbb, f->eleallq);
+  }
+  for (iall = 0; iall < f->elenum_all; ++iall)
+    if (f->elecheck_eleall[iall] == 1) netcharge_right -= f->eleallq[iall];
+  f->scalar_output = -(rightcharge - netcharge_right) / f->totsetq;
+  if (f->one_electrode) f->scalar_output += 2 * rightcharge / f->totsetq;
+  potdiff_conq = f->scalar_output;
+  for (i = 0; i < nall; ++i) {
+    if (!at->echeck[i]) continue;
+    iall = f->tag2eleall[at->tag[i]];
+    at->q[i] = f->eleallq[iall] + potdiff_conq * f->elesetq[iall];
+    if (f->qinit) at->q[i] += f->eleinitq[iall];
+  }
+  return potdiff_conq;
+}
+
+/* fix_conp.cpp:1456-1465 ferfcr_sqrt, :1477-1480 eta_force */
+static double orc_ferfcr_sqrt(double a2_r2) {
+  if (a2_r2 < ORC_ERFC_MAX * ORC_ERFC_MAX) {
+    double a_r = sqrt(a2_r2);
+    double expm2 = exp(-a2_r2);
+    double t = 1.0 / (1.0 + ORC_EWALD_P * a_r);
+    double erfcr = t * (ORC_A1 + t * (ORC_A2 + t * (ORC_A3 + t * (ORC_A4 + t * ORC_A5)))) * expm2 / a_r;
+    return erfcr + ORC_EWALD_F * expm2;
+  }
+  return 0.;
+}
+
+/* fix_conp.cpp:1163-1201 force_cal (ETA pair mode) + :1368-1444 blist_coul_cal_post_force.
+ * fadd[nall][3] is ACCUMULATED into (like atom->f); out[0] = kspace energy increment (:1167-1181),
+ * out[1] = eng_coul increment, out[2..7] = virial increment in LAMMPS order xx,yy,zz,xy,xz,yz as Pair::ev_tally adds them
+ * for eflag_global/vflag_global (pair.cpp ev_tally, newton_pair rule).  The reference applies del*forcecoul (not
+ * del*forcecoul/rsq) to the forces and gates on eta^2 r^2 < 5.8 (not 5.8^2) -- restated as written (:1418-1431). */
+void orc_fix_post_force(orc_fix *f, double qqrd2e, double *fadd, double *out) {
+  const orc_atoms *at = &f->at;
+  const orc_list *L = &f->blist;
+  const int nt1 = f->ntypes + 1;
+  int i, ii, jj, k;
+  double eleqsqsum = 0.0;
+  for (k = 0; k < 8; ++k) out[k] = 0.0;
+  for (i = 0; i < at->nlocal; i++)
+    if (at->echeck[i]) eleqsqsum += at->q[i] * at->q[i];
+  out[0] = qqrd2e * 1.0 * f->eta * eleqsqsum / (sqrt(2) * ORC_PIS);
+  for (ii = 0; ii < L->inum; ii++) {
+    int i = L->ilist[ii];
+    int eleilocal = !!at->echeck[i];
+    double qtmp = at->q[i];
+    double xtmp = at->x[3 * i], ytmp = at->x[3 * i + 1], ztmp = at->x[3 * i + 2];
+    int itype = at->type[i];
+    const int *jlist = L->neigh + L->first[i];
+    int jnum = L->numneigh[i];
+    for (jj = 0; jj < jnum; jj++) {
+      int j = jlist[jj] & ORC_NEIGHMASK;
+      int elejlocal = !!at->echeck[j];
+      if (eleilocal ^ elejlocal) {
+        double delx = xtmp - at->x[3 * j], dely = ytmp - at->x[3 * j + 1], delz = ztmp - at->x[3 * j + 2];
+        double rsq = delx * delx + dely * dely + delz * delz;
+        int jtype = at->type[j];
+        if (rsq < f->cutsq[itype * nt1 + jtype]) {
+          double etarij2 = f->eta * f->eta * rsq;
+          if (etarij2 < ORC_ERFC_MAX) {
+            double prefactor = qqrd2e * qtmp * at->q[j];
+            double forcecoul = prefactor * (-orc_ferfcr_sqrt(etarij2) * f->eta);
+            double fpair = forcecoul / rsq;
+            double ecoul, v[6], w = 0.0;
+            if (!eleilocal) {
+              fadd[3 * i] += delx * forcecoul; fadd[3 * i + 1] += dely * forcecoul; fadd[3 * i + 2] += delz * forcecoul;
+            } else if (f->newton || j < at->nlocal) {
+              fadd[3 * j] -= delx * forcecoul; fadd[3 * j + 1] -= dely * forcecoul; fadd[3 * j + 2] -= delz * forcecoul;
+            }
+            ecoul = prefactor * orc_eta_potential(f->eta, rsq);
+            /* Pair::ev_tally global accumulators */
+            if (f->newton) w = 1.0;
+            else { if (i < at->nlocal) w += 0.5; if (j < at->nlocal) w += 0.5; }
+            out[1] += w * ecoul;
+            v[0] = delx * delx * fpair; v[1] = dely * dely * fpair; v[2] = delz * delz * fpair;
+            v[3] = delx * dely * fpair; v[4] = delx * delz * fpair; v[5] = dely * delz * fpair;
+            for (k = 0; k < 6; ++k) out[2 + k] += w * v[k];
+          }
+        }
+      }
+    }
+  }
+}
+
 /* fix_conp.cpp:543-573 pre_force (the every-Nevery gate is the caller's) */
 void orc_fix_pre_force(orc_fix *f, double potdiff) {
   orc_fix_b_cal(f, 1);

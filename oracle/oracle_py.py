@@ -60,6 +60,10 @@ def load(fast: bool = False):
     lib.orc_fix_b_cal.argtypes = [vp, C.c_int]
     lib.orc_fix_update_charge.argtypes = [vp, C.c_double]
     lib.orc_fix_pre_force.argtypes = [vp, C.c_double]
+    lib.orc_fix_update_charge_conq.argtypes = [vp, C.c_double]
+    lib.orc_fix_update_charge_conq.restype = C.c_double
+    lib.orc_fix_post_force.argtypes = [vp, C.c_double, _dp, _dp]
+    lib.orc_fix_b_cal.argtypes = [vp, C.c_int]
     lib.orc_fix_sizes.argtypes = [vp, _ip]
     lib.orc_fix_scalars.argtypes = [vp, _dp]
     lib.orc_fix_get_maps.argtypes = [vp, _ip, _ip, _ip, _ip, _ip, _ip, _ip]
@@ -162,6 +166,16 @@ class Fix:
 
     def pre_force(self, potdiff):
         self.lib.orc_fix_pre_force(self.h, potdiff)
+
+    def pre_force_conq(self, rightcharge):
+        self.lib.orc_fix_b_cal(self.h, 1)
+        self.lib.orc_fix_equation_solve(self.h)
+        return self.lib.orc_fix_update_charge_conq(self.h, rightcharge)
+
+    def post_force(self, qqrd2e=332.06371):
+        fadd = np.zeros((self.at.nlocal + self.at.nghost, 3)); out = np.zeros(8)
+        self.lib.orc_fix_post_force(self.h, qqrd2e, fadd, out)
+        return fadd, out
 
     def sizes(self):
         o = np.zeros(8, np.int32); self.lib.orc_fix_sizes(self.h, o)

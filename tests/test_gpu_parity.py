@@ -296,3 +296,55 @@ def test_two_rank_sharding_on_one_gpu_matches_single_rank():
         ele = at.echeck != 0
         assert rel_err(q_atoms[ele], at.q[ele]) < 1e-11
     assert out[0][3][1] == out[1][3][0]
+
+
+def test_conq_matches_oracle(oracle):
+    """fix conq (fix_conq.cpp:41-90): prescribed electrode charge; the fix scalar is the potential difference"""
+    s = systems.deck("dilute", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    QR = 0.037
+    o = OracleRun(oracle, s, at, alist, blist)
+    o.setup()
+    dv_o = o.fx.pre_force_conq(QR)
+    fx = FixConp(s, style="conq")
+    assert fx.args.conq == 1
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, QR)
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < TOL_Q
+    assert fx.compute_scalar() == pytest.approx(dv_o, rel=1e-9)
+    loc = slice(0, at.nlocal)
+    assert at.q[loc][at.echeck[loc] == -1].sum() == pytest.approx(QR, rel=1e-9)     # group2 carries +QR
+    assert at.q[loc][at.echeck[loc] == 1].sum() == pytest.approx(-QR, rel=1e-9)
+    fx.close(); o.fx.close()
+
+
+def test_post_force_matches_oracle(oracle):
+    """force_cal + blist_coul_cal_post_force (fix_conp.cpp:1163-1201, 1368-1444).  The Gaussian correction only acts below
+    ~1.2 A (eta^2 r^2 < 5.8), so a few electrolyte atoms are pushed onto electrode atoms to exercise it."""
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab")
+    rng = np.random.default_rng(9)
+    ele_idx = np.nonzero(s.echeck != 0)[0]; sol_idx = np.nonzero((s.echeck == 0) & (s.q != 0))[0]
+    for k in range(6):
+        d = rng.normal(size=3); d *= rng.uniform(0.4, 1.1) / np.linalg.norm(d)
+        s.x[sol_idx[k]] = s.x[ele_idx[3 * k]] + d
+    s.x[:, :2] = s.boxlo[:2] + np.mod(s.x[:, :2] - s.boxlo[:2], s.prd[:2])
+    for newton in (False, True):
+        s.newton = newton
+        at, alist, blist = neighbor.build_lists(s)
+        o = OracleRun(oracle, s, at, alist, blist)
+        o.setup(); o.pre_force(s.potdiff)
+        fx = FixConp(s)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.setup_pre_force(at, 0, s.potdiff)
+        f_o, out_o = o.fx.post_force()
+        f_g, ek, ec, vir = fx.post_force(at)
+        assert np.abs(f_o).max() > 1.0                                 # the correction really is exercised
+        assert rel_err(f_g, f_o) < 1e-9
+        assert ek == pytest.approx(out_o[0], rel=1e-9)
+        assert ec == pytest.approx(out_o[1], rel=1e-9)
+        assert np.allclose(vir, out_o[2:8], rtol=1e-9, atol=1e-9 * np.abs(out_o[2:8]).max())
+        assert np.all(f_g[at.echeck != 0] == 0.0)                      # electrode atoms receive no force from this term
+        fx.close(); o.fx.close()
