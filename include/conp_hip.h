@@ -71,12 +71,16 @@ typedef struct {
   double g_ewald, accuracy, slab_volfactor;       /* force->kspace-> (km_ewald.cpp:66-69); accuracy ABSOLUTE */
   int slabflag;
   double xprd, yprd, zprd, boxlo_z;               /* domain-> (km_ewald.cpp:81-83, fix_conp.cpp:616-619) */
+  double boxlo_x, boxlo_y;                        /* domain->boxlo (pppm_conp.cpp:146-148; only the pppm path needs x, y) */
   int ntypes;
   const double *cutsq;                            /* coulpair->cutsq flattened [(ntypes+1)*(ntypes+1)] (fix_conp.cpp:1235) */
   double cut_coul;                                /* *coulpair->extract("cut_coul") (fix_conp.cpp:1237) */
   int one_electrode;                              /* groupbit == jgroupbit (fix_conp.cpp:295) */
   int device;                                     /* HIP device ordinal of this rank */
   int rank, nranks;                               /* shard id for the multi-GPU path (section "sharding") */
+  /* `pppm` keyword (fix_conp.cpp:162, 401-404): mesh and stencil order of the pppm/conp kspace style, i.e. LAMMPS PPPM's
+   * nx_pppm, ny_pppm, nz_pppm, order (pppm_conp.cpp:242, 206); ignored without the keyword */
+  int pppm_nx, pppm_ny, pppm_nz, pppm_order;
 } conp_env;
 
 /* FixConp::FixConp + FixConp::init (fix_conp.cpp:79-201, 245-300) */

@@ -96,6 +96,8 @@ struct conp_fix {
   // host state
   KTables kt;
   KPlan plan;
+  PppmPlan pppm;
+  PppmDev dpppm{};
   EleIndex idx;
   PairRows brows, arows;
   ListView alist, blist;
@@ -117,10 +119,11 @@ struct conp_fix {
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
-      d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc, d_f, d_pfacc;
+      d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
+      d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_pp_egrid, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -197,7 +200,21 @@ struct conp_fix {
   // fix_conp.cpp:393-424 linalg_init
   void linalg_init(const conp_atoms *at) {
     if (runstage != 0 || idx.initialised) return;
-    if (args.pppm) throw ConpError(CONP_ERR_ARG, "Fix conp couldn't detect a pppm/conp kspace style (which is required with the pppm flag)");
+    if (args.pppm) {
+      // fix_conp.cpp:401-404: the `pppm` keyword needs the pppm/conp kspace style; here: its mesh and order via conp_env
+      if (env.pppm_nx <= 0 || env.pppm_ny <= 0 || env.pppm_nz <= 0 || env.pppm_order <= 0)
+        throw ConpError(CONP_ERR_ARG, "Fix conp couldn't detect a pppm/conp kspace style (which is required with the pppm flag)");
+      const double lo[3] = {env.boxlo_x, env.boxlo_y, env.boxlo_z}, prd[3] = {env.xprd, env.yprd, env.zprd};
+      pppm.build(env.pppm_nx, env.pppm_ny, env.pppm_nz, env.pppm_order, env.g_ewald, env.slab_volfactor, lo, prd);
+      d_pp_coeff.upload(pppm.rho_coeff, stream); d_pp_green.upload(pppm.greensfn, stream);
+      d_pp_tw0.upload(pppm.twid[0], stream); d_pp_tw1.upload(pppm.twid[1], stream); d_pp_tw2.upload(pppm.twid[2], stream);
+      d_pp_re.reserve(pppm.nfft); d_pp_im.reserve(pppm.nfft);
+      dpppm.nx = pppm.nx; dpppm.ny = pppm.ny; dpppm.nz = pppm.nz; dpppm.order = pppm.order; dpppm.nlower = pppm.nlower;
+      dpppm.nfft = pppm.nfft; dpppm.shift = pppm.shift; dpppm.shiftone = pppm.shiftone; dpppm.delvolinv = pppm.delvolinv;
+      for (int c = 0; c < 3; ++c) { dpppm.delinv[c] = pppm.delinv[c]; dpppm.boxlo[c] = pppm.boxlo[c]; }
+      dpppm.rho_coeff = d_pp_coeff.p; dpppm.greensfn = d_pp_green.p;
+      dpppm.twid[0] = d_pp_tw0.p; dpppm.twid[1] = d_pp_tw1.p; dpppm.twid[2] = d_pp_tw2.p;
+    }
     double qsqsum = 0.0;                                   // km_ewald.cpp:72-78 (one rank)
     for (int i = 0; i < at->nlocal; i++) qsqsum += at->q[i] * at->q[i];
     km_conp_setup(qsqsum, (int64_t)at->nlocal);
@@ -323,6 +340,18 @@ struct conp_fix {
     electrode_plan_tables(kt, plan, ne, ne_pad, csk_h, snk_h, Rp, Tz);
     for (int i = 0; i < ne; ++i) z[i] = xele_h[3 * (size_t)i + 2];
     d_Rp.upload(Rp, stream); d_Tz.upload(Tz, stream); d_ele_z.upload(z, stream);
+    if (args.pppm) {   // aaa_map_rho (pppm_conp.cpp:318-344): stencil weights and lower-left mesh index of every electrode atom
+      std::vector<int> eg((size_t)ne * 3);
+      std::vector<double> ew((size_t)ne * 24, 0.0);
+      for (int i = 0; i < ne; ++i)
+        for (int c = 0; c < 3; ++c) {
+          const double xlo = xele_h[3 * (size_t)i + c] - pppm.boxlo[c];
+          const int n = static_cast<int>(xlo * pppm.delinv[c] + pppm.shift) - PppmPlan::OFFSET;
+          eg[3 * (size_t)i + c] = n;
+          pppm.rho1d(n + pppm.shiftone - xlo * pppm.delinv[c], &ew[(size_t)i * 24 + 8 * c]);
+        }
+      d_pp_egrid.upload(eg, stream); d_pp_ew.upload(ew, stream);
+    }
     // z classes: atoms with bitwise equal z share their Tz column
     {
       std::map<double, int> cls;
@@ -519,24 +548,35 @@ struct conp_fix {
   // km_ewald.cpp:153-167 b_cal + fix_conp.cpp:1281-1365 blist_coul_cal, this rank's shard, into d_b
   void b_cal_device(const double *dx, const double *dq, bool coulyes) {
     const int ne = idx.elenum_all;
-    prof.begin("elyte_phase", stream);
-    launch_elyte_phase(stream, nl, nl_pad, d_elyte_idx.p, dx, dq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
-                       plan.kymax, plan.nz, KPlan::ZSTRIDE, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
-    prof.end(stream);
-    prof.begin("sk_gemm", stream);
-    launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
-                   d_Gpart.p);
-    prof.end(stream);
-    prof.begin("sk_reduce", stream);
-    launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), d_Gpart.p, d_G.p, d_Gw.p);
-    prof.end(stream);
-    prof.begin("b_project", stream);
-    if (nzc > 0)
-      launch_b_project_zclass(stream, dplan, ne_pad, env.rank, env.nranks, nzc, d_Gw.p, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p,
-                              d_bk.p);
-    else
-      launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
-    prof.end(stream);
+    if (args.pppm) {
+      // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
+      prof.begin("pppm_b", stream);
+      if (env.rank == 0)
+        launch_pppm_b(stream, dpppm, nl, d_elyte_idx.p, dx, dq, ne, ne_pad, d_pp_egrid.p, d_pp_ew.p, d_pp_re.p, d_pp_im.p,
+                      d_slab_part.p, &n_slab_part, d_bk.p);
+      else
+        d_bk.zero(stream);
+      prof.end(stream);
+    } else {
+      prof.begin("elyte_phase", stream);
+      launch_elyte_phase(stream, nl, nl_pad, d_elyte_idx.p, dx, dq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
+                         plan.kymax, plan.nz, KPlan::ZSTRIDE, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
+      prof.end(stream);
+      prof.begin("sk_gemm", stream);
+      launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
+                     d_Gpart.p);
+      prof.end(stream);
+      prof.begin("sk_reduce", stream);
+      launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), d_Gpart.p, d_G.p, d_Gw.p);
+      prof.end(stream);
+      prof.begin("b_project", stream);
+      if (nzc > 0)
+        launch_b_project_zclass(stream, dplan, ne_pad, env.rank, env.nranks, nzc, d_Gw.p, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p,
+                                d_bk.p);
+      else
+        launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
+      prof.end(stream);
+    }
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     prof.begin("b_real_combine", stream);
     launch_b_real_combine(stream, ne, ne_pad, coulyes ? row0 : 0, coulyes ? row1 : 0, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,

@@ -187,6 +187,120 @@ void KPlan::build(const KTables &kt) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PppmPlan
+// ------------------------------------------------------------------------------------------------
+void PppmPlan::rho1d(double dx, double *w) const {
+  for (int k = 0; k < order; ++k) {
+    double r = 0.0;
+    for (int l = order - 1; l >= 0; --l) r = rho_coeff[(size_t)l * order + k] + r * dx;
+    w[k] = r;
+  }
+}
+
+void PppmPlan::build(int nx_, int ny_, int nz_, int order_, double g, double slabf, const double *lo, const double *prd) {
+  nx = nx_; ny = ny_; nz = nz_; order = order_;
+  if (order < 1 || order > MAXORDER) throw std::invalid_argument("pppm order out of range");
+  nlower = -(order - 1) / 2; nupper = order / 2;
+  if (order % 2) { shift = OFFSET + 0.5; shiftone = 0.0; } else { shift = OFFSET; shiftone = 0.5; }
+  const double zprd_slab = prd[2] * slabf;
+  for (int c = 0; c < 3; ++c) boxlo[c] = lo[c];
+  volume = prd[0] * prd[1] * zprd_slab;
+  delinv[0] = nx / prd[0]; delinv[1] = ny / prd[1]; delinv[2] = nz / zprd_slab;
+  delvolinv = delinv[0] * delinv[1] * delinv[2];
+  nfft = nx * ny * nz;
+  // assignment-function polynomials (Hockney & Eastwood recursion as in PPPM::compute_rho_coeff)
+  {
+    const int W = 2 * order + 1;
+    std::vector<double> a((size_t)order * W, 0.0);
+    auto A = [&](int l, int k) -> double & { return a[(size_t)l * W + (k + order)]; };
+    A(0, 0) = 1.0;
+    for (int j = 1; j < order; ++j)
+      for (int k = -j; k <= j; k += 2) {
+        double sacc = 0.0;
+        for (int l = 0; l < j; ++l) {
+          A(l + 1, k) = (A(l, k + 1) - A(l, k - 1)) / (l + 1);
+          sacc += std::pow(0.5, (double)l + 1) * (A(l, k - 1) + std::pow(-1.0, (double)l) * A(l, k + 1)) / (l + 1);
+        }
+        A(0, k) = sacc;
+      }
+    rho_coeff.assign((size_t)order * order, 0.0);
+    int m = 0;
+    for (int k = -(order - 1); k < order; k += 2, ++m)
+      for (int l = 0; l < order; ++l) rho_coeff[(size_t)l * order + m] = A(l, k);
+  }
+  // denominator polynomial (PPPM::compute_gf_denom)
+  double gf_b[MAXORDER];
+  {
+    for (int l = 1; l < order; ++l) gf_b[l] = 0.0;
+    gf_b[0] = 1.0;
+    for (int m = 1; m < order; ++m) {
+      int l;
+      for (l = m; l > 0; --l) gf_b[l] = 4.0 * (gf_b[l] * (l - m) * (l - m - 0.5) - gf_b[l - 1] * (l - m - 1) * (l - m - 1));
+      gf_b[0] = 4.0 * (gf_b[0] * (l - m) * (l - m - 0.5));
+    }
+    long long ifact = 1;
+    for (int k = 1; k < 2 * order; ++k) ifact *= k;
+    const double gaminv = 1.0 / ifact;
+    for (int l = 0; l < order; ++l) gf_b[l] *= gaminv;
+  }
+  auto gf_denom = [&](double x, double y, double z) {
+    double sx = 0, sy = 0, sz = 0;
+    for (int l = order - 1; l >= 0; --l) { sx = gf_b[l] + sx * x; sy = gf_b[l] + sy * y; sz = gf_b[l] + sz * z; }
+    const double sprod = sx * sy * sz;
+    return sprod * sprod;
+  };
+  auto powsinxx = [](double x, int n) { return x == 0.0 ? 1.0 : std::pow(std::sin(x) / x, n); };
+  auto sq = [](double v) { return v * v; };
+  // optimal influence function, ik differentiation (PPPM::compute_gf_ik)
+  const double xprd = prd[0], yprd = prd[1];
+  const double ukx = 2.0 * MY_PI / xprd, uky = 2.0 * MY_PI / yprd, ukz = 2.0 * MY_PI / zprd_slab;
+  const double hoc = std::pow(-std::log(1.0e-7), 0.25);
+  const int nbx = (int)((g * xprd / (MY_PI * nx)) * hoc), nby = (int)((g * yprd / (MY_PI * ny)) * hoc),
+            nbz = (int)((g * zprd_slab / (MY_PI * nz)) * hoc);
+  const int twoorder = 2 * order;
+  greensfn.assign(nfft, 0.0);
+  size_t n = 0;
+  for (int m = 0; m < nz; ++m) {
+    const int mper = m - nz * (2 * m / nz);
+    const double snz = sq(std::sin(0.5 * ukz * mper * zprd_slab / nz));
+    for (int l = 0; l < ny; ++l) {
+      const int lper = l - ny * (2 * l / ny);
+      const double sny = sq(std::sin(0.5 * uky * lper * yprd / ny));
+      for (int k = 0; k < nx; ++k, ++n) {
+        const int kper = k - nx * (2 * k / nx);
+        const double snx = sq(std::sin(0.5 * ukx * kper * xprd / nx));
+        const double sqk = sq(ukx * kper) + sq(uky * lper) + sq(ukz * mper);
+        if (sqk == 0.0) continue;
+        const double numerator = 12.5663706 / sqk;
+        const double denominator = gf_denom(snx, sny, snz);
+        double sum1 = 0.0;
+        for (int ax = -nbx; ax <= nbx; ++ax) {
+          const double qx = ukx * (kper + nx * ax), sx = std::exp(-0.25 * sq(qx / g)), wx = powsinxx(0.5 * qx * xprd / nx, twoorder);
+          for (int ay = -nby; ay <= nby; ++ay) {
+            const double qy = uky * (lper + ny * ay), sy = std::exp(-0.25 * sq(qy / g)), wy = powsinxx(0.5 * qy * yprd / ny, twoorder);
+            for (int az = -nbz; az <= nbz; ++az) {
+              const double qz = ukz * (mper + nz * az), sz = std::exp(-0.25 * sq(qz / g)), wz = powsinxx(0.5 * qz * zprd_slab / nz, twoorder);
+              const double dot1 = ukx * kper * qx + uky * lper * qy + ukz * mper * qz;
+              const double dot2 = qx * qx + qy * qy + qz * qz;
+              sum1 += (dot1 / dot2) * sx * sy * sz * wx * wy * wz;
+            }
+          }
+        }
+        greensfn[n] = numerator * sum1 / denominator;
+      }
+    }
+  }
+  const int dims[3] = {nx, ny, nz};
+  for (int c = 0; c < 3; ++c) {
+    twid[c].resize(2 * (size_t)dims[c]);
+    for (int t = 0; t < dims[c]; ++t) {
+      twid[c][2 * t] = std::cos(2.0 * MY_PI * t / dims[c]);
+      twid[c][2 * t + 1] = std::sin(2.0 * MY_PI * t / dims[c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // electrode phase tables
 // ------------------------------------------------------------------------------------------------
 void electrode_trig(const KTables &kt, int ne, const double *xele, std::vector<double> &csk, std::vector<double> &snk) {

@@ -66,6 +66,25 @@ struct KPlan {
   void build(const KTables &kt);
 };
 
+// ------------------------------------------------------------------------------------------------
+// PppmPlan: what PPPMCONP inherits from LAMMPS PPPM for the b vector (pppm_conp.cpp:126-344): mesh geometry, the
+// charge-assignment polynomial coefficients (PPPM::compute_rho_coeff) and the ik influence function
+// (PPPM::compute_gf_ik, compute_gf_denom).  Those LAMMPS routines are not part of the reference repository; they are
+// restated from the Hockney-Eastwood P3M formulation as LAMMPS implements it (parity unpinned).
+// ------------------------------------------------------------------------------------------------
+struct PppmPlan {
+  static constexpr int OFFSET = 16384;   // pppm_conp.cpp:32
+  static constexpr int MAXORDER = 8;
+  int nx = 0, ny = 0, nz = 0, order = 0, nlower = 0, nupper = 0, nfft = 0;
+  double shift = 0, shiftone = 0, delinv[3] = {0, 0, 0}, delvolinv = 0, boxlo[3] = {0, 0, 0}, volume = 0;
+  std::vector<double> rho_coeff;   // [order][order]: coefficient l of stencil point m
+  std::vector<double> greensfn;    // [nz][ny][nx]
+  std::vector<double> twid[3];     // per axis: cos, sin (2 pi t / n) interleaved
+
+  void build(int nx, int ny, int nz, int order, double g_ewald, double slab_volfactor, const double *boxlo, const double *prd);
+  void rho1d(double dx, double *w) const;   // PPPM::compute_rho1d, one axis
+};
+
 // electrode phase tables.  csk/snk: [ne][kcount_flat] exactly as km_ewald.cpp:426-477 (lowmem) computes them;
 // Rp: [R_pad][ne_pad] planar cos/sin rows in G's row layout, Tz: [C_pad][ne_pad] z cos/sin in G's col layout.
 void electrode_trig(const KTables &kt, int ne, const double *xele /*[ne][3]*/, std::vector<double> &csk,

@@ -21,6 +21,16 @@ struct RealParams {           // real-space pair kernels
   const double *cutsq;                // [(ntypes+1)^2]
 };
 
+struct PppmDev {              // device view of PppmPlan
+  int nx, ny, nz, order, nlower, nfft;
+  double shift, shiftone, delinv[3], delvolinv, boxlo[3];
+  const double *rho_coeff, *greensfn, *twid[3];
+};
+// pppm_conp.cpp:269-316 on the device (conp_pppm.hip): bk slot 0 <- PPPM k-space b of all electrode atoms
+void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_idx, const double *x, const double *q, int ne,
+                   int ne_pad, const int *egrid, const double *ew, double *re, double *im, double *slab_part, int *n_slab_part,
+                   double *bk);
+
 // ---- per-step electrolyte path -----------------------------------------------------------------
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,

@@ -78,6 +78,8 @@ void FixConpHip::init() {
     env.g_ewald = force->kspace->g_ewald; env.accuracy = force->kspace->accuracy;
     env.slab_volfactor = force->kspace->slab_volfactor; env.slabflag = force->kspace->slabflag;
     env.xprd = domain->xprd; env.yprd = domain->yprd; env.zprd = domain->zprd; env.boxlo_z = domain->boxlo[2];
+    env.boxlo_x = domain->boxlo[0]; env.boxlo_y = domain->boxlo[1];
+    // `pppm` keyword: mesh + order of the pppm/conp kspace style (a PPPM subclass exposing nx_pppm, ny_pppm, nz_pppm, order)
     env.ntypes = atom->ntypes; env.cutsq = cutsq_flat.data();
     env.cut_coul = *(double *)coulpair->extract("cut_coul", itmp);
     env.one_electrode = (groupbit == jgroupbit);                           // :295

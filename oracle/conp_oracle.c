@@ -1207,3 +1207,262 @@ void orc_multirank_maps(int nprocs, const int *counts_first, const int *tags_fir
   for (r = 0; r < nprocs; ++r) { displs_now[r] = pos; pos += counts_now[r]; }   /* :504-508 */
   for (i = 0; i < pos; ++i) elebuf2eleall[i] = tag2eleall[tags_now[i]];         /* :528-535 */
 }
+
+/* =============================================================================================
+ * PPPM b-vector (pppm_conp.cpp:109-124 elyte_map_rho_pois, :126-170 elyte_particle_map, :172-228 elyte_make_rho,
+ * :230-267 elyte_poisson, :269-316 b_cal, :318-344 aaa_map_rho), one rank, double precision.
+ *
+ * PARITY UNPINNED at the LAMMPS boundary: the stencil coefficients (PPPM::compute_rho_coeff / compute_rho1d), the
+ * influence function (PPPM::compute_gf_ik / gf_denom / compute_gf_denom) and the index conventions (shift, shiftone,
+ * OFFSET, nlower, nupper) live in LAMMPS src/KSPACE/pppm.cpp @ 27May2021, which is not under /root/reference.  They
+ * are restated here from the published Hockney-Eastwood P3M formulation as LAMMPS implements it; the reference's tests
+ * hold no numbers for them, so this part is only cross-checked against the Ewald b vector within the PPPM accuracy.
+ * The FFT is a plain O(N n) DFT per axis (small meshes only).
+ * ===========================================================================================*/
+#define ORC_PPPM_OFFSET 16384
+#define ORC_PPPM_MAXORDER 8
+#define ORC_EPS_HOC 1.0e-7
+
+typedef struct {
+  int nx, ny, nz, order, nlower, nupper, nfft;
+  double shift, shiftone, delinv[3], delvolinv, boxlo[3], prd[3], zprd_slab, volume, g_ewald;
+  int slabflag;
+  double rho_coeff[ORC_PPPM_MAXORDER][ORC_PPPM_MAXORDER]; /* [l][m - (1-order)/2] */
+  double gf_b[ORC_PPPM_MAXORDER];
+  double *greensfn;
+} orc_pppm;
+
+static void orc_pppm_rho_coeff(orc_pppm *p) { /* PPPM::compute_rho_coeff */
+  const int order = p->order;
+  double a[ORC_PPPM_MAXORDER][2 * ORC_PPPM_MAXORDER + 1]; /* a[l][k + order] */
+  int j, k, l, m;
+  for (l = 0; l < order; l++) for (k = -order; k <= order; k++) a[l][k + order] = 0.0;
+  a[0][order] = 1.0;
+  for (j = 1; j < order; j++) {
+    for (k = -j; k <= j; k += 2) {
+      double s = 0.0;
+      for (l = 0; l < j; l++) {
+        a[l + 1][k + order] = (a[l][k + 1 + order] - a[l][k - 1 + order]) / (l + 1);
+        s += pow(0.5, (double)l + 1) * (a[l][k - 1 + order] + pow(-1.0, (double)l) * a[l][k + 1 + order]) / (l + 1);
+      }
+      a[0][k + order] = s;
+    }
+  }
+  m = 0;
+  for (k = -(order - 1); k < order; k += 2) {
+    for (l = 0; l < order; l++) p->rho_coeff[l][m] = a[l][k + order];
+    m++;
+  }
+}
+
+static void orc_pppm_rho1d(const orc_pppm *p, double dx, double *w /*[order]*/) { /* PPPM::compute_rho1d, one axis */
+  int k, l;
+  for (k = 0; k < p->order; k++) {
+    double r = 0.0;
+    for (l = p->order - 1; l >= 0; l--) r = p->rho_coeff[l][k] + r * dx;
+    w[k] = r;
+  }
+}
+
+static void orc_pppm_gf_denom_setup(orc_pppm *p) { /* PPPM::compute_gf_denom */
+  const int order = p->order;
+  int k, l, m;
+  long long ifact = 1;
+  double gaminv;
+  for (l = 1; l < order; l++) p->gf_b[l] = 0.0;
+  p->gf_b[0] = 1.0;
+  for (m = 1; m < order; m++) {
+    for (l = m; l > 0; l--) p->gf_b[l] = 4.0 * (p->gf_b[l] * (l - m) * (l - m - 0.5) - p->gf_b[l - 1] * (l - m - 1) * (l - m - 1));
+    p->gf_b[0] = 4.0 * (p->gf_b[0] * (l - m) * (l - m - 0.5));
+  }
+  for (k = 1; k < 2 * order; k++) ifact *= k;
+  gaminv = 1.0 / ifact;
+  for (l = 0; l < order; l++) p->gf_b[l] *= gaminv;
+}
+
+static double orc_pppm_gf_denom(const orc_pppm *p, double x, double y, double z) {
+  double sx = 0, sy = 0, sz = 0, s;
+  int l;
+  for (l = p->order - 1; l >= 0; l--) { sx = p->gf_b[l] + sx * x; sy = p->gf_b[l] + sy * y; sz = p->gf_b[l] + sz * z; }
+  s = sx * sy * sz;
+  return s * s;
+}
+
+static double orc_powsinxx(double x, int n) {
+  double yy;
+  if (x == 0.0) return 1.0;
+  yy = sin(x) / x;
+  return pow(yy, n);
+}
+
+static void orc_pppm_gf_ik(orc_pppm *p) { /* PPPM::compute_gf_ik, single rank: the FFT brick is the whole mesh */
+  const double xprd = p->prd[0], yprd = p->prd[1], zprd_slab = p->zprd_slab, g = p->g_ewald;
+  const double unitkx = 2.0 * ORC_PI / xprd, unitky = 2.0 * ORC_PI / yprd, unitkz = 2.0 * ORC_PI / zprd_slab;
+  const int nbx = (int)((g * xprd / (ORC_PI * p->nx)) * pow(-log(ORC_EPS_HOC), 0.25));
+  const int nby = (int)((g * yprd / (ORC_PI * p->ny)) * pow(-log(ORC_EPS_HOC), 0.25));
+  const int nbz = (int)((g * zprd_slab / (ORC_PI * p->nz)) * pow(-log(ORC_EPS_HOC), 0.25));
+  const int twoorder = 2 * p->order;
+  int k, l, m, n = 0, ax, ay, az;
+  for (m = 0; m < p->nz; m++) {
+    const int mper = m - p->nz * (2 * m / p->nz);
+    const double snz = pow(sin(0.5 * unitkz * mper * zprd_slab / p->nz), 2);
+    for (l = 0; l < p->ny; l++) {
+      const int lper = l - p->ny * (2 * l / p->ny);
+      const double sny = pow(sin(0.5 * unitky * lper * yprd / p->ny), 2);
+      for (k = 0; k < p->nx; k++) {
+        const int kper = k - p->nx * (2 * k / p->nx);
+        const double snx = pow(sin(0.5 * unitkx * kper * xprd / p->nx), 2);
+        const double sqk = pow(unitkx * kper, 2) + pow(unitky * lper, 2) + pow(unitkz * mper, 2);
+        if (sqk != 0.0) {
+          const double numerator = 12.5663706 / sqk;
+          const double denominator = orc_pppm_gf_denom(p, snx, sny, snz);
+          double sum1 = 0.0;
+          for (ax = -nbx; ax <= nbx; ax++) {
+            const double qx = unitkx * (kper + p->nx * ax);
+            const double sx = exp(-0.25 * pow(qx / g, 2));
+            const double wx = orc_powsinxx(0.5 * qx * xprd / p->nx, twoorder);
+            for (ay = -nby; ay <= nby; ay++) {
+              const double qy = unitky * (lper + p->ny * ay);
+              const double sy = exp(-0.25 * pow(qy / g, 2));
+              const double wy = orc_powsinxx(0.5 * qy * yprd / p->ny, twoorder);
+              for (az = -nbz; az <= nbz; az++) {
+                const double qz = unitkz * (mper + p->nz * az);
+                const double sz = exp(-0.25 * pow(qz / g, 2));
+                const double wz = orc_powsinxx(0.5 * qz * zprd_slab / p->nz, twoorder);
+                const double dot1 = unitkx * kper * qx + unitky * lper * qy + unitkz * mper * qz;
+                const double dot2 = qx * qx + qy * qy + qz * qz;
+                sum1 += (dot1 / dot2) * sx * sy * sz * wx * wy * wz;
+              }
+            }
+          }
+          p->greensfn[n++] = numerator * sum1 / denominator;
+        } else p->greensfn[n++] = 0.0;
+      }
+    }
+  }
+}
+
+orc_pppm *orc_pppm_create(int nx, int ny, int nz, int order, double g_ewald, double slab_volfactor, int slabflag,
+                          const double *boxlo, const double *prd) {
+  orc_pppm *p = (orc_pppm *)calloc(1, sizeof(orc_pppm));
+  int c;
+  p->nx = nx; p->ny = ny; p->nz = nz; p->order = order; p->g_ewald = g_ewald; p->slabflag = slabflag;
+  p->nlower = -(order - 1) / 2; p->nupper = order / 2;
+  if (order % 2) { p->shift = ORC_PPPM_OFFSET + 0.5; p->shiftone = 0.0; }
+  else { p->shift = ORC_PPPM_OFFSET; p->shiftone = 0.5; }
+  for (c = 0; c < 3; ++c) { p->boxlo[c] = boxlo[c]; p->prd[c] = prd[c]; }
+  p->zprd_slab = prd[2] * slab_volfactor;
+  p->volume = prd[0] * prd[1] * p->zprd_slab;
+  p->delinv[0] = nx / prd[0]; p->delinv[1] = ny / prd[1]; p->delinv[2] = nz / p->zprd_slab;
+  p->delvolinv = p->delinv[0] * p->delinv[1] * p->delinv[2];
+  p->nfft = nx * ny * nz;
+  p->greensfn = (double *)malloc(sizeof(double) * p->nfft);
+  orc_pppm_rho_coeff(p);
+  orc_pppm_gf_denom_setup(p);
+  orc_pppm_gf_ik(p);
+  return p;
+}
+
+void orc_pppm_destroy(orc_pppm *p) { if (p) { free(p->greensfn); free(p); } }
+void orc_pppm_tables(const orc_pppm *p, double *rho_coeff /*[order*order] l-major*/, double *greensfn) {
+  int l, m;
+  for (l = 0; l < p->order; ++l) for (m = 0; m < p->order; ++m) rho_coeff[l * p->order + m] = p->rho_coeff[l][m];
+  memcpy(greensfn, p->greensfn, sizeof(double) * p->nfft);
+}
+
+/* plain DFT along one axis of a [nz][ny][nx] complex array (sign = -1 forward like LAMMPS FFT3d flag 1, +1 backward) */
+static void orc_dft_axis(double *re, double *im, int nx, int ny, int nz, int axis, int sign) {
+  const int n = axis == 0 ? nx : (axis == 1 ? ny : nz);
+  const int stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
+  double *cw = (double *)malloc(sizeof(double) * n), *sw = (double *)malloc(sizeof(double) * n);
+  double *tr = (double *)malloc(sizeof(double) * n), *ti = (double *)malloc(sizeof(double) * n);
+  int a, b, f, t;
+  const int na = axis == 0 ? ny : nx, nb = axis == 2 ? ny : nz;
+  for (t = 0; t < n; ++t) { cw[t] = cos(2.0 * ORC_PI * t / n); sw[t] = sign * sin(2.0 * ORC_PI * t / n); }
+  for (b = 0; b < nb; ++b)
+    for (a = 0; a < na; ++a) {
+      size_t base;
+      if (axis == 0) base = ((size_t)b * ny + a) * nx;
+      else if (axis == 1) base = (size_t)b * ny * nx + a;
+      else base = (size_t)b * nx + a;
+      for (f = 0; f < n; ++f) {
+        double sr = 0, si = 0;
+        for (t = 0; t < n; ++t) {
+          const int w = (int)(((long long)f * t) % n);
+          const double xr = re[base + (size_t)t * stride], xi = im[base + (size_t)t * stride];
+          sr += xr * cw[w] - xi * sw[w];
+          si += xr * sw[w] + xi * cw[w];
+        }
+        tr[f] = sr; ti[f] = si;
+      }
+      for (f = 0; f < n; ++f) { re[base + (size_t)f * stride] = tr[f]; im[base + (size_t)f * stride] = ti[f]; }
+    }
+  free(cw); free(sw); free(tr); free(ti);
+}
+
+static int orc_wrap(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+
+/* pppm_conp.cpp:269-316 b_cal for electrode coordinates xele[ne][3] (eleall order); bbb[ne] overwritten.
+ * u_out (optional, [nfft]) receives the mesh potential. */
+void orc_pppm_b_cal(const orc_pppm *p, int nlocal, const double *x, const double *q, const int *echeck, int ne,
+                    const double *xele, double *bbb, double *u_out) {
+  const int order = p->order, nx = p->nx, ny = p->ny, nz = p->nz;
+  double *rho = (double *)calloc(p->nfft, sizeof(double)), *im = (double *)calloc(p->nfft, sizeof(double));
+  double w[3][ORC_PPPM_MAXORDER];
+  double slabcorr = 0.0;
+  int i, c, l, m, n;
+  const double scaleinv = 1.0 / ((double)nx * ny * nz);
+  for (i = 0; i < nlocal; ++i) {   /* elyte_particle_map + elyte_make_rho */
+    int g[3];
+    double z0;
+    if (echeck[i] != 0 || q[i] == 0) continue;
+    for (c = 0; c < 3; ++c) {
+      const double xs = (x[3 * i + c] - p->boxlo[c]) * p->delinv[c];
+      g[c] = (int)(xs + p->shift) - ORC_PPPM_OFFSET;
+      orc_pppm_rho1d(p, g[c] + p->shiftone - xs, w[c]);
+    }
+    z0 = p->delvolinv * q[i];
+    for (n = 0; n < order; n++) {
+      const int mz = orc_wrap(n + p->nlower + g[2], nz);
+      const double y0 = z0 * w[2][n];
+      for (m = 0; m < order; m++) {
+        const int my = orc_wrap(m + p->nlower + g[1], ny);
+        const double x0 = y0 * w[1][m];
+        for (l = 0; l < order; l++) {
+          const int mx = orc_wrap(l + p->nlower + g[0], nx);
+          rho[((size_t)mz * ny + my) * nx + mx] += x0 * w[0][l];
+        }
+      }
+    }
+    slabcorr += 4 * q[i] * ORC_PI * x[3 * i + 2] / p->volume;
+  }
+  for (c = 0; c < 3; ++c) orc_dft_axis(rho, im, nx, ny, nz, c, -1);   /* elyte_poisson */
+  for (i = 0; i < p->nfft; ++i) { rho[i] *= scaleinv * p->greensfn[i]; im[i] *= scaleinv * p->greensfn[i]; }
+  for (c = 0; c < 3; ++c) orc_dft_axis(rho, im, nx, ny, nz, c, +1);
+  if (u_out) memcpy(u_out, rho, sizeof(double) * p->nfft);
+  for (i = 0; i < ne; ++i) {        /* aaa_map_rho weights + the stencil gather of b_cal */
+    int g[3];
+    double bbbtmp = 0;
+    for (c = 0; c < 3; ++c) {
+      const double xlo = xele[3 * i + c] - p->boxlo[c];
+      g[c] = (int)(xlo * p->delinv[c] + p->shift) - ORC_PPPM_OFFSET;
+      orc_pppm_rho1d(p, g[c] + p->shiftone - xlo * p->delinv[c], w[c]);
+    }
+    for (n = 0; n < order; ++n) {
+      const int mz = orc_wrap(n + p->nlower + g[2], nz);
+      const double z0 = w[2][n];
+      for (m = 0; m < order; ++m) {
+        const int my = orc_wrap(m + p->nlower + g[1], ny);
+        const double y0 = z0 * w[1][m];
+        for (l = 0; l < order; ++l) {
+          const int mx = orc_wrap(l + p->nlower + g[0], nx);
+          const double x0 = y0 * w[0][l];
+          bbbtmp -= x0 * rho[((size_t)mz * ny + my) * nx + mx];
+        }
+      }
+    }
+    bbb[i] = bbbtmp;
+  }
+  if (p->slabflag == 1) for (i = 0; i < ne; ++i) bbb[i] -= xele[3 * i + 2] * slabcorr;
+  free(rho); free(im);
+}

@@ -230,3 +230,26 @@ class Fix:
 def _nz(a):
     """ctypes ndpointer rejects zero-length arrays on some numpy versions; pad"""
     return a if a.size else np.zeros(1, np.int32)
+
+
+class Pppm:
+    """oracle restatement of the PPPM b vector (pppm_conp.cpp b_cal chain); parity unpinned at the LAMMPS boundary"""
+
+    def __init__(self, lib, s, mesh, order=5):
+        lib.orc_pppm_create.restype = C.c_void_p
+        lib.orc_pppm_create.argtypes = [C.c_int] * 4 + [C.c_double, C.c_double, C.c_int, _dp, _dp]
+        lib.orc_pppm_b_cal.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, C.c_int, _dp, _dp, C.c_void_p]
+        lib.orc_pppm_destroy.argtypes = [C.c_void_p]
+        self.lib = lib
+        self.h = lib.orc_pppm_create(mesh[0], mesh[1], mesh[2], order, s.g_ewald, s.slab_volfactor, int(s.slabflag),
+                                     np.ascontiguousarray(s.boxlo), np.ascontiguousarray(s.prd))
+
+    def b_cal(self, x, q, echeck, nlocal, xele):
+        b = np.zeros(len(xele))
+        self.lib.orc_pppm_b_cal(self.h, nlocal, np.ascontiguousarray(x), np.ascontiguousarray(q),
+                                np.ascontiguousarray(echeck, np.int32), len(xele), np.ascontiguousarray(xele), b, None)
+        return b
+
+    def close(self):
+        if self.h:
+            self.lib.orc_pppm_destroy(self.h); self.h = None
