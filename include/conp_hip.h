@@ -168,6 +168,25 @@ int conp_inv_project(conp_fix *fix, int n, double *aaa, int nullneutral, int zne
  * row-major n x n matrix (host pointer, overwritten).  CONP_ERR_NUMERIC ("Inversion failed!") on a singular matrix. */
 int conp_invert(conp_fix *fix, int n, double *aaa);
 
+/* ---- host-only logic, callable without a GPU (CPU unit tests of the integer contracts) ---------------------------------
+ * conp_host_ktables: the k-vector tables of KSpaceModuleEwald::conp_setup (km_ewald.cpp:63-132, 285-424) for the given
+ * parameters.  Call once with NULL arrays to get the counts in info[16] = {kcount, kcount_flat, kcount_expand, kxmax, kymax,
+ * kzmax, kmax, kmax3d, kcount_dims[0..6], n_planar}, then with arrays of those sizes.  plan_* (optional) return the GPU plan:
+ * per k the planar-vector index, kz index and sign. */
+int conp_host_ktables(double g_ewald, double accuracy, double slab_volfactor, int slabflag, double xprd, double yprd, double zprd,
+                      double qsqsum, int64_t natoms, double qqrd2e, double dielectric, int *info /*[16]*/, int *kxvecs,
+                      int *kyvecs, int *kzvecs, double *ug, int *kxy_list, int *kz_list, int *plan_p, int *plan_m, int *plan_sign);
+/* conp_host_index: FixConp::post_neighbor's maps (fix_conp.cpp:468-539) for a sequence of two neighbour builds: atoms as they
+ * are at the first post_neighbor (tag0/echeck0, n0 owned atoms) and at a later one (tag1/echeck1, n1).  Outputs like
+ * conp_fix_get_maps, for the state after the second call; sizes[4] = {elenum, elenum_all, elytenum, maxtag_all}. */
+int conp_host_index(int n0, const int *tag0, const int *echeck0, int n1, const int *tag1, const int *echeck1, int *sizes,
+                    int *ele2tag, int *ele2eleall, int *eleall2tag, int *eleall2ele, int *elebuf2eleall, int *tag2eleall);
+/* conp_host_pair_rows: the electrode-row regrouping of a LAMMPS half list (which = 1: blist_coul_cal membership,
+ * fix_conp.cpp:1313-1353; which = 0: alist_coul_cal, :1242-1276; which = 2: post-force pairs :1411).  Returns the number of
+ * pairs; with non-NULL arrays fills row_ptr[Ne+1] (which 0/1), ele_atom/oth_atom[npairs], col[npairs] (which 0). */
+int64_t conp_host_pair_rows(int which, const conp_neighlist *list, const conp_atoms *atoms, int newton, int *row_ptr,
+                            int *ele_atom, int *oth_atom, int *col);
+
 /* ---- device-resident operation (bench, GPU-resident MD engines, multi-GPU) -------------------------------------
  * x/q are DEVICE pointers with the same layout as conp_atoms.x/q; nothing crosses PCIe.  One charge update =
  *   conp_fix_b_cal_device  (this rank's shard of b into the bound b buffer: its k-shard for ALL rows + its rows of

@@ -69,7 +69,8 @@ SYMBOLS = [
     "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_post_force", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
     "conp_fix_equation_solve", "conp_fix_update_charge", "conp_km_conp_setup", "conp_km_a_cal", "conp_km_b_cal",
     "conp_fix_info", "conp_fix_get_ktables", "conp_fix_get_maps", "conp_fix_get_matrix", "conp_fix_set_matrix",
-    "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_invert", "conp_fix_set_stream",
+    "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_invert",
+    "conp_host_ktables", "conp_host_index", "conp_host_pair_rows", "conp_fix_set_stream",
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
 ]
@@ -114,6 +115,11 @@ def load_library():
     lib.conp_fix_get_ele_trig.argtypes = [vp, dp, dp]
     lib.conp_inv_project.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, dp, C.c_double, dp]
     lib.conp_invert.argtypes = [vp, C.c_int, dp]
+    lib.conp_host_ktables.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_int64, C.c_double, C.c_double, ip, ip, ip, ip, dp, ip, ip, ip, ip, ip]
+    lib.conp_host_index.argtypes = [C.c_int, ip, ip, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip]
+    lib.conp_host_pair_rows.argtypes = [C.c_int, C.POINTER(conp_neighlist), C.POINTER(conp_atoms), C.c_int, ip, ip, ip, ip]
+    lib.conp_host_pair_rows.restype = C.c_int64
     lib.conp_fix_set_stream.argtypes = [vp, vp]
     lib.conp_fix_bind_device_buffers.argtypes = [vp, vp, vp]
     lib.conp_fix_row_range.argtypes = [vp, ip, ip]
@@ -371,3 +377,70 @@ class FixConp:
             self.close()
         except Exception:
             pass
+
+
+# ---- host-only helpers (no GPU needed) -----------------------------------------------------------------------------
+def host_ktables(s: "_systems.System"):
+    lib = load_library()
+    info = np.zeros(16, np.int32)
+    args = (s.g_ewald, s.accuracy, s.slab_volfactor, int(s.slabflag), float(s.prd[0]), float(s.prd[1]), float(s.prd[2]), s.qsqsum,
+            int(s.natoms), _systems.QQRD2E, 1.0)
+    null_i, null_d = C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    rc = lib.conp_host_ktables(*args, _iptr(info), null_i, null_i, null_i, null_d, null_i, null_i, null_i, null_i, null_i)
+    if rc:
+        raise ConpError(rc, lib.conp_last_error().decode())
+    K, E = int(info[0]), max(int(info[2]), 1)
+    out = dict(kxvecs=np.zeros(K, np.int32), kyvecs=np.zeros(K, np.int32), kzvecs=np.zeros(K, np.int32), ug=np.zeros(K),
+               kxy_list=np.zeros(E, np.int32), kz_list=np.zeros(E, np.int32), plan_p=np.zeros(K, np.int32),
+               plan_m=np.zeros(K, np.int32), plan_sign=np.zeros(K, np.int32))
+    rc = lib.conp_host_ktables(*args, _iptr(info), _iptr(out["kxvecs"]), _iptr(out["kyvecs"]), _iptr(out["kzvecs"]), _dptr(out["ug"]),
+                               _iptr(out["kxy_list"]), _iptr(out["kz_list"]), _iptr(out["plan_p"]), _iptr(out["plan_m"]),
+                               _iptr(out["plan_sign"]))
+    if rc:
+        raise ConpError(rc, lib.conp_last_error().decode())
+    out["kxy_list"] = out["kxy_list"][:int(info[2])]; out["kz_list"] = out["kz_list"][:int(info[2])]
+    out.update(kcount=K, kcount_flat=int(info[1]), kcount_expand=int(info[2]), kxmax=int(info[3]), kymax=int(info[4]),
+               kzmax=int(info[5]), kmax=int(info[6]), kmax3d=int(info[7]), kcount_dims=info[8:15].copy(), n_planar=int(info[15]))
+    return out
+
+
+def host_index(tag0, echeck0, tag1=None, echeck1=None):
+    lib = load_library()
+    tag0 = np.ascontiguousarray(tag0, np.int32); echeck0 = np.ascontiguousarray(echeck0, np.int32)
+    if tag1 is None:
+        tag1, echeck1, n1 = tag0, echeck0, 0
+    else:
+        tag1 = np.ascontiguousarray(tag1, np.int32); echeck1 = np.ascontiguousarray(echeck1, np.int32); n1 = len(tag1)
+    ne = int((echeck0 != 0).sum()); mt = int(tag0.max())
+    sizes = np.zeros(4, np.int32)
+    m = dict(ele2tag=np.zeros(ne, np.int32), ele2eleall=np.zeros(ne, np.int32), eleall2tag=np.zeros(ne, np.int32),
+             eleall2ele=np.zeros(ne + 1, np.int32), elebuf2eleall=np.zeros(ne, np.int32), tag2eleall=np.zeros(mt + 1, np.int32))
+    rc = lib.conp_host_index(len(tag0), _iptr(tag0), _iptr(echeck0), n1, _iptr(tag1), _iptr(echeck1), _iptr(sizes),
+                             *[_iptr(m[k]) for k in ("ele2tag", "ele2eleall", "eleall2tag", "eleall2ele", "elebuf2eleall", "tag2eleall")])
+    if rc:
+        raise ConpError(rc, lib.conp_last_error().decode())
+    m["sizes"] = sizes
+    return m
+
+
+def host_pair_rows(which, lst, at, newton=False):
+    lib = load_library()
+    x = np.ascontiguousarray(at.x, dtype=np.float64)
+    neigh = lst.neigh if lst.neigh.size else np.zeros(1, np.int32)
+    av = conp_atoms(nlocal=at.nlocal, nghost=at.nghost, x=_dptr(x), q=_dptr(at.q), type=_iptr(at.type), tag=_iptr(at.tag),
+                    echeck=_iptr(at.echeck))
+    lv = conp_neighlist(inum=lst.inum, ilist=_iptr(lst.ilist), numneigh=_iptr(lst.numneigh), first=_iptr(lst.first),
+                        neigh=_iptr(neigh), nneigh=int(lst.neigh.size))
+    null_i = C.POINTER(C.c_int)()
+    n = lib.conp_host_pair_rows(which, C.byref(lv), C.byref(av), int(newton), null_i, null_i, null_i, null_i)
+    if n < 0:
+        raise ConpError(-2, lib.conp_last_error().decode())
+    ne = int((at.echeck[:at.nlocal] != 0).sum())
+    out = dict(row_ptr=np.zeros(ne + 1, np.int32), ele_atom=np.zeros(max(n, 1), np.int32), oth_atom=np.zeros(max(n, 1), np.int32),
+               col=np.zeros(max(n, 1), np.int32))
+    lib.conp_host_pair_rows(which, C.byref(lv), C.byref(av), int(newton), _iptr(out["row_ptr"]), _iptr(out["ele_atom"]),
+                            _iptr(out["oth_atom"]), _iptr(out["col"]))
+    for k in ("ele_atom", "oth_atom", "col"):
+        out[k] = out[k][:n]
+    out["npairs"] = int(n)
+    return out

@@ -1007,6 +1007,69 @@ int conp_invert(conp_fix *f, int n, double *aaa) {
   CONP_GUARD_END
 }
 
+int conp_host_ktables(double g_ewald, double accuracy, double slab_volfactor, int slabflag, double xprd, double yprd, double zprd,
+                      double qsqsum, int64_t natoms, double qqrd2e, double dielectric, int *info, int *kx, int *ky, int *kz,
+                      double *ug, int *kxy_list, int *kz_list, int *plan_p, int *plan_m, int *plan_sign) {
+  CONP_GUARD_BEGIN
+  KTables kt;
+  kt.build(g_ewald, accuracy, slab_volfactor, slabflag, xprd, yprd, zprd, qsqsum, natoms, qqrd2e, dielectric);
+  KPlan pl;
+  pl.build(kt);
+  if (info) {
+    const int v[9] = {kt.kcount, kt.kcount_flat, kt.kcount_expand, kt.kxmax, kt.kymax, kt.kzmax, kt.kmax, kt.kmax3d, 0};
+    for (int i = 0; i < 8; ++i) info[i] = v[i];
+    for (int i = 0; i < 7; ++i) info[8 + i] = kt.kcount_dims[i];
+    info[15] = pl.np;
+  }
+  const size_t K = kt.kcount, E = kt.kcount_expand;
+  if (kx) std::memcpy(kx, kt.kxvecs.data(), K * sizeof(int));
+  if (ky) std::memcpy(ky, kt.kyvecs.data(), K * sizeof(int));
+  if (kz) std::memcpy(kz, kt.kzvecs.data(), K * sizeof(int));
+  if (ug) std::memcpy(ug, kt.ug.data(), K * sizeof(double));
+  if (kxy_list) std::memcpy(kxy_list, kt.kxy_list.data(), E * sizeof(int));
+  if (kz_list) std::memcpy(kz_list, kt.kz_list.data(), E * sizeof(int));
+  if (plan_p) std::memcpy(plan_p, pl.k_p.data(), K * sizeof(int));
+  if (plan_m) std::memcpy(plan_m, pl.k_m.data(), K * sizeof(int));
+  if (plan_sign) std::memcpy(plan_sign, pl.k_sign.data(), K * sizeof(int));
+  CONP_GUARD_END
+}
+
+int conp_host_index(int n0, const int *tag0, const int *echeck0, int n1, const int *tag1, const int *echeck1, int *sizes,
+                    int *ele2tag, int *ele2eleall, int *eleall2tag, int *eleall2ele, int *elebuf2eleall, int *tag2eleall) {
+  CONP_GUARD_BEGIN
+  EleIndex x;
+  x.linalg_init(n0, tag0);
+  x.post_neighbor(n0, tag0, echeck0, nullptr);
+  if (n1 > 0) x.post_neighbor(n1, tag1, echeck1, nullptr);
+  if (sizes) { sizes[0] = x.elenum; sizes[1] = x.elenum_all; sizes[2] = x.elytenum; sizes[3] = x.maxtag_all; }
+  auto cp = [](int *dst, const std::vector<int> &v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(int)); };
+  cp(ele2tag, x.ele2tag); cp(ele2eleall, x.ele2eleall); cp(eleall2tag, x.eleall2tag); cp(eleall2ele, x.eleall2ele);
+  cp(elebuf2eleall, x.elebuf2eleall); cp(tag2eleall, x.tag2eleall);
+  CONP_GUARD_END
+}
+
+int64_t conp_host_pair_rows(int which, const conp_neighlist *l, const conp_atoms *at, int newton, int *row_ptr, int *ele_atom,
+                            int *oth_atom, int *col) {
+  try {
+    EleIndex x;
+    x.linalg_init(at->nlocal, at->tag);
+    x.post_neighbor(at->nlocal, at->tag, at->echeck, nullptr);
+    ListView v; v.inum = l->inum; v.ilist = l->ilist; v.numneigh = l->numneigh; v.first = l->first; v.neigh = l->neigh;
+    auto cp = [](int *dst, const std::vector<int> &s) { if (dst && !s.empty()) std::memcpy(dst, s.data(), s.size() * sizeof(int)); };
+    if (which == 2) {
+      std::vector<int> pi, pj;
+      build_pf_pairs(v, at->echeck, pi, pj);
+      cp(ele_atom, pi); cp(oth_atom, pj);
+      return (int64_t)pi.size();
+    }
+    PairRows r;
+    if (which == 1) build_b_rows(v, at->nlocal, at->tag, at->echeck, x, newton != 0, r);
+    else build_a_rows(v, at->nlocal, at->tag, at->echeck, x, newton != 0, r);
+    cp(row_ptr, r.row_ptr); cp(ele_atom, r.ele_atom); cp(oth_atom, r.oth_atom); cp(col, r.col);
+    return r.npairs();
+  } catch (const std::exception &e) { g_last_error = e.what(); return -1; }
+}
+
 int conp_fix_set_stream(conp_fix *f, void *s) {
   CONP_GUARD_BEGIN
   f->sync();
