@@ -348,3 +348,68 @@ def test_post_force_matches_oracle(oracle):
         assert np.allclose(vir, out_o[2:8], rtol=1e-9, atol=1e-9 * np.abs(out_o[2:8]).max())
         assert np.all(f_g[at.echeck != 0] == 0.0)                      # electrode atoms receive no force from this term
         fx.close(); o.fx.close()
+
+
+@pytest.mark.parametrize("case,extra,okw", [
+    ("noslab_zneutr", (), {}),                          # doubled antisymmetric cell, second neutrality constraint (fix_conp.cpp:1027-1060)
+    ("qinit", ("qinit",), dict(qinit=True)),           # initial electrode charges kept as an offset (:1107-1114, 1156)
+    ("nonneutral", ("nonneutral",), dict(nullneutral=False)),   # projection skipped, <e,e> still computed (:1011)
+    ("newton_on", (), {}),                              # ghost contributions routed through newtonbuf (:1345-1361)
+])
+def test_keyword_variants_match_oracle(oracle, case, extra, okw):
+    if case == "noslab_zneutr":
+        s = systems.deck("dilute", "noslab_zneutr", etypes=True)
+    else:
+        s = systems.deck("dilute", "slab", etypes=True)
+    if case == "qinit":
+        rng = np.random.default_rng(2)
+        ele = s.echeck != 0
+        s.q[ele] = rng.normal(scale=1e-3, size=int(ele.sum()))
+    if case == "newton_on":
+        s.newton = True
+    at, alist, blist = neighbor.build_lists(s)
+    o = OracleRun(oracle, s, at, alist, blist, **okw)
+    o.setup(); o.pre_force(s.potdiff)
+    fx = FixConp(s, extra_args=list(extra))
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    b_o, q_o, sq_o = o.fx.vectors()
+    b_g, q_g, sq_g = fx.vectors()
+    assert rel_err(b_g, b_o) < 1e-10 and rel_err(q_g, q_o) < TOL_Q and rel_err(sq_g, sq_o) < TOL_Q
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < TOL_Q
+    assert fx.info().totinve == pytest.approx(o.fx.scalars()["totinve"], rel=1e-7)      # the logged <e,e> / evscale
+    loc = slice(0, at.nlocal)
+    qe = at.q[loc][at.echeck[loc] != 0]
+    if case == "noslab_zneutr":
+        zpos = at.x[loc][at.echeck[loc] != 0][:, 2] > 0.5 * (s.boxlo[2] + s.boxhi[2])
+        assert abs(qe[zpos].sum()) < 1e-11 and abs(qe[~zpos].sum()) < 1e-11    # each half of the doubled cell is neutral
+    elif case == "nonneutral":
+        assert abs(qe.sum()) > 1e-6                                              # no projection -> not neutral
+    elif case == "qinit":
+        assert abs(qe.sum() - s.q[s.echeck != 0].sum()) < 1e-11                  # solved part neutral, offset kept
+    else:
+        assert abs(qe.sum()) < 1e-12
+    fx.close(); o.fx.close()
+
+
+def test_equivalent_formulations_give_the_same_charges():
+    """the reference's own test idea (tests/*/compare.gnu): slab-corrected p p f, finite-field p p p and the
+    doubled antisymmetric cell are formulations of the same physical system -> same electrode charge on the dilute deck"""
+    tot = {}
+    for mode in ("slab", "ffield", "noslab_zneutr"):
+        s = systems.deck("dilute", mode, etypes=True)
+        at, alist, blist = neighbor.build_lists(s)
+        fx = FixConp(s)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.setup_pre_force(at, 0, 1.0)
+        loc = slice(0, at.nlocal)
+        sel = at.echeck[loc] == 1
+        if mode == "noslab_zneutr":   # first copy of the cell only
+            sel &= at.tag[loc] <= 432
+        tot[mode] = at.q[loc][sel].sum()
+        fx.close()
+    assert tot["slab"] == pytest.approx(tot["ffield"], rel=2e-3)
+    assert tot["noslab_zneutr"] == pytest.approx(tot["ffield"], rel=2e-2)
