@@ -164,6 +164,15 @@ int conp_fix_get_ele_trig(conp_fix *fix, double *csk, double *snk);    /* [Ne][k
 int conp_inv_project(conp_fix *fix, int n, double *aaa, int nullneutral, int zneutr, const double *eleallz, double zhalf,
                      double *totinve_out);
 
+/* On-disk matrix formats of the reference.  write: which = 0 -> "amatrix" layout (fix_conp.cpp:833-849: a tag row
+ * of %20d, then rows of %20.12f), which = 1 -> "inv_a_matrix" layout (:960-977: %20d tags, %20.10f entries); the current device
+ * matrix is written.  read: FixConp::a_read (:721-773) for the `org F` / `inv F` keywords -- the first Ne tokens are the tags
+ * that define the permanent electrode numbering, the following Ne*Ne tokens the matrix; errors "Too many entries in A matrix
+ * file" / "Too few entries in A matrix file" as in the reference.  Call it between setup_post_neighbor and setup_pre_force
+ * (it stands for a_cal); the keyword decides whether the inverse is still computed (org) or taken as given (inv). */
+int conp_fix_write_matrix_file(conp_fix *fix, const char *path, int which);
+int conp_fix_read_matrix_file(conp_fix *fix, const conp_atoms *atoms, const char *path);
+
 /* the LU-quality inverse that stands where the reference calls dgetrf_/dgetri_ (fix_conp.cpp:947-949), on a caller-supplied
  * row-major n x n matrix (host pointer, overwritten).  CONP_ERR_NUMERIC ("Inversion failed!") on a singular matrix. */
 int conp_invert(conp_fix *fix, int n, double *aaa);

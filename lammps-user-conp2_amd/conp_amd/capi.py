@@ -70,7 +70,8 @@ SYMBOLS = [
     "conp_fix_equation_solve", "conp_fix_update_charge", "conp_km_conp_setup", "conp_km_a_cal", "conp_km_b_cal",
     "conp_fix_info", "conp_fix_get_ktables", "conp_fix_get_maps", "conp_fix_get_matrix", "conp_fix_set_matrix",
     "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_invert",
-    "conp_host_ktables", "conp_host_index", "conp_host_pair_rows", "conp_fix_set_stream",
+    "conp_host_ktables", "conp_host_index", "conp_host_pair_rows", "conp_fix_write_matrix_file", "conp_fix_read_matrix_file",
+    "conp_fix_set_stream",
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
 ]
@@ -120,6 +121,8 @@ def load_library():
     lib.conp_host_index.argtypes = [C.c_int, ip, ip, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip]
     lib.conp_host_pair_rows.argtypes = [C.c_int, C.POINTER(conp_neighlist), C.POINTER(conp_atoms), C.c_int, ip, ip, ip, ip]
     lib.conp_host_pair_rows.restype = C.c_int64
+    lib.conp_fix_write_matrix_file.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.conp_fix_read_matrix_file.argtypes = [vp, C.POINTER(conp_atoms), C.c_char_p]
     lib.conp_fix_set_stream.argtypes = [vp, vp]
     lib.conp_fix_bind_device_buffers.argtypes = [vp, vp, vp]
     lib.conp_fix_row_range.argtypes = [vp, ip, ip]
@@ -326,6 +329,12 @@ class FixConp:
         tot = C.c_double()
         self._check(self.lib.conp_inv_project(self.h, n, _dptr(a), int(nullneutral), int(zneutr), _dptr(z), zhalf, C.byref(tot)))
         return a, tot.value
+
+    def write_matrix_file(self, path, which):
+        self._check(self.lib.conp_fix_write_matrix_file(self.h, str(path).encode(), which))
+
+    def read_matrix_file(self, at, path):
+        self._check(self.lib.conp_fix_read_matrix_file(self.h, C.byref(self.atoms_view(at)), str(path).encode()))
 
     def invert(self, a):
         a = np.ascontiguousarray(a, dtype=np.float64).copy()

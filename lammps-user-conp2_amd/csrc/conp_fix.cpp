@@ -101,7 +101,7 @@ struct conp_fix {
   EleIndex idx;
   PairRows brows, arows;
   ListView alist, blist;
-  bool have_alist = false, have_blist = false, kspace_ready = false;
+  bool have_alist = false, have_blist = false, kspace_ready = false, matrix_loaded = false;
   int runstage = 0;          // fix_conp.cpp:181-183
   int ne_pad = 0, nl = 0, nl_pad = 0, nall = 0;
   int row0 = 0, row1 = 0, num_cus = 256;
@@ -409,6 +409,68 @@ struct conp_fix {
     launch_a_symmetrise(stream, ne, d_A.p);
     sync();
     runstage = 1;
+    if (args.matout) write_matrix_file("amatrix", 0);          // fix_conp.cpp:833-849
+  }
+
+  // fix_conp.cpp:721-773 a_read: `org F` / `inv F`
+  void a_read_file(const conp_atoms *at, const char *path) {
+    const int ne = idx.elenum_all;
+    FILE *fp = std::fopen(path, "r");
+    if (!fp) throw ConpError(CONP_ERR_IO, "Invalid fix conp command (Cannot open A matrix file)");   // :143
+    std::vector<int> tags;
+    std::vector<double> a((size_t)ne * ne);
+    size_t count = 0;
+    const size_t need = (size_t)ne + (size_t)ne * ne;
+    char tok[64];
+    bool too_many = false;
+    while (std::fscanf(fp, "%63s", tok) == 1) {
+      if (count < (size_t)ne) tags.push_back(std::atoi(tok));
+      else if (count < need) a[count - ne] = std::atof(tok);
+      else { too_many = true; break; }
+      ++count;
+    }
+    std::fclose(fp);
+    if (too_many) throw ConpError(CONP_ERR_IO, "Too many entries in A matrix file");        // :737
+    if (count != need) throw ConpError(CONP_ERR_IO, "Too few entries in A matrix file");     // :746
+    try { idx.renumber_from_tags(tags, at->nlocal, at->tag, at->echeck); }
+    catch (const std::exception &e) { throw ConpError(CONP_ERR_IO, e.what()); }
+    upload_atoms_static(at);                                   // atom2eleall follows the new numbering
+    build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
+    d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
+    HIP_TRY(hipMemcpyAsync(d_A.p, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    km_a_read(at);                                             // kspmod->a_read(): electrode phase tables (:772)
+    sync();
+    matrix_loaded = true;
+    runstage = 1;
+  }
+
+  // fix_conp.cpp:833-849 (amatrix) and :960-977 (inv_a_matrix)
+  void write_matrix_file(const char *path, int which) {
+    const int ne = idx.elenum_all;
+    std::vector<double> a((size_t)ne * ne);
+    HIP_TRY(hipMemcpyAsync(a.data(), d_A.p, a.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    FILE *fp = std::fopen(path, "w");
+    if (!fp) throw ConpError(CONP_ERR_IO, std::string("cannot open ") + path + " for writing");
+    if (which == 0) {
+      std::fprintf(fp, " ");
+      for (int i = 0; i < ne; ++i) std::fprintf(fp, "%20d", idx.eleall2tag[i]);
+      std::fprintf(fp, "\n");
+      for (int i = 0; i < ne; ++i) {
+        std::fprintf(fp, " ");
+        for (int j = 0; j < ne; ++j) std::fprintf(fp, "%20.12f", a[(size_t)i * ne + j]);
+        std::fprintf(fp, "\n");
+      }
+    } else {
+      for (int i = 0; i < ne; ++i) { if (i == 0) std::fprintf(fp, " "); std::fprintf(fp, "%20d", idx.eleall2tag[i]); }
+      std::fprintf(fp, "\n");
+      for (size_t k = 0; k < a.size(); ++k) {
+        if (k % ne != 0) std::fprintf(fp, " ");
+        std::fprintf(fp, "%20.10f", a[k]);
+        if ((k + 1) % ne == 0) std::fprintf(fp, "\n");
+      }
+    }
+    std::fclose(fp);
   }
 
   // fix_conp.cpp:609-637 b_setq_cal (host: Ne scalars)
@@ -482,6 +544,7 @@ struct conp_fix {
       const int ne = idx.elenum_all;
       invert_device(ne, d_A.p);
       if (!env.one_electrode) inv_project();
+      if (args.matout) write_matrix_file("inv_a_matrix", 1);   // :960-977
     }
     if (runstage == 2) runstage = 3;
   }
@@ -538,7 +601,7 @@ struct conp_fix {
   void linalg_setup(const conp_atoms *at) {
     if (runstage != 0) return;
     if (args.a_matrix_f == 0) a_cal(at);
-    else throw ConpError(CONP_ERR_STATE, "org/inv matrix files: load the matrix with conp_fix_set_matrix before setup");
+    else if (!matrix_loaded) a_read_file(at, args.a_matrix_file);      // fix_conp.cpp:443-446
     b_setq_cal(at);
     equation_solve();
     get_setq(at);
@@ -994,6 +1057,21 @@ int conp_inv_project(conp_fix *f, int n, double *aaa, int nullneutral, int zneut
   HIP_TRY(hipMemcpyAsync(aaa, dA.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();
   if (totinve_out) *totinve_out = f->totinve;
+  CONP_GUARD_END
+}
+
+int conp_fix_write_matrix_file(conp_fix *f, const char *path, int which) {
+  CONP_GUARD_BEGIN
+  if (f->runstage < 1) throw ConpError(CONP_ERR_STATE, "no matrix yet");
+  f->write_matrix_file(path, which);
+  CONP_GUARD_END
+}
+
+int conp_fix_read_matrix_file(conp_fix *f, const conp_atoms *at, const char *path) {
+  CONP_GUARD_BEGIN
+  if (!f->idx.initialised || f->idx.elenum_all == 0) throw ConpError(CONP_ERR_STATE, "read_matrix_file before setup_post_neighbor");
+  if (f->args.a_matrix_f == 0) f->args.a_matrix_f = 1;
+  f->a_read_file(at, path);
   CONP_GUARD_END
 }
 

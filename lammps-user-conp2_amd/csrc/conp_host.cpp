@@ -408,6 +408,25 @@ bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool
   return grew;
 }
 
+void EleIndex::renumber_from_tags(const std::vector<int> &file_tags, int nlocal, const int *tag, const int *echeck) {
+  if ((int)file_tags.size() != elenum_all) throw std::invalid_argument("matrix file tag row does not match the electrode count");
+  eleall2tag = file_tags;
+  for (int i = 0; i < elenum_all; ++i) {                 // :755-759
+    eleall2ele[i] = -1;
+    if (file_tags[i] < 0 || file_tags[i] > maxtag_all) throw std::invalid_argument("matrix file holds a tag outside 1..maxtag");
+    tag2eleall[file_tags[i]] = i;
+  }
+  int j = 0;
+  for (int i = 0; i < nlocal; ++i)                       // :763-770
+    if (echeck[i]) {
+      ele2tag[j] = tag[i];
+      ele2eleall[j] = tag2eleall[tag[i]];
+      eleall2ele[ele2eleall[j]] = j;
+      ++j;
+    }
+  for (int i = 0; i < elenum; ++i) elebuf2eleall[i] = ele2eleall[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // PairRows
 // ------------------------------------------------------------------------------------------------

@@ -105,6 +105,8 @@ struct EleIndex {
   // returns true when elenum_all grew (the reference then reallocates A, b, q ... :510-525)
   bool post_neighbor(int nlocal, const int *tag, const int *echeck, bool *elyte_grew);
   void map_atoms(int nlocal, const int *tag);
+  // FixConp::a_read (fix_conp.cpp:753-772): the matrix file's tag row becomes the permanent numbering
+  void renumber_from_tags(const std::vector<int> &file_tags, int nlocal, const int *tag, const int *echeck);
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -413,3 +413,76 @@ def test_equivalent_formulations_give_the_same_charges():
         fx.close()
     assert tot["slab"] == pytest.approx(tot["ffield"], rel=2e-3)
     assert tot["noslab_zneutr"] == pytest.approx(tot["ffield"], rel=2e-2)
+
+
+def test_matrix_files_round_trip(tmp_path):
+    """`matout` / `org F` / `inv F` (fix_conp.cpp:721-773, 833-849, 960-977): the reference's text layouts, a permuted
+    tag row re-defining the permanent numbering, and the reference's error messages"""
+    import os
+    from conp_amd import ConpError
+    s = systems.deck("dilute", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        fx = FixConp(s, extra_args=["matout"])
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.setup_pre_force(at, 0, 1.0)
+        q_ref = at.q.copy()
+        S = fx.matrix()
+        tags = fx.maps()["eleall2tag"]
+        fx.close()
+        # layout checks: tag row of %20d, rows of %20.12f / %20.10f
+        lines = open("amatrix").read().split("\n")
+        assert lines[0] == " " + "".join("%20d" % t for t in tags)
+        assert len(lines[1]) == 1 + 20 * len(tags)
+        A_file = np.loadtxt("amatrix", skiprows=1)
+        inv_lines = open("inv_a_matrix").read().split("\n")
+        assert inv_lines[1].startswith("%20.10f" % S[0, 0]) and inv_lines[1].split()[1] == ("%.10f" % S[0, 1])
+        # `org amatrix`: numbering from the file, inverse recomputed -> same charges (file precision 1e-12)
+        for kw, fname, tol in (("org", "amatrix", 1e-6), ("inv", "inv_a_matrix", 1e-4)):
+            at.q[:] = s.q[at.owner]
+            fy = FixConp(s, extra_args=[kw, fname])
+            fy.init_lists(alist, blist)
+            fy.setup_post_neighbor(at)
+            fy.setup_pre_force(at, 0, 1.0)
+            ele = at.echeck != 0
+            assert rel_err(at.q[ele], q_ref[ele]) < tol, kw
+            fy.close()
+        # a permuted tag row: the permanent numbering follows the file (a_read :753-759), charges per atom unchanged
+        perm = np.random.default_rng(0).permutation(len(tags))
+        with open("amatrix_perm", "w") as fh:
+            fh.write(" " + "".join("%20d" % t for t in tags[perm]) + "\n")
+            for i in perm:
+                fh.write(" " + "".join("%20.12f" % v for v in A_file[i][perm]) + "\n")
+        at.q[:] = s.q[at.owner]
+        fz = FixConp(s, extra_args=["org", "amatrix_perm"])
+        fz.init_lists(alist, blist)
+        fz.setup_post_neighbor(at)
+        fz.setup_pre_force(at, 0, 1.0)
+        assert np.array_equal(fz.maps()["eleall2tag"], tags[perm])
+        ele = at.echeck != 0
+        assert rel_err(at.q[ele], q_ref[ele]) < 1e-6
+        fz.close()
+        # error paths
+        with open("short", "w") as fh:
+            fh.write(" ".join(str(t) for t in tags) + "\n1.0 2.0\n")
+        for fname, msg in (("short", "Too few entries in A matrix file"), ("missing_file", "Cannot open A matrix file")):
+            fe = FixConp(s, extra_args=["org", fname])
+            fe.init_lists(alist, blist)
+            fe.setup_post_neighbor(at)
+            with pytest.raises(ConpError) as e:
+                fe.setup_pre_force(at, 0, 1.0)
+            assert msg in str(e.value)
+            fe.close()
+        with open("long", "w") as fh:
+            fh.write(open("amatrix").read() + " 1.0\n")
+        fe = FixConp(s, extra_args=["org", "long"])
+        fe.init_lists(alist, blist)
+        fe.setup_post_neighbor(at)
+        with pytest.raises(ConpError) as e:
+            fe.setup_pre_force(at, 0, 1.0)
+        assert "Too many entries in A matrix file" in str(e.value)
+        fe.close()
+    finally:
+        os.chdir(cwd)
