@@ -101,14 +101,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a one-GPU box: CONP_BENCH_REHEARSE=1 puts every rank on cuda:0 and runs the collectives over gloo
+    rehearse = os.environ.get("CONP_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     t_setup0 = time.perf_counter()
     s = make_workload(args.workload)
     at, alist, blist = neighbor.build_lists(s)
-    fx = FixConp(s, device=local_rank, rank=rank, nranks=world)
+    fx = FixConp(s, device=dev_index, rank=rank, nranks=world)
     fx.set_stream(torch.cuda.current_stream().cuda_stream)
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
@@ -132,11 +138,13 @@ def main():
 
         def b_local(self):
             fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())       # k-shard for all rows + own real-space rows -> d_b
-            return d_b
+            return d_b.cpu() if rehearse else d_b
 
         def solve_rows(self, b):
+            if rehearse:
+                d_b.copy_(b)
             fx.solve_device(potdiff)                              # own rows of S b -> d_sol[row0:row1]
-            return d_sol[row0:row1]
+            return d_sol[row0:row1].cpu() if rehearse else d_sol[row0:row1]
 
         def finish(self, q_all):
             if q_all.data_ptr() != d_sol.data_ptr():
@@ -166,7 +174,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
