@@ -173,7 +173,8 @@ struct conp_fix {
     kt.build(env.g_ewald, env.accuracy, env.slab_volfactor, env.slabflag, env.xprd, env.yprd, env.zprd, qsqsum, natoms,
              env.qqrd2e, env.dielectric);
     plan.build(kt);
-    std::vector<int> ikx(plan.n_row_tiles * 64, 0), iky(plan.n_row_tiles * 64, 0), sgn(plan.n_row_tiles * 64, 0);
+    // padding planar rows point at the all-zero X row kxmax+1 (they then contribute nothing)
+    std::vector<int> ikx(plan.n_row_tiles * 64, plan.kxmax + 1), iky(plan.n_row_tiles * 64, 0), sgn(plan.n_row_tiles * 64, 1);
     for (int p = 0; p < plan.np; ++p) { ikx[p] = plan.p_ikx[p]; iky[p] = plan.p_iky[p]; sgn[p] = plan.p_sgn[p]; }
     d_p_ikx.upload(ikx, stream); d_p_iky.upload(iky, stream); d_p_sgn.upload(sgn, stream);
     d_wfull.upload(plan.wfull, stream);
@@ -261,7 +262,7 @@ struct conp_fix {
     nl_pad = std::max(32, (nl + 31) / 32 * 32);
     d_elyte_idx.upload(elyte_idx_h, stream);
     build_items();
-    d_Xt.reserve((size_t)(plan.kxmax + 1) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
+    d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 255) / 256 + 1);
     d_Gpart.reserve((size_t)items_h.size() * 128 * 320);

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, co
     const double ang[3] = {ux * xx, uy * yy, uz * zz};
     const int nrow[3] = {kxmax + 1, kymax + 1, nz};
     double2 *tab[3] = {Xt, Yt, Zs};
+    Xt[(size_t)(kxmax + 1) * nl_pad + j] = make_double2(0.0, 0.0);   // row for padding planar vectors (no contribution)
     // X and Y: every row.  Z: row 0 of Zs is the unit step (cos, sin)(uz z); row 1 + s is the seed for m = s*zstride --
     // sk_gemm regenerates the m's in between with the same recurrence, so the values equal the full table's.
 #pragma unroll
@@ -59,15 +60,17 @@ __global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, co
       double2 *t = tab[c] + j;
       const int stride = (c == 2) ? zstride : 1;
       const int off = (c == 2) ? 1 : 0;
+      // the x table carries the charge (q cos, q sin): one multiply here instead of two per planar vector in sk_gemm
+      const double sc = (c == 0) ? qq : 1.0;
       if (c == 2) t[0] = make_double2(c1, s1);
-      t[(size_t)off * nl_pad] = make_double2(1.0, 0.0);
+      t[(size_t)off * nl_pad] = make_double2(sc, 0.0);
       double cm = c1, sm = s1;
-      if (nrow[c] > 1 && stride == 1) t[(size_t)(off + 1) * nl_pad] = make_double2(c1, s1);
+      if (nrow[c] > 1 && stride == 1) t[(size_t)(off + 1) * nl_pad] = make_double2(sc * c1, sc * s1);
       for (int m = 2; m < nrow[c]; ++m) {
         const double cn = cm * c1 - sm * s1;
         const double sn = sm * c1 + cm * s1;
         cm = cn; sm = sn;
-        if (m % stride == 0) t[(size_t)(off + m / stride) * nl_pad] = make_double2(cm, sm);
+        if (m % stride == 0) t[(size_t)(off + m / stride) * nl_pad] = make_double2(sc * cm, sc * sm);
       }
     }
   }
@@ -102,6 +105,9 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
 //    Software pipeline per chunk: issue global loads for chunk c+1 -> MFMA on chunk c -> build panel c+1 -> barrier.
 //    Partial tiles go to part[item][128][320]; sk_reduce sums a tile's splits in a fixed order (deterministic).
 // ================================================================================================
+#ifndef SK_LATE_MODE
+#define SK_LATE_MODE 2
+#endif
 constexpr int SK_J = 16;
 constexpr int SK_LD = SK_J + 1;   // 17 doubles: conflict-free for ds_read2st64_b64 / ds_write_b64 (banks mod 32, 16-lane groups)
 constexpr int SK_NF = 128 + 320;
@@ -118,7 +124,6 @@ __device__ __forceinline__ double2 zstep(double2 z, double2 st) {
 
 struct SkRaw {        // raw inputs of one thread for one chunk
   double2 X0, Y0, X1, Y1, Zseed, Zst;
-  double q;
 };
 
 struct SkCtx {        // per-thread constants of one work item
@@ -136,27 +141,23 @@ struct SkCtx {        // per-thread constants of one work item
 
 __device__ __forceinline__ void sk_load_raw(const SkCtx &c, int ch, SkRaw &r) {
   const unsigned jg = (unsigned)ch * SK_J + c.gj;
-  r.q = c.qc[jg];
   r.X0 = c.Xt[c.xoff0 + jg]; r.Y0 = c.Yt[c.yoff0 + jg];
   r.X1 = c.Xt[c.xoff1 + jg]; r.Y1 = c.Yt[c.yoff1 + jg];
   if (c.zact) { r.Zst = c.Zs[jg]; r.Zseed = c.Zs[c.zoff + jg]; }
 }
 
 __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, double *pn) {
-  // (kx, sg*ky): cos = cx cy - sg sx sy ; sin = sg cx sy + sx cy   (km_ewald.cpp:739-747)
+  // (kx, sg*ky): q cos = (q cx) cy - (q sx)(sg sy) ; q sin = (q cx)(sg sy) + (q sx) cy   (km_ewald.cpp:739-747); the X table
+  // already carries q, padding rows read an all-zero X row
   {
-    const double cth = r.X0.x * r.Y0.x - c.sg0 * (r.X0.y * r.Y0.y);
-    const double sth = c.sg0 * (r.X0.x * r.Y0.y) + r.X0.y * r.Y0.x;
-    const double live = c.sg0 * c.sg0;
-    pn[c.gs * SK_LD + c.gj] = live * (r.q * cth);
-    pn[(64 + c.gs) * SK_LD + c.gj] = live * (r.q * sth);
+    const double sy = c.sg0 * r.Y0.y;
+    pn[c.gs * SK_LD + c.gj] = r.X0.x * r.Y0.x - r.X0.y * sy;
+    pn[(64 + c.gs) * SK_LD + c.gj] = r.X0.x * sy + r.X0.y * r.Y0.x;
   }
   {
-    const double cth = r.X1.x * r.Y1.x - c.sg1 * (r.X1.y * r.Y1.y);
-    const double sth = c.sg1 * (r.X1.x * r.Y1.y) + r.X1.y * r.Y1.x;
-    const double live = c.sg1 * c.sg1;
-    pn[(32 + c.gs) * SK_LD + c.gj] = live * (r.q * cth);
-    pn[(96 + c.gs) * SK_LD + c.gj] = live * (r.q * sth);
+    const double sy = c.sg1 * r.Y1.y;
+    pn[(32 + c.gs) * SK_LD + c.gj] = r.X1.x * r.Y1.x - r.X1.y * sy;
+    pn[(96 + c.gs) * SK_LD + c.gj] = r.X1.x * sy + r.X1.y * r.Y1.x;
   }
   if (c.zact) {
     double2 Z = r.Zseed;
@@ -174,13 +175,14 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
 
 // MFMA phase of one chunk for a wave that owns NFW column fragments (fi = 4 g + cg, g < NFW)
 template <int NFW>
-__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const double *cur, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
+__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const double *cur, d4 (&acc)[4][NFW > 0 ? NFW : 1], int ks0 = 0,
+                                              int ks1 = SK_J / 4) {
   if (NFW > 0) {
     const double *ap = cur + c.a_off, *bp = cur + c.b_off;
     // not unrolled on purpose: 160 of the 256 VGPRs are accumulators; hoisting the LDS reads of several k-steps spills,
     // and the SIMD partner wave covers the LDS latency (measured: explicit double-buffering of the fragments gave nothing)
 #pragma unroll 1
-    for (int ks = 0; ks < SK_J / 4; ++ks) {
+    for (int ks = ks0; ks < ks1; ++ks) {
       double af[4], bf[NFW > 0 ? NFW : 1];
 #pragma unroll
       for (int f = 0; f < 4; ++f) af[f] = ap[(16 * f) * SK_LD + 4 * ks];
@@ -218,9 +220,20 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *o
       if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
       if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
     } else {
+#if SK_LATE_MODE == 1
+      // full stagger: build first, multiply second
       if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
       if (ch + 2 < c.it.c1 && !(c.dbg & 4)) sk_load_raw(c, ch + 2, raw);
       if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
+#else
+      // half stagger: the partner (early) wave multiplies all 4 k-steps first; this wave multiplies 2, builds, multiplies 2 --
+      // k-steps 0-1 of both waves overlap (LDS latency hidden behind the partner's MFMAs), each wave's build overlaps the
+      // other's k-steps 2-3
+      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc, 0, SK_J / 8);
+      if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
+      if (ch + 2 < c.it.c1 && !(c.dbg & 4)) sk_load_raw(c, ch + 2, raw);
+      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc, SK_J / 8, SK_J / 4);
+#endif
     }
     __syncthreads();
   }
