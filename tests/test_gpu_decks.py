@@ -119,3 +119,41 @@ def test_headline_properties(headline):
     fx.b_cal(at2)
     b3, _, _ = fx.vectors()
     assert np.array_equal(b2, b3)
+
+
+def test_large_box_structure_factors_against_direct_sums():
+    """BASELINE configs[4] geometry (16384 electrode / 262144 electrolyte atoms, K ~ 1.0e6, three kz column tiles): a sample of
+    structure factors and k-space b entries against direct numpy sums  S(k) = sum_j q_j exp(i k.r_j),
+    b_i = - sum_k 2 ug_k Re(conj(e^{i k.r_i}) S_k)  -- independent of the oracle and of the (planar, kz) factorisation"""
+    s = systems.synthetic_fast(n_cells_x=64, n_cells_y=32, lz=1200.0, n_elyte=262144, cutoff=12.0, accuracy_relative=1e-6,
+                               g_ewald=0.2554)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    info = fx.info()
+    assert info.elenum_all == 16384 and info.n_elyte_charged == 262144 and info.kcount > 1_000_000
+    b_g = fx.km_b_cal(at)
+    sr, si = fx.sfac()
+    kt = fx.ktables()
+    unitk = np.array(list(info.unitk))
+    sol = (at.echeck[:at.nlocal] == 0) & (at.q[:at.nlocal] != 0)
+    xs, qs = at.x[:at.nlocal][sol], at.q[:at.nlocal][sol]
+    rng = np.random.default_rng(5)
+    pick = np.concatenate([rng.integers(0, info.kcount, 60), [0, info.kcount_flat, info.kcount - 1]])
+    kv = np.stack([kt["kxvecs"][pick], kt["kyvecs"][pick], kt["kzvecs"][pick]], 1) * unitk
+    ph = xs @ kv.T
+    S_ref = (qs[:, None] * np.exp(1j * ph)).sum(0)
+    scale = np.abs(sr).max()
+    assert np.abs(sr[pick] - S_ref.real).max() / scale < 1e-10
+    assert np.abs(si[pick] - S_ref.imag).max() / scale < 1e-10
+    # b for a few electrode atoms from ALL structure factors the GPU produced
+    m = fx.maps()
+    loc = {int(t): i for i, t in enumerate(at.tag[:at.nlocal])}
+    kall = np.stack([kt["kxvecs"], kt["kyvecs"], kt["kzvecs"]], 1) * unitk
+    for ia in (0, 5000, 16383):
+        r = at.x[loc[int(m["eleall2tag"][ia])]]
+        e = np.exp(1j * (kall @ r))
+        b_ref = -np.sum(2.0 * kt["ug"] * (e.real * sr + e.imag * si))
+        assert b_g[ia] == pytest.approx(b_ref, rel=1e-9)
+    fx.close()
