@@ -408,6 +408,7 @@ struct conp_fix {
     launch_a_real(stream, ne, d_a_rowptr.p, d_a_ele.p, d_a_oth.p, d_a_col.p, d_x.p, d_type.p, real_params(), d_A.p);
     prof.end(stream);
     launch_a_symmetrise(stream, ne, d_A.p);
+    HIP_TRY(hipGetLastError());
     sync();
     runstage = 1;
     if (args.matout) write_matrix_file("amatrix", 0);          // fix_conp.cpp:833-849
@@ -647,6 +648,7 @@ struct conp_fix {
                           d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
                           4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
     prof.end(stream);
+    HIP_TRY(hipGetLastError());   // a refused launch (bad grid / LDS size) must not pass silently
   }
 
   // fix_conp.cpp:1135-1139: rows [row0,row1) of eleallq = S b (inverse solver), or the CG solve
@@ -678,6 +680,7 @@ struct conp_fix {
                            args.qinit ? d_eleinitq.p : nullptr, potdiff, nullptr, d_qele.p, d_q_atoms, d_scalars.p + 1);
     }
     prof.end(stream);
+    HIP_TRY(hipGetLastError());
   }
 
   void finish_scalar(double potdiff) {
