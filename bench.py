@@ -236,6 +236,12 @@ def main():
             base = cpu_baseline(s, at, alist, blist, S, args.cpu_threads)
             out["cpu_baseline"] = base
             out["speedup_vs_cpu_baseline"] = value / base["value"]
+            # the same port with OpenMP over k rows / electrode rows on this box's CPU share (16 threads per GPU): the analogue
+            # of running the reference on 16 MPI ranks ("all cores" figure)
+            if args.cpu_threads == 1:
+                mt = cpu_baseline(s, at, alist, blist, S, 16)
+                out["cpu_baseline_16_threads"] = mt
+                out["speedup_vs_cpu_baseline_16_threads"] = value / mt["value"]
         print(json.dumps(out))
     fx.close()
     if world > 1:
