@@ -58,6 +58,7 @@ typedef struct {
   char group2[128];        /* arg[4] :104 */
   char potdiff_var[128];   /* name after "v_" when potdiff_is_variable (potdiffstr :113) */
   int conq;                /* 1 when arg[2] names the conq style (fix_conq.h:21): DV is then the prescribed charge QR */
+  int cond;                /* 1 when arg[2] names the cond style (fix_cond.h): DV is the prescribed charge, potential from the cell dipole */
 } conp_fix_args;
 
 /* Parses arg[3..narg-1] of the fix command exactly like the reference constructor (same keywords, same
@@ -88,6 +89,12 @@ int conp_fix_create(const conp_fix_args *args, const conp_env *env, conp_fix **o
 void conp_fix_destroy(conp_fix *fix);   /* FixConp::~FixConp :205-229 */
 const char *conp_last_error(void);
 int conp_abi_version(void);
+
+/* FixConp::modify_param (fix_conp.cpp:1482-1515): `fix_modify ID ehgo kappa X` and `fix_modify ID ehgo coeff types eta u0|auto`
+ * (arg[0] = "ehgo").  Only valid with the `ehgo` keyword; *consumed = number of arguments used (3 or 5), like the reference's
+ * return value.  The per-type tables are finalised at setup (ehgo_setup_tables :1517-1559); without any coefficient the fix falls
+ * back to the plain eta model, as the reference does (with its warning text in conp_last_error()). */
+int conp_fix_modify_param(conp_fix *fix, int narg, const char *const *arg, int *consumed);
 
 /* ---- LAMMPS-owned per-atom arrays, re-fetched before every hook (may be reallocated on re-neighbour) ---- */
 typedef struct {

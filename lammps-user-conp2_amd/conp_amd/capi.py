@@ -30,7 +30,7 @@ class conp_fix_args(C.Structure):
                 ("qinit", C.c_int), ("lowmem", C.c_int), ("nullneutral", C.c_int), ("ehgo", C.c_int),
                 ("a_matrix_f", C.c_int), ("a_matrix_file", C.c_char * 512), ("smartlist", C.c_int),
                 ("eletypenum", C.c_int), ("eletypes", C.c_int * 32), ("minimizer", C.c_int), ("maxiter", C.c_int),
-                ("tolerance", C.c_double), ("logfile", C.c_char * 512), ("group2", C.c_char * 128), ("potdiff_var", C.c_char * 128), ("conq", C.c_int)]
+                ("tolerance", C.c_double), ("logfile", C.c_char * 512), ("group2", C.c_char * 128), ("potdiff_var", C.c_char * 128), ("conq", C.c_int), ("cond", C.c_int)]
 
 
 class conp_env(C.Structure):
@@ -66,7 +66,7 @@ class conp_info(C.Structure):
 SYMBOLS = [
     "conp_parse_fix_args", "conp_fix_create", "conp_fix_destroy", "conp_last_error", "conp_abi_version",
     "conp_fix_init_list", "conp_fix_setup_post_neighbor", "conp_fix_setup_pre_force", "conp_fix_post_neighbor",
-    "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_post_force", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
+    "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_post_force", "conp_fix_modify_param", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
     "conp_fix_equation_solve", "conp_fix_update_charge", "conp_km_conp_setup", "conp_km_a_cal", "conp_km_b_cal",
     "conp_fix_info", "conp_fix_get_ktables", "conp_fix_get_maps", "conp_fix_get_matrix", "conp_fix_set_matrix",
     "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_invert",
@@ -101,6 +101,7 @@ def load_library():
     lib.conp_fix_compute_scalar.argtypes = [vp]
     lib.conp_fix_compute_scalar.restype = C.c_double
     lib.conp_fix_post_force.argtypes = [vp, C.POINTER(conp_atoms), dp, dp, dp, dp]
+    lib.conp_fix_modify_param.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), ip]
     lib.conp_fix_equation_solve.argtypes = [vp]
     lib.conp_fix_update_charge.argtypes = [vp, C.POINTER(conp_atoms), C.c_double]
     lib.conp_km_conp_setup.argtypes = [vp, C.c_double, C.c_int64]
@@ -246,6 +247,13 @@ class FixConp:
     def update_charge(self, at, potdiff=None):
         pd = self.s.potdiff if potdiff is None else potdiff
         self._check(self.lib.conp_fix_update_charge(self.h, C.byref(self.atoms_view(at)), pd))
+
+    def modify_param(self, *tokens):
+        """fix_modify ID <tokens>, e.g. modify_param("ehgo", "coeff", "5", "1.979", "auto")"""
+        arr = (C.c_char_p * len(tokens))(*[str(t).encode() for t in tokens])
+        n = C.c_int()
+        self._check(self.lib.conp_fix_modify_param(self.h, len(tokens), arr, C.byref(n)))
+        return n.value
 
     def post_force(self, at):
         f = np.zeros((at.nlocal + at.nghost, 3)); ek = C.c_double(); ec = C.c_double(); vir = np.zeros(6)

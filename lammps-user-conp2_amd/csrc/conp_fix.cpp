@@ -112,6 +112,13 @@ struct conp_fix {
   int cg_iterations = 0;
   int nzc = 0;               // distinct electrode z values (<= 64: planar fast path of the projection), else 0
   std::vector<double> csk_h, snk_h, xele_h, d_vec_h;
+  // EHGO pair mode (fix_conp.cpp:1482-1598)
+  bool ehgo_active = false;
+  double kappa = 1.0;
+  std::vector<double> eta_i_h, u0_i_h, eta_ij_h, fo_ij_h;
+  std::string warning;
+  double cond_vmult = 0.0;       // fix cond (fix_cond.cpp:58-68)
+  bool cond_ready = false;
   std::vector<int> atom2eleall_h, elyte_idx_h, pf_i_h, pf_j_h;
   int nlocal_cur = 0;
   // device state
@@ -120,7 +127,7 @@ struct conp_fix {
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
       d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
-      d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew;
+      d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
       d_elecheck, d_zclass, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_pp_egrid, d_ipiv, d_info, d_cg_done;
@@ -144,6 +151,7 @@ struct conp_fix {
     const double cut_erfc = 5.8 * 5.8 / (env.g_ewald * env.g_ewald);
     if (cut_coulsq > cut_erfc) cut_coulsq = cut_erfc;
     rp.cut_coulsq = cut_coulsq; rp.ntypes = env.ntypes; rp.cutsq = d_cutsq.p;
+    rp.ehgo = ehgo_active ? 1 : 0; rp.eta_ij = d_eta_ij.p; rp.fo_ij = d_fo_ij.p; rp.u0_i = d_u0_i.p;
     return rp;
   }
 
@@ -166,6 +174,74 @@ struct conp_fix {
     d_cutsq.upload(cutsq_h, stream);
     d_scalars.reserve(16);
     d_scalars.zero(stream);
+  }
+
+  // FixConp::modify_param (fix_conp.cpp:1482-1515)
+  int modify_param(int narg, const char *const *arg) {
+    if (!args.ehgo) throw ConpError(CONP_ERR_ARG, "Can't fix_modify conp parameters in basic pair mode");
+    if (narg < 1 || std::strcmp(arg[0], "ehgo") != 0) return 0;
+    const int nt1 = env.ntypes + 1;
+    if (eta_i_h.empty()) { eta_i_h.assign(nt1, 0.0); u0_i_h.assign(nt1, 0.0); }       // ehgo_allocate :1575-1588
+    const double CON_s2overPIS = std::sqrt(2.0) / 1.77245385090551602729;
+    const double evs = env.qe2f / env.qqr2e;
+    if (narg >= 2 && std::strcmp(arg[1], "kappa") == 0) {
+      if (narg != 3) throw ConpError(CONP_ERR_ARG, "Invalid number of inputs for EHGO coeff setting");
+      kappa = std::atof(arg[2]);
+      return 3;
+    }
+    if (narg >= 2 && std::strcmp(arg[1], "coeff") == 0) {
+      if (narg != 5) throw ConpError(CONP_ERR_ARG, "Invalid number of inputs for EHGO coeff setting");
+      // utils::bounds(arg[2], 1, ntypes): "N", "*", "N*", "*M", "N*M"
+      int ilo = 1, ihi = env.ntypes;
+      const std::string b = arg[2];
+      const size_t star = b.find('*');
+      if (star == std::string::npos) ilo = ihi = std::atoi(b.c_str());
+      else {
+        if (star > 0) ilo = std::atoi(b.substr(0, star).c_str());
+        if (star + 1 < b.size()) ihi = std::atoi(b.substr(star + 1).c_str());
+      }
+      if (ilo < 1 || ihi > env.ntypes) throw ConpError(CONP_ERR_ARG, "Numeric index is out of bounds");
+      const double eta_one = std::atof(arg[3]);
+      const double u0_one = std::strcmp(arg[4], "auto") == 0 ? CON_s2overPIS * eta_one / evs : std::atof(arg[4]);
+      int count = 0;
+      for (int i = ilo; i <= ihi; ++i) { eta_i_h[i] = eta_one; u0_i_h[i] = u0_one * evs; ++count; }   // eV/e^2 -> 1/A :1506
+      if (count == 0) throw ConpError(CONP_ERR_ARG, "Couldn't set EHGO coeffs with mintype more than maxtype");
+      return 5;
+    }
+    throw ConpError(CONP_ERR_ARG, "Invalid entry for EHGO coeff setting");
+  }
+
+  // ehgo_setup_tables (fix_conp.cpp:1517-1559), called from init() in the reference = before the first setup here
+  void ehgo_setup_tables() {
+    if (!args.ehgo) return;
+    const int nt1 = env.ntypes + 1;
+    if (eta_i_h.empty()) { eta_i_h.assign(nt1, 0.0); u0_i_h.assign(nt1, 0.0); }
+    bool setflag = false;
+    for (int i = 1; i < nt1; ++i) if (eta_i_h[i] || u0_i_h[i]) setflag = true;
+    if (!setflag) {       // :1553-1558
+      ehgo_active = false;
+      warning = "No EHGO settings found, switching back to ETA mode";
+      return;
+    }
+    const double CON_s2overPIS = std::sqrt(2.0) / 1.77245385090551602729, sq8 = std::sqrt(8.0);
+    std::vector<double> f_i(nt1, 0.0);
+    eta_ij_h.assign((size_t)nt1 * nt1, 0.0); fo_ij_h.assign((size_t)nt1 * nt1, 0.0);
+    for (int i = 1; i < nt1; ++i) f_i[i] = u0_i_h[i] - CON_s2overPIS * eta_i_h[i];
+    for (int i = 1; i < nt1; ++i)
+      for (int j = 1; j <= i; ++j) {
+        if (eta_i_h[i] && eta_i_h[j]) {
+          const double etasq = eta_i_h[i] * eta_i_h[i] + eta_i_h[j] * eta_i_h[j];
+          const double etaprod = eta_i_h[i] * eta_i_h[j];
+          const double eij = etaprod / std::sqrt(etasq);
+          const double o_ij = sq8 * eij * eij * eij / (etaprod * std::sqrt(etaprod));
+          const double f_ij = 0.5 * kappa * (f_i[i] + f_i[j]);
+          eta_ij_h[(size_t)i * nt1 + j] = eij;
+          fo_ij_h[(size_t)i * nt1 + j] = f_ij * o_ij;
+        } else eta_ij_h[(size_t)i * nt1 + j] = eta_i_h[i] + eta_i_h[j];
+        if (i != j) { eta_ij_h[(size_t)j * nt1 + i] = eta_ij_h[(size_t)i * nt1 + j]; fo_ij_h[(size_t)j * nt1 + i] = fo_ij_h[(size_t)i * nt1 + j]; }
+      }
+    d_eta_ij.upload(eta_ij_h, stream); d_fo_ij.upload(fo_ij_h, stream); d_u0_i.upload(u0_i_h, stream);
+    ehgo_active = true;
   }
 
   // km_ewald.cpp:63-132 conp_setup
@@ -220,6 +296,7 @@ struct conp_fix {
     for (int i = 0; i < at->nlocal; i++) qsqsum += at->q[i] * at->q[i];
     km_conp_setup(qsqsum, (int64_t)at->nlocal);
     evscale = env.qe2f / env.qqr2e;                        // :412
+    ehgo_setup_tables();                                   // FixConp::init :296-299
     idx.linalg_init(at->nlocal, at->tag);
   }
 
@@ -399,7 +476,14 @@ struct conp_fix {
     const double diag_k = kt.ug_tot - (2.0 / MY_PIS) * kt.g_ewald;      // km_ewald.cpp:631-634
     const double diag_self = (std::sqrt(2.0) / MY_PIS) * args.eta;      // fix_conp.cpp:796-801
     const double pref = 12.56637061435917295384 / kt.volume;            // MY_4PI/volume km_ewald.cpp:648
-    launch_a_diag_slab(stream, ne, diag_k, diag_self, kt.slabflag == 1, pref, d_ele_z.p, d_A.p);
+    const double *diag_atom = nullptr;
+    if (ehgo_active) {            // :803-810: u0 of the atom's type on the diagonal
+      std::vector<double> da(ne_pad, 0.0);
+      for (int i = 0; i < idx.elenum; ++i) da[idx.ele2eleall[i]] = u0_i_h[at->type[idx.tag2local[idx.ele2tag[i]]]];
+      d_diag_atom.upload(da, stream);
+      diag_atom = d_diag_atom.p;
+    }
+    launch_a_diag_slab(stream, ne, diag_k, diag_self, diag_atom, kt.slabflag == 1, pref, d_ele_z.p, d_A.p);
     build_a_rows(alist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, arows);
     d_a_rowptr.upload(arows.row_ptr, stream); d_a_ele.upload(arows.ele_atom, stream);
     d_a_oth.upload(arows.oth_atom, stream); d_a_col.upload(arows.col, stream);
@@ -498,6 +582,12 @@ struct conp_fix {
     for (int i = 0; i < ne; ++i) ec[i] = idx.elecheck_eleall[i];
     d_elecheck.upload(ec, stream);
     HIP_TRY(hipMemcpyAsync(d_b, d_vec_h.data(), ne * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (args.cond) {               // FixCond::cond_setup (fix_cond.cpp:46-56): z-hat vector = preset vector / evscale
+      std::vector<double> sz(ne_pad, 0.0);
+      for (int i = 0; i < ne; ++i) sz[i] = d_vec_h[i] / evscale;
+      d_setzvec.upload(sz, stream);
+      cond_ready = false;
+    }
     sync();
     if (runstage == 1) runstage = 2;
   }
@@ -668,7 +758,26 @@ struct conp_fix {
   void scatter_device(double *d_q_atoms, double potdiff) {
     const int ne = idx.elenum_all;
     prof.begin("charge_write", stream);
-    if (args.conq) {
+    if (args.cond) {
+      // fix cond (fix_cond.cpp:58-126): vmult once (cond_setup2), then the potential from the cell dipole
+      if (!cond_ready) {
+        std::vector<double> sq(ne), sz(ne);
+        HIP_TRY(hipMemcpyAsync(sq.data(), d_elesetq.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(sz.data(), d_setzvec.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+        double zOAz = 0.;
+        for (int i = 0; i < ne; ++i) zOAz += sq[i] * sz[i];
+        double vm = 4 * 3.14159265358979323846 * zOAz * env.zprd / (evscale * env.xprd * env.yprd);
+        vm /= 1 + vm;
+        vm /= zOAz;
+        cond_vmult = vm;
+        cond_ready = true;
+      }
+      launch_cond_potdiff(stream, ne, d_setzvec.p, d_eleallq, d_slab_part.p, n_slab_part, env.zprd, potdiff, cond_vmult,
+                          d_scalars.p + 3);
+      launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
+                           args.qinit ? d_eleinitq.p : nullptr, 0.0, d_scalars.p + 3, d_qele.p, d_q_atoms, nullptr);
+    } else if (args.conq) {
       // fix conq (fix_conq.cpp:41-90): `potdiff` carries the prescribed charge QR; the potential difference follows from
       // the group-1 sum of S b, all on the device
       launch_left_sum(stream, ne, d_elecheck.p, d_eleallq, d_scalars.p + 1);
@@ -687,7 +796,7 @@ struct conp_fix {
     double h[4];
     HIP_TRY(hipMemcpyAsync(h, d_scalars.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
-    scalar_output = args.conq ? h[3] : potdiff * totsetq + h[1];   // fix_conp.cpp:1159 / fix_conq.cpp:78-80
+    scalar_output = (args.conq || args.cond) ? h[3] : potdiff * totsetq + h[1];   // fix_conp.cpp:1159 / fix_conq.cpp:78-80 / fix_cond.cpp:116
     slabcorr = h[2];
   }
 
@@ -721,7 +830,8 @@ struct conp_fix {
     HIP_TRY(hipMemcpyAsync(acc, d_pfacc.p, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     if (f) for (size_t k = 0; k < fh.size(); ++k) f[k] += fh[k];
-    if (ek) *ek = env.qqrd2e * 1.0 * args.eta * acc[7] / (std::sqrt(2.0) * 1.77245385090551602729);   // :1180
+    if (ek) *ek = ehgo_active ? env.qqrd2e * 1.0 * acc[7]                                                    // :1198
+                              : env.qqrd2e * 1.0 * args.eta * acc[7] / (std::sqrt(2.0) * 1.77245385090551602729);   // :1180
     if (ec) *ec = acc[0];
     if (vir) for (int k = 0; k < 6; ++k) vir[k] = acc[1 + k];
   }
@@ -779,6 +889,7 @@ int conp_parse_fix_args(int narg, const char *const *arg, int ntypes, conp_fix_a
   out->maxiter = 100; out->tolerance = 0.000001; out->minimizer = CONP_SOLVER_INV;   // :88-90
   out->lowmem = 1; out->nullneutral = 1; out->ff_flag = CONP_FF_NORMAL;
   out->conq = std::strncmp(arg[2], "conq", 4) == 0;   // FixStyle(conq,FixConq) fix_conq.h:21
+  out->cond = std::strncmp(arg[2], "cond", 4) == 0;   // FixStyle(cond,FixCond) fix_cond.h
   out->everynum = inumeric(arg[3], "fix conp Nevery");
   if (out->everynum <= 0) throw ConpError(CONP_ERR_ARG, "Illegal fix conp command (Nevery must be positive)");
   std::snprintf(out->group2, sizeof(out->group2), "%s", arg[4]);
@@ -838,7 +949,6 @@ int conp_parse_fix_args(int narg, const char *const *arg, int ntypes, conp_fix_a
 int conp_fix_create(const conp_fix_args *args, const conp_env *env, conp_fix **out) {
   CONP_GUARD_BEGIN
   if (!args || !env || !out) throw ConpError(CONP_ERR_ARG, "null argument");
-  if (args->ehgo) throw ConpError(CONP_ERR_ARG, "ehgo pair mode is not available in the HIP provider yet");
   if (args->split) throw ConpError(CONP_ERR_ARG, "split provider is not available in the HIP provider (experimental in the reference)");
   if (env->nranks < 1 || env->rank < 0 || env->rank >= env->nranks) throw ConpError(CONP_ERR_ARG, "bad rank/nranks");
   std::unique_ptr<conp_fix> f(new conp_fix());
@@ -898,6 +1008,13 @@ int conp_fix_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimestep, dou
 
 double conp_fix_compute_scalar(const conp_fix *f) { return f->scalar_output; }
 
+int conp_fix_modify_param(conp_fix *f, int narg, const char *const *arg, int *consumed) {
+  CONP_GUARD_BEGIN
+  const int n = f->modify_param(narg, arg);
+  if (consumed) *consumed = n;
+  CONP_GUARD_END
+}
+
 int conp_fix_post_force(conp_fix *f, const conp_atoms *at, double *fo, double *ek, double *ec, double *vir) {
   CONP_GUARD_BEGIN
   if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "post_force before setup");
@@ -942,7 +1059,7 @@ int conp_km_a_cal(conp_fix *f, const conp_atoms *at, double *aaa) {
   f->km_a_read(at);
   f->km_a_cal_device();
   const double MY_PIS = 1.77245385090551602729;
-  launch_a_diag_slab(f->stream, ne, f->kt.ug_tot - (2.0 / MY_PIS) * f->kt.g_ewald, 0.0, f->kt.slabflag == 1,
+  launch_a_diag_slab(f->stream, ne, f->kt.ug_tot - (2.0 / MY_PIS) * f->kt.g_ewald, 0.0, nullptr, f->kt.slabflag == 1,
                      12.56637061435917295384 / f->kt.volume, f->d_ele_z.p, f->d_A.p);
   HIP_TRY(hipMemcpyAsync(aaa, f->d_A.p, (size_t)ne * ne * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();

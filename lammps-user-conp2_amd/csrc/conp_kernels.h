@@ -19,6 +19,9 @@ struct RealParams {           // real-space pair kernels
   double g_ewald, eta, cut_coulsq;    // cut_coulsq already min(cut_coul^2, (5.8/g)^2)  fix_conp.cpp:1237-1240
   int ntypes;
   const double *cutsq;                // [(ntypes+1)^2]
+  int ehgo;                           // EHGO pair mode (fix_conp.cpp:1561-1573): per type-pair eta_ij, fo_ij
+  const double *eta_ij, *fo_ij;       // [(ntypes+1)^2]
+  const double *u0_i;                 // [ntypes+1] (post-force self energy :1182-1199)
 };
 
 struct PppmDev {              // device view of PppmPlan
@@ -56,6 +59,8 @@ void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S,
 void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleall, const int *elecheck, const double *eleallq,
                           const double *elesetq, const double *eleinitq, double potdiff, const double *d_potdiff, double *q_ele,
                           double *q_atoms, double *left_out);
+void launch_cond_potdiff(hipStream_t s, int ne, const double *setzvec, const double *eleallq, const double *slab_part,
+                         int n_slab_part, double lz, double rightcharge, double vmult, double *out);
 void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out);
 void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, int nlocal, int nall, int newton, const double *x,
                        const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
@@ -64,8 +69,8 @@ void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v
 
 // ---- once-per-run matrix work ------------------------------------------------------------------
 void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A);
-void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, int slab, double pref, const double *ele_z,
-                        double *A);
+void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, const double *diag_self_atom /*[ne] or NULL*/,
+                        int slab, double pref, const double *ele_z, double *A);
 void launch_a_real(hipStream_t s, int ne, const int *row_ptr, const int *ele_atom, const int *oth_atom, const int *col,
                    const double *x, const int *type, RealParams rp, double *A);
 void launch_a_symmetrise(hipStream_t s, int ne, double *A);

@@ -18,6 +18,8 @@ namespace conp {
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+__device__ double block_sum_1024(double v, double *red);
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -542,6 +544,21 @@ __device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
   return 0.0;
 }
 
+// pair_potential of the reference (fix_conp.cpp:1467-1475 eta_potential_A / eta_potential, :1561-1566 ehgo_potential)
+__device__ __forceinline__ double pair_potential_dev(const RealParams &rp, double rsq, int ti, int tj, bool for_a) {
+#pragma clang fp contract(off)
+  if (rp.ehgo) {
+    const double etaij = rp.eta_ij[ti * (rp.ntypes + 1) + tj], foij = rp.fo_ij[ti * (rp.ntypes + 1) + tj];
+    const double etarij2 = etaij * etaij * rsq;
+    return foij * exp(-0.5 * etarij2) - erfcr_sqrt_dev(etarij2) * etaij;
+  }
+  if (for_a) {
+    const double etarij2 = rp.eta * rp.eta * rsq / 2;
+    return -erfcr_sqrt_dev(etarij2) * rp.eta / sqrt(2.0);
+  }
+  return -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
+}
+
 // one wave per electrode row (global eleall index), fused with the assembly of this rank's b contribution:
 //   b[row] = bk_half0[row] + bk_half1[row]                       (k-space shard, km_ewald.cpp:789-825)
 //          - z_row * sum_j 4 pi q_j z_j / V                      (slab, km_ewald.cpp:827-847; rank 0 only)
@@ -568,7 +585,7 @@ __global__ __launch_bounds__(256) void b_real_combine_kernel(int ne, int ne_pad,
       const double rsq = dx * dx + dy * dy + dz * dz;
       if (rsq < rp.cutsq[type[ie] * nt1 + type[jo]] && rsq < rp.cut_coulsq) {
         double dudq = erfcr_sqrt_dev(rp.g_ewald * rp.g_ewald * rsq) * rp.g_ewald;
-        dudq += -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
+        dudq += pair_potential_dev(rp, rsq, type[ie], type[jo], false);
         sum -= q[jo] * dudq;
       }
     }
@@ -686,6 +703,29 @@ __global__ void conq_potdiff_kernel(const double *__restrict__ left, double righ
   *out = v;
 }
 
+// fix cond (fix_cond.cpp:99-116): dV = (Q - dipole/lz - setz . eleallq) * vmult, dipole = - sum_{electrolyte} q z
+// (slab_part holds the per-block partial sums of q z written by the phase / spread kernel); one workgroup, fixed trees
+__global__ __launch_bounds__(1024) void cond_potdiff_kernel(int ne, const double *__restrict__ setzvec,
+                                                            const double *__restrict__ eleallq,
+                                                            const double *__restrict__ slab_part, int n_slab_part, double lz,
+                                                            double rightcharge, double vmult, double *__restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < ne; i += 1024) s += setzvec[i] * eleallq[i];
+  s = block_sum_1024(s, red);
+  double qz = 0.0;
+  for (int k = threadIdx.x; k < n_slab_part; k += 1024) qz += slab_part[k];
+  qz = block_sum_1024(qz, red);
+  if (threadIdx.x == 0) *out = (rightcharge + qz / lz - s) * vmult;     // dipole = -qz
+}
+
+void launch_cond_potdiff(hipStream_t s, int ne, const double *setzvec, const double *eleallq, const double *slab_part,
+                         int n_slab_part, double lz, double rightcharge, double vmult, double *out) {
+  hipLaunchKernelGGL(cond_potdiff_kernel, dim3(1), dim3(1024), 0, s, ne, setzvec, eleallq, slab_part, n_slab_part, lz, rightcharge,
+                     vmult, out);
+}
+
 void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out) {
   hipLaunchKernelGGL(conq_potdiff_kernel, dim3(1), dim3(64), 0, s, left, rightcharge, totsetq, one_electrode, out);
 }
@@ -720,14 +760,20 @@ __global__ __launch_bounds__(256) void post_force_kernel(int npairs, const int *
   if (!(etarij2 < 5.8)) return;                                  // :1419 (ERFC_MAX, not its square -- kept as written)
   const bool eleilocal = atom2eleall[i] >= 0;
   const double prefactor = qqrd2e * q[i] * q[j];
-  const double forcecoul = prefactor * (-ferfcr_sqrt_dev(etarij2) * rp.eta);
+  double fterm;
+  if (rp.ehgo) {                                                  // ehgo_force :1568-1573
+    const double etaij = rp.eta_ij[type[i] * (rp.ntypes + 1) + type[j]], foij = rp.fo_ij[type[i] * (rp.ntypes + 1) + type[j]];
+    const double e2 = etaij * etaij * rsq;
+    fterm = e2 * foij * exp(-0.5 * e2) - ferfcr_sqrt_dev(e2) * etaij;
+  } else fterm = -ferfcr_sqrt_dev(etarij2) * rp.eta;             // eta_force :1477-1480
+  const double forcecoul = prefactor * fterm;
   const double fpair = forcecoul / rsq;
   if (!eleilocal) {
     atomicAdd(&f[3 * i], delx * forcecoul); atomicAdd(&f[3 * i + 1], dely * forcecoul); atomicAdd(&f[3 * i + 2], delz * forcecoul);
   } else if (newton || j < nlocal) {
     atomicAdd(&f[3 * j], -(delx * forcecoul)); atomicAdd(&f[3 * j + 1], -(dely * forcecoul)); atomicAdd(&f[3 * j + 2], -(delz * forcecoul));
   }
-  const double ecoul = prefactor * (-erfcr_sqrt_dev(etarij2) * rp.eta);
+  const double ecoul = prefactor * pair_potential_dev(rp, rsq, type[i], type[j], false);
   double w = 0.0;
   if (newton) w = 1.0;
   else { if (i < nlocal) w += 0.5; if (j < nlocal) w += 0.5; }
@@ -738,10 +784,12 @@ __global__ __launch_bounds__(256) void post_force_kernel(int npairs, const int *
 
 // Gaussian self energy sum over owned electrode atoms of q^2 (fix_conp.cpp:1167-1181), one workgroup, fixed tree
 __global__ __launch_bounds__(1024) void ele_qsq_kernel(int nlocal, const int *__restrict__ atom2eleall, const double *__restrict__ q,
+                                                       const int *__restrict__ type, const double *__restrict__ u0_i,
                                                        double *__restrict__ out) {
   __shared__ double red[16];
   double s = 0.0;
-  for (int i = threadIdx.x; i < nlocal; i += 1024) if (atom2eleall[i] >= 0) s += q[i] * q[i];
+  for (int i = threadIdx.x; i < nlocal; i += 1024)
+    if (atom2eleall[i] >= 0) s += u0_i ? u0_i[type[i]] * q[i] * q[i] : q[i] * q[i];       // EHGO weights by u0 of the type (:1189)
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -756,7 +804,7 @@ void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, 
   if (npairs > 0)
     hipLaunchKernelGGL(post_force_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, npairs, pi, pj, nlocal, newton, x, q, type,
                        atom2eleall, rp, qqrd2e, f, acc);
-  hipLaunchKernelGGL(ele_qsq_kernel, dim3(1), dim3(1024), 0, s, nlocal, atom2eleall, q, acc + 7);
+  hipLaunchKernelGGL(ele_qsq_kernel, dim3(1), dim3(1024), 0, s, nlocal, atom2eleall, q, type, rp.ehgo ? rp.u0_i : nullptr, acc + 7);
 }
 
 // sum of v over the group-1 ("left") electrode atoms (totsetq :1098-1104); one workgroup
@@ -847,8 +895,8 @@ void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const
 
 // diagonal ug_tot - 2g/sqrt(pi) + sqrt(2) eta/sqrt(pi) (km_ewald.cpp:631-634, fix_conp.cpp:796-801) and the slab
 // term 4 pi z_i z_j / V on j <= i (km_ewald.cpp:647-665)
-__global__ void a_diag_slab_kernel(int ne, double diag_k, double diag_self, int slab, double pref,
-                                   const double *__restrict__ ele_z, double *__restrict__ A) {
+__global__ void a_diag_slab_kernel(int ne, double diag_k, double diag_self, const double *__restrict__ diag_self_atom, int slab,
+                                   double pref, const double *__restrict__ ele_z, double *__restrict__ A) {
 #pragma clang fp contract(off)
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)ne * ne) return;
@@ -857,7 +905,7 @@ __global__ void a_diag_slab_kernel(int ne, double diag_k, double diag_self, int 
   double v = A[e];
   if (i == j) v = diag_k;
   if (slab) v += pref * ele_z[i] * ele_z[j];
-  if (i == j) v += diag_self;
+  if (i == j) v += diag_self_atom ? diag_self_atom[i] : diag_self;     // sqrt(2) eta / sqrt(pi), or u0 of the atom's type (EHGO :803-810)
   A[e] = v;
 }
 
@@ -876,8 +924,7 @@ __global__ void a_real_kernel(int ne, const int *__restrict__ row_ptr, const int
     const double rsq = dx * dx + dy * dy + dz * dz;
     if (rsq < rp.cutsq[type[ie] * nt1 + type[jo]] && rsq < rp.cut_coulsq) {
       double dudq = erfcr_sqrt_dev(rp.g_ewald * rp.g_ewald * rsq) * rp.g_ewald;
-      const double etarij2 = rp.eta * rp.eta * rsq / 2;
-      dudq += -erfcr_sqrt_dev(etarij2) * rp.eta / sqrt(2.0);
+      dudq += pair_potential_dev(rp, rsq, type[ie], type[jo], true);
       A[(size_t)row * ne + col[p]] += dudq;
     }
   }
@@ -904,11 +951,11 @@ void launch_a_symmetrise(hipStream_t s, int ne, double *A) {
   hipLaunchKernelGGL(a_symmetrise_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, ne, A);
 }
 
-void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, int slab, double pref, const double *ele_z,
-                        double *A) {
+void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, const double *diag_self_atom, int slab, double pref,
+                        const double *ele_z, double *A) {
   const size_t n2 = (size_t)ne * ne;
-  hipLaunchKernelGGL(a_diag_slab_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, ne, diag_k, diag_self, slab,
-                     pref, ele_z, A);
+  hipLaunchKernelGGL(a_diag_slab_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, ne, diag_k, diag_self, diag_self_atom,
+                     slab, pref, ele_z, A);
 }
 
 // ================================================================================================

@@ -85,6 +85,13 @@ void FixConpHip::init() {
     env.one_electrode = (groupbit == jgroupbit);                           // :295
     env.device = 0; env.rank = 0; env.nranks = 1;
     fail_if(conp_fix_create(&args, &env, &h));
+    for (auto &toks : pending_modify) {
+      std::vector<const char *> ptrs;
+      for (auto &tk : toks) ptrs.push_back(tk.c_str());
+      int n = 0;
+      fail_if(conp_fix_modify_param(h, (int)ptrs.size(), ptrs.data(), &n));
+    }
+    pending_modify.clear();
   }
 }
 
@@ -196,6 +203,22 @@ void FixConpHip::post_force(int) {
 void FixConpHip::end_of_step() {
   if (!postforceflag) post_force(0);
   postforceflag = false;
+}
+
+// fix_conp.cpp:1482-1515: fix_modify ID ehgo kappa X | ehgo coeff types eta u0|auto
+// fix_modify arrives before init(), i.e. before the library handle exists (the handle needs g_ewald, which kspace only
+// knows at init): remember the tokens, replay them in init()
+int FixConpHip::modify_param(int narg, char **arg) {
+  if (narg < 1 || std::strcmp(arg[0], "ehgo") != 0) return 0;
+  if (!args.ehgo) error->all(FLERR, "Can't fix_modify conp parameters in basic pair mode");
+  int used = 0;
+  if (narg >= 2 && std::strcmp(arg[1], "kappa") == 0) used = 3;
+  else if (narg >= 2 && std::strcmp(arg[1], "coeff") == 0) used = 5;
+  else error->all(FLERR, "Invalid entry for EHGO coeff setting");
+  if (narg != used) error->all(FLERR, "Invalid number of inputs for EHGO coeff setting");
+  if (h) { int n = 0; fail_if(conp_fix_modify_param(h, narg, arg, &n)); }
+  else pending_modify.emplace_back(arg, arg + narg);
+  return used;
 }
 
 double FixConpHip::compute_scalar() { return conp_fix_compute_scalar(h); }  // :592-595

@@ -5,12 +5,14 @@
 
 FixStyle(conp/hip,FixConpHip)
 FixStyle(conq/hip,FixConpHip)
+FixStyle(cond/hip,FixConpHip)
 
 #else
 
 #ifndef LMP_FIX_CONP_HIP_H
 #define LMP_FIX_CONP_HIP_H
 
+#include <string>
 #include <vector>
 
 #include "conp_hip.h"
@@ -36,6 +38,7 @@ class FixConpHip : public Fix {
   void post_force(int) override;
   void end_of_step() override;
   double compute_scalar() override;
+  int modify_param(int, char **) override;
 
  private:
   conp_fix_args args;
@@ -47,6 +50,7 @@ class FixConpHip : public Fix {
   FILE *outf;
   bool postforceflag;
   std::vector<double> fbuf;
+  std::vector<std::vector<std::string>> pending_modify;
   std::vector<double> xbuf, cutsq_flat;
   std::vector<int> echeck, first_a, first_b, neigh_a, neigh_b;
   conp_atoms view();

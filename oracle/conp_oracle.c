@@ -525,6 +525,9 @@ typedef struct {
   double *cutsq;    /* [(ntypes+1)^2] */
   double boxlo_z, zprd;
   orc_kspace *ks;
+  /* EHGO pair mode (fix_conp.cpp:1482-1598): per-type eta_i, u0_i (already * evscale), kappa -> eta_ij, fo_ij */
+  int ehgo;
+  double kappa, *eta_i, *u0_i, *eta_ij, *fo_ij;
   /* bookkeeping (fix_conp.cpp:468-539) */
   int elenum, elenum_all, elytenum, maxtag_all;
   int *ele2tag, *ele2eleall, *tag2eleall, *eleall2tag, *eleall2ele, *elecheck_eleall, *elebuf2eleall;
@@ -556,11 +559,53 @@ orc_fix *orc_fix_create(double eta, int ff_flag, int zneutr, int nullneutral, in
 
 void orc_fix_destroy(orc_fix *f) {
   if (!f) return;
+  free(f->eta_i); free(f->u0_i); free(f->eta_ij); free(f->fo_ij);
   free(f->cutsq); free(f->ele2tag); free(f->ele2eleall); free(f->tag2eleall); free(f->eleall2tag);
   free(f->eleall2ele); free(f->elecheck_eleall); free(f->elebuf2eleall); free(f->tag2local);
   free(f->aaa_all); free(f->bbb_all); free(f->eleallq); free(f->elesetq); free(f->eleinitq); free(f->bbb);
   free(f->csk); free(f->snk); free(f->xele_all);
   free(f);
+}
+
+/* fix_modify ... ehgo kappa / coeff (fix_conp.cpp:1482-1515) already parsed: per-type arrays [ntypes+1], u0 in eV/e^2
+ * (or auto = sqrt(2) eta / sqrt(pi) / evscale), then ehgo_setup_tables (:1517-1559).  Returns 0 if no coefficient is set
+ * (the reference then falls back to ETA with a warning). */
+int orc_fix_set_ehgo(orc_fix *f, double kappa, const double *eta_i, const double *u0_ev) {
+  const int nt1 = f->ntypes + 1;
+  const double CON_s2overPIS = sqrt(2.0) / ORC_PIS, sq8 = sqrt(8.0);
+  double *f_i = (double *)calloc(nt1, sizeof(double));
+  int i, j, setflag = 0;
+  f->kappa = kappa;
+  f->eta_i = (double *)calloc(nt1, sizeof(double)); f->u0_i = (double *)calloc(nt1, sizeof(double));
+  f->eta_ij = (double *)calloc((size_t)nt1 * nt1, sizeof(double)); f->fo_ij = (double *)calloc((size_t)nt1 * nt1, sizeof(double));
+  for (i = 1; i < nt1; ++i) { f->eta_i[i] = eta_i[i]; f->u0_i[i] = u0_ev[i] * f->evscale; if (f->eta_i[i] || f->u0_i[i]) setflag = 1; }
+  if (setflag) {
+    for (i = 1; i < nt1; ++i) f_i[i] = f->u0_i[i] - CON_s2overPIS * f->eta_i[i];
+    for (i = 1; i < nt1; ++i)
+      for (j = 1; j <= i; ++j) {
+        if (f->eta_i[i] && f->eta_i[j]) {
+          double etasq = f->eta_i[i] * f->eta_i[i] + f->eta_i[j] * f->eta_i[j];
+          double etaprod = f->eta_i[i] * f->eta_i[j];
+          double eij = etaprod / sqrt(etasq);
+          double o_ij = sq8 * eij * eij * eij / (etaprod * sqrt(etaprod));
+          double f_ij = 0.5 * kappa * (f_i[i] + f_i[j]);
+          f->eta_ij[i * nt1 + j] = eij;
+          f->fo_ij[i * nt1 + j] = f_ij * o_ij;
+        } else f->eta_ij[i * nt1 + j] = f->eta_i[i] + f->eta_i[j];
+        if (i != j) { f->eta_ij[j * nt1 + i] = f->eta_ij[i * nt1 + j]; f->fo_ij[j * nt1 + i] = f->fo_ij[i * nt1 + j]; }
+      }
+    f->ehgo = 1;
+  }
+  free(f_i);
+  return setflag;
+}
+
+/* fix_conp.cpp:1561-1573 */
+static double orc_ehgo_potential(const orc_fix *f, double rsq, int itype, int jtype) {
+  double etaij = f->eta_ij[itype * (f->ntypes + 1) + jtype];
+  double foij = f->fo_ij[itype * (f->ntypes + 1) + jtype];
+  double etarij2 = etaij * etaij * rsq;
+  return foij * exp(-0.5 * etarij2) - orc_erfcr_sqrt(etarij2) * etaij;
 }
 
 void orc_fix_set_atoms(orc_fix *f, int nlocal, int nghost, const double *x, double *q, const int *type,
@@ -680,7 +725,7 @@ static void orc_alist_coul_cal(orc_fix *f, double *m) {
           if (rsq < cut_coulsq) {
             double dudq = orc_erfcr_sqrt(f->g_ewald * f->g_ewald * rsq) * f->g_ewald;
             int elealli, eleallj, elei;
-            dudq += orc_eta_potential_A(f->eta, rsq);
+            dudq += f->ehgo ? orc_ehgo_potential(f, rsq, itype, jtype) : orc_eta_potential_A(f->eta, rsq);
             elealli = f->tag2eleall[at->tag[i]];
             eleallj = f->tag2eleall[at->tag[j]];
             elei = f->eleall2ele[elealli];
@@ -721,7 +766,7 @@ static void orc_blist_coul_cal(orc_fix *f, double *m) {
         if (rsq < f->cutsq[itype * nt1 + jtype]) {
           if (rsq < cut_coulsq) {
             double dudq = orc_erfcr_sqrt(f->g_ewald * f->g_ewald * rsq) * f->g_ewald;
-            dudq += orc_eta_potential(f->eta, rsq);
+            dudq += f->ehgo ? orc_ehgo_potential(f, rsq, itype, jtype) : orc_eta_potential(f->eta, rsq);
             if (ecib) {
               elei = f->eleall2ele[f->tag2eleall[at->tag[i]]];
               m[elei] -= at->q[j] * dudq;
@@ -760,7 +805,8 @@ void orc_fix_a_cal(orc_fix *f) {
   for (i = 0; i < f->elenum; ++i)
     memcpy(aaa + (size_t)i * ne, aaa_perm + (size_t)f->ele2eleall[i] * ne, sizeof(double) * ne);
   free(aaa_perm);
-  for (i = 0; i < f->elenum; ++i) aaa[(size_t)i * ne + f->ele2eleall[i]] += CON_s2overPIS * f->eta; /* :796-801 */
+  for (i = 0; i < f->elenum; ++i) /* :796-810 */
+    aaa[(size_t)i * ne + f->ele2eleall[i]] += f->ehgo ? f->u0_i[f->at.type[f->tag2local[f->ele2tag[i]]]] : CON_s2overPIS * f->eta;
   orc_alist_coul_cal(f, aaa);
   /* Allgatherv of rows (:816-822): one rank, rows are in local ele order -> rank-major == local */
   memcpy(f->aaa_all, aaa, sizeof(double) * (size_t)f->elenum * ne);
@@ -1073,6 +1119,39 @@ double orc_fix_update_charge_conq(orc_fix *f, double rightcharge) {
   return potdiff_conq;
 }
 
+/* fix_cond.cpp:46-126 FixCond: cond_setup (setzvec = preset vector / evscale, taken right after b_setq_cal), cond_setup2
+ * (vmult) and update_charge.  xprd/yprd: box lengths (Axy).  Returns the potential difference (= fix scalar). */
+double orc_fix_update_charge_cond(orc_fix *f, double rightcharge, double xprd, double yprd, const double *setzvec) {
+  const orc_atoms *at = &f->at;
+  const double lz = f->zprd, Axy = xprd * yprd;
+  double zOAz = 0., vmult, dipole = 0., potdiff;
+  int i, iall, iloc;
+  for (i = 0; i < f->elenum_all; ++i) zOAz += f->elesetq[i] * setzvec[i];            /* cond_setup2 :58-68 */
+  vmult = 4 * ORC_PI * zOAz * lz / (f->evscale * Axy);
+  vmult /= 1 + vmult;
+  vmult /= zOAz;
+  if (f->minimizer == 1) {
+    for (iloc = 0; iloc < f->elenum; ++iloc) {
+      iall = f->ele2eleall[iloc];
+      f->bbb[iloc] = orc_ddot(f->elenum_all, f->aaa_all + (size_t)iall * f->elenum_all, f->bbb_all);
+    }
+    orc_b_comm(f, f->bbb, f->eleallq);
+  }
+  for (i = 0; i < at->nlocal; ++i) if (!at->echeck[i]) dipole -= at->q[i] * at->x[3 * i + 2];   /* :101-106 */
+  potdiff = rightcharge - dipole / lz;
+  for (iall = 0; iall < f->elenum_all; ++iall) potdiff -= setzvec[iall] * f->eleallq[iall];
+  potdiff *= vmult;
+  f->scalar_output = potdiff;
+  for (iall = 0; iall < f->elenum_all; ++iall) {                                        /* :118-124: owned atoms via atom->map */
+    i = f->tag2local[f->eleall2tag[iall]];
+    if (i != -1) {
+      at->q[i] = f->eleallq[iall] + potdiff * f->elesetq[iall];
+      if (f->qinit) at->q[i] += f->eleinitq[iall];
+    }
+  }
+  return potdiff;
+}
+
 /* fix_conp.cpp:1456-1465 ferfcr_sqrt, :1477-1480 eta_force */
 static double orc_ferfcr_sqrt(double a2_r2) {
   if (a2_r2 < ORC_ERFC_MAX * ORC_ERFC_MAX) {
@@ -1097,9 +1176,15 @@ void orc_fix_post_force(orc_fix *f, double qqrd2e, double *fadd, double *out) {
   int i, ii, jj, k;
   double eleqsqsum = 0.0;
   for (k = 0; k < 8; ++k) out[k] = 0.0;
-  for (i = 0; i < at->nlocal; i++)
-    if (at->echeck[i]) eleqsqsum += at->q[i] * at->q[i];
-  out[0] = qqrd2e * 1.0 * f->eta * eleqsqsum / (sqrt(2) * ORC_PIS);
+  if (!f->ehgo) {
+    for (i = 0; i < at->nlocal; i++)
+      if (at->echeck[i]) eleqsqsum += at->q[i] * at->q[i];
+    out[0] = qqrd2e * 1.0 * f->eta * eleqsqsum / (sqrt(2) * ORC_PIS);
+  } else { /* :1182-1199 */
+    for (i = 0; i < at->nlocal; i++)
+      if (at->echeck[i]) eleqsqsum += f->u0_i[at->type[i]] * at->q[i] * at->q[i];
+    out[0] = qqrd2e * 1.0 * eleqsqsum;
+  }
   for (ii = 0; ii < L->inum; ii++) {
     int i = L->ilist[ii];
     int eleilocal = !!at->echeck[i];
@@ -1119,7 +1204,13 @@ void orc_fix_post_force(orc_fix *f, double qqrd2e, double *fadd, double *out) {
           double etarij2 = f->eta * f->eta * rsq;
           if (etarij2 < ORC_ERFC_MAX) {
             double prefactor = qqrd2e * qtmp * at->q[j];
-            double forcecoul = prefactor * (-orc_ferfcr_sqrt(etarij2) * f->eta);
+            double forcecoul;
+            if (!f->ehgo) forcecoul = prefactor * (-orc_ferfcr_sqrt(etarij2) * f->eta);
+            else { /* ehgo_force :1568-1573 */
+              double etaij = f->eta_ij[itype * nt1 + jtype], foij = f->fo_ij[itype * nt1 + jtype];
+              double e2 = etaij * etaij * rsq;
+              forcecoul = prefactor * (e2 * foij * exp(-0.5 * e2) - orc_ferfcr_sqrt(e2) * etaij);
+            }
             double fpair = forcecoul / rsq;
             double ecoul, v[6], w = 0.0;
             if (!eleilocal) {
@@ -1127,7 +1218,7 @@ void orc_fix_post_force(orc_fix *f, double qqrd2e, double *fadd, double *out) {
             } else if (f->newton || j < at->nlocal) {
               fadd[3 * j] -= delx * forcecoul; fadd[3 * j + 1] -= dely * forcecoul; fadd[3 * j + 2] -= delz * forcecoul;
             }
-            ecoul = prefactor * orc_eta_potential(f->eta, rsq);
+            ecoul = prefactor * (f->ehgo ? orc_ehgo_potential(f, rsq, itype, jtype) : orc_eta_potential(f->eta, rsq));
             /* Pair::ev_tally global accumulators */
             if (f->newton) w = 1.0;
             else { if (i < at->nlocal) w += 0.5; if (j < at->nlocal) w += 0.5; }

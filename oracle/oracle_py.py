@@ -64,6 +64,10 @@ def load(fast: bool = False):
     lib.orc_fix_update_charge_conq.restype = C.c_double
     lib.orc_fix_post_force.argtypes = [vp, C.c_double, _dp, _dp]
     lib.orc_fix_b_cal.argtypes = [vp, C.c_int]
+    lib.orc_fix_update_charge_cond.argtypes = [vp, C.c_double, C.c_double, C.c_double, _dp]
+    lib.orc_fix_update_charge_cond.restype = C.c_double
+    lib.orc_fix_set_ehgo.argtypes = [vp, C.c_double, _dp, _dp]
+    lib.orc_fix_set_ehgo.restype = C.c_int
     lib.orc_fix_sizes.argtypes = [vp, _ip]
     lib.orc_fix_scalars.argtypes = [vp, _dp]
     lib.orc_fix_get_maps.argtypes = [vp, _ip, _ip, _ip, _ip, _ip, _ip, _ip]
@@ -167,10 +171,19 @@ class Fix:
     def pre_force(self, potdiff):
         self.lib.orc_fix_pre_force(self.h, potdiff)
 
+    def set_ehgo(self, kappa, eta_i, u0_ev):
+        return self.lib.orc_fix_set_ehgo(self.h, kappa, np.ascontiguousarray(eta_i, np.float64), np.ascontiguousarray(u0_ev, np.float64))
+
     def pre_force_conq(self, rightcharge):
         self.lib.orc_fix_b_cal(self.h, 1)
         self.lib.orc_fix_equation_solve(self.h)
         return self.lib.orc_fix_update_charge_conq(self.h, rightcharge)
+
+    def pre_force_cond(self, rightcharge, setzvec):
+        self.lib.orc_fix_b_cal(self.h, 1)
+        self.lib.orc_fix_equation_solve(self.h)
+        return self.lib.orc_fix_update_charge_cond(self.h, rightcharge, float(self.s.prd[0]), float(self.s.prd[1]),
+                                                   np.ascontiguousarray(setzvec))
 
     def post_force(self, qqrd2e=332.06371):
         fadd = np.zeros((self.at.nlocal + self.at.nghost, 3)); out = np.zeros(8)

@@ -486,3 +486,97 @@ def test_matrix_files_round_trip(tmp_path):
         fe.close()
     finally:
         os.chdir(cwd)
+
+
+def _ehgo_setup(oracle, s, kappa, coeffs, special=None):
+    """coeffs: list of (type, eta, u0_eV or 'auto')"""
+    at, alist, blist = neighbor.build_lists(s)
+    o = OracleRun(oracle, s, at, alist, blist)
+    nt1 = s.ntypes + 1
+    eta_i = np.zeros(nt1); u0 = np.zeros(nt1)
+    fx = FixConp(s, extra_args=["ehgo"])
+    assert fx.modify_param("ehgo", "kappa", kappa) == 3
+    for t, eta, u in coeffs:
+        assert fx.modify_param("ehgo", "coeff", t, eta, u) == 5
+        lo, hi = (int(v) if v else d for v, d in zip(str(t).split("*") if "*" in str(t) else (t, t), (1, s.ntypes)))
+        for ty in range(lo, hi + 1):
+            eta_i[ty] = float(eta)
+            u0[ty] = np.sqrt(2.0) / np.sqrt(np.pi) * float(eta) / systems.EVSCALE if u == "auto" else float(u)
+    assert o.fx.set_ehgo(float(kappa), eta_i, u0) == 1
+    o.setup(); o.pre_force(s.potdiff)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    return at, o, fx
+
+
+def test_ehgo_pair_mode(oracle):
+    """EHGO (fix_conp.cpp:1482-1598).  (a) the reference deck's usage (tests/il_onelayer/input:103-106: kappa 0, coeff etype
+    1.979 auto) reduces to the plain eta model; (b) general coefficients against the oracle, incl. the post-force term"""
+    from conp_amd import ConpError
+    s = systems.deck("dilute", "slab", etypes=True)
+    # (a)
+    at, o, fx = _ehgo_setup(oracle, s, 0, [(3, 1.979, "auto")])
+    q_ehgo = at.q.copy()
+    at2, al2, bl2 = neighbor.build_lists(s)
+    fp = FixConp(s)
+    fp.init_lists(al2, bl2); fp.setup_post_neighbor(at2); fp.setup_pre_force(at2, 0, s.potdiff)
+    ele = at.echeck != 0
+    assert rel_err(q_ehgo[ele], at2.q[ele]) < 1e-12
+    assert rel_err(q_ehgo[ele], o.q[ele]) < TOL_Q
+    fp.close(); fx.close(); o.fx.close()
+    # (b) Gaussian electrolyte sites with their own widths, explicit self-interaction u0, kappa 1
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab")
+    rng = np.random.default_rng(9)
+    ele_idx = np.nonzero(s.echeck != 0)[0]; sol_idx = np.nonzero((s.echeck == 0) & (s.q != 0))[0]
+    for k in range(6):        # close contacts so that the post-force correction is non-zero
+        d = rng.normal(size=3); d *= rng.uniform(0.5, 1.1) / np.linalg.norm(d)
+        s.x[sol_idx[k]] = s.x[ele_idx[3 * k]] + d
+    s.x[:, :2] = s.boxlo[:2] + np.mod(s.x[:, :2] - s.boxlo[:2], s.prd[:2])
+    at, o, fx = _ehgo_setup(oracle, s, 1.0, [(5, 1.979, 11.0), ("1*2", 1.2, 6.5), (4, 0.9, "auto")])
+    ele = at.echeck != 0
+    b_o, q_o, sq_o = o.fx.vectors(); b_g, q_g, sq_g = fx.vectors()
+    assert rel_err(b_g, b_o) < 1e-10 and rel_err(sq_g, sq_o) < TOL_Q and rel_err(at.q[ele], o.q[ele]) < TOL_Q
+    assert rel_err(fx.matrix(), o.fx.matrix()) < TOL_Q
+    f_o, out_o = o.fx.post_force()
+    f_g, ek, ec, vir = fx.post_force(at)
+    assert np.abs(f_o).max() > 0.1 and rel_err(f_g, f_o) < 1e-9
+    assert ek == pytest.approx(out_o[0], rel=1e-9) and ec == pytest.approx(out_o[1], rel=1e-9)
+    assert np.allclose(vir, out_o[2:8], rtol=1e-9, atol=1e-9 * np.abs(out_o[2:8]).max())
+    fx.close(); o.fx.close()
+    # error paths of modify_param
+    fe = FixConp(s)
+    with pytest.raises(ConpError) as e:
+        fe.modify_param("ehgo", "kappa", 1.0)
+    assert "Can't fix_modify conp parameters in basic pair mode" in str(e.value)
+    fe.close()
+    fe = FixConp(s, extra_args=["ehgo"])
+    for toks, msg in ((("ehgo", "kappa"), "Invalid number of inputs"), (("ehgo", "coeff", "1", "2.0"), "Invalid number of inputs"),
+                      (("ehgo", "frob", "1"), "Invalid entry for EHGO coeff setting")):
+        with pytest.raises(ConpError) as e:
+            fe.modify_param(*toks)
+        assert msg in str(e.value)
+    fe.close()
+
+
+def test_cond_matches_oracle(oracle):
+    """fix cond (fix_cond.cpp:46-126): prescribed charge, potential difference from the electrolyte dipole (ffield geometry)"""
+    s = systems.deck("dilute", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    Q = 0.021
+    o = OracleRun(oracle, s, at, alist, blist)
+    o.fx.lib.orc_fix_a_cal(o.fx.h); o.fx.lib.orc_fix_b_setq_cal(o.fx.h)
+    setz = o.fx.vectors()[0] / systems.EVSCALE                         # cond_setup: preset vector / evscale
+    assert o.fx.lib.orc_fix_equation_solve(o.fx.h) == 0
+    o.fx.lib.orc_fix_get_setq(o.fx.h)
+    dv_o = o.fx.pre_force_cond(Q, setz)
+    fx = FixConp(s, style="cond")
+    assert fx.args.cond == 1 and fx.args.conq == 0
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, Q)
+    loc = slice(0, at.nlocal)
+    ele = at.echeck[loc] != 0
+    assert rel_err(at.q[loc][ele], o.q[loc][ele]) < TOL_Q
+    assert fx.compute_scalar() == pytest.approx(dv_o, rel=1e-8)
+    fx.close(); o.fx.close()
