@@ -30,6 +30,9 @@ CASES = {
     # rough electrodes: every atom has its own z -> the general (non z-class) projection kernel
     "small_rough_ffield": lambda: rough(systems.small_random(ne_side=4, n_elyte=96, lz=60.0)),
     "dilute_rough_slab": lambda: rough(systems.deck("dilute", "slab", etypes=True)),
+    # tall slab box: kzmax > 160 -> more than one kz column tile, in the planar fast path and in the general projection kernel
+    "small_tall_slab": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=400.0, mode="slab"),
+    "small_rough_tall_slab": lambda: rough(systems.small_random(ne_side=4, n_elyte=96, lz=400.0, mode="slab")),
 }
 
 
@@ -106,6 +109,8 @@ def test_full_chain_matches_oracle(oracle, case):
     assert abs(at.q[:at.nlocal][at.echeck[:at.nlocal] != 0].sum()) < 1e-12   # electroneutral
     assert np.array_equal(o.fx.maps()["elecheck_eleall"], fx.maps()["elecheck_eleall"])
     assert (fx.info().n_zclasses == 0) == ("rough" in case)      # planar decks take the z-class fast path
+    if "tall" in case:
+        assert fx.info().kzmax > 160                              # really more than one column tile
     sc_o = o.fx.scalars()
     assert fx.compute_scalar() == pytest.approx(sc_o["scalar_output"], rel=1e-7, abs=1e-12)
     assert fx.info().totsetq == pytest.approx(sc_o["totsetq"], rel=1e-7)
