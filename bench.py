@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels with HIP events")
+    ap.add_argument("--pppm", type=int, nargs=3, metavar=("NX", "NY", "NZ"), default=None,
+                    help="k-space b through the PPPM mesh (`pppm` keyword, BASELINE configs[3]) with this mesh, order 5")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +116,8 @@ def main():
     t_setup0 = time.perf_counter()
     s = make_workload(args.workload)
     at, alist, blist = neighbor.build_lists(s)
-    fx = FixConp(s, device=dev_index, rank=rank, nranks=world)
+    fx = FixConp(s, device=dev_index, rank=rank, nranks=world, extra_args=["pppm"] if args.pppm else [],
+                 pppm_mesh=tuple(args.pppm) if args.pppm else None)
     fx.set_stream(torch.cuda.current_stream().cuda_stream)
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
@@ -224,7 +227,8 @@ def main():
                    config=dict(workload=s.name, Ne=int(ne), Nl=int(nl), K=int(K), kflat=int(info.kcount_flat),
                                box=[float(v) for v in s.prd], cutoff=s.cutoff, g_ewald=s.g_ewald,
                                accuracy_relative=s.accuracy_relative, mode="ffield" if s.ff_flag == 1 else "slab",
-                               solver="inv", blist_pairs=int(info.n_blist_pairs),
+                               solver="inv", kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
+                               blist_pairs=int(info.n_blist_pairs),
                                parallelism=f"k-shard+row-shard x{world}"),
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),

@@ -502,14 +502,22 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_row_tiles, int R_p
   const int zc = zclass[i];
   const size_t hp = (size_t)R_pad * 64;
   double sum = 0.0;
-  for (int rt = rank; rt < n_row_tiles; rt += nranks) {
-    const int rbase = rt * 128 + blockIdx.y * 32;           // this quarter's 32 rows of the tile
+  // 4 row tiles at a time: 8 Rp rows + their Hc entries in flight per thread
+  for (int rt0 = rank; rt0 < n_row_tiles; rt0 += 4 * nranks) {
+    double rp[8], hc[8];
 #pragma unroll
-    for (int rr = w; rr < 32; rr += 16) {
-      const size_t r = rbase + rr;
-      const double h = (Hc4[r * 64 + zc] + Hc4[hp + r * 64 + zc]) + (Hc4[2 * hp + r * 64 + zc] + Hc4[3 * hp + r * 64 + zc]);
-      sum += Rp[r * ne_pad + i] * h;
+    for (int u = 0; u < 4; ++u) {
+      const int rt = rt0 + u * nranks;
+      const bool ok = rt < n_row_tiles;
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const size_t r = (size_t)(ok ? rt : rt0) * 128 + blockIdx.y * 32 + w + 16 * v;
+        rp[2 * u + v] = ok ? Rp[r * ne_pad + i] : 0.0;
+        hc[2 * u + v] = (Hc4[r * 64 + zc] + Hc4[hp + r * 64 + zc]) + (Hc4[2 * hp + r * 64 + zc] + Hc4[3 * hp + r * 64 + zc]);
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += rp[k] * hc[k];
   }
   red[w][a] = sum;
   __syncthreads();
@@ -660,9 +668,14 @@ __global__ __launch_bounds__(256) void charge_finish_kernel(int ne, int nall, co
   if (blockIdx.x == gridDim.x - 1) {
     if (!left_out) return;
     __shared__ double red[4];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < ne; i += 256) if (elecheck[i] == 1) s += eleallq[i];
-    s = wave_sum(s);
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};           // 4 loads in flight per thread; fixed association -> reproducible
+    int i = threadIdx.x;
+    for (; i + 768 < ne; i += 1024) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += (elecheck[i + 256 * u] == 1) ? eleallq[i + 256 * u] : 0.0;
+    }
+    for (int u = 0; i < ne; i += 256, ++u) s4[u] += (elecheck[i] == 1) ? eleallq[i] : 0.0;
+    double s = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) *left_out = (red[0] + red[1]) + (red[2] + red[3]);

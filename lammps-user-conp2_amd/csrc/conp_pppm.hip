@@ -1,8 +1,8 @@
 // PPPM k-space b vector on gfx950 (pppm_conp.cpp:109-316): charge spreading, Poisson solve on the mesh, stencil gather at
 // the electrode atoms.  Double precision, one rank owns the whole mesh, periodic wrap instead of ghost planes
 // (equivalent to GridComm's reverse/forward exchange on one rank, pppm_conp.cpp:114,122).
-// The three 1-D transforms are plain O(n^2) DFTs per mesh line staged through LDS: correct for any mesh size (LAMMPS
-// picks sizes with factors 2, 3, 5), fast enough for the decks' meshes (27x24x144); a radix FFT is the next step for large ones.
+// The three 1-D transforms are mixed-radix (2/3/4/5) Stockham FFTs per mesh line in LDS -- LAMMPS only picks 2,3,5-smooth mesh
+// sizes; any other length falls back to a plain O(n^2) DFT per line.
 #include <hip/hip_runtime.h>
 
 #include "conp_kernels.h"
@@ -19,18 +19,24 @@ __device__ __forceinline__ void rho1d_dev(const double *__restrict__ coeff, int 
   }
 }
 
-// elyte_particle_map + elyte_make_rho (pppm_conp.cpp:126-228): one thread per charged electrolyte atom, order^3 atomic adds.
-// Also the per-block partial sums of q z for the slab term (:301-314).
+// elyte_particle_map + elyte_make_rho (pppm_conp.cpp:126-228): order^2 threads per charged electrolyte atom (one (z, y) stencil
+// row each, `order` atomic adds along x).  slab_part[block] = partial sums of q z for the slab term (:301-314), taken by the
+// row-0 thread of every atom.
 __global__ __launch_bounds__(256) void pppm_spread_kernel(PppmDev pd, int nl, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
-                                                          double *__restrict__ rho, double *__restrict__ slab_part) {
+                                                          double *__restrict__ rho, double *__restrict__ slab_part,
+                                                          int npass) {
   __shared__ double coeff[64];
   __shared__ double red[4];
   if (threadIdx.x < pd.order * pd.order) coeff[threadIdx.x] = pd.rho_coeff[threadIdx.x];
   __syncthreads();
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o2 = pd.order * pd.order;
+  const int apb = blockDim.x / o2;                  // atoms per pass
+  const int ja = threadIdx.x / o2, row = threadIdx.x - ja * o2;
   double qz = 0.0;
-  if (j < nl) {
+  for (int pass = 0; pass < npass; ++pass) {
+    const int j = (blockIdx.x * npass + pass) * apb + ja;
+    if (ja >= apb || j >= nl) continue;
     const int i = elyte_idx[j];
     const double qq = q[i];
     int g[3];
@@ -41,20 +47,13 @@ __global__ __launch_bounds__(256) void pppm_spread_kernel(PppmDev pd, int nl, co
       g[c] = static_cast<int>(xs + pd.shift) - 16384;
       rho1d_dev(coeff, pd.order, g[c] + pd.shiftone - xs, w[c]);
     }
-    qz = qq * x[3 * i + 2];
-    const double z0 = pd.delvolinv * qq;
-    for (int n = 0; n < pd.order; ++n) {
-      const int mz = pwrap(n + pd.nlower + g[2], pd.nz);
-      const double y0 = z0 * w[2][n];
-      for (int m = 0; m < pd.order; ++m) {
-        const int my = pwrap(m + pd.nlower + g[1], pd.ny);
-        const double x0 = y0 * w[1][m];
-        for (int l = 0; l < pd.order; ++l) {
-          const int mx = pwrap(l + pd.nlower + g[0], pd.nx);
-          atomicAdd(&rho[((size_t)mz * pd.ny + my) * pd.nx + mx], x0 * w[0][l]);
-        }
-      }
-    }
+    if (row == 0) qz += qq * x[3 * i + 2];
+    const int n = row / pd.order, m = row - n * pd.order;
+    const int mz = pwrap(n + pd.nlower + g[2], pd.nz);
+    const int my = pwrap(m + pd.nlower + g[1], pd.ny);
+    const double x0 = (pd.delvolinv * qq * w[2][n]) * w[1][m];
+    double *line = rho + ((size_t)mz * pd.ny + my) * pd.nx;
+    for (int l = 0; l < pd.order; ++l) atomicAdd(&line[pwrap(l + pd.nlower + g[0], pd.nx)], x0 * w[0][l]);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) qz += __shfl_down(qz, off, 64);
@@ -108,6 +107,130 @@ __global__ __launch_bounds__(256) void pppm_dft_kernel(int nx, int ny, int nz, i
   }
 }
 
+// Mixed-radix Stockham FFT along `axis` (autosort, radices 2/3/4/5 -- LAMMPS meshes are 2,3,5-smooth), XT adjacent lines per
+// workgroup, ping-pong in LDS.  Stage with radix R and sub-transform length Ns: butterfly j (0 <= j < n/R), k = j mod Ns:
+//   v[r] = in[j + r n/R] * W_n^{r k n/(Ns R)} ;  out[(j - k) R + k + q Ns] = sum_r v[r] W_R^{q r}
+// W_n^t = (cos, sign*sin)(2 pi t / n) from the same twiddle table the plain DFT uses; no scaling.
+struct FftPlan { int nrad; int rad[12]; };
+
+// one radix-R stage over XT = 1 << xs lines held in LDS
+template <int R>
+__device__ __forceinline__ void fft_stage(const double2 *__restrict__ in, double2 *__restrict__ out,
+                                          const double *__restrict__ tw, int n, int Ns, int xs, double sign) {
+  const int nb = n / R;                  // butterflies per line; also W_R = W_n^{nb}
+  const int tstep = nb / Ns;             // twiddle index step: W_n^{r k tstep}, r k tstep < n
+  const float inv_ns = 1.0f / (float)Ns;
+  double wc[R], ws[R];
+#pragma unroll
+  for (int m = 1; m < R; ++m) { wc[m] = tw[2 * m * nb]; ws[m] = sign * tw[2 * m * nb + 1]; }
+  const int XT = 1 << xs;
+  for (int w = threadIdx.x; w < (nb << xs); w += blockDim.x) {
+    const int j = w >> xs, lx = w & (XT - 1);
+    const int k = j - Ns * (int)(((float)j + 0.5f) * inv_ns);      // j mod Ns (j < 2^20: exact in float)
+    double2 v[R];
+    v[0] = in[(j << xs) + lx];
+    int ti = 0;
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      const double2 x = in[((j + r * nb) << xs) + lx];
+      ti += k * tstep;
+      const double c = tw[2 * ti], sn = sign * tw[2 * ti + 1];
+      v[r] = make_double2(x.x * c - x.y * sn, x.x * sn + x.y * c);
+    }
+    const int j0 = (j - k) * R + k;
+    if (R == 2) {
+      out[(j0 << xs) + lx] = make_double2(v[0].x + v[1].x, v[0].y + v[1].y);
+      out[((j0 + Ns) << xs) + lx] = make_double2(v[0].x - v[1].x, v[0].y - v[1].y);
+    } else if (R == 4) {
+      // W_4 = (0, sign): multiplying by W_4 maps (a, b) -> (-sign b, sign a)
+      const double2 s02 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), d02 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
+      const double2 s13 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y), d13 = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
+      const double2 id13 = make_double2(-sign * d13.y, sign * d13.x);
+      out[(j0 << xs) + lx] = make_double2(s02.x + s13.x, s02.y + s13.y);
+      out[((j0 + Ns) << xs) + lx] = make_double2(d02.x + id13.x, d02.y + id13.y);
+      out[((j0 + 2 * Ns) << xs) + lx] = make_double2(s02.x - s13.x, s02.y - s13.y);
+      out[((j0 + 3 * Ns) << xs) + lx] = make_double2(d02.x - id13.x, d02.y - id13.y);
+    } else {
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        double sr = v[0].x, si = v[0].y;
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+          const int m = (q * r) % R;
+          if (m == 0) { sr += v[r].x; si += v[r].y; }
+          else { sr += v[r].x * wc[m] - v[r].y * ws[m]; si += v[r].x * ws[m] + v[r].y * wc[m]; }
+        }
+        out[((j0 + q * Ns) << xs) + lx] = make_double2(sr, si);
+      }
+    }
+  }
+}
+
+// flags: 1 = input is real (im not read), 2 = only the real part of the output is stored.  gmul != nullptr: the output is
+// multiplied by gscale*gmul[] (the influence function, pppm_conp.cpp:242-249) on the way out.
+__global__ __launch_bounds__(256) void pppm_fft_kernel(int nx, int ny, int nz, int axis, double sign, FftPlan fp,
+                                                       const double *__restrict__ twid, double *__restrict__ re,
+                                                       double *__restrict__ im, int xs, int flags,
+                                                       const double *__restrict__ gmul, double gscale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = axis == 0 ? nx : (axis == 1 ? ny : nz);
+  const int XT = 1 << xs;
+  double2 *buf0 = reinterpret_cast<double2 *>(smem);     // [n][XT]
+  double2 *buf1 = buf0 + (size_t)n * XT;
+  double *tw = reinterpret_cast<double *>(buf1 + (size_t)n * XT);   // [n][2]
+  for (int t = threadIdx.x; t < 2 * n; t += blockDim.x) tw[t] = twid[t];
+  const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)nx : (size_t)nx * ny);
+  const int nlines = axis == 0 ? ny * nz : (axis == 1 ? nx * nz : nx * ny);
+  const int line0 = blockIdx.x * XT;
+  auto base_of = [&](int line) -> size_t {
+    if (axis == 0) return (size_t)line * nx;
+    if (axis == 1) return (size_t)(line / nx) * nx * ny + (line % nx);
+    return (size_t)line;
+  };
+  const bool real_in = flags & 1, real_out = flags & 2;
+  for (int e = threadIdx.x; e < n * XT; e += blockDim.x) {
+    const int t = axis == 0 ? e % n : e >> xs, lx = axis == 0 ? e / n : e & (XT - 1);
+    const int line = line0 + lx;
+    double2 v = make_double2(0.0, 0.0);
+    if (line < nlines) { const size_t a = base_of(line) + (size_t)t * stride; v = make_double2(re[a], real_in ? 0.0 : im[a]); }
+    buf0[(t << xs) + lx] = v;
+  }
+  __syncthreads();
+  double2 *in = buf0, *out = buf1;
+  int Ns = 1;
+  for (int st = 0; st < fp.nrad; ++st) {
+    const int R = fp.rad[st];
+    switch (R) {
+      case 2: fft_stage<2>(in, out, tw, n, Ns, xs, sign); break;
+      case 3: fft_stage<3>(in, out, tw, n, Ns, xs, sign); break;
+      case 4: fft_stage<4>(in, out, tw, n, Ns, xs, sign); break;
+      default: fft_stage<5>(in, out, tw, n, Ns, xs, sign); break;
+    }
+    __syncthreads();
+    double2 *tmp = in; in = out; out = tmp;
+    Ns *= R;
+  }
+  for (int e = threadIdx.x; e < n * XT; e += blockDim.x) {
+    const int f = axis == 0 ? e % n : e >> xs, lx = axis == 0 ? e / n : e & (XT - 1);
+    const int line = line0 + lx;
+    if (line < nlines) {
+      const size_t a = base_of(line) + (size_t)f * stride;
+      double2 v = in[(f << xs) + lx];
+      if (gmul) { const double g = gscale * gmul[a]; v.x *= g; v.y *= g; }
+      re[a] = v.x;
+      if (!real_out) im[a] = v.y;
+    }
+  }
+}
+
+static bool fft_factor(int n, FftPlan &fp) {
+  fp.nrad = 0;
+  while (n % 4 == 0 && fp.nrad < 12) { fp.rad[fp.nrad++] = 4; n /= 4; }
+  for (int r : {2, 3, 5})
+    while (n % r == 0 && fp.nrad < 12) { fp.rad[fp.nrad++] = r; n /= r; }
+  return n == 1;
+}
+
 // rho(k) -> V(k): scale by 1/N and the influence function (pppm_conp.cpp:242-249)
 __global__ void pppm_greens_kernel(int nfft, double scaleinv, const double *__restrict__ greensfn, double *__restrict__ re,
                                    double *__restrict__ im) {
@@ -118,39 +241,61 @@ __global__ void pppm_greens_kernel(int nfft, double scaleinv, const double *__re
 }
 
 // b_i = - sum over the order^3 stencil of w_x w_y w_z u (pppm_conp.cpp:278-299); weights/indices cached per electrode atom
-// like ele2rho / part2grid (aaa_map_rho :318-344)
-__global__ void pppm_gather_kernel(PppmDev pd, int ne, const int *__restrict__ egrid /*[ne][3]*/,
-                                   const double *__restrict__ ew /*[ne][3][8]*/, const double *__restrict__ u,
-                                   double *__restrict__ bk) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// like ele2rho / part2grid (aaa_map_rho :318-344).  One wavefront per electrode atom: lanes take (z, y) stencil rows, then a
+// shuffle reduction; slots 1..3 of bk are cleared here.
+__global__ __launch_bounds__(256) void pppm_gather_kernel(PppmDev pd, int ne, int ne_pad, const int *__restrict__ egrid /*[ne][3]*/,
+                                                          const double *__restrict__ ew /*[ne][3][8]*/,
+                                                          const double *__restrict__ u, double *__restrict__ bk) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= ne) return;
   const int gx = egrid[3 * i], gy = egrid[3 * i + 1], gz = egrid[3 * i + 2];
   const double *w = ew + (size_t)i * 24;
-  double bbbtmp = 0.0;
-  for (int n = 0; n < pd.order; ++n) {
-    const int mz = pwrap(n + pd.nlower + gz, pd.nz);
-    const double z0 = w[16 + n];
-    for (int m = 0; m < pd.order; ++m) {
-      const int my = pwrap(m + pd.nlower + gy, pd.ny);
-      const double y0 = z0 * w[8 + m];
-      for (int l = 0; l < pd.order; ++l) {
-        const int mx = pwrap(l + pd.nlower + gx, pd.nx);
-        const double x0 = y0 * w[l];
-        bbbtmp -= x0 * u[((size_t)mz * pd.ny + my) * pd.nx + mx];
-      }
-    }
+  const int o2 = pd.order * pd.order;
+  double acc = 0.0;
+  for (int row = lane; row < o2; row += 64) {
+    const int n = row / pd.order, m = row - n * pd.order;
+    const int mz = pwrap(n + pd.nlower + gz, pd.nz), my = pwrap(m + pd.nlower + gy, pd.ny);
+    const double y0 = w[16 + n] * w[8 + m];
+    const double *line = u + ((size_t)mz * pd.ny + my) * pd.nx;
+    for (int l = 0; l < pd.order; ++l) acc -= (y0 * w[l]) * line[pwrap(l + pd.nlower + gx, pd.nx)];
   }
-  bk[i] = bbbtmp;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) { bk[i] = acc; bk[ne_pad + i] = 0.0; bk[2 * ne_pad + i] = 0.0; bk[3 * ne_pad + i] = 0.0; }
 }
 
 __global__ void zero_kernel(size_t n, double *p) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
 }
 
-static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, double *im) {
+static bool mesh_smooth(const PppmDev &pd) {
+  FftPlan fp;
+  return fft_factor(pd.nx, fp) && fft_factor(pd.ny, fp) && fft_factor(pd.nz, fp);
+}
+
+// forward (sign -1) or backward 3-D transform.  fused (radix path only): the forward transform takes real input and applies
+// gscale*greensfn on its last pass; the backward one stores only the real part.
+static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, double *im, bool fused, double gscale) {
   const int dims[3] = {pd.nx, pd.ny, pd.nz};
   for (int axis = 0; axis < 3; ++axis) {
     const int n = dims[axis];
+    FftPlan fp;
+    if (fft_factor(n, fp)) {              // 2,3,5-smooth length (every mesh LAMMPS picks): radix FFT
+      int xs = 0;
+      while (xs < 4 && (size_t)n * 32 * (2u << xs) <= 64 * 1024) ++xs;
+      const int XT = 1 << xs;
+      const int nlines = axis == 0 ? pd.ny * pd.nz : (axis == 1 ? pd.nx * pd.nz : pd.nx * pd.ny);
+      const size_t lds = ((size_t)2 * n * XT) * sizeof(double2) + (size_t)2 * n * sizeof(double);
+      int flags = 0;
+      const double *gmul = nullptr;
+      if (fused && sign < 0 && axis == 0) flags |= 1;
+      if (fused && sign < 0 && axis == 2) gmul = pd.greensfn;
+      if (fused && sign > 0 && axis == 2) flags |= 2;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pppm_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(pppm_fft_kernel, dim3((nlines + XT - 1) / XT), dim3(256), lds, s, pd.nx, pd.ny, pd.nz, axis, sign, fp,
+                         pd.twid[axis], re, im, xs, flags, gmul, gscale);
+      continue;
+    }
     int XT = (int)(48 * 1024 / ((size_t)n * 16));
     XT = XT < 1 ? 1 : (XT > 16 ? 16 : XT);
     const int nlines = axis == 0 ? pd.ny * pd.nz : (axis == 1 ? pd.nx * pd.nz : pd.nx * pd.ny);
@@ -165,17 +310,21 @@ static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, doub
 void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_idx, const double *x, const double *q, int ne,
                    int ne_pad, const int *egrid, const double *ew, double *re, double *im, double *slab_part, int *n_slab_part,
                    double *bk) {
+  const bool fused = mesh_smooth(pd);
+  const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
   hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, re);
-  hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, im);
-  hipLaunchKernelGGL(zero_kernel, dim3(64), dim3(256), 0, s, (size_t)4 * ne_pad, bk);
-  const int nb = (nl + 255) / 256 > 0 ? (nl + 255) / 256 : 1;
+  if (!fused) hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, im);
+  const int apb = 256 / (pd.order * pd.order);
+  const int ngroups = (nl + apb - 1) / apb > 0 ? (nl + apb - 1) / apb : 1;
+  const int npass = (ngroups + 1023) / 1024;       // at most 1024 slab partial sums (launch_b_real_combine reads them per wave)
+  const int nb = (ngroups + npass - 1) / npass;
   *n_slab_part = nb;
-  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, nl, elyte_idx, x, q, re, slab_part);
-  dft3(s, pd, -1.0, re, im);
-  hipLaunchKernelGGL(pppm_greens_kernel, dim3((pd.nfft + 255) / 256), dim3(256), 0, s, pd.nfft,
-                     1.0 / ((double)pd.nx * pd.ny * pd.nz), pd.greensfn, re, im);
-  dft3(s, pd, +1.0, re, im);
-  hipLaunchKernelGGL(pppm_gather_kernel, dim3((ne + 255) / 256), dim3(256), 0, s, pd, ne, egrid, ew, re, bk);
+  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, nl, elyte_idx, x, q, re, slab_part, npass);
+  dft3(s, pd, -1.0, re, im, fused, gscale);
+  if (!fused)
+    hipLaunchKernelGGL(pppm_greens_kernel, dim3((pd.nfft + 255) / 256), dim3(256), 0, s, pd.nfft, gscale, pd.greensfn, re, im);
+  dft3(s, pd, +1.0, re, im, fused, gscale);
+  hipLaunchKernelGGL(pppm_gather_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, pd, ne, ne_pad, egrid, ew, re, bk);
 }
 
 }  // namespace conp

@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
     ("dilute", "slab", (27, 24, 432), 5, 1e-4),
     ("il_onelayer", "ffield", (40, 45, 180), 5, 1e-4),  # BASELINE configs[3]
     ("il_onelayer", "ffield", (36, 40, 150), 4, 1e-3),  # even order: the other rounding convention (shift/shiftone)
+    ("dilute", "ffield", (28, 22, 128), 5, 1e-3),       # 7 and 11 are not radix-2/3/5: x, y lines take the plain-DFT fallback
+    ("dilute", "ffield", (32, 25, 160), 7, 1e-4),       # radix 4/2/5 only; highest stencil order LAMMPS allows
 ])
 def test_pppm_b_matches_oracle_and_ewald(oracle, deck, mode, mesh, order, acc):
     s = systems.deck(deck, mode, etypes=True)
