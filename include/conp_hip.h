@@ -221,6 +221,20 @@ int conp_fix_pre_force_device(conp_fix *fix, const double *d_x, double *d_q, dou
 int conp_fix_profile(conp_fix *fix, int enable);
 int conp_fix_profile_read(conp_fix *fix, int *nkernels, const char **names /*[16]*/, double *avg_ms /*[16]*/, int *counts /*[16]*/);
 
+
+/* ---- the fix's log file (fix_conp.cpp:119 `outf`) ----
+ * The library buffers the lines the reference prints there -- "A matrix calculating ..." / "A matrix calculation time  = %g"
+ * (:787, :857), the CG "Iteration %d: res = %g" / "***** Converged at iteration ..." lines (:919-928) -- and the host appends
+ * them to its file.  conp_fix_write_timing adds the three lines FixConp::pre_force prints on the last step of a run
+ * (:553-568: B vector / Coulomb / Kspace calculation time, seconds accumulated over the host-buffer pre_force calls, measured
+ * with HIP events around the k-space and real-space halves of b_cal).  conp_fix_log_drain returns the buffered text
+ * (valid until the next call on this fix) and empties the buffer. */
+int conp_fix_write_timing(conp_fix *fix);
+const char *conp_fix_log_drain(conp_fix *fix);
+/* same for the two lines the reference sends to utils::logmesg (screen + LAMMPS log): "conp output: <e,e> = %.8g" after the
+ * inverse's row sums (fix_conp.cpp:1006-1009) and "conp output: <d,d> = %.8g" at the end of linalg_setup (:458-461) */
+const char *conp_fix_mesg_drain(conp_fix *fix);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ SYMBOLS = [
     "conp_fix_set_stream",
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
+    "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
 ]
 
 
@@ -133,6 +134,11 @@ def load_library():
     lib.conp_fix_pre_force_device.argtypes = [vp, vp, vp, C.c_double]
     lib.conp_fix_profile.argtypes = [vp, C.c_int]
     lib.conp_fix_profile_read.argtypes = [vp, ip, C.POINTER(C.c_char_p), dp, ip]
+    lib.conp_fix_write_timing.argtypes = [vp]
+    lib.conp_fix_log_drain.argtypes = [vp]
+    lib.conp_fix_log_drain.restype = C.c_char_p
+    lib.conp_fix_mesg_drain.argtypes = [vp]
+    lib.conp_fix_mesg_drain.restype = C.c_char_p
     _LIB = lib
     return lib
 
@@ -383,6 +389,18 @@ class FixConp:
         cnt = (C.c_int * 16)()
         self._check(self.lib.conp_fix_profile_read(self.h, C.byref(n), names, ms, cnt))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+    def write_timing(self):
+        """the three timing lines of fix_conp.cpp:564-566 go to the log buffer"""
+        self._check(self.lib.conp_fix_write_timing(self.h))
+
+    def log_drain(self):
+        """text the reference would have printed to its log file (fix_conp.cpp:119) since the last drain"""
+        return self.lib.conp_fix_log_drain(self.h).decode()
+
+    def mesg_drain(self):
+        """the `conp output: <e,e>` / `<d,d>` lines of fix_conp.cpp:1006-1009, 458-461"""
+        return self.lib.conp_fix_mesg_drain(self.h).decode()
 
     def close(self):
         if self.h:

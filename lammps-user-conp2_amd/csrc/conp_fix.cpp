@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -110,6 +112,11 @@ struct conp_fix {
   std::vector<int> ct_ptr_h, seg_ptr_h;
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
+  // the fix's log file (fix_conp.cpp:119): lines are buffered here and handed to the host by conp_fix_log_drain
+  std::string logbuf, logdrain, mesgbuf, mesgdrain;   // mesgbuf: what the reference sends to utils::logmesg (:460, :1008)
+  double Btime = 0., Ctime = 0., Ktime = 0.;      // accumulated like :549-552 (seconds)
+  hipEvent_t ev_b[3] = {nullptr, nullptr, nullptr};
+  bool ev_pending = false;
   int nzc = 0;               // distinct electrode z values (<= 64: planar fast path of the projection), else 0
   std::vector<double> csk_h, snk_h, xele_h, d_vec_h;
   // EHGO pair mode (fix_conp.cpp:1482-1598)
@@ -125,7 +132,7 @@ struct conp_fix {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
-      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
+      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_hist, d_cg_p,
       d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
@@ -141,6 +148,7 @@ struct conp_fix {
 
   ~conp_fix() {
     prof.collect();
+    for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 
@@ -470,6 +478,8 @@ struct conp_fix {
   void a_cal(const conp_atoms *at) {
     if (!have_alist) throw ConpError(CONP_ERR_STATE, "a_cal: no electrode neighbor list (init_list not called)");
     const int ne = idx.elenum_all;
+    logf("A matrix calculating ...\n");                                   // :787
+    const auto t_a0 = std::chrono::steady_clock::now();
     km_a_read(at);
     km_a_cal_device();
     const double MY_PIS = 1.77245385090551602729;
@@ -496,6 +506,8 @@ struct conp_fix {
     sync();
     runstage = 1;
     if (args.matout) write_matrix_file("amatrix", 0);          // fix_conp.cpp:833-849
+    logf("A matrix calculation time  = %g\n",                               // :857
+         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a0).count());
   }
 
   // fix_conp.cpp:721-773 a_read: `org F` / `inv F`
@@ -598,6 +610,7 @@ struct conp_fix {
     launch_inv_project(stream, n, A, 0, nullptr, d_ainve.p, d_scalars.p + 4, 0);
     HIP_TRY(hipMemcpyAsync(&totinve, d_scalars.p + 4, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
+    mesgf("conp output: <e,e> = %.8g\n", totinve * evscale);             // :1006-1009
     if (args.nullneutral) {
       launch_inv_project_apply(stream, n, A, d_ainve.p, d_scalars.p + 4);
       if (args.zneutr) {
@@ -644,7 +657,7 @@ struct conp_fix {
   // fix_conp.cpp:864-930 cg
   void cg() {
     const int ne = idx.elenum_all;
-    d_cg_res.reserve(ne); d_cg_p.reserve(ne); d_cg_ap.reserve(ne); d_cg_scal.reserve(8); d_cg_done.reserve(1);
+    d_cg_res.reserve(ne); d_cg_p.reserve(ne); d_cg_ap.reserve(ne); d_cg_scal.reserve(8); d_cg_done.reserve(1); d_cg_hist.reserve(args.maxiter + 1);
     d_cg_done.zero(stream);
     prof.begin("cg", stream);
     launch_cg_init(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_scal.p);
@@ -653,7 +666,7 @@ struct conp_fix {
       const int batch_end = std::min(args.maxiter, iter + 8);
       for (; iter < batch_end; ++iter)
         launch_cg_iter(stream, ne, d_A.p, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_ap.p, d_cg_scal.p, args.tolerance,
-                       d_cg_done.p, iter);
+                       d_cg_done.p, iter, d_cg_hist.p);
       HIP_TRY(hipMemcpyAsync(&done, d_cg_done.p, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync();
     }
@@ -662,6 +675,21 @@ struct conp_fix {
     HIP_TRY(hipMemcpyAsync(sc, d_cg_scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     cg_iterations = done ? (int)sc[6] : 0;
+    // the log lines of :919-928: one per iteration, the converged one with the net charge (summed in index order like :917-918)
+    const int last = done ? cg_iterations : args.maxiter - 1;
+    std::vector<double> hist(last + 1, 0.0), qh(ne);
+    if (last >= 1) HIP_TRY(hipMemcpyAsync(hist.data(), d_cg_hist.p, (last + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(qh.data(), d_eleallq, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    for (int it = 1; it <= last; ++it) {
+      if (done && it == last) {
+        double netr = 0.0;
+        for (int i = 0; i < ne; ++i) netr += qh[i];
+        logf("***** Converged at iteration %d. res = %g netcharge = %g\n", it, hist[it], netr);
+      } else {
+        logf("Iteration %d: res = %g\n", it, hist[it]);
+      }
+    }
   }
 
   // fix_conp.cpp:698-718 equation_solve
@@ -697,12 +725,17 @@ struct conp_fix {
     b_setq_cal(at);
     equation_solve();
     get_setq(at);
+    mesgf("conp output: <d,d> = %.8g\n", -totsetq);                      // :458-461
   }
 
   // ---- per-step device path -------------------------------------------------------------------
   // km_ewald.cpp:153-167 b_cal + fix_conp.cpp:1281-1365 blist_coul_cal, this rank's shard, into d_b
-  void b_cal_device(const double *dx, const double *dq, bool coulyes) {
+  void b_cal_device(const double *dx, const double *dq, bool coulyes, bool timed = false) {
     const int ne = idx.elenum_all;
+    if (timed) {
+      for (auto &e : ev_b) if (!e) HIP_TRY(hipEventCreate(&e));
+      HIP_TRY(hipEventRecord(ev_b[0], stream));
+    }
     if (args.pppm) {
       // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
       prof.begin("pppm_b", stream);
@@ -732,13 +765,44 @@ struct conp_fix {
         launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
       prof.end(stream);
     }
+    if (timed) HIP_TRY(hipEventRecord(ev_b[1], stream));
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     prof.begin("b_real_combine", stream);
     launch_b_real_combine(stream, ne, ne_pad, coulyes ? row0 : 0, coulyes ? row1 : 0, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
                           d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
                           4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
     prof.end(stream);
+    if (timed) { HIP_TRY(hipEventRecord(ev_b[2], stream)); ev_pending = true; }
     HIP_TRY(hipGetLastError());   // a refused launch (bad grid / LDS size) must not pass silently
+  }
+
+  // Btime / Ctime / Ktime of fix_conp.cpp:549-552 and km/blist timers, from the events around the two halves of b_cal
+  void collect_b_times() {
+    if (!ev_pending) return;
+    ev_pending = false;
+    float k_ms = 0.f, c_ms = 0.f;
+    HIP_TRY(hipEventSynchronize(ev_b[2]));
+    HIP_TRY(hipEventElapsedTime(&k_ms, ev_b[0], ev_b[1]));
+    HIP_TRY(hipEventElapsedTime(&c_ms, ev_b[1], ev_b[2]));
+    Ktime += 1e-3 * k_ms; Ctime += 1e-3 * c_ms; Btime += 1e-3 * (k_ms + c_ms);
+  }
+
+  void mesgf(const char *fmt, ...) {
+    char line[256];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    mesgbuf += line;
+  }
+
+  void logf(const char *fmt, ...) {
+    char line[256];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    logbuf += line;
   }
 
   // fix_conp.cpp:1135-1139: rows [row0,row1) of eleallq = S b (inverse solver), or the CG solve
@@ -808,6 +872,7 @@ struct conp_fix {
     std::vector<double> qe(ne);
     HIP_TRY(hipMemcpyAsync(qe.data(), d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
     finish_scalar(potdiff);
+    collect_b_times();
     const int n = at->nlocal + at->nghost;
     for (int i = 0; i < n; ++i) {        // owned and ghost electrode atoms :1153-1158
       if (!at->echeck[i]) continue;
@@ -840,7 +905,7 @@ struct conp_fix {
   void b_cal(const conp_atoms *at) {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
     upload_xq(at);
-    b_cal_device(d_x.p, d_q.p, true);
+    b_cal_device(d_x.p, d_q.p, true, true);
   }
 
   // fix_conp.cpp:543-573 pre_force
@@ -1319,6 +1384,27 @@ int conp_fix_pre_force_device(conp_fix *f, const double *dx, double *dq, double 
   f->solve_device();
   f->scatter_device(dq, potdiff);
   CONP_GUARD_END
+}
+
+int conp_fix_write_timing(conp_fix *f) {
+  CONP_GUARD_BEGIN
+  f->collect_b_times();
+  f->logf("B vector calculation time = %g\n", f->Btime);          // fix_conp.cpp:564-566
+  f->logf("Coulomb calculation time = %g\n", f->Ctime);
+  f->logf("Kspace calculation time = %g\n", f->Ktime);
+  CONP_GUARD_END
+}
+
+const char *conp_fix_mesg_drain(conp_fix *f) {
+  f->mesgdrain.swap(f->mesgbuf);
+  f->mesgbuf.clear();
+  return f->mesgdrain.c_str();
+}
+
+const char *conp_fix_log_drain(conp_fix *f) {
+  f->logdrain.swap(f->logbuf);
+  f->logbuf.clear();
+  return f->logdrain.c_str();
 }
 
 int conp_fix_profile(conp_fix *f, int enable) {

@@ -84,6 +84,6 @@ void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
 void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, double *q, double *res, double *p,
                     double *scal /*[8]*/);
 void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *res, double *p, double *ap, double *scal,
-                    double tolerance, int *done, int iter);
+                    double tolerance, int *done, int iter, double *hist);
 
 }  // namespace conp

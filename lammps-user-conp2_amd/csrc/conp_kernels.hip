@@ -1060,7 +1060,7 @@ void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, doub
 __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restrict__ q, double *__restrict__ res,
                                                          double *__restrict__ p, const double *__restrict__ ap,
                                                          double *__restrict__ scal, double tolerance, int *__restrict__ done,
-                                                         int iter) {
+                                                         int iter, double *__restrict__ hist) {
   __shared__ double red[16];
   if (*done) return;
   double ptap = 0;
@@ -1084,6 +1084,7 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restri
   lr = block_sum_1024(lr, red);
   if (threadIdx.x == 0) {
     scal[0] = lr; scal[1] = lg; scal[2] = netr; scal[3] = ptap; scal[4] = alpha; scal[5] = beta;
+    hist[iter] = lr;
     if (lr / n < tolerance) { *done = 1; scal[6] = (double)iter; }
   }
 }
@@ -1102,9 +1103,9 @@ __global__ __launch_bounds__(256) void gemv_rows_guarded_kernel(int n, const dou
 }
 
 void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *res, double *p, double *ap, double *scal,
-                    double tolerance, int *done, int iter) {
+                    double tolerance, int *done, int iter, double *hist) {
   hipLaunchKernelGGL(gemv_rows_guarded_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, A, p, ap, done);
-  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, s, n, q, res, p, ap, scal, tolerance, done, iter);
+  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, s, n, q, res, p, ap, scal, tolerance, done, iter, hist);
 }
 
 }  // namespace conp

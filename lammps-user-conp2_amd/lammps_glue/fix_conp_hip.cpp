@@ -172,6 +172,7 @@ void FixConpHip::setup_pre_force(int) {                                    // :3
   force->kspace->setup();
   conp_atoms a = view();
   fail_if(conp_fix_setup_pre_force(h, &a, (int64_t)update->ntimestep, potdiff_now()));
+  flush_log();                            // "A matrix calculating ..." / "A matrix calculation time" (:787, :857), CG lines
 }
 
 void FixConpHip::post_neighbor() {                                         // :468-539
@@ -183,6 +184,17 @@ void FixConpHip::post_neighbor() {                                         // :4
 void FixConpHip::pre_force(int) {                                          // :543-573
   conp_atoms a = view();
   fail_if(conp_fix_pre_force(h, &a, (int64_t)update->ntimestep, potdiff_now()));
+  if (update->ntimestep % args.everynum == 0 && update->laststep == update->ntimestep)    // :553-568
+    fail_if(conp_fix_write_timing(h));
+  flush_log();
+}
+
+// the reference prints to `outf` from rank 0 only (me == 0 guards at :563, :786, :856, :920)
+void FixConpHip::flush_log() {
+  const char *text = conp_fix_log_drain(h);
+  if (outf && comm->me == 0 && text[0]) { fputs(text, outf); fflush(outf); }
+  const char *mesg = conp_fix_mesg_drain(h);                      // "conp output: <e,e> / <d,d>" -> screen + log.lammps
+  if (comm->me == 0 && mesg[0]) utils::logmesg(lmp, mesg);
 }
 
 // fix_conp.cpp:577-588 post_force / end_of_step -> force_cal (:1163-1201)

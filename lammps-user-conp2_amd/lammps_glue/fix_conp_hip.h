@@ -57,6 +57,7 @@ class FixConpHip : public Fix {
   void push_list(int which, class NeighList *l, std::vector<int> &first, std::vector<int> &neigh);
   double potdiff_now();
   void fail_if(int status);
+  void flush_log();
   void request_smartlist();
 };
 

@@ -25,6 +25,9 @@ class KSpaceModuleIface {
   virtual void a_read() {}
   virtual void b_cal(double *) {}
   virtual void update_charge() {}
+  virtual double compute_particle_potential(int) { return 0.; }
+  virtual void compute_group_potential(int, double *) {}
+  virtual double return_qsum() { return 0.; }
 };
 
 class KSpaceModuleHip : public KSpaceModuleIface, protected Pointers {
@@ -35,6 +38,11 @@ class KSpaceModuleHip : public KSpaceModuleIface, protected Pointers {
   void conp_setup(bool lowmem) override;                 /* km_ewald.cpp:63-132 */
   void a_cal(double *aaa) override;                      /* km_ewald.cpp:147-151 : aaa[elenum][elenum_all], k-space part */
   void b_cal(double *bbb) override;                      /* km_ewald.cpp:153-167 : bbb[elenum], local electrode order */
+  /* km_ewald.cpp:232-275 / :134-145 only (re)allocate and fill the provider's phase tables; the library sizes its device
+   * tables from the atoms handed to a_cal / b_cal, so these two hooks have nothing left to do.  update_charge,
+   * compute_particle_potential, compute_group_potential and return_qsum keep the base-class defaults, as in KSpaceModuleEwald. */
+  void conp_post_neighbor(bool, bool) override {}
+  void a_read() override {}
 
  private:
   conp_fix *h;

@@ -208,6 +208,65 @@ def test_cg_solver_matches_oracle(oracle):
     fx.close(); o.fx.close()
 
 
+def test_log_file_lines_inverse_solver():
+    """what the reference prints to its log file (fix_conp.cpp:787, 857, 564-566), in the same order and format"""
+    import re
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s, extra_args=[])
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    lines = fx.log_drain().splitlines()
+    assert lines[0] == "A matrix calculating ..."
+    m = re.fullmatch(r"A matrix calculation time  = (\S+)", lines[1])
+    assert m and 0.0 < float(m.group(1)) < 60.0
+    assert fx.log_drain() == ""                      # drained
+    mesg = fx.mesg_drain().splitlines()              # utils::logmesg lines :1006-1009, :458-461
+    assert mesg[0].startswith("conp output: <e,e> = ") and mesg[1].startswith("conp output: <d,d> = ") and len(mesg) == 2
+    inf = fx.info()
+    assert float(mesg[0].split("=")[1]) == pytest.approx(inf.totinve * systems.EVSCALE, rel=1e-7)
+    assert float(mesg[1].split("=")[1]) == pytest.approx(-inf.totsetq, rel=1e-7)
+    for step in range(1, 4):
+        fx.pre_force(at, step, s.potdiff)
+    assert fx.log_drain() == ""                      # nothing is printed per step
+    fx.write_timing()
+    lines = fx.log_drain().splitlines()
+    names = ["B vector calculation time = ", "Coulomb calculation time = ", "Kspace calculation time = "]
+    assert [l[:len(n)] for l, n in zip(lines, names)] == names and len(lines) == 3
+    tb, tc, tk = (float(l.split("=")[1]) for l in lines)
+    assert tb > 0 and tc > 0 and tk > 0 and abs(tb - (tc + tk)) <= 1e-9 + 1e-6 * tb      # three b_cal calls, seconds
+    assert tb < 5.0
+    fx.close()
+
+
+def test_log_file_lines_cg(oracle):
+    """CG residual lines (fix_conp.cpp:919-928): one per iteration, the last one with the net charge"""
+    import re
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s, extra_args=["cg"])
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    lines = [l for l in fx.log_drain().splitlines() if not l.startswith("A matrix")]
+    n = fx.info().cg_iterations
+    # two solves during setup: the preset vector (linalg_setup -> equation_solve, :456) and the first pre_force (:390)
+    first_end = next(k for k, l in enumerate(lines) if l.startswith("*****"))
+    lines = lines[first_end + 1:]
+    assert n >= 2 and len(lines) == n
+    res = []
+    for k, l in enumerate(lines[:-1], start=1):
+        m = re.fullmatch(r"Iteration (\d+): res = (\S+)", l)
+        assert m and int(m.group(1)) == k
+        res.append(float(m.group(2)))
+    m = re.fullmatch(r"\*\*\*\*\* Converged at iteration (\d+)\. res = (\S+) netcharge = (\S+)", lines[-1])
+    assert m and int(m.group(1)) == n
+    assert float(m.group(2)) / fx.info().elenum_all < 1e-6 <= res[-1] / fx.info().elenum_all    # the stop rule :915
+    assert abs(float(m.group(3))) < 1e-9                                                         # neutrality constraint
+    fx.close()
+
+
 def test_pre_force_respects_nevery_and_reneighbor(oracle):
     """Nevery gate (fix_conp.cpp:546) and a re-neighbour with re-ordered atoms: permanent numbering survives"""
     s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
