@@ -104,7 +104,9 @@ def deck(name: str, mode: str = "ffield", etypes: bool = True, shuffle_seed: Opt
          g_ewald: Optional[float] = None) -> System:
     """The reference's test decks.
 
-    name: 'dilute' (tests/dilute), 'il_onelayer', 'il_twolayer' (tests/il_*).
+    name: 'dilute' (tests/dilute), 'il_onelayer', 'il_twolayer' (tests/il_*), 'cond' (tests/cond: the il_onelayer data
+          file and groups), 'cond2' (tests/cond2: its own data file, 2 x 1248 electrode atoms with rough inner layers,
+          cutoff 15).
     mode: 'slab' (boundary p p f + kspace_modify slab 3.0), 'ffield' (p p p), 'noslab_zneutr'
           (doubled antisymmetric cell, tests/dilute/input:50-63 trial 4 / il trial 6).
     g_ewald normally comes from LAMMPS PPPM; persist.log:112 gives 0.77236341 for dilute/ffield.  For the
@@ -115,10 +117,14 @@ def deck(name: str, mode: str = "ffield", etypes: bool = True, shuffle_seed: Opt
         d = np.load(os.path.join(gd, "deck_dilute.npz"))
         left, right, etype, cutoff, acc, skin = (81,), (82,), (3,), 4.0, 1.0e-6, 2.0
         g_default = 0.77236341
-    elif name in ("il_onelayer", "il_twolayer"):
+    elif name == "cond2":
+        d = np.load(os.path.join(gd, "deck_cond2.npz"))
+        left, right, etype, cutoff, acc, skin = (1443,), (1444,), (5,), 15.0, 1.0e-7, 2.0   # tests/cond2/input:19,29-31,33
+        g_default = 0.21          # LAMMPS' own estimate is not stored in the reference; any explicit `kspace_modify gewald`
+    elif name in ("il_onelayer", "il_twolayer", "cond"):
         d = np.load(os.path.join(gd, "deck_il.npz"))
         etype, cutoff, acc, skin = (5,), 16.0, 1.0e-7, 2.0
-        if name == "il_onelayer":
+        if name in ("il_onelayer", "cond"):
             left, right = (641,), (642,)
         else:  # tests/il_twolayer/input:41-42 relabels 643->641, 644->642
             left, right = (641, 643), (642, 644)

@@ -349,7 +349,7 @@ struct conp_fix {
     build_items();
     d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
-    d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 255) / 256 + 1025);
+    d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
     d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
     // real-space rows of b
     build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);

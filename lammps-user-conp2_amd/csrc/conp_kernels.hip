@@ -32,7 +32,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 //    Xt[kx][j], Yt[ky][j], Zt[m][j] as (cos, sin), k-major / atom-contiguous like the reference's cs/sn.
 //    Row 0 of each table is (1, 0).  Also compacts q and emits per-block partial sums of q*z (slab, :835-841).
 // ================================================================================================
-__global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, const int *__restrict__ elyte_idx,
+// One thread per (atom, axis): blockIdx.y = 0 (x), 1 (y), 2 (z) -- the three recurrences are independent, the z one is the
+// long one (nz steps), so splitting them puts 3x as many wavefronts on the chip for the same serial depth.
+constexpr int EP_THREADS = 128;
+__global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nl, int nl_pad, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double ux, double uy, double uz, int kxmax, int kymax, int nz,
                                                           int zstride, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
@@ -40,56 +43,57 @@ __global__ __launch_bounds__(256) void elyte_phase_kernel(int nl, int nl_pad, co
                                                           double *__restrict__ slab_part) {
 #pragma clang fp contract(off)
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
   double qz = 0.0;
   if (j < nl_pad) {
-    double xx = 0, yy = 0, zz = 0, qq = 0;
+    double xc = 0, qq = 0;
     if (j < nl) {
       const int i = elyte_idx[j];
-      xx = x[3 * i]; yy = x[3 * i + 1]; zz = x[3 * i + 2]; qq = q[i];
+      xc = x[3 * i + c]; qq = q[i];
     }
-    qc[j] = qq;
-    qz = qq * zz;
-    const double ang[3] = {ux * xx, uy * yy, uz * zz};
-    const int nrow[3] = {kxmax + 1, kymax + 1, nz};
-    double2 *tab[3] = {Xt, Yt, Zs};
-    Xt[(size_t)(kxmax + 1) * nl_pad + j] = make_double2(0.0, 0.0);   // row for padding planar vectors (no contribution)
+    const double ang = (c == 0 ? ux : (c == 1 ? uy : uz)) * xc;
+    const int nrow = c == 0 ? kxmax + 1 : (c == 1 ? kymax + 1 : nz);
+    double2 *t = (c == 0 ? Xt : (c == 1 ? Yt : Zs)) + j;
     // X and Y: every row.  Z: row 0 of Zs is the unit step (cos, sin)(uz z); row 1 + s is the seed for m = s*zstride --
     // sk_gemm regenerates the m's in between with the same recurrence, so the values equal the full table's.
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      double c1, s1;
-      sincos(ang[c], &s1, &c1);
-      double2 *t = tab[c] + j;
-      const int stride = (c == 2) ? zstride : 1;
-      const int off = (c == 2) ? 1 : 0;
-      // the x table carries the charge (q cos, q sin): one multiply here instead of two per planar vector in sk_gemm
-      const double sc = (c == 0) ? qq : 1.0;
-      if (c == 2) t[0] = make_double2(c1, s1);
-      t[(size_t)off * nl_pad] = make_double2(sc, 0.0);
-      double cm = c1, sm = s1;
-      if (nrow[c] > 1 && stride == 1) t[(size_t)(off + 1) * nl_pad] = make_double2(sc * c1, sc * s1);
-      for (int m = 2; m < nrow[c]; ++m) {
-        const double cn = cm * c1 - sm * s1;
-        const double sn = sm * c1 + cm * s1;
-        cm = cn; sm = sn;
-        if (m % stride == 0) t[(size_t)(off + m / stride) * nl_pad] = make_double2(sc * cm, sc * sm);
-      }
+    const int stride = (c == 2) ? zstride : 1;
+    const int off = (c == 2) ? 1 : 0;
+    // the x table carries the charge (q cos, q sin): one multiply here instead of two per planar vector in sk_gemm
+    const double sc = (c == 0) ? qq : 1.0;
+    double c1, s1;
+    sincos(ang, &s1, &c1);
+    if (c == 0) Xt[(size_t)(kxmax + 1) * nl_pad + j] = make_double2(0.0, 0.0);   // row for padding planar vectors (no contribution)
+    if (c == 2) { t[0] = make_double2(c1, s1); qc[j] = qq; qz = qq * xc; }
+    t[(size_t)off * nl_pad] = make_double2(sc, 0.0);
+    double cm = c1, sm = s1;
+    if (nrow > 1 && stride == 1) t[(size_t)(off + 1) * nl_pad] = make_double2(sc * c1, sc * s1);
+    int next = stride > 2 ? stride : 2;   // first stored m >= 2 that is a multiple of stride
+    for (int m = 2; m < nrow; ++m) {
+      const double cn = cm * c1 - sm * s1;
+      const double sn = sm * c1 + cm * s1;
+      cm = cn; sm = sn;
+      if (m == next) { t[(size_t)(off + m / stride) * nl_pad] = make_double2(sc * cm, sc * sm); next += stride; }
     }
   }
+  if (c != 2) return;
   // block partial of sum q z
-  __shared__ double red[4];
+  __shared__ double red[EP_THREADS / 64];
   double v = wave_sum(qz);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) slab_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w];
+    slab_part[blockIdx.x] = tot;
+  }
 }
 
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part) {
-  const int nb = (nl_pad + 255) / 256;
+  const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS;
   *n_slab_part = nb;
-  hipLaunchKernelGGL(elyte_phase_kernel, dim3(nb), dim3(256), 0, s, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
+  hipLaunchKernelGGL(elyte_phase_kernel, dim3(nb, 3), dim3(EP_THREADS), 0, s, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
                      kymax, nz, zstride, Xt, Yt, Zs, qc, slab_part);
 }
 

@@ -3,9 +3,9 @@
 
 Run in the authoring container only (needs /root/reference):
     python tests/golden/make_deck_fixtures.py
-Inputs : /root/reference/tests/{dilute,il_onelayer}/data   (LAMMPS data files, 'atom_style full')
-Outputs: tests/golden/deck_dilute.npz, tests/golden/deck_il.npz  (data only: box, id, mol, type, q, x)
-         il_onelayer, il_twolayer, cond and zmirror share one data file.
+Inputs : /root/reference/tests/{dilute,il_onelayer,cond2}/data   (LAMMPS data files, 'atom_style full')
+Outputs: tests/golden/deck_dilute.npz, deck_il.npz, deck_cond2.npz  (data only: box, id, mol, type, q, x)
+         il_onelayer, il_twolayer, cond and zmirror share one data file; cond2 has its own.
 The known-answer numbers of tests/dilute/persist.log are written to tests/golden/dilute_persist.json.
 """
 import json
@@ -62,6 +62,9 @@ def main():
     d = parse_data(os.path.join(REF, "il_onelayer", "data"))
     np.savez_compressed(os.path.join(HERE, "deck_il.npz"), **d)
     print("il:", len(d["tag"]), "atoms, ntypes", d["ntypes"])
+    d = parse_data(os.path.join(REF, "cond2", "data"))
+    np.savez_compressed(os.path.join(HERE, "deck_cond2.npz"), **d)
+    print("cond2:", len(d["tag"]), "atoms, ntypes", d["ntypes"])
     # known-answer material: tests/dilute/persist.log
     log = open(os.path.join(REF, "dilute", "persist.log")).read()
     g = float(re.search(r"G vector \(1/distance\) = ([0-9.eE+-]+)", log).group(1))

@@ -54,6 +54,49 @@ def test_il_decks_match_oracle(oracle, deck, mode, extra):
     fx.close(); o.fx.close()
 
 
+@pytest.mark.parametrize("deck,mode,Q", [
+    ("cond", "slab", 0.35),       # tests/cond/input N = 0 (conp, dv 2) and N = 1 (conq, Q 0.35)
+    ("cond", "ffield", 0.35),     # N = 2 (conp ffield), 3 (conq ffield), 4 (cond ffield)
+    ("cond2", "ffield", 50.0),    # tests/cond2/input: rough 2 x 1248-atom electrodes, Q = 50
+])
+def test_cond_decks_all_three_fix_styles(deck, mode, Q):
+    """the reference's tests/cond and tests/cond2 decks: one A matrix, then the conp / conq / cond charge rules on it"""
+    import oracle_py
+    lib = oracle_py.load(fast=True)                  # OpenMP build: the A matrix of cond2 (Ne 2496) takes a minute otherwise
+    s = systems.deck(deck, mode, etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    o = OracleRun(lib, s, at, alist, blist)
+    o.fx.lib.orc_fix_a_cal(o.fx.h); o.fx.lib.orc_fix_b_setq_cal(o.fx.h)
+    setz = o.fx.vectors()[0] / systems.EVSCALE       # FixCond::cond_setup (fix_cond.cpp:46-56)
+    assert o.fx.lib.orc_fix_equation_solve(o.fx.h) == 0
+    o.fx.lib.orc_fix_get_setq(o.fx.h)
+    loc = slice(0, at.nlocal)
+    ele = at.echeck[loc] != 0
+    q_start = at.q.copy()
+    styles = ["conp", "conq"] + (["cond"] if mode == "ffield" else [])
+    for style in styles:
+        at.q[:] = q_start; o.q[:] = q_start
+        arg = 2.0 if style == "conp" else Q
+        if style == "conp":
+            o.pre_force(arg); want = o.fx.scalars()["scalar_output"]
+        elif style == "conq":
+            want = o.fx.pre_force_conq(arg)
+        else:
+            want = o.fx.pre_force_cond(arg, setz)
+        fx = FixConp(s, style=style)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.setup_pre_force(at, 0, arg)
+        assert fx.info().elenum_all == (832 if deck == "cond" else 2496)
+        assert rel_err(fx.vectors()[0], o.fx.vectors()[0]) < 1e-10, style
+        assert rel_err(at.q[loc][ele], o.q[loc][ele]) < 1e-7, style
+        assert fx.compute_scalar() == pytest.approx(want, rel=1e-7, abs=1e-10), style
+        if style == "conq":                          # prescribed charge on group 2 (fix_conq.cpp:63-76)
+            assert at.q[loc][at.echeck[loc] == -1].sum() == pytest.approx(Q, rel=1e-8)
+        fx.close()
+    o.fx.close()
+
+
 @pytest.fixture(scope="module")
 def headline():
     s = systems.synthetic_fast()          # 4096 electrode / 32768 electrolyte, ffield (bench.py's workload)
