@@ -108,7 +108,8 @@ def deck(name: str, mode: str = "ffield", etypes: bool = True, shuffle_seed: Opt
           file and groups), 'cond2' (tests/cond2: its own data file, 2 x 1248 electrode atoms with rough inner layers,
           cutoff 15).
     mode: 'slab' (boundary p p f + kspace_modify slab 3.0), 'ffield' (p p p), 'noslab_zneutr'
-          (doubled antisymmetric cell, tests/dilute/input:50-63 trial 4 / il trial 6).
+          (doubled antisymmetric cell, tests/dilute/input:50-63 trial 4 / il trial 6), 'zmirror' (doubled mirrored cell of
+          tests/zmirror/input, `noslab zneutr`).
     g_ewald normally comes from LAMMPS PPPM; persist.log:112 gives 0.77236341 for dilute/ffield.  For the
     IL decks the LAMMPS estimate is not stored anywhere in the reference, so SURVEY.md's 0.20693 is used.
     """
@@ -151,6 +152,20 @@ def deck(name: str, mode: str = "ffield", etypes: bool = True, shuffle_seed: Opt
         boxhi[2] = boxlo[2] + 2 * lz
         shift = -(boxlo[2] + lz)  # change_box z final -lz' /2 .. lz'/2 remap
         x[:, 2] += shift; boxlo[2] += shift; boxhi[2] += shift
+        periodic, slabf, slabflag, ff, zneutr = (True, True, True), 1.0, 0, 2, True
+    elif mode == "zmirror":
+        # tests/zmirror/input:33-40: replicate 1 1 2, recentre on z = 0, then reflect the upper copy (z -> lz/2 - z); both
+        # copies keep their electrode roles (group eleleft = molecule molleft and molleft + molmax)
+        lz = boxhi[2] - boxlo[2]
+        x2 = x.copy(); x2[:, 2] += lz
+        x = np.concatenate([x, x2]); q = np.concatenate([q, q]); typ = np.concatenate([typ, typ])
+        tag = np.concatenate([tag, tag + len(tag)]).astype(np.int32)
+        echeck = np.concatenate([echeck, echeck]).astype(np.int32)
+        boxhi[2] = boxlo[2] + 2 * lz
+        shift = -(boxlo[2] + lz)
+        x[:, 2] += shift; boxlo[2] += shift; boxhi[2] += shift
+        pos = x[:, 2] >= 0.0                       # region pos block EDGE EDGE EDGE EDGE 0 EDGE
+        x[pos, 2] = lz - x[pos, 2]                 # variable newz atom lz/2-z with the doubled lz
         periodic, slabf, slabflag, ff, zneutr = (True, True, True), 1.0, 0, 2, True
     else:
         raise ValueError(mode)

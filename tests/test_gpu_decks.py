@@ -97,6 +97,41 @@ def test_cond_decks_all_three_fix_styles(deck, mode, Q):
     o.fx.close()
 
 
+def test_zmirror_deck_conp_and_conq():
+    """tests/zmirror/input N = 0 (conp 2 V) and N = 3 (conq 0.7): doubled, mirrored il cell with `noslab zneutr`"""
+    import oracle_py
+    lib = oracle_py.load(fast=True)
+    s = systems.deck("il_onelayer", "zmirror", etypes=True)
+    assert s.zneutr and s.ff_flag == 2
+    at, alist, blist = neighbor.build_lists(s)
+    o = OracleRun(lib, s, at, alist, blist)
+    o.setup()
+    loc = slice(0, at.nlocal)
+    ele = at.echeck[loc] != 0
+    upper = at.x[loc][:, 2] > 0
+    q_start = at.q.copy()
+    for style, arg in (("conp", 2.0), ("conq", 0.7)):
+        at.q[:] = q_start; o.q[:] = q_start
+        if style == "conp":
+            o.pre_force(arg); want = o.fx.scalars()["scalar_output"]
+        else:
+            want = o.fx.pre_force_conq(arg)
+        fx = FixConp(s, style=style)
+        assert fx.args.zneutr == 1 and fx.args.ff_flag == 2
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.setup_pre_force(at, 0, arg)
+        assert fx.info().elenum_all == 1664
+        assert rel_err(fx.vectors()[0], o.fx.vectors()[0]) < 1e-10, style
+        assert rel_err(at.q[loc][ele], o.q[loc][ele]) < 1e-7, style
+        assert fx.compute_scalar() == pytest.approx(want, rel=1e-7, abs=1e-10), style
+        # zneutr (fix_conp.cpp:1027-1060): each half of the doubled cell is neutral on its own
+        qe = at.q[loc][ele]
+        assert abs(qe[upper[ele]].sum()) < 1e-9 and abs(qe[~upper[ele]].sum()) < 1e-9, style
+        fx.close()
+    o.fx.close()
+
+
 @pytest.fixture(scope="module")
 def headline():
     s = systems.synthetic_fast()          # 4096 electrode / 32768 electrolyte, ffield (bench.py's workload)
