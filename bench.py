@@ -8,7 +8,7 @@ graphene-electrode / ionic-liquid box the metric is quoted on (4096 electrode / 
 N > 1: k-vectors (planar row tiles) and electrode rows are sharded over the ranks; one all-reduce of b (Ne doubles) and
 one all-gather of q (Ne doubles) per update over RCCL -> "strong" scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|big|il_onelayer] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|big|il_onelayer|il_twolayer|dilute|cond2] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -36,8 +36,8 @@ def make_workload(name):
         return systems.synthetic_fast(n_cells_x=64, n_cells_y=32, lz=1200.0, n_elyte=262144, cutoff=12.0,
                                       accuracy_relative=1e-6, g_ewald=0.2554, mode="ffield", seed=12345,
                                       name="synthetic graphene/IL 16384 electrode + 262144 electrolyte, ffield")
-    if name == "il_onelayer":
-        return systems.deck("il_onelayer", "ffield")
+    if name in ("il_onelayer", "il_twolayer", "dilute", "cond2"):      # the reference's own decks (tests/*)
+        return systems.deck(name, "ffield")
     raise SystemExit(f"unknown workload {name}")
 
 

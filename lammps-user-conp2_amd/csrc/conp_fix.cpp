@@ -274,7 +274,7 @@ struct conp_fix {
     ct_ptr_h.assign(plan.n_col_tiles + 1, 0);
     for (int ct = 0; ct < plan.n_col_tiles; ++ct) {
       for (int rt = env.rank; rt < plan.n_row_tiles; rt += env.nranks)
-        if (plan.nba(rt, ct) > 0) tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0});
+        if (plan.nba(rt, ct) > 0) tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0, plan.nba16(rt, ct)});
       ct_ptr_h[ct + 1] = (int)tiles_h.size();
     }
     d_ct_ptr.upload(ct_ptr_h, stream);
@@ -361,21 +361,33 @@ struct conp_fix {
   }
 
   // sk_gemm schedule ("stream-K" over the atom chunks): the work of all tiles of this rank is laid out on one axis,
-  // tile after tile, chunk after chunk, with cost (nba + SK_C0) per chunk of 16 atoms (MFMA work ~ nba, operand
+  // tile after tile, chunk after chunk, with cost (mean nba of the 4 row fragments + SK_C0) per chunk of 16 atoms (MFMA work ~ nba, operand
   // generation + barrier ~ SK_C0), and cut into num_cus equal shares.  A share is a list of segments (tile, chunk
   // range); every segment writes one partial tile, sk_reduce adds a tile's segments in order.
   double SK_C0 = getenv("CONP_SK_C0") ? atof(getenv("CONP_SK_C0")) : 2.0;
   void build_items() {
     const int nchunks = nl_pad / 16;
-    const int nwg = std::max(1, num_cus);
     const size_t nt = tiles_h.size();
+    // one workgroup per CU, except for small problems: sk_reduce walks a tile's splits serially (~1 us per split), so a tile
+    // is cut into more than 16 segments only when a segment still holds >= 8 chunks (measured on the decks: il_onelayer
+    // 57 -> 52 us per update with 32 instead of 256 workgroups)
+    int nwg = std::max(1, num_cus);
+    nwg = std::min(nwg, std::max((int)(16 * nt), (int)((nt * (size_t)nchunks + 7) / 8)));
+    nwg = std::max(1, nwg);
+    if (getenv("CONP_SK_NWG")) nwg = std::max(1, atoi(getenv("CONP_SK_NWG")));
     std::vector<double> start(nt + 1, 0.0);
-    for (size_t i = 0; i < nt; ++i) start[i + 1] = start[i] + nchunks * (tiles_h[i].nba + SK_C0);
+    // MFMA work of a tile ~ mean over its 4 row fragments of their active kz blocks (per-fragment sphere culling)
+    auto cost = [&](const SkTile &t) {
+      double sum = 0.0;
+      for (int f = 0; f < 4; ++f) sum += (double)((t.nbf >> (8 * f)) & 255u);
+      return 0.25 * sum + SK_C0;
+    };
+    for (size_t i = 0; i < nt; ++i) start[i + 1] = start[i] + nchunks * cost(tiles_h[i]);
     const double W = start.back();
     auto locate = [&](double pos, size_t &ti, int &ch) {
       ti = 0;
       while (ti + 1 < nt && pos >= start[ti + 1]) ++ti;
-      ch = (int)std::lround((pos - start[ti]) / (tiles_h[ti].nba + SK_C0));
+      ch = (int)std::lround((pos - start[ti]) / cost(tiles_h[ti]));
       ch = std::max(0, std::min(nchunks, ch));
     };
     items_h.clear();
@@ -388,11 +400,11 @@ struct conp_fix {
       int ce = nchunks;
       if (w + 1 < nwg) locate(W * (w + 1) / nwg, te, ce);
       while (ti < te) {
-        if (ch < nchunks) items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, nchunks});
+        if (ch < nchunks) items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, nchunks, tiles_h[ti].nbf});
         ++ti; ch = 0;
       }
       if (ti == te && ch < ce) {
-        items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, ce});
+        items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, ce, tiles_h[ti].nbf});
         ch = ce;
       }
     }

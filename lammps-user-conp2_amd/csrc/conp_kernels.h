@@ -12,8 +12,9 @@ struct DevPlan {              // device copy of KPlan geometry
   const double *wfull;                // [R_pad][C_pad]
 };
 
-struct SkItem { int rt, ct, nba, c0, c1; };            // one sk_gemm segment: tile + chunk range [c0, c1) of 16 atoms
-struct SkTile { int rt, ct, nba, item0, nsplit; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
+struct SkItem { int rt, ct, nba, c0, c1; unsigned nbf; };   // one sk_gemm segment: tile + chunk range [c0, c1) of 16 atoms;
+                                                          // nbf = active kz blocks per 16-row fragment, 4 x 8 bit
+struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
   double g_ewald, eta, cut_coulsq;    // cut_coulsq already min(cut_coul^2, (5.8/g)^2)  fix_conp.cpp:1237-1240

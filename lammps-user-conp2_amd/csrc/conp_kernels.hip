@@ -140,6 +140,7 @@ struct SkCtx {        // per-thread constants of one work item
   double sg0, sg1;
   bool zact;
   int a_off, b_off, fr, fk, rh, cg;
+  unsigned fmask;                   // bit 5 f + g: column fragment g of this wave is inside the sphere for row fragment f
   const double2 *Xt, *Yt, *Zs;
   const double *qc;
   int dbg;
@@ -197,7 +198,8 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const double *cur,
 #pragma unroll
       for (int g = 0; g < NFW; ++g)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+        for (int f = 0; f < 4; ++f)
+          if (c.fmask & (1u << (5 * f + g))) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);   // wave-uniform skip
     }
   }
 }
@@ -283,6 +285,16 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     c.it = items[sg];
     const int nfrag = 2 * c.it.nba;                     // active column fragments of this tile
     const int nfw = (nfrag - c.cg + 3) >> 2;            // fragments of this wave: fi = 4 g + cg < nfrag   (wave-uniform)
+    // per row fragment f (16 planar vectors) only the leading nbf_f <= nba kz blocks are inside the cut-off sphere
+    c.fmask = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int nff = 2 * (int)((c.it.nbf >> (8 * f)) & 255u);
+      int n = (nff - c.cg + 3) >> 2;
+      n = n < 0 ? 0 : n;
+      c.fmask |= ((1u << n) - 1u) << (5 * f);
+    }
+    c.fmask = __builtin_amdgcn_readfirstlane(c.fmask);
     const int p0 = c.it.rt * 64 + c.gs, p1 = p0 + 32;
     c.xoff0 = (unsigned)pl.p_ikx[p0] * nl_pad; c.yoff0 = (unsigned)pl.p_iky[p0] * nl_pad;
     c.xoff1 = (unsigned)pl.p_ikx[p1] * nl_pad; c.yoff1 = (unsigned)pl.p_iky[p1] * nl_pad;
