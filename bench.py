@@ -118,7 +118,10 @@ def main():
     at, alist, blist = neighbor.build_lists(s)
     fx = FixConp(s, device=dev_index, rank=rank, nranks=world, extra_args=["pppm"] if args.pppm else [],
                  pppm_mesh=tuple(args.pppm) if args.pppm else None)
-    fx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # multi-rank: the library shares torch's current stream with the RCCL collectives (stream order = data dependence).
+    # One rank: the library keeps its own stream (fences below are device-wide), which lets it replay the update as a HIP graph.
+    if world > 1:
+        fx.set_stream(torch.cuda.current_stream().cuda_stream)
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
     t_a0 = time.perf_counter()

@@ -148,6 +148,7 @@ struct conp_fix {
 
   ~conp_fix() {
     prof.collect();
+    drop_graph();
     for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -920,6 +921,67 @@ struct conp_fix {
     b_cal_device(d_x.p, d_q.p, true, true);
   }
 
+  // ---- one device-resident update as a HIP graph ------------------------------------------------
+  // The decks' updates are launch-bound (7-8 dependent kernels of 5-15 us each), the textbook case for a graph.  Measured on
+  // MI355X / ROCm 7.2 it does NOT pay: graph replay is 5-12 % slower than the plain in-order launches (il_onelayer 57.2 vs
+  // 51.2 us, dilute 47.5 vs 44.8, cond2 78.1 vs 71.5, headline 374 vs 371 us per update), so it is opt-in (CONP_GRAPH=1) and
+  // kept for re-measurement on later ROCm releases.  The graph is dropped by every C-ABI call that can change buffers, plans
+  // or parameters (drop_graph()) and re-captured on the next update; a potential difference that changes from step to step
+  // (`v_name`) keeps the direct-launch path.
+  hipGraph_t upd_graph = nullptr;
+  hipGraphExec_t upd_exec = nullptr;
+  const double *g_dx = nullptr;
+  double *g_dq = nullptr;
+  double g_pot = 0.0;
+  int g_warm = 0, g_pot_changes = 0;
+  bool graph_off = getenv("CONP_GRAPH") == nullptr || atoi(getenv("CONP_GRAPH")) == 0;
+  void drop_graph() {
+    if (upd_exec) { (void)hipGraphExecDestroy(upd_exec); upd_exec = nullptr; }
+    if (upd_graph) { (void)hipGraphDestroy(upd_graph); upd_graph = nullptr; }
+    g_warm = 0;
+  }
+  void update_direct(const double *dx, double *dq, double potdiff) {
+    b_cal_device(dx, dq, true);
+    solve_device();
+    scatter_device(dq, potdiff);
+  }
+  void update_device(const double *dx, double *dq, double potdiff) {
+    // (the legacy default stream cannot be captured)
+    const bool can = !graph_off && stream != nullptr && !prof.on && args.minimizer == CONP_SOLVER_INV && runstage >= 3 &&
+                     (!args.cond || cond_ready);
+    if (can && upd_exec && potdiff != g_pot && ++g_pot_changes > 2) graph_off = true;     // variable potential: stay direct
+    if (!can || graph_off) { if (upd_exec) drop_graph(); update_direct(dx, dq, potdiff); return; }
+    if (upd_exec && (dx != g_dx || dq != g_dq || potdiff != g_pot)) drop_graph();
+    if (!upd_exec) {
+      // the first update after a (re)setup runs directly (lazy allocations happen there); the second one is captured
+      if (g_warm++ == 0) { update_direct(dx, dq, potdiff); return; }
+      if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        graph_off = true;
+        update_direct(dx, dq, potdiff);
+        return;
+      }
+      try {
+        update_direct(dx, dq, potdiff);
+      } catch (...) {
+        hipGraph_t junk = nullptr;
+        (void)hipStreamEndCapture(stream, &junk);
+        if (junk) (void)hipGraphDestroy(junk);
+        graph_off = true;
+        throw;
+      }
+      HIP_TRY(hipStreamEndCapture(stream, &upd_graph));
+      if (hipGraphInstantiate(&upd_exec, upd_graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        upd_exec = nullptr; drop_graph(); graph_off = true;
+        update_direct(dx, dq, potdiff);
+        return;
+      }
+      g_dx = dx; g_dq = dq; g_pot = potdiff;
+    }
+    HIP_TRY(hipGraphLaunch(upd_exec, stream));
+  }
+
   // fix_conp.cpp:543-573 pre_force
   void pre_force(const conp_atoms *at, int64_t ntimestep, double potdiff) {
     if (runstage < 2) throw ConpError(CONP_ERR_STATE, "pre_force before setup_pre_force");
@@ -1043,6 +1105,7 @@ void conp_fix_destroy(conp_fix *fix) { delete fix; }
 
 int conp_fix_init_list(conp_fix *f, int which, const conp_neighlist *l) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   if (!f || !l) throw ConpError(CONP_ERR_ARG, "null argument");
   ListView v; v.inum = l->inum; v.ilist = l->ilist; v.numneigh = l->numneigh; v.first = l->first; v.neigh = l->neigh;
   if (which == 0 || which == 2) { f->alist = v; f->have_alist = true; }
@@ -1053,6 +1116,7 @@ int conp_fix_init_list(conp_fix *f, int which, const conp_neighlist *l) {
 
 int conp_fix_setup_post_neighbor(conp_fix *f, const conp_atoms *at) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->linalg_init(at);
   f->post_neighbor(at);
   CONP_GUARD_END
@@ -1060,18 +1124,21 @@ int conp_fix_setup_post_neighbor(conp_fix *f, const conp_atoms *at) {
 
 int conp_fix_post_neighbor(conp_fix *f, const conp_atoms *at) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->post_neighbor(at);
   CONP_GUARD_END
 }
 
 int conp_fix_linalg_setup(conp_fix *f, const conp_atoms *at) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->linalg_setup(at);
   CONP_GUARD_END
 }
 
 int conp_fix_setup_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimestep, double potdiff) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->linalg_setup(at);
   f->pre_force(at, ntimestep, potdiff);
   CONP_GUARD_END
@@ -1079,6 +1146,7 @@ int conp_fix_setup_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimeste
 
 int conp_fix_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimestep, double potdiff) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->pre_force(at, ntimestep, potdiff);
   CONP_GUARD_END
 }
@@ -1087,6 +1155,7 @@ double conp_fix_compute_scalar(const conp_fix *f) { return f->scalar_output; }
 
 int conp_fix_modify_param(conp_fix *f, int narg, const char *const *arg, int *consumed) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   const int n = f->modify_param(narg, arg);
   if (consumed) *consumed = n;
   CONP_GUARD_END
@@ -1094,6 +1163,7 @@ int conp_fix_modify_param(conp_fix *f, int narg, const char *const *arg, int *co
 
 int conp_fix_post_force(conp_fix *f, const conp_atoms *at, double *fo, double *ek, double *ec, double *vir) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "post_force before setup");
   f->post_force(at, fo, ek, ec, vir);
   CONP_GUARD_END
@@ -1101,12 +1171,14 @@ int conp_fix_post_force(conp_fix *f, const conp_atoms *at, double *fo, double *e
 
 int conp_fix_a_cal(conp_fix *f, const conp_atoms *at) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->a_cal(at);
   CONP_GUARD_END
 }
 
 int conp_fix_b_cal(conp_fix *f, const conp_atoms *at) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->b_cal(at);
   f->sync();
   CONP_GUARD_END
@@ -1114,24 +1186,28 @@ int conp_fix_b_cal(conp_fix *f, const conp_atoms *at) {
 
 int conp_fix_equation_solve(conp_fix *f) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->equation_solve();
   CONP_GUARD_END
 }
 
 int conp_fix_update_charge(conp_fix *f, const conp_atoms *at, double potdiff) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->update_charge(at, potdiff);
   CONP_GUARD_END
 }
 
 int conp_km_conp_setup(conp_fix *f, double qsqsum, int64_t natoms) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->km_conp_setup(qsqsum, natoms);
   CONP_GUARD_END
 }
 
 int conp_km_a_cal(conp_fix *f, const conp_atoms *at, double *aaa) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   const int ne = f->idx.elenum_all;
   f->km_a_read(at);
   f->km_a_cal_device();
@@ -1145,6 +1221,7 @@ int conp_km_a_cal(conp_fix *f, const conp_atoms *at, double *aaa) {
 
 int conp_km_b_cal(conp_fix *f, const conp_atoms *at, double *bbb) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   if (f->d_Rp.n == 0) f->km_a_read(at);
   if (at->nlocal + at->nghost != f->nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
   f->upload_xq(at);
@@ -1196,6 +1273,7 @@ int conp_fix_get_maps(const conp_fix *f, int *ele2tag, int *ele2eleall, int *ele
 
 int conp_fix_get_matrix(conp_fix *f, double *aaa) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   const size_t ne = f->idx.elenum_all;
   HIP_TRY(hipMemcpyAsync(aaa, f->d_A.p, ne * ne * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();
@@ -1204,6 +1282,7 @@ int conp_fix_get_matrix(conp_fix *f, double *aaa) {
 
 int conp_fix_set_matrix(conp_fix *f, const double *aaa, int runstage) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   const size_t ne = f->idx.elenum_all;
   f->d_A.reserve(ne * ne);
   HIP_TRY(hipMemcpyAsync(f->d_A.p, aaa, ne * ne * sizeof(double), hipMemcpyHostToDevice, f->stream));
@@ -1214,6 +1293,7 @@ int conp_fix_set_matrix(conp_fix *f, const double *aaa, int runstage) {
 
 int conp_fix_get_vectors(conp_fix *f, double *bbb_all, double *eleallq, double *elesetq) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   const size_t nb = f->idx.elenum_all * sizeof(double);
   if (bbb_all) HIP_TRY(hipMemcpyAsync(bbb_all, f->d_b, nb, hipMemcpyDeviceToHost, f->stream));
   if (eleallq) HIP_TRY(hipMemcpyAsync(eleallq, f->d_eleallq, nb, hipMemcpyDeviceToHost, f->stream));
@@ -1224,6 +1304,7 @@ int conp_fix_get_vectors(conp_fix *f, double *bbb_all, double *eleallq, double *
 
 int conp_fix_get_sfac(conp_fix *f, double *sr, double *si) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   const int K = f->kt.kcount;
   f->d_sfr.reserve(K); f->d_sfi.reserve(K);
   launch_sfac_gather(f->stream, K, f->plan.C_pad, KPlan::PT, f->d_sf_row_a.p, f->d_sf_col_c.p, f->d_k_sign.p, f->d_G.p,
@@ -1236,6 +1317,7 @@ int conp_fix_get_sfac(conp_fix *f, double *sr, double *si) {
 
 int conp_fix_get_ele_trig(conp_fix *f, double *csk, double *snk) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   if (f->csk_h.empty()) throw ConpError(CONP_ERR_STATE, "electrode tables not built (a_cal / a_read first)");
   std::memcpy(csk, f->csk_h.data(), f->csk_h.size() * sizeof(double));
   std::memcpy(snk, f->snk_h.data(), f->snk_h.size() * sizeof(double));
@@ -1245,6 +1327,7 @@ int conp_fix_get_ele_trig(conp_fix *f, double *csk, double *snk) {
 int conp_inv_project(conp_fix *f, int n, double *aaa, int nullneutral, int zneutr, const double *eleallz, double zhalf,
                      double *totinve_out) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   DevBuf<double> dA;
   dA.upload(aaa, (size_t)n * n, f->stream);
   const int save_nn = f->args.nullneutral, save_zn = f->args.zneutr;
@@ -1260,6 +1343,7 @@ int conp_inv_project(conp_fix *f, int n, double *aaa, int nullneutral, int zneut
 
 int conp_fix_write_matrix_file(conp_fix *f, const char *path, int which) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   if (f->runstage < 1) throw ConpError(CONP_ERR_STATE, "no matrix yet");
   f->write_matrix_file(path, which);
   CONP_GUARD_END
@@ -1267,6 +1351,7 @@ int conp_fix_write_matrix_file(conp_fix *f, const char *path, int which) {
 
 int conp_fix_read_matrix_file(conp_fix *f, const conp_atoms *at, const char *path) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   if (!f->idx.initialised || f->idx.elenum_all == 0) throw ConpError(CONP_ERR_STATE, "read_matrix_file before setup_post_neighbor");
   if (f->args.a_matrix_f == 0) f->args.a_matrix_f = 1;
   f->a_read_file(at, path);
@@ -1275,6 +1360,7 @@ int conp_fix_read_matrix_file(conp_fix *f, const conp_atoms *at, const char *pat
 
 int conp_invert(conp_fix *f, int n, double *aaa) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   DevBuf<double> dA;
   dA.upload(aaa, (size_t)n * n, f->stream);
   f->invert_device(n, dA.p);
@@ -1348,6 +1434,7 @@ int64_t conp_host_pair_rows(int which, const conp_neighlist *l, const conp_atoms
 
 int conp_fix_set_stream(conp_fix *f, void *s) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->sync();
   if (f->own_stream && f->stream) { (void)hipStreamDestroy(f->stream); f->own_stream = false; }
   f->stream = static_cast<hipStream_t>(s);
@@ -1356,6 +1443,7 @@ int conp_fix_set_stream(conp_fix *f, void *s) {
 
 int conp_fix_bind_device_buffers(conp_fix *f, double *d_b, double *d_q) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->sync();
   const size_t nb = f->idx.elenum_all * sizeof(double);
   if (d_b) { if (f->d_b && nb) HIP_TRY(hipMemcpy(d_b, f->d_b, nb, hipMemcpyDeviceToDevice)); f->d_b = d_b; }
@@ -1371,6 +1459,7 @@ int conp_fix_row_range(const conp_fix *f, int *r0, int *r1) {
 
 int conp_fix_b_cal_device(conp_fix *f, const double *dx, const double *dq) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "b_cal_device before setup");
   f->b_cal_device(dx, dq, true);
   CONP_GUARD_END
@@ -1378,6 +1467,7 @@ int conp_fix_b_cal_device(conp_fix *f, const double *dx, const double *dq) {
 
 int conp_fix_solve_device(conp_fix *f, double potdiff) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   (void)potdiff;
   f->solve_device();
   CONP_GUARD_END
@@ -1385,6 +1475,7 @@ int conp_fix_solve_device(conp_fix *f, double potdiff) {
 
 int conp_fix_scatter_device(conp_fix *f, double *d_q_atoms, double potdiff) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->scatter_device(d_q_atoms, potdiff);
   CONP_GUARD_END
 }
@@ -1392,9 +1483,7 @@ int conp_fix_scatter_device(conp_fix *f, double *d_q_atoms, double potdiff) {
 int conp_fix_pre_force_device(conp_fix *f, const double *dx, double *dq, double potdiff) {
   CONP_GUARD_BEGIN
   if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "pre_force_device before setup");
-  f->b_cal_device(dx, dq, true);
-  f->solve_device();
-  f->scatter_device(dq, potdiff);
+  f->update_device(dx, dq, potdiff);
   CONP_GUARD_END
 }
 
@@ -1421,6 +1510,7 @@ const char *conp_fix_log_drain(conp_fix *f) {
 
 int conp_fix_profile(conp_fix *f, int enable) {
   CONP_GUARD_BEGIN
+  f->drop_graph();
   f->sync();
   f->prof.reset();
   f->prof.on = enable != 0;

@@ -17,3 +17,17 @@ def pytest_configure(config):
 def oracle():
     import oracle_py
     return oracle_py.load()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_owns_the_gpu_first():
+    """A few -m gpu tests keep tensors on the device with torch in the same process as libconp_hip.so.  torch's bundled
+    HIP runtime only finds the GPU if it initialises BEFORE the library's first HIP call (bench.py and smoke() have that
+    order anyway), so do it once up front.  On the CPU box this is a no-op."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield

@@ -300,6 +300,46 @@ def test_pre_force_respects_nevery_and_reneighbor(oracle):
     fx.close(); o.fx.close()
 
 
+def test_device_update_graph_replay_matches_direct_launches():
+    """with CONP_GRAPH=1 conp_fix_pre_force_device replays the update as a HIP graph from its second call on: same charges as
+    the host-buffer path (direct launches) for moving atoms, a changed potential difference and across a re-neighbour"""
+    import os
+    import torch
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
+    at, alist, blist = neighbor.build_lists(s)
+    os.environ["CONP_GRAPH"] = "1"                     # read when the handle is created
+    try:
+        fx = FixConp(s)
+    finally:
+        del os.environ["CONP_GRAPH"]
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    ref = FixConp(s)                                   # second handle: host-buffer hooks only (never captured)
+    ref.init_lists(alist, blist)
+    ref.setup_post_neighbor(at)
+    ref.setup_pre_force(at, 0, s.potdiff)
+    rng = np.random.default_rng(5)
+    sol = at.echeck == 0
+    ele = at.echeck != 0
+    d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda()
+    d_q = torch.from_numpy(at.q.copy()).cuda()
+    dv = s.potdiff
+    for step in range(1, 9):
+        if step == 5:
+            dv = 0.5 * s.potdiff                       # new potential difference: the graph is re-captured
+        if step == 7:
+            fx.post_neighbor(at); ref.post_neighbor(at)    # any other ABI call drops the graph
+        at.x[sol] += rng.normal(scale=0.02, size=(int(sol.sum()), 3))      # well inside the skin
+        d_x.copy_(torch.from_numpy(np.ascontiguousarray(at.x)))
+        fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), dv)
+        torch.cuda.synchronize()
+        q_dev = d_q.cpu().numpy()
+        ref.pre_force(at, step, dv)
+        assert np.array_equal(q_dev[ele], at.q[ele]), step      # same kernels, same order -> bitwise equal
+    fx.close(); ref.close()
+
+
 def _gpu_shard_worker(rank, world, port, out):
     import os, sys
     import torch
