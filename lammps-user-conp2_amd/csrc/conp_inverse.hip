@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "conp_kernels.h"
 
@@ -105,6 +106,130 @@ __global__ __launch_bounds__(1024) void inv_panel_lu_kernel(int m, int k0, int n
       }
     }
     __syncthreads();
+  }
+}
+
+// ---- 1c. the same panel factorisation spread over many workgroups (cooperative launch) ---------------------------
+// The single-workgroup panel above is bound by what one CU can stream (3.9 ms per 4096-row panel, 15.7 ms per 16384-row
+// panel: 57 % of the inverse at Ne = 4096, 80 % at 16384).  Here workgroup w keeps panel rows [w rpw, (w+1) rpw) in LDS for
+// the whole panel and the workgroups meet ONCE per column:
+//   before the barrier  every workgroup publishes its pivot candidate for column j (|value|, row index, the 64-wide row);
+//                       the owner of row j publishes row j
+//   after the barrier   every workgroup picks the same winner (largest |value|, lowest row index on ties = LAPACK idamax),
+//                       reads the winner's row, the owners of rows j / p exchange them in LDS, everybody eliminates
+// Slots are double-buffered by column parity (a workgroup can be at most one barrier ahead).  Only the pivots and the top
+// 64 x 64 block (L11, U11) leave the kernel -- nothing downstream reads L21.  The barrier is a monotonic agent-scope counter;
+// the spin is bounded so that every wave terminates even if a workgroup were not resident (info = -7).
+constexpr int PC_MAXG = 256;
+constexpr int PC_LD = INV_NB + 1;
+
+__device__ __forceinline__ bool pc_better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int nbw, int rpw, const double *__restrict__ M,
+                                                             double *__restrict__ P, int *__restrict__ piv, int *__restrict__ info,
+                                                             double *__restrict__ cval, int *__restrict__ cidx,
+                                                             double *__restrict__ crow, double *__restrict__ rowj,
+                                                             unsigned *__restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *rows = reinterpret_cast<double *>(smem);          // [rpw][PC_LD]
+  double *s_row = rows + (size_t)rpw * PC_LD;               // [64]
+  double *s_rv = s_row + INV_NB;                            // [4]
+  int *s_ri = reinterpret_cast<int *>(s_rv + 4);            // [4] candidate row, [4] candidate workgroup
+  __shared__ int s_p, s_win, s_abort;
+  __shared__ double s_best;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = n - k0, G = gridDim.x, wg = blockIdx.x;
+  const int r0 = wg * rpw;
+  const int nr = (m - r0 < rpw) ? m - r0 : rpw;
+  if (t == 0) s_abort = 0;
+  for (int e = t; e < nr * INV_NB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    rows[r * PC_LD + c] = (c < nbw) ? M[(size_t)(k0 + r0 + r) * n + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < nbw; ++j) {
+    const int par = j & 1;
+    if (wave == 0) {                       // this workgroup's candidate: first largest |rows[.][j]| among rows r0 + r >= j
+      double best = -1.0;
+      int bi = 0x7fffffff;
+      for (int r = lane; r < nr; r += 64)
+        if (r0 + r >= j) {
+          const double v = fabs(rows[r * PC_LD + j]);
+          if (pc_better(v, r0 + r, best, bi)) { best = v; bi = r0 + r; }
+        }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (pc_better(ov, oi, best, bi)) { best = ov; bi = oi; }
+      }
+      best = __shfl(best, 0, 64); bi = __shfl(bi, 0, 64);
+      if (lane == 0) { cval[par * PC_MAXG + wg] = best; cidx[par * PC_MAXG + wg] = bi; }
+      if (best >= 0.0) crow[((size_t)par * PC_MAXG + wg) * INV_NB + lane] = rows[(bi - r0) * PC_LD + lane];
+    } else if (wave == 1 && j >= r0 && j < r0 + nr) {
+      rowj[par * INV_NB + lane] = rows[(j - r0) * PC_LD + lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the published slots leave this XCD's L2 before the arrival count
+    __syncthreads();
+    if (t == 0) {                          // grid barrier #(j+1)
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)G * (unsigned)(j + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > (1u << 22)) { s_abort = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (s_abort) { if (t == 0) *info = -7; return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the same winner in every workgroup
+    double v = -2.0;
+    int vi = 0x7fffffff, vw = 0;
+    if (t < G) { v = cval[par * PC_MAXG + t]; vi = cidx[par * PC_MAXG + t]; vw = t; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_down(v, off, 64);
+      const int oi = __shfl_down(vi, off, 64), ow = __shfl_down(vw, off, 64);
+      if (pc_better(ov, oi, v, vi)) { v = ov; vi = oi; vw = ow; }
+    }
+    if (lane == 0) { s_rv[wave] = v; s_ri[wave] = vi; s_ri[4 + wave] = vw; }
+    __syncthreads();
+    if (t == 0) {
+      double b = s_rv[0];
+      int pi = s_ri[0], pw = s_ri[4];
+      for (int w = 1; w < 4; ++w)
+        if (pc_better(s_rv[w], s_ri[w], b, pi)) { b = s_rv[w]; pi = s_ri[w]; pw = s_ri[4 + w]; }
+      s_best = b; s_p = pi; s_win = pw;
+      if (wg == 0) {
+        piv[j] = k0 + pi;
+        if (!(b > 0.0)) *info = k0 + j + 1;
+      }
+    }
+    __syncthreads();
+    const int p = s_p;
+    if (wave == 0) s_row[lane] = crow[((size_t)par * PC_MAXG + s_win) * INV_NB + lane];
+    __syncthreads();
+    if (p != j) {                          // rows j and p change places
+      if (wave == 1 && p >= r0 && p < r0 + nr) rows[(p - r0) * PC_LD + lane] = rowj[par * INV_NB + lane];
+      if (wave == 2 && j >= r0 && j < r0 + nr) rows[(j - r0) * PC_LD + lane] = s_row[lane];
+    }
+    __syncthreads();
+    const double dinv = 1.0 / s_row[j];
+    for (int r = wave; r < nr; r += 4) {
+      if (r0 + r <= j) continue;
+      double *row = rows + r * PC_LD;
+      const double l = row[j] * dinv;
+      const double cur = row[lane];
+      if (lane > j && lane < nbw) row[lane] = cur - l * s_row[lane];
+      if (lane == j) row[j] = l;
+    }
+    __syncthreads();
+  }
+  // the factored top block (rows < 64 of the panel) for inv_block_kernel
+  for (int e = t; e < nr * INV_NB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if (r0 + r < INV_NB) P[(size_t)(r0 + r) * INV_NB + c] = rows[r * PC_LD + c];
   }
 }
 
@@ -267,7 +392,9 @@ __global__ void inv_col_swaps_kernel(int n, const int *__restrict__ piv_all, dou
 // workspace: P (n*64) + Wb (64*ld) + Cct (64*ld) + Dinv (64*64) doubles; piv (n) + info (1) ints
 size_t inverse_workspace_doubles(int n) {
   const size_t ld = ((size_t)n + 127) / 128 * 128;
-  return (size_t)n * INV_NB + 2 * INV_NB * ld + INV_NB * INV_NB;
+  // + the cooperative panel's exchange slots: cval[2][G], crow[2][G][64], rowj[2][64] (doubles), cidx[2][G] + counters (as doubles' worth)
+  const size_t coop = 2 * PC_MAXG + 2 * (size_t)PC_MAXG * INV_NB + 2 * INV_NB + PC_MAXG + ((size_t)n / INV_NB + 2);
+  return (size_t)n * INV_NB + 2 * INV_NB * ld + INV_NB * INV_NB + coop;
 }
 
 void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/) {
@@ -276,12 +403,54 @@ void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
   double *Wb = P + (size_t)n * INV_NB;
   double *Cct = Wb + (size_t)INV_NB * ld;
   double *Dinv = Cct + (size_t)INV_NB * ld;
+  double *cval = Dinv + (size_t)INV_NB * INV_NB;
+  double *crow = cval + 2 * PC_MAXG;
+  double *rowj = crow + 2 * (size_t)PC_MAXG * INV_NB;
+  int *cidx = reinterpret_cast<int *>(rowj + 2 * INV_NB);            // 2 * PC_MAXG ints
+  unsigned *counters = reinterpret_cast<unsigned *>(cidx + 2 * PC_MAXG);   // one per panel
+  const int npanels = (n + INV_NB - 1) / INV_NB;
   (void)hipMemsetAsync(info, 0, sizeof(int), s);
+  (void)hipMemsetAsync(counters, 0, (size_t)npanels * sizeof(unsigned), s);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 1;
+  }
+  // test / fallback switches, read per call: CONP_PANEL_SINGLE = old one-workgroup panel, CONP_PANEL_MAXG = cap on workgroups
+  bool coop = getenv("CONP_PANEL_SINGLE") == nullptr;
+  const int maxg_env = getenv("CONP_PANEL_MAXG") ? atoi(getenv("CONP_PANEL_MAXG")) : PC_MAXG;
   for (int k0 = 0; k0 < n; k0 += INV_NB) {
     const int nbw = (n - k0 < INV_NB) ? n - k0 : INV_NB;
-    const size_t tot = (size_t)(n - k0) * INV_NB;
-    hipLaunchKernelGGL(inv_panel_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, k0, nbw, M, P);
-    hipLaunchKernelGGL(inv_panel_lu_kernel, dim3(1), dim3(1024), 0, s, n - k0, k0, nbw, P, piv_all + k0, info);
+    const int m = n - k0;
+    if (coop) {
+      int maxg = ncu < PC_MAXG ? ncu : PC_MAXG;
+      if (maxg_env >= 1 && maxg_env < maxg) maxg = maxg_env;
+      int rpw = (m + maxg - 1) / maxg;
+      rpw = rpw < 64 ? 64 : (rpw + 15) / 16 * 16;
+      const int G = (m + rpw - 1) / rpw;
+      const size_t lds = ((size_t)rpw * PC_LD + INV_NB + 4) * sizeof(double) + 8 * sizeof(int);
+      if (lds > 150 * 1024) coop = false;
+      else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_panel_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int a_n = n, a_k0 = k0, a_nbw = nbw, a_rpw = rpw;
+        const double *a_M = M;
+        double *a_P = P;
+        int *a_piv = piv_all + k0, *a_info = info;
+        unsigned *a_cnt = counters + k0 / INV_NB;
+        void *kargs[] = {&a_n, &a_k0, &a_nbw, &a_rpw, &a_M, &a_P, &a_piv, &a_info, &cval, &cidx, &crow, &rowj, &a_cnt};
+        if (hipLaunchCooperativeKernel(reinterpret_cast<const void *>(inv_panel_coop_kernel), dim3(G), dim3(256), kargs, lds, s) !=
+            hipSuccess) {
+          (void)hipGetLastError();
+          coop = false;          // not co-resident / not supported: the single-workgroup panel below
+        }
+      }
+    }
+    if (!coop) {
+      const size_t tot = (size_t)m * INV_NB;
+      hipLaunchKernelGGL(inv_panel_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, k0, nbw, M, P);
+      hipLaunchKernelGGL(inv_panel_lu_kernel, dim3(1), dim3(1024), 0, s, m, k0, nbw, P, piv_all + k0, info);
+    }
     hipLaunchKernelGGL(inv_row_swaps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, k0, nbw, piv_all + k0, M);
     hipLaunchKernelGGL(inv_block_kernel, dim3(1), dim3(256), 0, s, nbw, P, Dinv);
     hipLaunchKernelGGL(inv_prep_kernel, dim3(ld / 256 + 1), dim3(256), 0, s, n, ld, k0, nbw, M, Dinv, Wb, Cct);

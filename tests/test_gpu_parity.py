@@ -177,6 +177,23 @@ def test_inverse_matches_numpy():
         ref = np.linalg.inv(a)
         assert np.abs(inv - ref).max() / np.abs(ref).max() < 1e-9 * max(1.0, np.linalg.cond(a) / 1e4), n
         assert np.abs(inv @ a - np.eye(n)).max() < 1e-8 * max(1.0, np.linalg.cond(a) / 1e4), n
+    # the panel factorisation runs on many cooperating workgroups: more rows than one workgroup holds, more than 64 rows per
+    # workgroup (forced by capping the workgroup count), and the single-workgroup fallback -- same pivots, same inverse
+    import os
+    a = rng.normal(size=(2500, 2500))
+    ref = np.linalg.inv(a)
+    results = []
+    for env in ({}, {"CONP_PANEL_MAXG": "5"}, {"CONP_PANEL_SINGLE": "1"}):
+        os.environ.update(env)
+        try:
+            inv = fx.invert(a)
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert np.abs(inv - ref).max() / np.abs(ref).max() < 1e-9 * max(1.0, np.linalg.cond(a) / 1e4), env
+        results.append(inv)
+    assert np.abs(results[0] - results[1]).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(results[0] - results[2]).max() <= 1e-12 * np.abs(ref).max()
     m = rng.normal(size=(300, 300)); spd = m @ m.T / 300 + np.eye(300)
     inv = fx.invert(spd)
     assert np.abs(inv - np.linalg.inv(spd)).max() / np.abs(inv).max() < 1e-12
