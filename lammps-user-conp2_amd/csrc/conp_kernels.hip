@@ -863,7 +863,7 @@ void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v
 //    (4 x 4 fragments); operands are formed in registers: A = w * Rp_i * Tz_i, B = Rp_j * Tz_j.
 //    Only tiles with (row block >= col block) run; the strict upper triangle is left for a_symmetrise.
 // ================================================================================================
-__global__ __launch_bounds__(256, 1) void a_kspace_kernel(int R_pad, int C_pad, int ne, int ne_pad,
+__global__ __launch_bounds__(256, 2) void a_kspace_kernel(int R_pad, int C_pad, int ne, int ne_pad,
                                                           const int *__restrict__ nb_act, const double *__restrict__ wfull, const double *__restrict__ Rp,
                                                           const double *__restrict__ Tz, double *__restrict__ A) {
   // triangular tile index -> (bi >= bj)
@@ -916,10 +916,95 @@ __global__ __launch_bounds__(256, 1) void a_kspace_kernel(int R_pad, int C_pad, 
       }
 }
 
+// Same contraction with the Tz operand staged through LDS.  The kernel above re-reads 8 Tz values per lane and k-step from
+// L2 (the tile's Tz slab, 320 x 256 doubles, does not fit in LDS and is walked once per G row): 9 global loads per 16
+// MFMAs, MFMA pipe 49 % busy.  Here the (r, t) loop nest is turned inside out: a 32-t chunk of Tz (= one 16-kz block = 8
+// k-steps) for the tile's 128 + 128 atoms stays in LDS while r runs over every G row whose sphere cut reaches that block
+// (row tiles are rings sorted by |k_p|: in practice a prefix of the rows); per r: 8 Rp + 8 w global loads for
+// 128 MFMAs.  LDS row stride 272 doubles: the two t rows a half-wave reads land in disjoint bank halves.
+constexpr int AK_TC = 32;          // t rows per chunk
+constexpr int AK_LD = 272;         // 256 atoms + 16 pad
+__global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_pad, int ne, int ne_pad, int n_row_tiles,
+                                                              const int *__restrict__ nb_act, const double *__restrict__ wfull,
+                                                              const double *__restrict__ Rp, const double *__restrict__ Tz,
+                                                              double *__restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) char ak_smem[];
+  double *L = reinterpret_cast<double *>(ak_smem);      // [AK_TC][AK_LD]
+  int tidx = blockIdx.x, bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= tidx) ++bi;
+  const int bj = tidx - bi * (bi + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int ibase = bi * 128 + wi * 64 + fr, jbase = bj * 128 + wj * 64 + fr;
+  const bool idle = (bi == bj && wj > wi);       // wave tile strictly above the diagonal: helps with the staging only
+  d4 acc[4][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
+  int nchunk = 0;
+  for (int rt = 0; rt < n_row_tiles; ++rt) nchunk = nb_act[rt] > nchunk ? nb_act[rt] : nchunk;
+  const double *li = L + fk * AK_LD + wi * 64 + fr, *lj = L + fk * AK_LD + 128 + wj * 64 + fr;
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < AK_TC * 256; e += 256) {
+      const int t = e >> 8, a = e & 255;
+      const int atom = (a < 128) ? bi * 128 + a : bj * 128 + (a - 128);
+      L[t * AK_LD + a] = Tz[(size_t)(AK_TC * c + t) * ne_pad + atom];
+    }
+    __syncthreads();
+    if (idle) continue;
+    for (int r = 0; r < R_pad; ++r) {
+      if (nb_act[r >> 7] <= c) { r |= 127; continue; }      // this row tile's sphere cut ends before kz block c
+      double ri[4], rj[4], ww[8];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        ri[f] = Rp[(size_t)r * ne_pad + ibase + 16 * f];
+        rj[f] = Rp[(size_t)r * ne_pad + jbase + 16 * f];
+      }
+      const double *wrow = wfull + (size_t)r * C_pad + AK_TC * c + fk;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) ww[ks] = wrow[4 * ks];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          af[f] = ww[ks] * ri[f] * li[(4 * ks) * AK_LD + 16 * f];
+          bf[f] = rj[f] * lj[(4 * ks) * AK_LD + 16 * f];
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+      }
+    }
+  }
+  if (idle) return;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = bi * 128 + wi * 64 + 16 * f + fk + 4 * r;
+        const int j = bj * 128 + wj * 64 + 16 * g + fr;
+        if (i < ne && j < i) A[(size_t)i * ne + j] = acc[f][g][r];
+      }
+}
+
 void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A) {
   const int nb = ne_pad / 128;
   const int ntiles = nb * (nb + 1) / 2;
-  hipLaunchKernelGGL(a_kspace_kernel, dim3(ntiles), dim3(256), 0, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.nb_act, pl.wfull, Rp, Tz, A);
+  if (getenv("CONP_A_OLD"))
+    hipLaunchKernelGGL(a_kspace_kernel, dim3(ntiles), dim3(256), 0, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.nb_act, pl.wfull, Rp, Tz, A);
+  else {
+    const size_t lds = (size_t)AK_TC * AK_LD * sizeof(double);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(a_kspace_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(a_kspace_lds_kernel, dim3(ntiles), dim3(256), lds, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.n_row_tiles, pl.nb_act,
+                       pl.wfull, Rp, Tz, A);
+  }
 }
 
 // diagonal ug_tot - 2g/sqrt(pi) + sqrt(2) eta/sqrt(pi) (km_ewald.cpp:631-634, fix_conp.cpp:796-801) and the slab
