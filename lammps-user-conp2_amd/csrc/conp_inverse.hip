@@ -291,28 +291,43 @@ __global__ __launch_bounds__(256) void inv_block_kernel(int nbw, const double *_
 }
 
 // ---- 4. Wb[k][j] = sum_l Dinv[k][l] M[k0+l][j] (0 for j in K);  Cct[k][i] = M[i][k0+k] (0 for i in K) --------------
+// One workgroup per 64 columns j; thread (jl, kg) forms 16 of the 64 k outputs of its column from an LDS copy of the
+// 64 x 64 slab of M; the transposed copy Cct goes through LDS so that reads (along k) and writes (along i) both coalesce.
 __global__ __launch_bounds__(256) void inv_prep_kernel(int n, int ld, int k0, int nbw, const double *__restrict__ M,
                                                        const double *__restrict__ Dinv, double *__restrict__ Wb,
                                                        double *__restrict__ Cct) {
-  __shared__ double D[INV_NB][INV_NB + 1];
-  for (int e = threadIdx.x; e < INV_NB * INV_NB; e += 256) D[e / INV_NB][e % INV_NB] = Dinv[e];
+  extern __shared__ __attribute__((aligned(16))) char inv_smem[];
+  double (*D)[INV_NB + 1] = reinterpret_cast<double (*)[INV_NB + 1]>(inv_smem);
+  double (*Cc)[INV_NB + 1] = D + INV_NB;
+  const int t = threadIdx.x, jl = t & 63, kg = t >> 6;
+  const int j0 = blockIdx.x * INV_NB;
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {
+    const int l = e >> 6, c = e & 63, j = j0 + c;
+    D[l][c] = Dinv[e];
+    const bool use = l < nbw && j < n && !(j >= k0 && j < k0 + nbw);
+    Cc[l][c] = use ? M[(size_t)(k0 + l) * n + j] : 0.0;
+  }
   __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;   // column for Wb, row for Cct
-  if (j >= ld) return;
-  const bool inK = j >= k0 && j < k0 + nbw;
-  double col[INV_NB];
-  if (j < n && !inK) {
-#pragma unroll 8
-    for (int l = 0; l < INV_NB; ++l) col[l] = (l < nbw) ? M[(size_t)(k0 + l) * n + j] : 0.0;
-    for (int k = 0; k < INV_NB; ++k) {
+  if (j0 + jl < ld) {
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = kg * 16 + kk;
       double s = 0.0;
-#pragma unroll 8
-      for (int l = 0; l < INV_NB; ++l) s += D[k][l] * col[l];
-      Wb[(size_t)k * ld + j] = s;
+#pragma unroll 16
+      for (int l = 0; l < INV_NB; ++l) s += D[k][l] * Cc[l][jl];
+      Wb[(size_t)k * ld + j0 + jl] = s;
     }
-    for (int k = 0; k < INV_NB; ++k) Cct[(size_t)k * ld + j] = (k < nbw) ? M[(size_t)j * n + k0 + k] : 0.0;
-  } else {
-    for (int k = 0; k < INV_NB; ++k) { Wb[(size_t)k * ld + j] = 0.0; Cct[(size_t)k * ld + j] = 0.0; }
+  }
+  __syncthreads();
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {       // rows i = j0 + r of M, columns K, read along k
+    const int r = e >> 6, k = e & 63, i = j0 + r;
+    const bool use = k < nbw && i < n && !(i >= k0 && i < k0 + nbw);
+    Cc[k][r] = use ? M[(size_t)i * n + k0 + k] : 0.0;
+  }
+  __syncthreads();
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {
+    const int k = e >> 6, r = e & 63;
+    if (j0 + r < ld) Cct[(size_t)k * ld + j0 + r] = Cc[k][r];
   }
 }
 
@@ -351,30 +366,42 @@ __global__ __launch_bounds__(256, 1) void inv_update_kernel(int n, int ld, const
 }
 
 // ---- 6. fix-up of the K rows / K columns ------------------------------------------------------------------------
+// One workgroup per 64 indices j.  M[j,K] = -C[j,:] Dinv (j not in K) is formed by thread (jl, kg) for 16 of the 64 k and
+// written row-wise through LDS;  M[K,j] = Wb[:,j] (j not in K), M[K,K] = Dinv.
 __global__ __launch_bounds__(256) void inv_fixup_kernel(int n, int ld, int k0, int nbw, const double *__restrict__ Dinv,
                                                         const double *__restrict__ Wb, const double *__restrict__ Cct,
                                                         double *__restrict__ M) {
-  __shared__ double D[INV_NB][INV_NB + 1];
-  for (int e = threadIdx.x; e < INV_NB * INV_NB; e += 256) D[e / INV_NB][e % INV_NB] = Dinv[e];
+  extern __shared__ __attribute__((aligned(16))) char inv_smem[];
+  double (*D)[INV_NB + 1] = reinterpret_cast<double (*)[INV_NB + 1]>(inv_smem);
+  double (*Cc)[INV_NB + 1] = D + INV_NB;
+  double (*Out)[INV_NB + 1] = Cc + INV_NB;
+  const int t = threadIdx.x, jl = t & 63, kg = t >> 6;
+  const int j0 = blockIdx.x * INV_NB;
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {
+    const int l = e >> 6, c = e & 63;
+    D[l][c] = Dinv[e];
+    Cc[l][c] = (j0 + c < ld) ? Cct[(size_t)l * ld + j0 + c] : 0.0;
+  }
   __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const bool inK = j >= k0 && j < k0 + nbw;
-  if (!inK) {
-    // row j, columns K:  -C[j,:] * Dinv ;  rows K, column j: Wb[:, j]
-    double c[INV_NB];
-#pragma unroll 8
-    for (int l = 0; l < INV_NB; ++l) c[l] = Cct[(size_t)l * ld + j];
-    for (int k = 0; k < nbw; ++k) {
-      double s = 0.0;
-#pragma unroll 8
-      for (int l = 0; l < INV_NB; ++l) s += c[l] * D[l][k];
-      M[(size_t)j * n + k0 + k] = -s;
+#pragma unroll 4
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = kg * 16 + kk;
+    double s = 0.0;
+#pragma unroll 16
+    for (int l = 0; l < INV_NB; ++l) s += Cc[l][jl] * D[l][k];
+    Out[jl][k] = -s;
+  }
+  __syncthreads();
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {
+    const int r = e >> 6, k = e & 63, j = j0 + r;        // row j of M, columns K
+    if (j < n && k < nbw && !(j >= k0 && j < k0 + nbw)) M[(size_t)j * n + k0 + k] = Out[r][k];
+  }
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {
+    const int k = e >> 6, c = e & 63, j = j0 + c;        // rows K of M, column j
+    if (j < n && k < nbw) {
+      const bool inK = j >= k0 && j < k0 + nbw;
+      M[(size_t)(k0 + k) * n + j] = inK ? D[k][j - k0] : Wb[(size_t)k * ld + j];
     }
-    for (int k = 0; k < nbw; ++k) M[(size_t)(k0 + k) * n + j] = Wb[(size_t)k * ld + j];
-  } else {
-    const int c = j - k0;
-    for (int k = 0; k < nbw; ++k) M[(size_t)(k0 + k) * n + j] = D[k][c];
   }
 }
 
@@ -417,6 +444,9 @@ void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 1;
   }
+  const size_t lds_prep = 2 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double), lds_fix = 3 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fix);
   // test / fallback switches, read per call: CONP_PANEL_SINGLE = old one-workgroup panel, CONP_PANEL_MAXG = cap on workgroups
   bool coop = getenv("CONP_PANEL_SINGLE") == nullptr;
   const int maxg_env = getenv("CONP_PANEL_MAXG") ? atoi(getenv("CONP_PANEL_MAXG")) : PC_MAXG;
@@ -453,9 +483,9 @@ void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
     }
     hipLaunchKernelGGL(inv_row_swaps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, k0, nbw, piv_all + k0, M);
     hipLaunchKernelGGL(inv_block_kernel, dim3(1), dim3(256), 0, s, nbw, P, Dinv);
-    hipLaunchKernelGGL(inv_prep_kernel, dim3(ld / 256 + 1), dim3(256), 0, s, n, ld, k0, nbw, M, Dinv, Wb, Cct);
+    hipLaunchKernelGGL(inv_prep_kernel, dim3(ld / INV_NB), dim3(256), lds_prep, s, n, ld, k0, nbw, M, Dinv, Wb, Cct);
     hipLaunchKernelGGL(inv_update_kernel, dim3(ld / 128, ld / 128), dim3(256), 0, s, n, ld, Cct, Wb, M);
-    hipLaunchKernelGGL(inv_fixup_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, ld, k0, nbw, Dinv, Wb, Cct, M);
+    hipLaunchKernelGGL(inv_fixup_kernel, dim3((n + INV_NB - 1) / INV_NB), dim3(256), lds_fix, s, n, ld, k0, nbw, Dinv, Wb, Cct, M);
   }
   hipLaunchKernelGGL(inv_col_swaps_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, piv_all, M);
 }
