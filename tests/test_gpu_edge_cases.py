@@ -1,0 +1,101 @@
+"""-m gpu: ragged and degenerate inputs of the charge update, each against the CPU oracle through the C ABI.
+
+The reference has no special cases for these -- its loops simply run zero or few times (km_ewald.cpp:686 filters the
+electrolyte by `electrode_check == 0 && q != 0`, fix_conp.cpp:1326-1334 filters pairs) -- so the library must not have any
+either: no electrolyte at all, fewer charged atoms than one 16-atom MFMA chunk, electrolyte atoms that are all neutral,
+electrode sizes that are not multiples of any tile, and one group serving as both electrodes (fix_conp.cpp:295)."""
+import numpy as np
+import pytest
+
+from conp_amd import FixConp, neighbor, systems
+from helpers import OracleRun, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _trim_electrolyte(s, keep_charged):
+    """keep only the first `keep_charged` charged non-electrode atoms (and every electrode atom)"""
+    sol = np.nonzero((s.echeck == 0) & (s.q != 0))[0]
+    drop = np.zeros(len(s.q), dtype=bool)
+    drop[sol[keep_charged:]] = True
+    drop |= (s.echeck == 0) & (s.q == 0)
+    keep = ~drop
+    s.x, s.q, s.type, s.echeck = s.x[keep].copy(), s.q[keep].copy(), s.type[keep].copy(), s.echeck[keep].copy()
+    s.tag = np.arange(1, keep.sum() + 1, dtype=np.int32)
+    return s
+
+
+def _run_both(oracle, s, **okw):
+    at, alist, blist = neighbor.build_lists(s)
+    o = OracleRun(oracle, s, at, alist, blist, **okw)
+    o.setup()
+    o.pre_force(s.potdiff)
+    fx = FixConp(s, one_electrode=bool(okw.get("one_electrode", False)))
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    return at, o, fx
+
+
+@pytest.mark.parametrize("n_charged", [0, 1, 3, 15, 17])
+def test_few_or_no_electrolyte_charges(oracle, n_charged):
+    s = _trim_electrolyte(systems.small_random(ne_side=4, n_elyte=96, lz=60.0), n_charged)
+    assert int(((s.echeck == 0) & (s.q != 0)).sum()) == n_charged
+    at, o, fx = _run_both(oracle, s)
+    assert fx.info().n_elyte_charged == n_charged
+    b_o, q_o, sq_o = o.fx.vectors()
+    b_g, q_g, sq_g = fx.vectors()
+    scale = max(np.abs(b_o).max(), 1e-300)
+    assert np.abs(b_g - b_o).max() <= 1e-10 * scale + 1e-14
+    if n_charged == 0:
+        assert not b_g.any()                                   # b = 0: the charges are dV * elesetq exactly
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < 1e-8
+    assert fx.compute_scalar() == pytest.approx(o.fx.scalars()["scalar_output"], rel=1e-7, abs=1e-12)
+    fx.close(); o.fx.close()
+
+
+def test_neutral_electrolyte_atoms_are_ignored(oracle):
+    """atoms with q == 0 between the electrodes are not electrolyte (km_ewald.cpp:686) but are in the neighbour lists"""
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
+    sol = np.nonzero(s.echeck == 0)[0]
+    s.q[sol[::2]] = 0.0
+    at, o, fx = _run_both(oracle, s)
+    assert fx.info().n_elyte_charged == int(((s.echeck == 0) & (s.q != 0)).sum())
+    assert rel_err(fx.vectors()[0], o.fx.vectors()[0]) < 1e-10
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < 1e-8
+    fx.close(); o.fx.close()
+
+
+@pytest.mark.parametrize("drop", [1, 7, 29])
+def test_electrode_sizes_off_every_tile_boundary(oracle, drop):
+    """Ne = 64 - 2*drop: not a multiple of 16 / 64 / 128 and, with vacancies, no longer a perfect lattice"""
+    s = systems.small_random(ne_side=4, n_elyte=64, lz=60.0)
+    left = np.nonzero(s.echeck == 1)[0][:drop]
+    right = np.nonzero(s.echeck == -1)[0][-drop:]
+    keep = np.ones(len(s.q), dtype=bool); keep[left] = False; keep[right] = False
+    s.x, s.q, s.type, s.echeck = s.x[keep].copy(), s.q[keep].copy(), s.type[keep].copy(), s.echeck[keep].copy()
+    s.tag = np.arange(1, keep.sum() + 1, dtype=np.int32)
+    at, o, fx = _run_both(oracle, s)
+    assert fx.info().elenum_all == int((s.echeck != 0).sum())
+    assert rel_err(fx.matrix(), o.fx.matrix()) < 1e-8
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < 1e-8
+    assert abs(at.q[:at.nlocal][at.echeck[:at.nlocal] != 0].sum()) < 1e-11
+    fx.close(); o.fx.close()
+
+
+def test_one_group_as_both_electrodes(oracle):
+    """`fix ID g conp 1 g ...`: groupbit == jgroupbit (fix_conp.cpp:295) -- every electrode atom is in group 1, the
+    projection is applied after get_setq instead of after the inverse (:958, :1115)"""
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
+    s.echeck = np.where(s.echeck != 0, 1, 0).astype(np.int32)
+    at, o, fx = _run_both(oracle, s, one_electrode=True)
+    b_o, q_o, sq_o = o.fx.vectors()
+    b_g, q_g, sq_g = fx.vectors()
+    assert rel_err(b_g, b_o) < 1e-10 and rel_err(sq_g, sq_o) < 1e-8
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < 1e-8
+    assert fx.compute_scalar() == pytest.approx(o.fx.scalars()["scalar_output"], rel=1e-7, abs=1e-12)
+    fx.close(); o.fx.close()
