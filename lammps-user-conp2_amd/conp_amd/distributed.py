@@ -19,9 +19,19 @@ def row_range(ne: int, rank: int, world: int):
     return ne * rank // world, ne * (rank + 1) // world
 
 
-def my_row_tiles(n_row_tiles: int, rank: int, world: int):
-    """row tiles (rings of planar k-vectors) are dealt round-robin; must match conp_fix.cpp km_conp_setup"""
-    return list(range(rank, n_row_tiles, world))
+def my_row_tiles(n_row_tiles: int, rank: int, world: int, costs=None):
+    """Row tiles (rings of planar k-vectors) go heaviest first to the least loaded rank (lowest rank on ties) -- the rule of
+    conp_fix.cpp km_conp_setup, where a tile's cost is its number of active kz blocks.  With equal costs (the default here:
+    the CPU model of the exchange only needs SOME disjoint cover, b is a sum over tiles) this is round-robin."""
+    costs = [1] * n_row_tiles if costs is None else list(costs)
+    order = sorted(range(n_row_tiles), key=lambda t: (-costs[t], t))
+    load = [0] * world
+    owner = [0] * n_row_tiles
+    for t in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[t] = r
+        load[r] += costs[t]
+    return [t for t in range(n_row_tiles) if owner[t] == rank]
 
 
 def sharded_update(backend, ne: int, rank: int, world: int, group=None):

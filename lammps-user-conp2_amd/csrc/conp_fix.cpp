@@ -109,7 +109,7 @@ struct conp_fix {
   int row0 = 0, row1 = 0, num_cus = 256;
   std::vector<SkItem> items_h;   // sk_gemm work items of this rank
   std::vector<SkTile> tiles_h;   // (row tile, col tile) pairs of this rank, sorted by col tile
-  std::vector<int> ct_ptr_h, seg_ptr_h;
+  std::vector<int> ct_ptr_h, seg_ptr_h, rt_owner_h, own_rt_h;   // rt_owner_h: rank that owns each row tile; own_rt_h: this rank's
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
   // the fix's log file (fix_conp.cpp:119): lines are buffered here and handed to the host by conp_fix_log_drain
@@ -137,12 +137,13 @@ struct conp_fix {
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_pp_egrid, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_pp_egrid, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   int n_slab_part = 0;
+  int max_nsplit = 0;              // most sk_gemm segments any tile is cut into (chooses sk_reduce's one- or two-level sum)
   DevPlan dplan{};
   Profiler prof;
 
@@ -270,11 +271,37 @@ struct conp_fix {
                     plan.kxmax, plan.kymax, d_p_ikx.p, d_p_iky.p, d_p_sgn.p, d_nb_act.p, d_wfull.p};
     d_G.reserve((size_t)plan.R_pad * plan.C_pad); d_Gw.reserve((size_t)plan.R_pad * plan.C_pad);
     d_G.zero(stream); d_Gw.zero(stream);
-    // k-shard: row tiles are rings of increasing |k_p| with decreasing kz range; dealing them round-robin balances ranks
+    // k-shard: row tiles (rings of increasing |k_p| with decreasing kz range) are dealt to the ranks heaviest first, each to
+    // the least loaded rank so far (every rank computes the same map).  Cost of a tile = its active kz blocks per fragment.
+    {
+      std::vector<std::pair<long, int>> order;
+      for (int rt = 0; rt < plan.n_row_tiles; ++rt) {
+        long c = 0;
+        for (int f = 0; f < 4; ++f) c += plan.nb_act16[4 * rt + f];
+        order.push_back({-(c + 8), rt});                 // + the per-chunk fixed cost (4 fragments x SK_C0)
+      }
+      std::stable_sort(order.begin(), order.end());
+      std::vector<long> load(env.nranks, 0);
+      rt_owner_h.assign(plan.n_row_tiles, 0);
+      for (auto &e : order) {
+        int best = 0;
+        for (int r = 1; r < env.nranks; ++r) if (load[r] < load[best]) best = r;
+        rt_owner_h[e.second] = best;
+        load[best] += -e.first;
+      }
+      std::vector<int> mine(plan.n_row_tiles, 0);
+      own_rt_h.clear();
+      for (int rt = 0; rt < plan.n_row_tiles; ++rt)
+        if (rt_owner_h[rt] == env.rank) { mine[rt] = 1; own_rt_h.push_back(rt); }
+      d_rt_mine.upload(mine, stream);
+      std::vector<int> own_up = own_rt_h;
+      if (own_up.empty()) own_up.push_back(0);
+      d_own_rt.upload(own_up, stream);
+    }
     tiles_h.clear();
     ct_ptr_h.assign(plan.n_col_tiles + 1, 0);
     for (int ct = 0; ct < plan.n_col_tiles; ++ct) {
-      for (int rt = env.rank; rt < plan.n_row_tiles; rt += env.nranks)
+      for (int rt : own_rt_h)
         if (plan.nba(rt, ct) > 0) tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0, plan.nba16(rt, ct)});
       ct_ptr_h[ct + 1] = (int)tiles_h.size();
     }
@@ -412,9 +439,11 @@ struct conp_fix {
     for (int w = 0; w <= nwg; ++w) if (w == nwg || nt == 0) seg_ptr_h[w] = (int)items_h.size();
     // tiles -> their segments (contiguous in items_h)
     size_t it = 0;
+    max_nsplit = 0;
     for (auto &tl : tiles_h) {
       tl.item0 = (int)it; tl.nsplit = 0;
       while (it < items_h.size() && items_h[it].rt == tl.rt && items_h[it].ct == tl.ct) { ++it; ++tl.nsplit; }
+      max_nsplit = std::max(max_nsplit, tl.nsplit);
     }
     d_items.upload(items_h, stream);
     d_seg_ptr.upload(seg_ptr_h, stream);
@@ -745,6 +774,8 @@ struct conp_fix {
   // km_ewald.cpp:153-167 b_cal + fix_conp.cpp:1281-1365 blist_coul_cal, this rank's shard, into d_b
   void b_cal_device(const double *dx, const double *dq, bool coulyes, bool timed = false) {
     const int ne = idx.elenum_all;
+    if (!kspace_ready || d_Rp.n == 0 || d_b == nullptr)
+      throw ConpError(CONP_ERR_STATE, "b_cal before the k tables / electrode phase tables exist (setup_post_neighbor, a_cal)");
     if (timed) {
       for (auto &e : ev_b) if (!e) HIP_TRY(hipEventCreate(&e));
       HIP_TRY(hipEventRecord(ev_b[0], stream));
@@ -768,11 +799,11 @@ struct conp_fix {
                      d_Gpart.p);
       prof.end(stream);
       prof.begin("sk_reduce", stream);
-      launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), d_Gpart.p, d_G.p, d_Gw.p);
+      launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, d_Gw.p);
       prof.end(stream);
       prof.begin("b_project", stream);
       if (nzc > 0)
-        launch_b_project_zclass(stream, dplan, ne_pad, env.rank, env.nranks, nzc, d_Gw.p, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p,
+        launch_b_project_zclass(stream, dplan, ne_pad, d_rt_mine.p, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Gw.p, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p,
                                 d_bk.p);
       else
         launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
@@ -917,6 +948,7 @@ struct conp_fix {
   // fix_conp.cpp:677-695 b_cal / update_bk
   void b_cal(const conp_atoms *at) {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
+    if (d_Rp.n == 0) km_a_read(at);      // electrode phase tables (kspmod->a_read) not built yet: b_cal before a_cal
     upload_xq(at);
     b_cal_device(d_x.p, d_q.p, true, true);
   }

@@ -41,14 +41,14 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part);
-void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, const double *part, double *G,
+void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);
 void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,
                         const int *k_sign, const double *G, double *sfacrl, double *sfacim);
 void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr /*[n_col_tiles+1]*/, const SkTile *tiles,
                       const double *Gwf, const double *Rp, const double *Tz, double *bk_part /*[4][ne_pad] overwritten*/);
 // planar-electrode fast path of the projection (<= 64 distinct electrode z values)
-void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, int rank, int nranks, int nzc, const double *Gwf,
+void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
                              const double *Tzc /*[C_pad][64]*/, const double *Rp, const int *zclass /*[ne_pad]*/,
                              double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/);
 // this rank's contribution to b in one launch: k-space halves + slab (rank 0) + real-space rows row0..row1

@@ -337,36 +337,55 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 //   Gwf[((rf * (C_pad/4)) + ts) * 64 + fk * 16 + fr]  = (w G)[16 rf + fr][4 ts + fk]
 // One block per (tile, 16-row fragment, 80-column quarter): its Gwf output is one contiguous run of 1280 doubles,
 // transposed through LDS so that partial reads, G writes and Gwf writes are all coalesced.
+// A thread walks its splits serially (8 loads in flight), so heavily split tiles (multi-GPU shards: one tile cut 256 ways)
+// are summed in two levels:  level 1 (blockIdx.y = group g) adds splits [16 g, 16 g + 16) into slot 16 g in place,
+// level 2 adds the group slots (stride 16) and writes G / Gwf.  level 0 = everything in one pass.
+constexpr int SKR_GROUP = 16;
 __global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
-                                                        const double *__restrict__ part, const double *__restrict__ wfull,
-                                                        double *__restrict__ G, double *__restrict__ Gwf) {
+                                                        double *__restrict__ part, const double *__restrict__ wfull,
+                                                        double *__restrict__ G, double *__restrict__ Gwf, int level) {
   __shared__ double tr[1280];
   const SkTile tl = tiles[blockIdx.x >> 5];
   const int f16 = (blockIdx.x >> 2) & 7;       // 16-row fragment inside the 128-row tile
   const int q = blockIdx.x & 3;                // 80-column quarter of the 320-column tile
   const size_t plane = 128 * 320;
+  int first = 0, count = tl.nsplit, stride = 1;
+  if (level == 1) {
+    first = SKR_GROUP * blockIdx.y;
+    if (first >= tl.nsplit) return;
+    count = tl.nsplit - first < SKR_GROUP ? tl.nsplit - first : SKR_GROUP;
+  } else if (level == 2) {
+    stride = SKR_GROUP;
+    count = (tl.nsplit + SKR_GROUP - 1) / SKR_GROUP;
+  }
+  const size_t step = (size_t)stride * plane;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int e = threadIdx.x + 320 * k;
     const int row = e / 80, cl = e % 80;
     const int rowl = 16 * f16 + row, col = 80 * q + cl;
     double sum = 0.0;
+    double *src = part + (size_t)(tl.item0 + first) * plane + rowl * 320 + col;
     if (col < 32 * tl.nba) {
-      const double *src = part + (size_t)tl.item0 * plane + rowl * 320 + col;
       // 8 loads in flight; the association ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)) is fixed -> bitwise reproducible
       double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int sp = 0;
-      for (; sp + 8 <= tl.nsplit; sp += 8) {
+      for (; sp + 8 <= count; sp += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * plane];
+        for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * step];
       }
-      for (int u = 0; sp < tl.nsplit; ++sp, ++u) s8[u] += src[(size_t)sp * plane];
+      for (int u = 0; sp < count; ++sp, ++u) s8[u] += src[(size_t)sp * step];
       sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
+    if (level == 1) {
+      if (col < 32 * tl.nba) src[0] = sum;       // this thread is the only reader and writer of the element
+      continue;
     }
     const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
     G[grow * C_pad + gcol] = sum;
     tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sum;
   }
+  if (level == 1) return;
   __syncthreads();
   const size_t rf = (size_t)tl.rt * 8 + f16;
   double *dst = Gwf + (rf * (C_pad / 4) + (size_t)tl.ct * 80 + 20 * q) * 64;
@@ -374,10 +393,16 @@ __global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile 
   for (int k = 0; k < 4; ++k) dst[threadIdx.x + 320 * k] = tr[threadIdx.x + 320 * k];
 }
 
-void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, const double *part, double *G,
+void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf) {
   if (ntiles <= 0) return;
-  hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf);
+  if (max_nsplit > 2 * SKR_GROUP) {
+    const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 1);
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 2);
+  } else {
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 0);
+  }
 }
 
 // structure factors in the reference's k order (parity read-back; km_ewald.cpp sfacrl_all / sfacim_all)
@@ -483,7 +508,7 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
 //     b_i      = - sum_r Rp[r][i] * Hc[r][zclass(i)]        one 2*n_p-term dot product per atom
 // Same arithmetic per term as the general kernel; only the grouping of equal columns changes.
 // grid = (R_pad/16 row fragments, 4 k-quarters); one wave per (fragment, quarter, 16-class group)
-__global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, int rank, int nranks, int nzc16,
+__global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, const int *__restrict__ rt_mine, int nzc16,
                                                    const int *__restrict__ nb_act, const double *__restrict__ Gwf,
                                                    const double *__restrict__ Tzc /*[C_pad][64]*/,
                                                    double *__restrict__ Hc4 /*[4][R_pad][64]*/, int R_pad) {
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, i
   const int fr = lane & 15, fk = lane >> 4;
   if (wave >= nzc16) return;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-  if (rt % nranks == rank) {
+  if (rt_mine[rt]) {
     for (int ct = 0; ct < n_col_tiles; ++ct) {
       int nba = nb_act[rt] - 10 * ct;
       nba = nba < 0 ? 0 : (nba > 10 ? 10 : nba);
@@ -509,7 +534,7 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, i
 }
 
 // grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16
-__global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_row_tiles, int R_pad, int ne_pad, int rank, int nranks,
+__global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad,
                                                         const double *__restrict__ Rp, const double *__restrict__ Hc4,
                                                         const int *__restrict__ zclass, double *__restrict__ bk) {
   __shared__ double red[16][64];
@@ -519,15 +544,15 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_row_tiles, int R_p
   const size_t hp = (size_t)R_pad * 64;
   double sum = 0.0;
   // 4 row tiles at a time: 8 Rp rows + their Hc entries in flight per thread
-  for (int rt0 = rank; rt0 < n_row_tiles; rt0 += 4 * nranks) {
+  for (int k0 = 0; k0 < n_own; k0 += 4) {        // this rank's row tiles
     double rp[8], hc[8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int rt = rt0 + u * nranks;
-      const bool ok = rt < n_row_tiles;
+      const bool ok = k0 + u < n_own;
+      const int rt = own_rt[ok ? k0 + u : k0];
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
-        const size_t r = (size_t)(ok ? rt : rt0) * 128 + blockIdx.y * 32 + w + 16 * v;
+        const size_t r = (size_t)rt * 128 + blockIdx.y * 32 + w + 16 * v;
         rp[2 * u + v] = ok ? Rp[r * ne_pad + i] : 0.0;
         hc[2 * u + v] = (Hc4[r * 64 + zc] + Hc4[hp + r * 64 + zc]) + (Hc4[2 * hp + r * 64 + zc] + Hc4[3 * hp + r * 64 + zc]);
       }
@@ -545,12 +570,12 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_row_tiles, int R_p
   }
 }
 
-void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, int rank, int nranks, int nzc, const double *Gwf,
+void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
                              const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part) {
   const int nzc16 = (nzc + 15) / 16;
-  hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rank, nranks, nzc16,
+  hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
-  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), 0, s, pl.n_row_tiles, pl.R_pad, ne_pad, rank, nranks, Rp, Hc,
+  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), 0, s, n_own, own_rt, pl.R_pad, ne_pad, Rp, Hc,
                      zclass, bk_part);
 }
 
@@ -860,65 +885,12 @@ void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v
 // 6. once-per-run: Ewald A matrix.
 //    k-space (km_ewald.cpp:584-645):  A_ij = sum_{r,t} w(r,t) Rp[r][i] Tz[t][i] Rp[r][j] Tz[t][j]   for i > j
 //    -- a SYRK over the (r,t) index on the FP64 matrix cores.  Workgroup = 4 waves = 128 x 128 tile, wave = 64 x 64
-//    (4 x 4 fragments); operands are formed in registers: A = w * Rp_i * Tz_i, B = Rp_j * Tz_j.
+//    (4 x 4 fragments); operands are formed in registers from Rp (global) and Tz (LDS): A = w * Rp_i * Tz_i, B = Rp_j * Tz_j.
 //    Only tiles with (row block >= col block) run; the strict upper triangle is left for a_symmetrise.
 // ================================================================================================
-__global__ __launch_bounds__(256, 2) void a_kspace_kernel(int R_pad, int C_pad, int ne, int ne_pad,
-                                                          const int *__restrict__ nb_act, const double *__restrict__ wfull, const double *__restrict__ Rp,
-                                                          const double *__restrict__ Tz, double *__restrict__ A) {
-  // triangular tile index -> (bi >= bj)
-  int tidx = blockIdx.x, bi = 0;
-  while ((bi + 1) * (bi + 2) / 2 <= tidx) ++bi;
-  const int bj = tidx - bi * (bi + 1) / 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wi = wave >> 1, wj = wave & 1;
-  const int fr = lane & 15, fk = lane >> 4;
-  const int ibase = bi * 128 + wi * 64 + fr, jbase = bj * 128 + wj * 64 + fr;
-  if (bi == bj && wj > wi) return;   // wave tile strictly above the diagonal
-  d4 acc[4][4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int r = 0; r < R_pad; ++r) {
-    double ri[4], rj[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      ri[f] = Rp[(size_t)r * ne_pad + ibase + 16 * f];
-      rj[f] = Rp[(size_t)r * ne_pad + jbase + 16 * f];
-    }
-    const double *wrow = wfull + (size_t)r * C_pad + fk;
-    const int nks = 8 * nb_act[r >> 7];           // only the leading kz blocks of this row tile carry weight
-    for (int ts = 0; ts < nks; ++ts) {
-      const double ww = wrow[4 * ts];
-      const double *tzr = Tz + (size_t)(4 * ts + fk) * ne_pad;
-      double af[4], bf[4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        af[f] = ww * ri[f] * tzr[ibase + 16 * f];
-        bf[f] = rj[f] * tzr[jbase + 16 * f];
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
-    }
-  }
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = bi * 128 + wi * 64 + 16 * f + fk + 4 * r;
-        const int j = bj * 128 + wj * 64 + 16 * g + fr;
-        if (i < ne && j < i) A[(size_t)i * ne + j] = acc[f][g][r];
-      }
-}
-
-// Same contraction with the Tz operand staged through LDS.  The kernel above re-reads 8 Tz values per lane and k-step from
-// L2 (the tile's Tz slab, 320 x 256 doubles, does not fit in LDS and is walked once per G row): 9 global loads per 16
-// MFMAs, MFMA pipe 49 % busy.  Here the (r, t) loop nest is turned inside out: a 32-t chunk of Tz (= one 16-kz block = 8
+// The Tz operand is staged through LDS.  (A first version formed both operands from global loads: the tile's Tz slab, 320 x
+// 256 doubles, does not fit in LDS and was re-read from L2 once per G row -- 9 global loads per 16 MFMAs, MFMA pipe 49 % busy,
+// 103 ms at Ne = 4096.)  The (r, t) loop nest is turned inside out instead: a 32-t chunk of Tz (= one 16-kz block = 8
 // k-steps) for the tile's 128 + 128 atoms stays in LDS while r runs over every G row whose sphere cut reaches that block
 // (row tiles are rings sorted by |k_p|: in practice a prefix of the rows); per r: 8 Rp + 8 w global loads for
 // 128 MFMAs.  LDS row stride 272 doubles: the two t rows a half-wave reads land in disjoint bank halves.
@@ -997,9 +969,7 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
 void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A) {
   const int nb = ne_pad / 128;
   const int ntiles = nb * (nb + 1) / 2;
-  if (getenv("CONP_A_OLD"))
-    hipLaunchKernelGGL(a_kspace_kernel, dim3(ntiles), dim3(256), 0, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.nb_act, pl.wfull, Rp, Tz, A);
-  else {
+  {
     const size_t lds = (size_t)AK_TC * AK_LD * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(a_kspace_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(a_kspace_lds_kernel, dim3(ntiles), dim3(256), lds, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.n_row_tiles, pl.nb_act,

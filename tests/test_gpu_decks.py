@@ -54,6 +54,33 @@ def test_il_decks_match_oracle(oracle, deck, mode, extra):
     fx.close(); o.fx.close()
 
 
+def test_heavily_split_tiles_use_the_two_level_partial_sum(oracle, monkeypatch):
+    """multi-GPU shards cut one tile into hundreds of sk_gemm segments; forced here with 256 workgroups on il_onelayer's two
+    tiles (80 segments each -> sk_reduce level 1 + level 2): same structure factors and b vector"""
+    monkeypatch.setenv("CONP_SK_NWG", "256")
+    s = systems.deck("il_onelayer", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    q0 = at.q.copy()
+    fx.b_cal(at)
+    import oracle_py
+    ks = oracle_py.KSpace.from_system(oracle, s)
+    sr_o, si_o = ks.sincos_b(at.x, q0, at.echeck, at.nlocal)
+    ks.close()
+    sr_g, si_g = fx.sfac()
+    scale = max(np.abs(sr_o).max(), np.abs(si_o).max())
+    assert max(np.abs(sr_g - sr_o).max(), np.abs(si_g - si_o).max()) / scale < 1e-11
+    monkeypatch.delenv("CONP_SK_NWG")
+    fy = FixConp(s)                                  # default schedule (32 workgroups, one-level sum)
+    fy.init_lists(alist, blist)
+    fy.setup_post_neighbor(at)
+    fy.b_cal(at)
+    assert rel_err(fx.vectors()[0], fy.vectors()[0]) < 1e-12
+    fx.close(); fy.close()
+
+
 @pytest.mark.parametrize("deck,mode,Q", [
     ("cond", "slab", 0.35),       # tests/cond/input N = 0 (conp, dv 2) and N = 1 (conq, Q 0.35)
     ("cond", "ffield", 0.35),     # N = 2 (conp ffield), 3 (conq ffield), 4 (cond ffield)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-rank compute time of the sharded update WITHOUT the collectives: one process builds the handle of rank r of N
+(conp_env.rank / nranks) on the single GPU and times b_cal_device + solve_device + scatter_device.  Used to see how the
+k-shard / row-shard scales before an N-GPU node is available; the two 32-KB RCCL collectives come on top.
+usage: python tools/rank_emulation.py [N ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lammps-user-conp2_amd"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import bench
+    from conp_amd import FixConp, neighbor
+    s = bench.make_workload("headline")
+    at, alist, blist = neighbor.build_lists(s)
+    d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda()
+    d_q = torch.from_numpy(at.q.copy()).cuda()
+    for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+        worst = None
+        for rank in sorted({0, n - 1, n // 2}):
+            fx = FixConp(s, device=0, rank=rank, nranks=n)
+            fx.init_lists(alist, blist)
+            fx.setup_post_neighbor(at)
+            fx.linalg_setup(at)
+            ne = fx.info().elenum_all
+            d_b = torch.zeros(ne, dtype=torch.float64, device="cuda")
+            d_sol = torch.zeros(ne, dtype=torch.float64, device="cuda")
+            fx.bind_device_buffers(d_b.data_ptr(), d_sol.data_ptr())
+
+            def step():
+                fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())
+                fx.solve_device(s.potdiff)
+                fx.scatter_device(d_q.data_ptr(), s.potdiff)
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 200 * 1e3
+            fx.profile(True)
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            prof = {k: round(v[0], 4) for k, v in fx.profile_read().items()}
+            fx.profile(False)
+            print(f"N={n} rank={rank}: {ms:.4f} ms/update (compute only)  {prof}", flush=True)
+            worst = ms if worst is None else max(worst, ms)
+            fx.close()
+        print(f"N={n}: slowest sampled rank {worst:.4f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
