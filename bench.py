@@ -186,6 +186,18 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
 
+    # ---- the host-buffer hook (what FixConpHip::pre_force calls): H2D of x, q and D2H of the charges every update.
+    #      PCIe-inclusive, reported beside `value`, never as `value`.
+    host_ms = None
+    if world == 1:
+        nh = max(10, args.steps // 4)
+        for k in range(3):
+            fx.pre_force(at, k, potdiff)
+        t0 = time.perf_counter()
+        for k in range(nh):
+            fx.pre_force(at, k, potdiff)
+        host_ms = (time.perf_counter() - t0) / nh * 1e3
+
     # ---- the same K updates again with a HIP-event pair around every kernel on the library's stream: per-kernel
     #      average launch durations for the roofline (the event records cost host time, so this pass is not `value`)
     prof = {}
@@ -234,6 +246,7 @@ def main():
                                blist_pairs=int(info.n_blist_pairs),
                                parallelism=f"k-shard+row-shard x{world}"),
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
+                   ms_per_step_host_buffers_pcie=host_ms,
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),
                    kernels_ms={k: round(v[0], 5) for k, v in prof.items()},
                    ms_per_step_profiled_pass=dt_prof / args.steps * 1e3,
