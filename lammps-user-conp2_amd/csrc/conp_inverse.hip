@@ -4,7 +4,9 @@
 // (not necessarily positive definite) matrix.  Row-major storage, leading dimension n.
 //
 // One block step (NB = 64 columns K = [k0, k0+NB)):
-//   1. copy the panel rows k0.. of columns K, LU-factor the copy with partial pivoting (one workgroup) -> pivots
+//   1. LU-factor the panel (rows k0.., columns K) with partial pivoting -> pivots and the factored top 64 x 64 block:
+//      up to 256 cooperating workgroups, rows resident in LDS, one grid barrier per column (1c); a one-workgroup version
+//      (1a + 1b) remains as the fallback when a cooperative launch is not possible
 //   2. apply the row swaps to the whole matrix
 //   3. Dinv = (M[K,K])^-1 from the panel's L11, U11 (one workgroup, LDS)
 //   4. Wb = Dinv * M[K,:] with the K columns zeroed;  Cct = M[:,K]^T with the K rows zeroed      (both k-major)
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(1024) void inv_panel_lu_kernel(int m, int k0, int n
     __syncthreads();
     const double dinv = 1.0 / s_row[j];
     // scale the column below the pivot and update the trailing panel columns; 8 rows per wave in flight (the loop is
-    // bound by what ONE CU can stream (~25-50 GB/s): the panel step moves m x 64 doubles per column.  Measured 3.7 ms per
-    // 4096-row panel = 0.24 s of the 0.44 s setup at Ne = 4096; a multi-workgroup panel (tournament pivoting) is next-round work)
+    // bound by what ONE CU can stream (~25-50 GB/s): the panel step moves m x 64 doubles per column, 3.7 ms per 4096-row
+    // panel -- which is why the cooperative kernel 1c is the default)
     for (int i0 = j + 1 + 8 * (t >> 6); i0 < m; i0 += 16 * 8) {
       double lv[8], rv[8];
 #pragma unroll
