@@ -52,9 +52,9 @@ def potential_at_electrodes(s, x, q, echeck, kt, unitk, volume):
     return ele, phi
 
 
-@pytest.mark.parametrize("mode", ["slab", "ffield"])
-def test_electrode_potential_is_the_applied_one(mode):
-    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode=mode)
+@pytest.mark.parametrize("system,mode", [("small", "slab"), ("small", "ffield"), ("dilute", "ffield"), ("dilute", "slab")])
+def test_electrode_potential_is_the_applied_one(system, mode):
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode=mode) if system == "small" else systems.deck("dilute", mode)
     at, alist, blist = neighbor.build_lists(s)
     fx = FixConp(s)
     fx.init_lists(alist, blist)
