@@ -143,6 +143,7 @@ struct conp_fix {
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   int n_slab_part = 0;
+  const bool no_fuse = getenv("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
   int max_nsplit = 0;              // most sk_gemm segments any tile is cut into (chooses sk_reduce's one- or two-level sum)
   DevPlan dplan{};
   Profiler prof;
@@ -496,7 +497,7 @@ struct conp_fix {
         for (int t = 0; t < plan.C_pad; ++t)
           for (int c = 0; c < nzc; ++c) Tzc[(size_t)t * 64 + c] = Tz[(size_t)t * ne_pad + rep[c]];
         d_Tzc.upload(Tzc, stream); d_zclass.upload(zclass, stream);
-        d_Hc.reserve((size_t)4 * plan.R_pad * 64);
+        d_Hc.reserve((size_t)4 * plan.R_pad * 64); d_Hc.zero(stream);
       }
     }
     sync();
@@ -798,16 +799,24 @@ struct conp_fix {
       launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                      d_Gpart.p);
       prof.end(stream);
-      prof.begin("sk_reduce", stream);
-      launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, d_Gw.p);
-      prof.end(stream);
-      prof.begin("b_project", stream);
-      if (nzc > 0)
-        launch_b_project_zclass(stream, dplan, ne_pad, d_rt_mine.p, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Gw.p, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p,
-                                d_bk.p);
-      else
-        launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
-      prof.end(stream);
+      if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
+        // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot
+        prof.begin("reduce_project", stream);
+        launch_reduce_project_zclass(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, ne_pad,
+                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p);
+        prof.end(stream);
+      } else {
+        prof.begin("sk_reduce", stream);
+        launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, d_Gw.p);
+        prof.end(stream);
+        prof.begin("b_project", stream);
+        if (nzc > 0)
+          launch_b_project_zclass(stream, dplan, ne_pad, d_rt_mine.p, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Gw.p, d_Tzc.p, d_Rp.p,
+                                  d_zclass.p, d_Hc.p, d_bk.p);
+        else
+          launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
+        prof.end(stream);
+      }
     }
     if (timed) HIP_TRY(hipEventRecord(ev_b[1], stream));
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;

@@ -48,6 +48,9 @@ void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int 
 void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr /*[n_col_tiles+1]*/, const SkTile *tiles,
                       const double *Gwf, const double *Rp, const double *Tz, double *bk_part /*[4][ne_pad] overwritten*/);
 // planar-electrode fast path of the projection (<= 64 distinct electrode z values)
+void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
+                                  double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
+                                  const int *zclass, double *Hc, double *bk_part);
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
                              const double *Tzc /*[C_pad][64]*/, const double *Rp, const int *zclass /*[ne_pad]*/,
                              double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/);

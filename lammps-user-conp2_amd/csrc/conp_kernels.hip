@@ -570,6 +570,77 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
   }
 }
 
+// Planar electrodes with one column tile (nz <= 160): the last partial-tile sum and the Hc product in ONE kernel -- a block
+// of sk_reduce already holds its 16 x 80 piece of (w G) in LDS in MFMA-fragment order, exactly the A operand b_hc needs, so the
+// Gwf round trip and one launch go away (the decks' updates are launch-bound).  Same sums in the same order as the two
+// kernels; Hc4 slot = the block's 80-column quarter.
+__global__ __launch_bounds__(320) void sk_reduce_hc_kernel(int C_pad, const SkTile *__restrict__ tiles, const double *__restrict__ part,
+                                                           const double *__restrict__ wfull, double *__restrict__ G,
+                                                           const double *__restrict__ Tzc /*[C_pad][64]*/,
+                                                           double *__restrict__ Hc4 /*[4][R_pad][64]*/, int R_pad, int nzc16,
+                                                           int level) {
+  __shared__ double tr[1280];
+  const SkTile tl = tiles[blockIdx.x >> 5];
+  const int f16 = (blockIdx.x >> 2) & 7;
+  const int q = blockIdx.x & 3;
+  const size_t plane = 128 * 320;
+  const int stride = level == 2 ? SKR_GROUP : 1;
+  const int count = level == 2 ? (tl.nsplit + SKR_GROUP - 1) / SKR_GROUP : tl.nsplit;
+  const size_t step = (size_t)stride * plane;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = threadIdx.x + 320 * k;
+    const int row = e / 80, cl = e % 80;
+    const int rowl = 16 * f16 + row, col = 80 * q + cl;
+    double sum = 0.0;
+    if (col < 32 * tl.nba) {
+      const double *src = part + (size_t)tl.item0 * plane + rowl * 320 + col;
+      double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int sp = 0;
+      for (; sp + 8 <= count; sp += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * step];
+      }
+      for (int u = 0; sp < count; ++sp, ++u) s8[u] += src[(size_t)sp * step];
+      sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
+    const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
+    G[grow * C_pad + gcol] = sum;
+    tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sum;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave >= nzc16) return;
+  const int fr = lane & 15, fk = lane >> 4;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  const int nks = 8 * tl.nba;
+  const double *bp = Tzc + (size_t)(tl.ct * 320 + 80 * q + fk) * 64 + 16 * wave + fr;
+#pragma unroll 4
+  for (int tsl = 0; tsl < 20; ++tsl)
+    if (20 * q + tsl < nks) acc = MFMA_F64(tr[tsl * 64 + lane], bp[(size_t)tsl * 256], acc);
+  double *out = Hc4 + (size_t)q * R_pad * 64;
+  const int rf = tl.rt * 8 + f16;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(size_t)(16 * rf + fk + 4 * r) * 64 + 16 * wave + fr] = acc[r];
+}
+
+// sk_reduce (+ level 1 when tiles are heavily split) with the Hc product fused in, then the per-atom dot
+void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
+                                  double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
+                                  const int *zclass, double *Hc, double *bk_part) {
+  if (ntiles <= 0) return;
+  const int nzc16 = (nzc + 15) / 16;
+  int level = 0;
+  if (max_nsplit > 2 * SKR_GROUP) {
+    const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, nullptr, 1);
+    level = 2;
+  }
+  hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
+                     nzc16, level);
+  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), 0, s, n_own, own_rt, pl.R_pad, ne_pad, Rp, Hc, zclass, bk_part);
+}
+
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
                              const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part) {
   const int nzc16 = (nzc + 15) / 16;
