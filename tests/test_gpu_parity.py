@@ -204,6 +204,40 @@ def test_inverse_matches_numpy():
     fx.close()
 
 
+@pytest.mark.parametrize("mode", ["slab", "ffield"])
+def test_kspace_provider_surface_matches_oracle(oracle, mode):
+    """INTEGRATION.md mode B: the reference's FixConp stays on the CPU and only the k-space provider is replaced.  The three
+    calls KSpaceModuleHip makes (conp_km_conp_setup / a_cal / b_cal = km_ewald.cpp:63-132, 147-151, 153-167) against the
+    oracle's provider functions: k-space A incl. its diagonal and slab term, one orientation per pair; k-space b incl. slab"""
+    import oracle_py
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode=mode)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    n = at.nlocal
+    fx.km_conp_setup(float((at.q[:n] ** 2).sum()), n)
+    a_g = fx.km_a_cal(at)
+    b_g = fx.km_b_cal(at)
+    ks = oracle_py.KSpace.from_system(oracle, s)
+    for name in ("kxvecs", "kyvecs", "kzvecs", "ug"):
+        assert np.array_equal(fx.ktables()[name], getattr(ks, name)), name
+    m = fx.maps()
+    loc = {int(t): i for i, t in enumerate(at.tag[:n])}
+    xele = np.array([at.x[loc[int(t)]] for t in m["eleall2tag"]])
+    csk, snk = ks.ele_trig(xele)
+    a_o = ks.aaa(csk, snk, xele)
+    # either orientation of a pair may carry the value (fix_conp.cpp:826-831 symmetrises): compare the symmetrised matrices
+    sym = lambda a: np.tril(a, -1) + np.tril(a, -1).T + np.triu(a, 1) + np.triu(a, 1).T + np.diag(np.diag(a))
+    assert rel_err(sym(a_g), sym(a_o)) < 1e-11
+    sr, si = ks.sincos_b(at.x, at.q, at.echeck, n)
+    b_o = ks.bbb(csk, snk, sr, si)
+    if s.slabflag:
+        oracle.orc_slabcorr(ks.h, n, np.ascontiguousarray(at.x), at.q, at.echeck, len(xele), xele, b_o)
+    assert rel_err(b_g, b_o) < 1e-11
+    ks.close(); fx.close()
+
+
 def test_cg_solver_matches_oracle(oracle):
     s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
     at, alist, blist = neighbor.build_lists(s)
