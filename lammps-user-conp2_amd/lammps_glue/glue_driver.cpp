@@ -1,0 +1,184 @@
+// glue_driver -- a miniature host that drives FixConpHip the way LAMMPS does, on top of the interface mock.
+// It exists to EXECUTE the C++ glue (constructor / init / init_list / setup_* / post_neighbor / pre_force / post_force /
+// compute_scalar / modify_param, log-file writing, error->all propagation) against libconp_hip.so on a real GPU; the numerical
+// content is checked by tests/test_gpu_glue.py against the ctypes path through the same library.
+//
+// usage: glue_driver CASEFILE   (whitespace-separated tokens, written by the test)
+//   ntypes nlocal nghost
+//   xprd yprd zprd boxlo_x boxlo_y boxlo_z
+//   g_ewald accuracy slab_volfactor slabflag
+//   qqrd2e qqr2e qe2f dielectric newton_pair cut_coul
+//   cutsq[(ntypes+1)^2]
+//   ngroups  { name bit } ...
+//   per atom (nlocal + nghost): tag type mask q x y z
+//   nlists   { inum  { i numneigh j... } ... } ...      list 0 = only / ele-ele list, list 1 = ele-electrolyte list
+//   variable: name value   ("-" = none)
+//   nmodify { ntok tok... } ...                          fix_modify lines
+//   narg tok...                                          the fix command
+//   nsteps { ntimestep potdiff_value reneighbor(0/1) has_x(0/1) [x y z per atom] } ...
+// output (stdout): "scalar STEP VALUE", "q STEP TAG VALUE" for electrode atoms, "f STEP ..." sums, "ERROR: msg" + exit 2.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define CONP_GLUE_MOCK 1
+#include "fix_conp_hip.h"
+
+using namespace LAMMPS_NS;
+
+int main(int argc, char **argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: glue_driver CASEFILE\n"); return 1; }
+  std::ifstream in(argv[1]);
+  if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
+
+  LAMMPS lmp{};
+  Memory memory; Error error; Atom atom{}; Force force{}; Domain domain{}; Update update{}; Comm comm{}; Group group{};
+  Variable variable; Input input{}; Neighbor neighbor{}; Modify modify; KSpace kspace{}; Pair pair{};
+  lmp.memory = &memory; lmp.error = &error; lmp.atom = &atom; lmp.force = &force; lmp.domain = &domain; lmp.update = &update;
+  lmp.comm = &comm; lmp.group = &group; lmp.input = &input; lmp.neighbor = &neighbor; lmp.modify = &modify;
+  lmp.screen = stdout; lmp.logfile = nullptr;
+  input.variable = &variable;
+  force.kspace = &kspace; force.pair = &pair;
+  comm.me = 0; comm.nprocs = 1;
+  char style[] = "verlet";
+  update.integrate_style = style;
+
+  int ntypes, nlocal, nghost;
+  in >> ntypes >> nlocal >> nghost;
+  const int nall = nlocal + nghost;
+  in >> domain.xprd >> domain.yprd >> domain.zprd >> domain.boxlo[0] >> domain.boxlo[1] >> domain.boxlo[2];
+  domain.zprd_half = 0.5 * domain.zprd;
+  in >> kspace.g_ewald >> kspace.accuracy >> kspace.slab_volfactor >> kspace.slabflag;
+  kspace.energy = 0.0;
+  in >> force.qqrd2e >> force.qqr2e >> force.qe2f >> force.dielectric >> force.newton_pair >> pair.cut_coul;
+  const int nt1 = ntypes + 1;
+  std::vector<double> cutsq_store((size_t)nt1 * nt1);
+  std::vector<double *> cutsq_rows(nt1);
+  for (auto &v : cutsq_store) in >> v;
+  for (int i = 0; i < nt1; ++i) cutsq_rows[i] = cutsq_store.data() + (size_t)i * nt1;
+  pair.cutsq = cutsq_rows.data();
+  pair.eng_coul = 0.0;
+  for (double &v : pair.virial) v = 0.0;
+
+  int ngroups;
+  in >> ngroups;
+  std::vector<int> bitmask(32, 0);
+  group.bitmask = bitmask.data();
+  group.ngroup = ngroups;
+  for (int g = 0; g < ngroups; ++g) in >> group.names[g] >> bitmask[g];
+
+  std::vector<int> tag(nall), type(nall), mask(nall);
+  std::vector<double> q(nall), xs((size_t)nall * 3), fs((size_t)nall * 3, 0.0);
+  std::vector<double *> xrows(nall), frows(nall);
+  int maxtag = 0;
+  for (int i = 0; i < nall; ++i) {
+    in >> tag[i] >> type[i] >> mask[i] >> q[i] >> xs[3 * (size_t)i] >> xs[3 * (size_t)i + 1] >> xs[3 * (size_t)i + 2];
+    xrows[i] = &xs[3 * (size_t)i]; frows[i] = &fs[3 * (size_t)i];
+    if (tag[i] > maxtag) maxtag = tag[i];
+  }
+  std::vector<int> map_array(maxtag + 1, -1);
+  for (int i = nall - 1; i >= 0; --i) map_array[tag[i]] = i;      // owned atoms win over their ghosts, like Atom::map
+  atom.nlocal = nlocal; atom.nghost = nghost; atom.ntypes = ntypes; atom.natoms = nlocal;
+  atom.x = xrows.data(); atom.f = frows.data(); atom.q = q.data(); atom.type = type.data(); atom.mask = mask.data();
+  atom.tag = tag.data(); atom.map_array = map_array.data(); atom.map_size = maxtag + 1;
+
+  int nlists;
+  in >> nlists;
+  struct ListStore { std::vector<int> ilist, numneigh, neigh; std::vector<size_t> first; std::vector<int *> firstneigh; NeighList nl{}; };
+  std::vector<ListStore> lists(nlists);
+  for (auto &L : lists) {
+    int inum;
+    in >> inum;
+    L.numneigh.assign(nall, 0); L.first.assign(nall, 0);
+    for (int ii = 0; ii < inum; ++ii) {
+      int i, n;
+      in >> i >> n;
+      L.ilist.push_back(i); L.numneigh[i] = n; L.first[i] = L.neigh.size();
+      for (int k = 0; k < n; ++k) { int j; in >> j; L.neigh.push_back(j); }
+    }
+    if (L.neigh.empty()) L.neigh.push_back(0);
+    L.firstneigh.assign(nall, L.neigh.data());
+    for (int i = 0; i < nall; ++i) L.firstneigh[i] = L.neigh.data() + L.first[i];
+    L.nl.inum = inum; L.nl.ilist = L.ilist.data(); L.nl.numneigh = L.numneigh.data(); L.nl.firstneigh = L.firstneigh.data();
+  }
+
+  std::string vname;
+  double vvalue;
+  in >> vname >> vvalue;
+  if (vname != "-") { variable.name = vname; variable.value = vvalue; }
+
+  int nmodify;
+  in >> nmodify;
+  std::vector<std::vector<std::string>> modify_lines(nmodify);
+  for (auto &ml : modify_lines) { int n; in >> n; ml.resize(n); for (auto &t : ml) in >> t; }
+
+  int narg;
+  in >> narg;
+  std::vector<std::string> toks(narg);
+  for (auto &t : toks) in >> t;
+  std::vector<char *> fargv;
+  for (auto &t : toks) fargv.push_back(const_cast<char *>(t.c_str()));
+
+  std::vector<NeighRequest *> requests(8, nullptr);
+  neighbor.requests = requests.data();
+
+  try {
+    FixConpHip fix(&lmp, narg, fargv.data());
+    for (auto &ml : modify_lines) {                    // fix_modify arrives before init(), as in an input script
+      std::vector<char *> margv;
+      for (auto &t : ml) margv.push_back(const_cast<char *>(t.c_str()));
+      const int used = fix.modify_param((int)margv.size(), margv.data());
+      if (used == 0) throw std::runtime_error("Illegal fix_modify command");
+    }
+    fix.init();
+    // Neighbor::init hands every request its list (Neighbor::init -> Fix::init_list); an occasional skip list is the
+    // ele-ele list (list 0), the perpetual one the ele-electrolyte list (last list)
+    for (int r = 0; r < neighbor.nrequest; ++r) {
+      const bool occasional = requests[r]->occasional != 0;
+      ListStore &L = (neighbor.nrequest == 1 || occasional) ? lists.front() : lists.back();
+      L.nl.index = r; L.nl.occasional = requests[r]->occasional;
+      fix.init_list(0, &L.nl);
+    }
+    update.ntimestep = 0;
+    int nsteps;
+    in >> nsteps;
+    std::vector<long> step_no(nsteps);
+    // Verlet::setup order: modify->setup_post_neighbor(), then modify->setup_pre_force()
+    bool first = true;
+    for (int s = 0; s < nsteps; ++s) {
+      long ts; double pd; int reneigh, has_x;
+      in >> ts >> pd >> reneigh >> has_x;
+      if (has_x) for (size_t k = 0; k < xs.size(); ++k) in >> xs[k];
+      update.ntimestep = ts; update.laststep = -1;
+      if (s == nsteps - 1) update.laststep = ts;
+      variable.value = pd;
+      if (first) {
+        fix.setup_post_neighbor();
+        fix.setup_pre_force(0);
+        first = false;
+      } else {
+        if (reneigh) fix.post_neighbor();
+        fix.pre_force(0);
+      }
+      std::fill(fs.begin(), fs.end(), 0.0);
+      if (fix.setmask() & FixConst::POST_FORCE) fix.post_force(0);
+      fix.end_of_step();
+      std::printf("scalar %ld %.17g\n", ts, fix.compute_scalar());
+      for (int i = 0; i < nlocal; ++i)
+        if (mask[i] & (fix.groupbit | bitmask[group.find(toks[4])])) std::printf("q %ld %d %.17g\n", ts, tag[i], q[i]);
+      double fsum[3] = {0, 0, 0}, fabs_ = 0;
+      for (int i = 0; i < nlocal; ++i) for (int c = 0; c < 3; ++c) { fsum[c] += fs[3 * (size_t)i + c]; fabs_ += std::abs(fs[3 * (size_t)i + c]); }
+      std::printf("f %ld %.17g %.17g %.17g %.17g eng_coul %.17g kspace_energy %.17g\n", ts, fsum[0], fsum[1], fsum[2], fabs_,
+                  pair.eng_coul, kspace.energy);
+    }
+  } catch (const std::exception &e) {
+    std::printf("ERROR: %s\n", e.what());
+    return 2;
+  }
+  return 0;
+}

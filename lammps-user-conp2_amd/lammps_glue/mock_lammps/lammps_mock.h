@@ -1,6 +1,8 @@
-// INTERFACE MOCK -- NOT LAMMPS.  Declares just enough of the LAMMPS 27May2021 class surface for a syntax / type check of
-// the glue in this directory (`make check`).  LAMMPS itself is not in the build image; against a real LAMMPS tree the
-// glue includes the real headers instead.  Nothing here is linked or executed.
+// INTERFACE MOCK -- NOT LAMMPS.  Declares just enough of the LAMMPS 27May2021 class surface for the glue in this directory:
+// `make check` type-checks the glue against it, and mock_runtime.cpp gives the declarations minimal bodies so that
+// glue_driver.cpp can drive FixConpHip through the same hook sequence LAMMPS' Modify / Verlet use (tests/test_gpu_glue.py).
+// LAMMPS itself is not in the build image; against a real LAMMPS tree the glue includes the real headers instead
+// (INTEGRATION.md).  This is a test host for OUR glue, not a way to build the reference.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -15,19 +17,21 @@ typedef int64_t bigint;
 
 class Error { public: [[noreturn]] void all(const char *, int, const std::string &); void warning(const char *, int, const std::string &); };
 class Memory {};
-class Atom { public: int nlocal, nghost, ntypes; bigint natoms; double **x, **f, *q; int *type, *mask; tagint *tag; int map(tagint); };
-class KSpace { public: double g_ewald, accuracy, slab_volfactor, energy; int slabflag; virtual void setup(); };
-class Pair { public: double **cutsq; double eng_coul, virial[6]; virtual void *extract(const char *, int &); void ev_tally(int, int, int, int, double, double, double, double, double, double); };
+class Atom { public: int nlocal, nghost, ntypes; bigint natoms; double **x, **f, *q; int *type, *mask; tagint *tag; int map(tagint);
+             int *map_array = nullptr; int map_size = 0; };
+class KSpace { public: double g_ewald, accuracy, slab_volfactor, energy; int slabflag; virtual ~KSpace() {} virtual void setup(); };
+class Pair { public: double **cutsq; double eng_coul, virial[6]; double cut_coul = 0.0; virtual ~Pair() {} virtual void *extract(const char *, int &); void ev_tally(int, int, int, int, double, double, double, double, double, double); };
 class Force { public: double qqrd2e, qqr2e, qe2f, dielectric; int newton_pair; KSpace *kspace; Pair *pair; Pair *pair_match(const std::string &, int, int nsub = 0); };
 class Domain { public: double xprd, yprd, zprd, zprd_half, boxlo[3]; };
 class Update { public: bigint ntimestep, laststep; char *integrate_style; };
 class Comm { public: int me, nprocs; };
-class Group { public: int *bitmask; int find(const std::string &); };
-class Variable { public: int find(const char *); int equalstyle(int); double compute_equal(int); };
+class Group { public: int *bitmask; int find(const std::string &); int ngroup = 0; std::string names[32]; };
+class Variable { public: int find(const char *); int equalstyle(int); double compute_equal(int);
+                 std::string name; double value = 0.0; };   // the mock knows one equal-style variable
 class Input { public: Variable *variable; };
 class NeighRequest { public: int pair, fix, half, full, occasional, skip, intel; int *iskip, **ijskip; };
 class NeighList { public: int index, inum, occasional; int *ilist, *numneigh, **firstneigh; };
-class Neighbor { public: NeighRequest **requests; int request(void *, int instance = 0); void build(int); void build_one(NeighList *, int preflag = 0); };
+class Neighbor { public: NeighRequest **requests; int nrequest = 0; int request(void *, int instance = 0); void build(int); void build_one(NeighList *, int preflag = 0); };
 class Modify { public: int find_fix(const std::string &); };
 
 class LAMMPS { public: Memory *memory; Error *error; Atom *atom; Force *force; Domain *domain; Update *update; Comm *comm; Group *group; Input *input; Neighbor *neighbor; Modify *modify; FILE *screen, *logfile; };
@@ -48,7 +52,11 @@ namespace FixConst { enum { POST_NEIGHBOR = 1 << 3, PRE_FORCE = 1 << 5, POST_FOR
 
 class Fix : protected Pointers {
  public:
-  Fix(LAMMPS *l, int, char **) : Pointers(l) {}
+  Fix(LAMMPS *l, int narg, char **arg) : Pointers(l) {      // like Fix::Fix: arg[1] is the fix group
+    igroup = narg > 1 ? l->group->find(arg[1]) : 0;
+    groupbit = igroup >= 0 ? l->group->bitmask[igroup] : 0;
+    instance_me = 0;
+  }
   virtual ~Fix() {}
   int igroup, groupbit, instance_me, scalar_flag, extscalar, global_freq, respa_level;
   virtual int setmask() = 0;

@@ -1,0 +1,159 @@
+"""-m gpu: the C++ LAMMPS glue (FixConpHip) EXECUTED -- not only type-checked -- by lammps_glue/glue_driver, a miniature
+host on top of the interface mock that calls the hooks in LAMMPS' order (constructor, fix_modify, init, init_list,
+setup_post_neighbor, setup_pre_force, [post_neighbor], pre_force, post_force, end_of_step, compute_scalar).
+The numbers must equal what the ctypes harness gets from the same library on the same inputs (bitwise: same kernels), the log
+file must carry the reference's lines, and error->all must carry the reference's messages."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conp_amd import FixConp, neighbor, systems
+from conp_amd.capi import fix_command_for
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "lammps-user-conp2_amd", "lammps_glue", "glue_driver")
+BIT = {"all": 1, "eleleft": 2, "eleright": 4}
+
+
+def write_case(path, s, at, lists, tokens, steps, variable=("-", 0.0), modify=()):
+    out = []
+    w = lambda *a: out.append(" ".join(repr(float(v)) if isinstance(v, (float, np.floating)) else str(v) for v in a))
+    w(s.ntypes, at.nlocal, at.nghost)
+    w(*[float(v) for v in s.prd], *[float(v) for v in s.boxlo])
+    w(float(s.g_ewald), float(s.accuracy), float(s.slab_volfactor), int(s.slabflag))
+    w(systems.QQRD2E, systems.QQR2E, systems.QE2F, 1.0, int(s.newton), float(s.cutoff))
+    w(*[float(v) for v in s.cutsq_table().ravel()])
+    w(len(BIT)); [w(k, v) for k, v in BIT.items()]
+    for i in range(at.nall):
+        mask = 1 | (2 if at.echeck[i] == 1 else 0) | (4 if at.echeck[i] == -1 else 0)
+        w(int(at.tag[i]), int(at.type[i]), mask, float(at.q[i]), *[float(v) for v in at.x[i]])
+    w(len(lists))
+    for L in lists:
+        w(L.inum)
+        for i in L.ilist[:L.inum]:
+            n = int(L.numneigh[i]); f = int(L.first[i])
+            w(int(i), n, *[int(j) for j in L.neigh[f:f + n]])
+    w(variable[0], float(variable[1]))
+    w(len(modify)); [w(len(m), *m) for m in modify]
+    w(len(tokens), *tokens)
+    w(len(steps))
+    for (ts, pd, reneigh, x) in steps:
+        w(ts, float(pd), int(reneigh), 0 if x is None else 1)
+        if x is not None:
+            w(*[float(v) for v in np.asarray(x).ravel()])
+    with open(path, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+
+
+def run_driver(case, cwd):
+    if not os.path.exists(DRIVER):            # normally built by __graft_entry__.build(); g++ is on the GPU box too
+        subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "driver"])
+    p = subprocess.run([DRIVER, case], cwd=cwd, capture_output=True, text=True, timeout=300)
+    res = {"scalar": {}, "q": {}, "f": {}, "error": None, "screen": [], "rc": p.returncode}
+    for line in p.stdout.splitlines():
+        t = line.split()
+        if line.startswith("scalar "):
+            res["scalar"][int(t[1])] = float(t[2])
+        elif line.startswith("q "):
+            res["q"].setdefault(int(t[1]), {})[int(t[2])] = float(t[3])
+        elif line.startswith("f "):
+            res["f"][int(t[1])] = [float(v) for v in t[2:6]] + [float(t[7]), float(t[9])]
+        elif line.startswith("ERROR: "):
+            res["error"] = line[len("ERROR: "):]
+        else:
+            res["screen"].append(line)
+    return res, p
+
+
+@pytest.mark.parametrize("etypes", [True, False])
+def test_hook_sequence_gives_the_same_charges_as_the_ctypes_path(tmp_path, etypes):
+    s = systems.deck("dilute", "ffield", etypes=etypes)
+    at, alist, blist = neighbor.build_lists(s)
+    rng = np.random.default_rng(2)
+    sol = at.echeck == 0
+    frames = []
+    x = at.x.copy()
+    for step in (1, 2, 3):
+        x = x.copy(); x[sol] += rng.normal(scale=0.02, size=(int(sol.sum()), 3))
+        frames.append(x)
+    steps = [(0, s.potdiff, 0, None), (1, s.potdiff, 0, frames[0]), (2, 0.5, 1, frames[1]), (3, 0.5, 0, frames[2])]
+    tokens = fix_command_for(s)
+    tokens[6] = "v_dv"                                   # the potential difference as an equal-style variable (:266-272, :1143)
+    lists = [alist] if alist is blist else [alist, blist]
+    case = str(tmp_path / "case.txt")
+    write_case(case, s, at, lists, tokens, steps, variable=("dv", s.potdiff))
+    res, proc = run_driver(case, str(tmp_path))
+    assert res["rc"] == 0 and res["error"] is None, proc.stdout[-2000:] + proc.stderr[-2000:]
+
+    fx = FixConp(s)                                      # same library through ctypes
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    ele = np.nonzero(at.echeck[:at.nlocal] != 0)[0]
+    def check(ts):
+        for i in ele:
+            assert res["q"][ts][int(at.tag[i])] == at.q[i], (ts, i)
+        assert res["scalar"][ts] == fx.compute_scalar()
+    check(0)
+    for ts, pd, reneigh, xs in steps[1:]:
+        at.x[:] = xs
+        if reneigh:
+            fx.post_neighbor(at)
+        fx.pre_force(at, ts, pd)
+        check(ts)
+    fx.close()
+    # the reference's screen and log-file lines (fix_conp.cpp:458-461, 1006-1009, 787, 857, 564-566)
+    screen = "\n".join(res["screen"])
+    assert "conp output: <e,e> = " in screen and "conp output: <d,d> = " in screen
+    log = open(tmp_path / "log_conp").read().splitlines()
+    assert log[0] == "A matrix calculating ..." and log[1].startswith("A matrix calculation time  = ")
+    assert [l.split("=")[0] for l in log[2:]] == ["B vector calculation time ", "Coulomb calculation time ", "Kspace calculation time "]
+
+
+def test_post_force_through_the_glue_matches_the_ctypes_path(tmp_path):
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab")
+    rng = np.random.default_rng(9)
+    ele_idx = np.nonzero(s.echeck != 0)[0]; sol_idx = np.nonzero((s.echeck == 0) & (s.q != 0))[0]
+    for k in range(6):                                    # a few electrolyte atoms inside the Gaussian overlap range
+        d = rng.normal(size=3); d *= rng.uniform(0.4, 1.1) / np.linalg.norm(d)
+        s.x[sol_idx[k]] = s.x[ele_idx[3 * k]] + d
+    s.x[:, :2] = s.boxlo[:2] + np.mod(s.x[:, :2] - s.boxlo[:2], s.prd[:2])
+    at, alist, blist = neighbor.build_lists(s)
+    lists = [alist] if alist is blist else [alist, blist]
+    case = str(tmp_path / "case.txt")
+    write_case(case, s, at, lists, fix_command_for(s), [(0, s.potdiff, 0, None)])
+    res, proc = run_driver(case, str(tmp_path))
+    assert res["rc"] == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    f, ek, ec, vir = fx.post_force(at)
+    f = f.reshape(-1, 3)[:at.nlocal]
+    got = res["f"][0]
+    assert np.abs(f).sum() > 0
+    assert np.allclose(got[:3], f.sum(axis=0), rtol=0, atol=1e-9 * np.abs(f).sum())
+    assert got[3] == pytest.approx(np.abs(f).sum(), rel=1e-12)
+    assert got[4] == pytest.approx(ec, rel=1e-12)         # what Pair::ev_tally would have accumulated
+    fx.close()
+
+
+@pytest.mark.parametrize("tokens,modify,message", [
+    (["e", "eleleft", "conp", "1", "eleright", "1.979", "1.0", "log_conp", "bogus"], (), "unknown option"),
+    (["e", "eleleft", "conp", "1", "nogroup", "1.979", "1.0", "log_conp"], (), "Fix conp group ID does not exist"),
+    (["e", "eleleft", "conp", "1", "eleright", "1.979", "v_nope", "log_conp"], (), "potential difference variable does not exist"),
+    (["e", "eleleft", "conp", "1", "eleright", "1.979", "1.0", "log_conp", "pppm"], (), "pppm"),
+    (["e", "eleleft", "conp", "1", "eleright", "1.979", "1.0", "log_conp"], (["ehgo", "kappa", "1.0"],), "basic pair mode"),
+])
+def test_errors_reach_error_all_with_the_reference_messages(tmp_path, tokens, modify, message):
+    s = systems.small_random(ne_side=4, n_elyte=32, lz=60.0)
+    at, alist, blist = neighbor.build_lists(s)
+    case = str(tmp_path / "case.txt")
+    write_case(case, s, at, [alist] if alist is blist else [alist, blist], tokens, [(0, 1.0, 0, None)], modify=modify)
+    res, proc = run_driver(case, str(tmp_path))
+    assert res["rc"] == 2 and res["error"] is not None, proc.stdout[-1000:]
+    assert message in res["error"], res["error"]
