@@ -3,7 +3,10 @@
 // compute_scalar / modify_param, log-file writing, error->all propagation) against libconp_hip.so on a real GPU; the numerical
 // content is checked by tests/test_gpu_glue.py against the ctypes path through the same library.
 //
-// usage: glue_driver CASEFILE   (whitespace-separated tokens, written by the test)
+// usage: glue_driver CASEFILE [provider]   (whitespace-separated tokens, written by the test)
+//   with `provider`: INTEGRATION.md mode B instead -- a handle is set up through the C ABI the way FixConp::init /
+//   setup_post_neighbor would, then KSpaceModuleHip::{conp_setup, a_cal, b_cal} run with the fix's public maps and the result
+//   is printed as "a I J VALUE" (local row I, global column J) and "b I VALUE".
 //   ntypes nlocal nghost
 //   xprd yprd zprd boxlo_x boxlo_y boxlo_z
 //   g_ewald accuracy slab_volfactor slabflag
@@ -28,6 +31,7 @@
 
 #define CONP_GLUE_MOCK 1
 #include "fix_conp_hip.h"
+#include "kspacemodule_hip.h"
 
 using namespace LAMMPS_NS;
 
@@ -126,6 +130,67 @@ int main(int argc, char **argv) {
 
   std::vector<NeighRequest *> requests(8, nullptr);
   neighbor.requests = requests.data();
+
+  if (argc > 2 && std::string(argv[2]) == "provider") {
+    try {
+      auto must = [&](int rc) { if (rc != CONP_OK) throw std::runtime_error(conp_last_error()); };
+      conp_fix_args fa;
+      std::vector<const char *> cargv;
+      for (auto &t : toks) cargv.push_back(t.c_str());
+      must(conp_parse_fix_args(narg, cargv.data(), ntypes, &fa));
+      const int gb = bitmask[group.find(toks[1])], jgb = bitmask[group.find(toks[4])];
+      conp_env env;
+      std::memset(&env, 0, sizeof(env));
+      env.qqrd2e = force.qqrd2e; env.qqr2e = force.qqr2e; env.qe2f = force.qe2f; env.dielectric = force.dielectric;
+      env.newton_pair = force.newton_pair; env.g_ewald = kspace.g_ewald; env.accuracy = kspace.accuracy;
+      env.slab_volfactor = kspace.slab_volfactor; env.slabflag = kspace.slabflag;
+      env.xprd = domain.xprd; env.yprd = domain.yprd; env.zprd = domain.zprd;
+      env.boxlo_x = domain.boxlo[0]; env.boxlo_y = domain.boxlo[1]; env.boxlo_z = domain.boxlo[2];
+      env.ntypes = ntypes; env.cutsq = cutsq_store.data(); env.cut_coul = pair.cut_coul; env.nranks = 1;
+      conp_fix *h = nullptr;
+      must(conp_fix_create(&fa, &env, &h));
+      std::vector<std::vector<int>> firsts(nlists);
+      for (int l = 0; l < nlists; ++l) {
+        ListStore &L = lists[l];
+        firsts[l].assign(L.first.begin(), L.first.end());
+        conp_neighlist v;
+        v.inum = L.nl.inum; v.ilist = L.ilist.data(); v.numneigh = L.numneigh.data(); v.first = firsts[l].data();
+        v.neigh = L.neigh.data(); v.nneigh = (int64_t)L.neigh.size();
+        must(conp_fix_init_list(h, nlists == 1 ? 2 : l, &v));
+      }
+      std::vector<int> ec(nall);
+      for (int i = 0; i < nall; ++i) ec[i] = (mask[i] & gb) ? 1 : ((mask[i] & jgb) ? -1 : 0);
+      conp_atoms a;
+      a.nlocal = nlocal; a.nghost = nghost; a.x = xs.data(); a.q = q.data(); a.type = type.data(); a.tag = tag.data();
+      a.echeck = ec.data();
+      must(conp_fix_setup_post_neighbor(h, &a));
+      conp_info info;
+      must(conp_fix_info(h, &info));
+      int elenum = info.elenum, elenum_all = info.elenum_all;
+      std::vector<int> ele2tag(elenum), ele2eleall(elenum), eleall2tag(elenum_all), eleall2ele(elenum_all + 1), echk(elenum_all),
+          ebuf(elenum_all), tag2eleall(info.maxtag_all + 1);
+      must(conp_fix_get_maps(h, ele2tag.data(), ele2eleall.data(), eleall2tag.data(), eleall2ele.data(), echk.data(), ebuf.data(),
+                             tag2eleall.data()));
+      const int *e2ea = ele2eleall.data();
+      KSpaceModuleHip km(&lmp, h, gb, jgb, &e2ea, &elenum, &elenum_all);
+      km.conp_setup(true);
+      km.conp_post_neighbor(true, true);
+      km.a_read();
+      std::vector<double> aaa((size_t)elenum * elenum_all, 0.0), bbb(elenum, 0.0);
+      km.a_cal(aaa.data());
+      km.b_cal(bbb.data());
+      for (int i = 0; i < elenum; ++i) {
+        std::printf("b %d %.17g\n", i, bbb[i]);
+        for (int j = 0; j < elenum_all; ++j) std::printf("a %d %d %.17g\n", i, j, aaa[(size_t)i * elenum_all + j]);
+      }
+      for (int i = 0; i < elenum; ++i) std::printf("m %d %d\n", i, ele2eleall[i]);
+      conp_fix_destroy(h);
+    } catch (const std::exception &e) {
+      std::printf("ERROR: %s\n", e.what());
+      return 2;
+    }
+    return 0;
+  }
 
   try {
     FixConpHip fix(&lmp, narg, fargv.data());

@@ -49,10 +49,10 @@ def write_case(path, s, at, lists, tokens, steps, variable=("-", 0.0), modify=()
         fh.write("\n".join(out) + "\n")
 
 
-def run_driver(case, cwd):
+def run_driver(case, cwd, *extra):
     if not os.path.exists(DRIVER):            # normally built by __graft_entry__.build(); g++ is on the GPU box too
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "driver"])
-    p = subprocess.run([DRIVER, case], cwd=cwd, capture_output=True, text=True, timeout=300)
+    p = subprocess.run([DRIVER, case, *extra], cwd=cwd, capture_output=True, text=True, timeout=300)
     res = {"scalar": {}, "q": {}, "f": {}, "error": None, "screen": [], "rc": p.returncode}
     for line in p.stdout.splitlines():
         t = line.split()
@@ -157,3 +157,38 @@ def test_errors_reach_error_all_with_the_reference_messages(tmp_path, tokens, mo
     res, proc = run_driver(case, str(tmp_path))
     assert res["rc"] == 2 and res["error"] is not None, proc.stdout[-1000:]
     assert message in res["error"], res["error"]
+
+
+@pytest.mark.parametrize("mode", ["slab", "ffield"])
+def test_kspace_provider_class_executed(tmp_path, mode):
+    """INTEGRATION.md mode B: KSpaceModuleHip::{conp_setup, a_cal, b_cal} called like FixConp calls its provider
+    (aaa[elenum][elenum_all] accumulated, bbb[elenum] overwritten, local electrode order) == the C-ABI provider calls"""
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode=mode)
+    at, alist, blist = neighbor.build_lists(s)
+    case = str(tmp_path / "case.txt")
+    write_case(case, s, at, [alist] if alist is blist else [alist, blist], fix_command_for(s), [(0, s.potdiff, 0, None)])
+    res, proc = run_driver(case, str(tmp_path), "provider")
+    assert res["rc"] == 0 and res["error"] is None, proc.stdout[-2000:] + proc.stderr[-2000:]
+    a_loc, b_loc, e2ea = {}, {}, {}
+    for line in proc.stdout.splitlines():
+        t = line.split()
+        if t[0] == "a":
+            a_loc[(int(t[1]), int(t[2]))] = float(t[3])
+        elif t[0] == "b":
+            b_loc[int(t[1])] = float(t[2])
+        elif t[0] == "m":
+            e2ea[int(t[1])] = int(t[2])
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    n = at.nlocal
+    fx.km_conp_setup(float((at.q[:n] ** 2).sum()), n)
+    a_full = fx.km_a_cal(at)
+    b_all = fx.km_b_cal(at)
+    ne = fx.info().elenum_all
+    assert len(b_loc) == fx.info().elenum and len(a_loc) == len(b_loc) * ne
+    assert np.array_equal(np.array([e2ea[i] for i in range(len(e2ea))]), fx.maps()["ele2eleall"])
+    for i in range(len(b_loc)):
+        assert b_loc[i] == b_all[e2ea[i]]
+        assert np.array_equal(np.array([a_loc[(i, j)] for j in range(ne)]), a_full[e2ea[i]])
+    fx.close()
