@@ -79,7 +79,12 @@ void FixConpHip::init() {
     env.slab_volfactor = force->kspace->slab_volfactor; env.slabflag = force->kspace->slabflag;
     env.xprd = domain->xprd; env.yprd = domain->yprd; env.zprd = domain->zprd; env.boxlo_z = domain->boxlo[2];
     env.boxlo_x = domain->boxlo[0]; env.boxlo_y = domain->boxlo[1];
-    // `pppm` keyword: mesh + order of the pppm/conp kspace style (a PPPM subclass exposing nx_pppm, ny_pppm, nz_pppm, order)
+    // `pppm` keyword (fix_conp.cpp:400-405 looks for a pppm/conp kspace style): the mesh and stencil order LAMMPS' PPPM chose are
+    // public KSpace members; with a non-mesh style they stay 0 and the library answers with the reference's error message
+    if (args.pppm) {
+      env.pppm_nx = force->kspace->nx_pppm; env.pppm_ny = force->kspace->ny_pppm; env.pppm_nz = force->kspace->nz_pppm;
+      env.pppm_order = force->kspace->order;
+    }
     env.ntypes = atom->ntypes; env.cutsq = cutsq_flat.data();
     env.cut_coul = *(double *)coulpair->extract("cut_coul", itmp);
     env.one_electrode = (groupbit == jgroupbit);                           // :295

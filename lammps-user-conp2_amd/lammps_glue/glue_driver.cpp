@@ -9,7 +9,7 @@
 //   is printed as "a I J VALUE" (local row I, global column J) and "b I VALUE".
 //   ntypes nlocal nghost
 //   xprd yprd zprd boxlo_x boxlo_y boxlo_z
-//   g_ewald accuracy slab_volfactor slabflag
+//   g_ewald accuracy slab_volfactor slabflag nx_pppm ny_pppm nz_pppm order      (mesh 0 0 0 0 = not a PPPM style)
 //   qqrd2e qqr2e qe2f dielectric newton_pair cut_coul
 //   cutsq[(ntypes+1)^2]
 //   ngroups  { name bit } ...
@@ -57,7 +57,8 @@ int main(int argc, char **argv) {
   const int nall = nlocal + nghost;
   in >> domain.xprd >> domain.yprd >> domain.zprd >> domain.boxlo[0] >> domain.boxlo[1] >> domain.boxlo[2];
   domain.zprd_half = 0.5 * domain.zprd;
-  in >> kspace.g_ewald >> kspace.accuracy >> kspace.slab_volfactor >> kspace.slabflag;
+  in >> kspace.g_ewald >> kspace.accuracy >> kspace.slab_volfactor >> kspace.slabflag >> kspace.nx_pppm >> kspace.ny_pppm >>
+      kspace.nz_pppm >> kspace.order;
   kspace.energy = 0.0;
   in >> force.qqrd2e >> force.qqr2e >> force.qe2f >> force.dielectric >> force.newton_pair >> pair.cut_coul;
   const int nt1 = ntypes + 1;

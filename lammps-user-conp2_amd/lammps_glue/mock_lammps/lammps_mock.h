@@ -19,7 +19,8 @@ class Error { public: [[noreturn]] void all(const char *, int, const std::string
 class Memory {};
 class Atom { public: int nlocal, nghost, ntypes; bigint natoms; double **x, **f, *q; int *type, *mask; tagint *tag; int map(tagint);
              int *map_array = nullptr; int map_size = 0; };
-class KSpace { public: double g_ewald, accuracy, slab_volfactor, energy; int slabflag; virtual ~KSpace() {} virtual void setup(); };
+class KSpace { public: double g_ewald, accuracy, slab_volfactor, energy; int slabflag; int nx_pppm = 0, ny_pppm = 0, nz_pppm = 0, order = 0;
+               virtual ~KSpace() {} virtual void setup(); };
 class Pair { public: double **cutsq; double eng_coul, virial[6]; double cut_coul = 0.0; virtual ~Pair() {} virtual void *extract(const char *, int &); void ev_tally(int, int, int, int, double, double, double, double, double, double); };
 class Force { public: double qqrd2e, qqr2e, qe2f, dielectric; int newton_pair; KSpace *kspace; Pair *pair; Pair *pair_match(const std::string &, int, int nsub = 0); };
 class Domain { public: double xprd, yprd, zprd, zprd_half, boxlo[3]; };

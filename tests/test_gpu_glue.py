@@ -19,12 +19,12 @@ DRIVER = os.path.join(ROOT, "lammps-user-conp2_amd", "lammps_glue", "glue_driver
 BIT = {"all": 1, "eleleft": 2, "eleright": 4}
 
 
-def write_case(path, s, at, lists, tokens, steps, variable=("-", 0.0), modify=()):
+def write_case(path, s, at, lists, tokens, steps, variable=("-", 0.0), modify=(), mesh=(0, 0, 0, 0)):
     out = []
     w = lambda *a: out.append(" ".join(repr(float(v)) if isinstance(v, (float, np.floating)) else str(v) for v in a))
     w(s.ntypes, at.nlocal, at.nghost)
     w(*[float(v) for v in s.prd], *[float(v) for v in s.boxlo])
-    w(float(s.g_ewald), float(s.accuracy), float(s.slab_volfactor), int(s.slabflag))
+    w(float(s.g_ewald), float(s.accuracy), float(s.slab_volfactor), int(s.slabflag), *mesh)
     w(systems.QQRD2E, systems.QQR2E, systems.QE2F, 1.0, int(s.newton), float(s.cutoff))
     w(*[float(v) for v in s.cutsq_table().ravel()])
     w(len(BIT)); [w(k, v) for k, v in BIT.items()]
@@ -191,4 +191,25 @@ def test_kspace_provider_class_executed(tmp_path, mode):
     for i in range(len(b_loc)):
         assert b_loc[i] == b_all[e2ea[i]]
         assert np.array_equal(np.array([a_loc[(i, j)] for j in range(ne)]), a_full[e2ea[i]])
+    fx.close()
+
+
+def test_pppm_keyword_takes_the_mesh_from_the_kspace_style(tmp_path):
+    """`pppm`: FixConpHip reads nx_pppm / ny_pppm / nz_pppm / order from force->kspace (the public KSpace members a PPPM style
+    fills) -- same charges as the ctypes path given the same mesh"""
+    s = systems.deck("dilute", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    case = str(tmp_path / "case.txt")
+    tokens = fix_command_for(s, extra=["pppm"])
+    write_case(case, s, at, [alist, blist], tokens, [(0, s.potdiff, 0, None)], mesh=(27, 24, 144, 5))
+    res, proc = run_driver(case, str(tmp_path))
+    assert res["rc"] == 0 and res["error"] is None, proc.stdout[-2000:] + proc.stderr[-2000:]
+    fx = FixConp(s, extra_args=["pppm"], pppm_mesh=(27, 24, 144), pppm_order=5)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    ele = np.nonzero(at.echeck[:at.nlocal] != 0)[0]
+    got = np.array([res["q"][0][int(at.tag[i])] for i in ele])
+    # the mesh spread uses f64 atomics: equal up to the order of the additions
+    assert np.abs(got - at.q[ele]).max() <= 1e-12 * np.abs(at.q[ele]).max()
     fx.close()
