@@ -57,3 +57,23 @@ def test_no_cpu_fallback():
     with pytest.raises(capi.ConpError) as e:
         capi.FixConp(systems.deck("dilute"))
     assert e.value.code == -3
+
+
+def test_glue_driver_fails_loudly_without_a_gpu(tmp_path):
+    """the C++ glue on a box without a GPU: FixConpHip::init -> conp_fix_create -> error->all, no CPU path behind it"""
+    import os
+    import subprocess
+    from helpers import has_gpu
+    if has_gpu():
+        pytest.skip("GPU present")
+    from conp_amd import neighbor
+    from conp_amd.capi import fix_command_for
+    from test_gpu_glue import DRIVER, write_case
+    subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "driver"], stdout=subprocess.DEVNULL)
+    s = systems.small_random(ne_side=4, n_elyte=32, lz=60.0)
+    at, alist, blist = neighbor.build_lists(s)
+    case = str(tmp_path / "case.txt")
+    write_case(case, s, at, [alist] if alist is blist else [alist, blist], fix_command_for(s), [(0, 1.0, 0, None)])
+    p = subprocess.run([DRIVER, case], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2
+    assert "ERROR: " in p.stdout and "no CPU fallback" in p.stdout
