@@ -132,14 +132,13 @@ void FixConpHip::init_list(int, NeighList *ptr) {                         // :36
 
 conp_atoms FixConpHip::view() {
   const int nall = atom->nlocal + atom->nghost;
-  xbuf.resize(3 * (size_t)nall);
   echeck.resize(nall);
-  for (int i = 0; i < nall; ++i) {
-    for (int c = 0; c < 3; ++c) xbuf[3 * (size_t)i + c] = atom->x[i][c];
+  for (int i = 0; i < nall; ++i)
     echeck[i] = (atom->mask[i] & groupbit) ? 1 : ((atom->mask[i] & jgroupbit) ? -1 : 0);   // electrode_check :599-605
-  }
   conp_atoms a;
-  a.nlocal = atom->nlocal; a.nghost = atom->nghost; a.x = xbuf.data(); a.q = atom->q; a.type = atom->type; a.tag = atom->tag;
+  // atom->x is a LAMMPS 2-d array (Memory::create): one contiguous [nmax][3] block behind the row pointers
+  a.nlocal = atom->nlocal; a.nghost = atom->nghost; a.x = nall ? &atom->x[0][0] : nullptr; a.q = atom->q; a.type = atom->type;
+  a.tag = atom->tag;
   a.echeck = echeck.data();
   return a;
 }

@@ -51,7 +51,7 @@ class FixConpHip : public Fix {
   bool postforceflag;
   std::vector<double> fbuf;
   std::vector<std::vector<std::string>> pending_modify;
-  std::vector<double> xbuf, cutsq_flat;
+  std::vector<double> cutsq_flat;
   std::vector<int> echeck, first_a, first_b, neigh_a, neigh_b;
   conp_atoms view();
   void push_list(int which, class NeighList *l, std::vector<int> &first, std::vector<int> &neigh);
