@@ -151,6 +151,7 @@ struct conp_fix {
   ~conp_fix() {
     prof.collect();
     drop_graph();
+    if (h_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_pin); }
     for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -503,9 +504,35 @@ struct conp_fix {
     sync();
   }
 
+  // Library-owned page-locked staging for the host-buffer hooks: the charges and scalars come back in ONE place with one
+  // stream synchronisation (a hipMemcpyAsync into pageable memory blocks per call), and small x / q uploads go through it so
+  // that they are real asynchronous DMA transfers.
+  double *h_pin = nullptr;
+  size_t h_pin_n = 0;
+  double *pinned(size_t n) {
+    if (n > h_pin_n) {
+      if (h_pin) { sync(); (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_n = 0; }
+      const size_t want = n + n / 4 + 64;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_pin), want * sizeof(double), hipHostMallocDefault));
+      h_pin_n = want;
+    }
+    return h_pin;
+  }
+  static constexpr size_t STAGE_MAX = 1u << 16;      // doubles: above 512 KB the pageable copy pipelines better than memcpy + DMA
   void upload_xq(const conp_atoms *at) {
-    HIP_TRY(hipMemcpyAsync(d_x.p, at->x, (size_t)nall * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(d_q.p, at->q, (size_t)nall * sizeof(double), hipMemcpyHostToDevice, stream));
+    const size_t nx = (size_t)nall * 3, nq = (size_t)nall;
+    if (nx + nq <= STAGE_MAX) {
+      // results live in the first ne_pad + 8 doubles (update_charge); uploads behind them
+      double *st = pinned((size_t)ne_pad + 8 + nx + nq) + ne_pad + 8;
+      sync();                                          // the previous update's transfers out of the staging area are done
+      std::memcpy(st, at->x, nx * sizeof(double));
+      std::memcpy(st + nx, at->q, nq * sizeof(double));
+      HIP_TRY(hipMemcpyAsync(d_x.p, st, nx * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(d_q.p, st + nx, nq * sizeof(double), hipMemcpyHostToDevice, stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(d_x.p, at->x, nx * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(d_q.p, at->q, nq * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
   }
 
   // km_ewald.cpp:147-151 + :584-666 : k-space part of A into d_A (strict lower triangle + diagonal + slab on j <= i)
@@ -910,7 +937,7 @@ struct conp_fix {
   }
 
   void finish_scalar(double potdiff) {
-    double h[4];
+    double *h = pinned((size_t)ne_pad + 8) + ne_pad;
     HIP_TRY(hipMemcpyAsync(h, d_scalars.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     scalar_output = (args.conq || args.cond) ? h[3] : potdiff * totsetq + h[1];   // fix_conp.cpp:1159 / fix_conq.cpp:78-80 / fix_cond.cpp:116
@@ -922,9 +949,9 @@ struct conp_fix {
     const int ne = idx.elenum_all;
     if (args.minimizer == CONP_SOLVER_INV) solve_device();
     scatter_device(nullptr, potdiff);
-    std::vector<double> qe(ne);
-    HIP_TRY(hipMemcpyAsync(qe.data(), d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
-    finish_scalar(potdiff);
+    double *qe = pinned((size_t)ne_pad + 8);
+    HIP_TRY(hipMemcpyAsync(qe, d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+    finish_scalar(potdiff);                 // one synchronisation for the charges and the scalars
     collect_b_times();
     const int n = at->nlocal + at->nghost;
     for (int i = 0; i < n; ++i) {        // owned and ghost electrode atoms :1153-1158

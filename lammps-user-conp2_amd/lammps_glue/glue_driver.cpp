@@ -20,6 +20,7 @@
 //   narg tok...                                          the fix command
 //   nsteps { ntimestep potdiff_value reneighbor(0/1) has_x(0/1) [x y z per atom] } ...
 // output (stdout): "scalar STEP VALUE", "q STEP TAG VALUE" for electrode atoms, "f STEP ..." sums, "ERROR: msg" + exit 2.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -241,6 +242,15 @@ int main(int argc, char **argv) {
       for (int i = 0; i < nlocal; ++i) for (int c = 0; c < 3; ++c) { fsum[c] += fs[3 * (size_t)i + c]; fabs_ += std::abs(fs[3 * (size_t)i + c]); }
       std::printf("f %ld %.17g %.17g %.17g %.17g eng_coul %.17g kspace_energy %.17g\n", ts, fsum[0], fsum[1], fsum[2], fabs_,
                   pair.eng_coul, kspace.energy);
+    }
+    // GLUE_DRIVER_TIME=N: wall time of N more pre_force calls -- the PCIe-inclusive rate a LAMMPS run would see through the glue
+    if (const char *tn = std::getenv("GLUE_DRIVER_TIME")) {
+      const int n = std::atoi(tn);
+      for (int k = 0; k < 3; ++k) { update.ntimestep += 1; fix.pre_force(0); }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int k = 0; k < n; ++k) { update.ntimestep += 1; fix.pre_force(0); }
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (n > 0 ? n : 1);
+      std::printf("time_pre_force_ms %.6f\n", ms);
     }
   } catch (const std::exception &e) {
     std::printf("ERROR: %s\n", e.what());
