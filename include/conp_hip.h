@@ -82,6 +82,12 @@ typedef struct {
   /* `pppm` keyword (fix_conp.cpp:162, 401-404): mesh and stencil order of the pppm/conp kspace style, i.e. LAMMPS PPPM's
    * nx_pppm, ny_pppm, nz_pppm, order (pppm_conp.cpp:242, 206); ignored without the keyword */
   int pppm_nx, pppm_ny, pppm_nz, pppm_order;
+  /* 1: every ghost atom is a periodic image of an owned atom and moves with it -- what LAMMPS' forward communication
+   * guarantees between re-neighbourings (orthogonal box).  The host-buffer hooks then upload the owned x, q only and rebuild
+   * the ghosts on the device as x_owner + n*prd (the arithmetic of Comm's pack_comm: same bits).  Checked at every
+   * (setup_)post_neighbor; a ghost that is not an exact image switches the handle back to full uploads.  0: x, q of ghosts
+   * are read from the caller's arrays at every hook, like the reference reads atom->x. */
+  int ghost_images;
 } conp_env;
 
 /* FixConp::FixConp + FixConp::init (fix_conp.cpp:79-201, 245-300) */

@@ -39,7 +39,8 @@ class conp_env(C.Structure):
                 ("slab_volfactor", C.c_double), ("slabflag", C.c_int), ("xprd", C.c_double), ("yprd", C.c_double),
                 ("zprd", C.c_double), ("boxlo_z", C.c_double), ("boxlo_x", C.c_double), ("boxlo_y", C.c_double), ("ntypes", C.c_int), ("cutsq", C.POINTER(C.c_double)),
                 ("cut_coul", C.c_double), ("one_electrode", C.c_int), ("device", C.c_int), ("rank", C.c_int),
-                ("nranks", C.c_int), ("pppm_nx", C.c_int), ("pppm_ny", C.c_int), ("pppm_nz", C.c_int), ("pppm_order", C.c_int)]
+                ("nranks", C.c_int), ("pppm_nx", C.c_int), ("pppm_ny", C.c_int), ("pppm_nz", C.c_int), ("pppm_order", C.c_int),
+                ("ghost_images", C.c_int)]
 
 
 class conp_atoms(C.Structure):
@@ -181,7 +182,8 @@ class FixConp:
     init_list -> setup_post_neighbor -> setup_pre_force -> [post_neighbor] -> pre_force ...."""
 
     def __init__(self, s: "_systems.System", extra_args: Sequence[str] = (), device: int = 0, rank: int = 0,
-                 nranks: int = 1, one_electrode: bool = False, style: str = "conp", pppm_mesh=None, pppm_order: int = 5):
+                 nranks: int = 1, one_electrode: bool = False, style: str = "conp", pppm_mesh=None, pppm_order: int = 5,
+                 ghost_images: bool = False):
         self.lib = load_library()
         self.s = s
         self.args = parse_fix_command(fix_command_for(s, extra_args, style), s.ntypes)
@@ -193,7 +195,8 @@ class FixConp:
                        cut_coul=s.cutoff, one_electrode=int(one_electrode), device=device, rank=rank, nranks=nranks,
                        boxlo_x=float(s.boxlo[0]), boxlo_y=float(s.boxlo[1]),
                        pppm_nx=pppm_mesh[0] if pppm_mesh else 0, pppm_ny=pppm_mesh[1] if pppm_mesh else 0,
-                       pppm_nz=pppm_mesh[2] if pppm_mesh else 0, pppm_order=pppm_order if pppm_mesh else 0)
+                       pppm_nz=pppm_mesh[2] if pppm_mesh else 0, pppm_order=pppm_order if pppm_mesh else 0,
+                       ghost_images=int(ghost_images))
         self.h = C.c_void_p()
         self._check(self.lib.conp_fix_create(C.byref(self.args), C.byref(env), C.byref(self.h)))
         self._keep = {}

@@ -369,6 +369,7 @@ struct conp_fix {
       row1 = (int)((long long)ne * (env.rank + 1) / env.nranks);
     }
     upload_atoms_static(at);
+    map_ghosts(at);
     // electrolyte atoms that enter the structure factors (km_ewald.cpp:686) -- list fixed until the next re-neighbour
     elyte_idx_h.clear();
     for (int i = 0; i < at->nlocal; ++i) if (at->echeck[i] == 0 && at->q[i] != 0) elyte_idx_h.push_back(i);
@@ -518,9 +519,41 @@ struct conp_fix {
     }
     return h_pin;
   }
+  // conp_env.ghost_images: which owned atom and which periodic image every ghost is (verified here, at a re-neighbour)
+  bool ghost_mode = false;
+  DevBuf<int> d_ghost_owner, d_ghost_img;
+  void map_ghosts(const conp_atoms *at) {
+    ghost_mode = false;
+    if (!env.ghost_images || at->nghost <= 0) return;
+    const int nl_ = at->nlocal, ng = at->nghost;
+    const double prd[3] = {env.xprd, env.yprd, env.zprd};
+    std::vector<int> owner(ng), img((size_t)ng * 3);
+    for (int g = 0; g < ng; ++g) {
+      const int i = nl_ + g, t = at->tag[i];
+      const int o = (t >= 0 && t < (int)idx.tag2local.size()) ? idx.tag2local[t] : -1;
+      if (o < 0 || at->q[i] != at->q[o]) return;                       // not an image of an owned atom: full uploads
+      for (int c = 0; c < 3; ++c) {
+        const double xo = at->x[3 * (size_t)o + c], xg = at->x[3 * (size_t)i + c];
+        const int n = (int)std::lround((xg - xo) / prd[c]);
+        const double shift = n * prd[c];
+        if (xo + shift != xg) return;
+        img[3 * (size_t)g + c] = n;
+      }
+      owner[g] = o;
+    }
+    d_ghost_owner.upload(owner, stream); d_ghost_img.upload(img, stream);
+    ghost_mode = true;
+  }
+
   static constexpr size_t STAGE_MAX = 1u << 16;      // doubles: above 512 KB the pageable copy pipelines better than memcpy + DMA
   void upload_xq(const conp_atoms *at) {
-    const size_t nx = (size_t)nall * 3, nq = (size_t)nall;
+    const int nup = ghost_mode ? at->nlocal : nall;    // ghost_images: owned atoms only, ghosts rebuilt on the device
+    upload_xq_n(at, nup);
+    if (ghost_mode)
+      launch_ghost_fill(stream, at->nlocal, at->nghost, d_ghost_owner.p, d_ghost_img.p, env.xprd, env.yprd, env.zprd, d_x.p, d_q.p);
+  }
+  void upload_xq_n(const conp_atoms *at, int nup) {
+    const size_t nx = (size_t)nup * 3, nq = (size_t)nup;
     if (nx + nq <= STAGE_MAX) {
       // results live in the first ne_pad + 8 doubles (update_charge); uploads behind them
       double *st = pinned((size_t)ne_pad + 8 + nx + nq) + ne_pad + 8;

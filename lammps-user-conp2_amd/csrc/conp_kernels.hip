@@ -88,6 +88,25 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nl, int nl_
   }
 }
 
+// ghost atoms as periodic images of owned atoms: x_g = x_owner + n * prd, q_g = q_owner (conp_env.ghost_images).
+// `n * prd` is formed first and then added, like Comm::pack_comm adds `pbc * prd` -- the same bits as LAMMPS' own ghosts.
+__global__ void ghost_fill_kernel(int nlocal, int nghost, const int *__restrict__ owner, const int *__restrict__ img,
+                                  double px, double py, double pz, double *__restrict__ x, double *__restrict__ q) {
+#pragma clang fp contract(off)
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nghost) return;
+  const int o = owner[g], i = nlocal + g;
+  const double dx = img[3 * g] * px, dy = img[3 * g + 1] * py, dz = img[3 * g + 2] * pz;
+  x[3 * i] = x[3 * o] + dx; x[3 * i + 1] = x[3 * o + 1] + dy; x[3 * i + 2] = x[3 * o + 2] + dz;
+  q[i] = q[o];
+}
+
+void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, const int *img, double px, double py, double pz,
+                       double *x, double *q) {
+  if (nghost <= 0) return;
+  hipLaunchKernelGGL(ghost_fill_kernel, dim3((nghost + 255) / 256), dim3(256), 0, s, nlocal, nghost, owner, img, px, py, pz, x, q);
+}
+
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part) {

@@ -89,6 +89,7 @@ void FixConpHip::init() {
     env.cut_coul = *(double *)coulpair->extract("cut_coul", itmp);
     env.one_electrode = (groupbit == jgroupbit);                           // :295
     env.device = 0; env.rank = 0; env.nranks = 1;
+    env.ghost_images = 1;     // LAMMPS ghosts are images of owned atoms kept current by forward communication
     fail_if(conp_fix_create(&args, &env, &h));
     for (auto &toks : pending_modify) {
       std::vector<const char *> ptrs;

@@ -391,6 +391,57 @@ def test_device_update_graph_replay_matches_direct_launches():
     fx.close(); ref.close()
 
 
+def test_ghost_image_mode_uploads_owned_atoms_only_and_gives_the_same_bits():
+    """conp_env.ghost_images (what the LAMMPS glue sets): ghosts are rebuilt on the device from their owners and image shifts
+    instead of being uploaded -- identical charges, also after the atoms moved and after a re-neighbour; a ghost that is NOT an
+    exact image makes the handle fall back to full uploads"""
+    s = systems.deck("dilute", "slab", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    assert at.nghost > 0
+    prd = s.prd
+    img = np.rint((at.x[at.nlocal:] - at.x[at.owner[at.nlocal:]]) / prd)
+    def refresh_ghosts():
+        at.x[at.nlocal:] = at.x[at.owner[at.nlocal:]] + img * prd        # what forward communication does
+        at.q[at.nlocal:] = at.q[at.owner[at.nlocal:]]
+    refresh_ghosts()
+    fg = FixConp(s, ghost_images=True)
+    ff = FixConp(s)
+    rng = np.random.default_rng(4)
+    loc_sol = np.nonzero(at.echeck[:at.nlocal] == 0)[0]
+    qa = at.q.copy()
+    for fx in (fg, ff):
+        at.q[:] = qa
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.setup_pre_force(at, 0, s.potdiff)
+    q_first = at.q.copy()
+    for step in range(1, 5):
+        at.x[loc_sol] += rng.normal(scale=0.02, size=(len(loc_sol), 3))
+        refresh_ghosts()
+        res = []
+        for fx in (fg, ff):
+            if step == 3:
+                fx.post_neighbor(at)
+            fx.pre_force(at, step, s.potdiff)
+            res.append(at.q.copy())
+        assert np.array_equal(res[0], res[1]), step
+        assert not np.array_equal(res[0], q_first)
+    # stale ghost arrays are fine in image mode (the library does not read them between re-neighbours) ...
+    x_keep = at.x.copy()
+    at.x[at.nlocal:] += 0.3
+    fg.pre_force(at, 5, s.potdiff); qg = at.q.copy()
+    at.x[:] = x_keep
+    ff.pre_force(at, 5, s.potdiff)
+    assert np.array_equal(qg, at.q)
+    # ... and a ghost that is not an image at a re-neighbour switches the handle to full uploads
+    at.x[at.nlocal] += 1e-3
+    fg.post_neighbor(at); ff.post_neighbor(at)
+    fg.pre_force(at, 6, s.potdiff); qg = at.q.copy()
+    ff.pre_force(at, 6, s.potdiff)
+    assert np.array_equal(qg, at.q)
+    fg.close(); ff.close()
+
+
 def _gpu_shard_worker(rank, world, port, out):
     import os, sys
     import torch
