@@ -360,6 +360,9 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 // are summed in two levels:  level 1 (blockIdx.y = group g) adds splits [16 g, 16 g + 16) into slot 16 g in place,
 // level 2 adds the group slots (stride 16) and writes G / Gwf.  level 0 = everything in one pass.
 constexpr int SKR_GROUP = 16;
+// two levels (one more launch) once the most-split tile has more than this many partials: measured break-even on the headline
+// box -- 40 partials (one GPU) 4 us faster in one level, 57 (two ranks) equal, 113 (four ranks) 12 us faster in two
+static int skr_two_level_from() { static const int v = getenv("CONP_SKR_TWO") ? atoi(getenv("CONP_SKR_TWO")) : 4 * SKR_GROUP; return v; }
 __global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
                                                         double *__restrict__ part, const double *__restrict__ wfull,
                                                         double *__restrict__ G, double *__restrict__ Gwf, int level) {
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile 
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf) {
   if (ntiles <= 0) return;
-  if (max_nsplit > 2 * SKR_GROUP) {
+  if (max_nsplit > skr_two_level_from()) {
     const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
     hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 1);
     hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 2);
@@ -650,7 +653,7 @@ void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile
   if (ntiles <= 0) return;
   const int nzc16 = (nzc + 15) / 16;
   int level = 0;
-  if (max_nsplit > 2 * SKR_GROUP) {
+  if (max_nsplit > skr_two_level_from()) {
     const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
     hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, nullptr, 1);
     level = 2;
