@@ -494,6 +494,8 @@ struct conp_fix {
       }
       const bool off = getenv("CONP_NO_ZCLASS") != nullptr;
       nzc = (!off && cls.size() <= 64 && 4 * cls.size() <= (size_t)ne) ? (int)cls.size() : 0;   // worthwhile only if it compresses
+      // b_zc_dot keeps Hc for 32 rows of every row tile and every class in LDS
+      if ((size_t)plan.n_row_tiles * 32 * (size_t)nzc * sizeof(double) > 96 * 1024) nzc = 0;
       if (nzc > 0) {
         std::vector<double> Tzc((size_t)plan.C_pad * 64, 0.0);
         for (int t = 0; t < plan.C_pad; ++t)

@@ -555,28 +555,39 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
   for (int r = 0; r < 4; ++r) out[(size_t)(16 * rf + fk + 4 * r) * 64 + 16 * wave + fr] = acc[r];
 }
 
-// grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16
-__global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad,
+// grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16.
+// The block first sums the 4 k-quarter slots of Hc for ITS rows and the nzc classes in use into LDS (one pass of coalesced
+// loads) -- reading them per thread and per row from global cost more than the 42 MB Rp stream itself (20 -> 11 us).
+__global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
                                                         const double *__restrict__ Rp, const double *__restrict__ Hc4,
                                                         const int *__restrict__ zclass, double *__restrict__ bk) {
+  extern __shared__ __attribute__((aligned(16))) char zc_smem[];
+  double *H = reinterpret_cast<double *>(zc_smem);          // [n_own * 32][nzc]
   __shared__ double red[16][64];
   const int a = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + a;
   const int zc = zclass[i];
   const size_t hp = (size_t)R_pad * 64;
+  for (int e = threadIdx.x; e < n_own * 32 * nzc; e += 1024) {
+    const int rowl = e / nzc, cls = e - rowl * nzc;
+    const size_t r = (size_t)own_rt[rowl >> 5] * 128 + blockIdx.y * 32 + (rowl & 31);
+    H[e] = (Hc4[r * 64 + cls] + Hc4[hp + r * 64 + cls]) + (Hc4[2 * hp + r * 64 + cls] + Hc4[3 * hp + r * 64 + cls]);
+  }
+  __syncthreads();
   double sum = 0.0;
-  // 4 row tiles at a time: 8 Rp rows + their Hc entries in flight per thread
+  // 4 row tiles at a time: 8 Rp rows in flight per thread
   for (int k0 = 0; k0 < n_own; k0 += 4) {        // this rank's row tiles
     double rp[8], hc[8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const bool ok = k0 + u < n_own;
-      const int rt = own_rt[ok ? k0 + u : k0];
+      const int kk = ok ? k0 + u : k0;
+      const int rt = own_rt[kk];
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const size_t r = (size_t)rt * 128 + blockIdx.y * 32 + w + 16 * v;
         rp[2 * u + v] = ok ? Rp[r * ne_pad + i] : 0.0;
-        hc[2 * u + v] = (Hc4[r * 64 + zc] + Hc4[hp + r * 64 + zc]) + (Hc4[2 * hp + r * 64 + zc] + Hc4[3 * hp + r * 64 + zc]);
+        hc[2 * u + v] = H[(kk * 32 + w + 16 * v) * nzc + zc];
       }
     }
 #pragma unroll
@@ -590,6 +601,13 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
     for (int k = 0; k < 16; ++k) tot += red[k][a];
     bk[(size_t)blockIdx.y * ne_pad + i] = -tot;
   }
+}
+
+static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
+                            const double *Hc, const int *zclass, double *bk_part) {
+  const size_t lds = (size_t)(n_own > 0 ? n_own : 1) * 32 * nzc * sizeof(double);      // the host keeps this <= 96 KB (conp_fix.cpp)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(b_zc_dot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 // Planar electrodes with one column tile (nz <= 160): the last partial-tile sum and the Hc product in ONE kernel -- a block
@@ -660,7 +678,7 @@ void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile
   }
   hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
                      nzc16, level);
-  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), 0, s, n_own, own_rt, pl.R_pad, ne_pad, Rp, Hc, zclass, bk_part);
+  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
@@ -668,8 +686,7 @@ void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const
   const int nzc16 = (nzc + 15) / 16;
   hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
-  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), 0, s, n_own, own_rt, pl.R_pad, ne_pad, Rp, Hc,
-                     zclass, bk_part);
+  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 // ================================================================================================
