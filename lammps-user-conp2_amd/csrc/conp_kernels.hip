@@ -360,10 +360,11 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 // are summed in two levels:  level 1 (blockIdx.y = group g) adds splits [16 g, 16 g + 16) into slot 16 g in place,
 // level 2 adds the group slots (stride 16) and writes G / Gwf.  level 0 = everything in one pass.
 constexpr int SKR_GROUP = 16;
+constexpr int SKR_T = 640, SKR_K = 1280 / SKR_T;   // threads per block, elements (of the block's 16 x 80 piece) per thread
 // two levels (one more launch) once the most-split tile has more than this many partials: measured break-even on the headline
 // box -- 40 partials (one GPU) 4 us faster in one level, 57 (two ranks) equal, 113 (four ranks) 12 us faster in two
 static int skr_two_level_from() { static const int v = getenv("CONP_SKR_TWO") ? atoi(getenv("CONP_SKR_TWO")) : 4 * SKR_GROUP; return v; }
-__global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
+__global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
                                                         double *__restrict__ part, const double *__restrict__ wfull,
                                                         double *__restrict__ G, double *__restrict__ Gwf, int level) {
   __shared__ double tr[1280];
@@ -382,8 +383,8 @@ __global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile 
   }
   const size_t step = (size_t)stride * plane;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = threadIdx.x + 320 * k;
+  for (int k = 0; k < SKR_K; ++k) {
+    const int e = threadIdx.x + SKR_T * k;
     const int row = e / 80, cl = e % 80;
     const int rowl = 16 * f16 + row, col = 80 * q + cl;
     double sum = 0.0;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(320) void sk_reduce_kernel(int C_pad, const SkTile 
   const size_t rf = (size_t)tl.rt * 8 + f16;
   double *dst = Gwf + (rf * (C_pad / 4) + (size_t)tl.ct * 80 + 20 * q) * 64;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) dst[threadIdx.x + 320 * k] = tr[threadIdx.x + 320 * k];
+  for (int k = 0; k < SKR_K; ++k) dst[threadIdx.x + SKR_T * k] = tr[threadIdx.x + SKR_T * k];
 }
 
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
@@ -420,10 +421,10 @@ void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int
   if (ntiles <= 0) return;
   if (max_nsplit > skr_two_level_from()) {
     const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 1);
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 2);
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 1);
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 2);
   } else {
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 0);
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 0);
   }
 }
 
@@ -614,7 +615,7 @@ static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_p
 // of sk_reduce already holds its 16 x 80 piece of (w G) in LDS in MFMA-fragment order, exactly the A operand b_hc needs, so the
 // Gwf round trip and one launch go away (the decks' updates are launch-bound).  Same sums in the same order as the two
 // kernels; Hc4 slot = the block's 80-column quarter.
-__global__ __launch_bounds__(320) void sk_reduce_hc_kernel(int C_pad, const SkTile *__restrict__ tiles, const double *__restrict__ part,
+__global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const SkTile *__restrict__ tiles, const double *__restrict__ part,
                                                            const double *__restrict__ wfull, double *__restrict__ G,
                                                            const double *__restrict__ Tzc /*[C_pad][64]*/,
                                                            double *__restrict__ Hc4 /*[4][R_pad][64]*/, int R_pad, int nzc16,
@@ -628,8 +629,8 @@ __global__ __launch_bounds__(320) void sk_reduce_hc_kernel(int C_pad, const SkTi
   const int count = level == 2 ? (tl.nsplit + SKR_GROUP - 1) / SKR_GROUP : tl.nsplit;
   const size_t step = (size_t)stride * plane;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = threadIdx.x + 320 * k;
+  for (int k = 0; k < SKR_K; ++k) {
+    const int e = threadIdx.x + SKR_T * k;
     const int row = e / 80, cl = e % 80;
     const int rowl = 16 * f16 + row, col = 80 * q + cl;
     double sum = 0.0;
@@ -673,10 +674,10 @@ void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile
   int level = 0;
   if (max_nsplit > skr_two_level_from()) {
     const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, nullptr, 1);
+    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, nullptr, 1);
     level = 2;
   }
-  hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(320), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
+  hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
                      nzc16, level);
   launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
