@@ -442,6 +442,34 @@ def test_ghost_image_mode_uploads_owned_atoms_only_and_gives_the_same_bits():
     fg.close(); ff.close()
 
 
+@pytest.mark.parametrize("deck,world", [("il_onelayer", 4), ("dilute", 3), ("cond2", 8)])
+def test_rank_shards_of_b_add_up_to_the_single_rank_vector(deck, world):
+    """k-shard (row tiles dealt by cost) + row-shard of the real-space term: the b vectors of the `world` rank handles, built
+    one after the other on this GPU, sum to the unsharded b.  il_onelayer has 2 row tiles -> two of the four ranks own none;
+    cond2 takes the general projection kernel (rough electrodes)."""
+    s = systems.deck(deck, "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    def b_of(rank, nranks):
+        fx = FixConp(s, rank=rank, nranks=nranks)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.b_cal(at)
+        b = fx.vectors()[0].copy()
+        r0, r1 = fx.row_range()
+        fx.close()
+        return b, (r0, r1)
+    b1, rr = b_of(0, 1)
+    assert rr == (0, len(b1))
+    total = np.zeros_like(b1)
+    edges = []
+    for r in range(world):
+        b, (r0, r1) = b_of(r, world)
+        total += b
+        edges.append((r0, r1))
+    assert edges[0][0] == 0 and edges[-1][1] == len(b1) and all(edges[k][1] == edges[k + 1][0] for k in range(world - 1))
+    assert rel_err(total, b1) < 1e-12
+
+
 def _gpu_shard_worker(rank, world, port, out):
     import os, sys
     import torch
