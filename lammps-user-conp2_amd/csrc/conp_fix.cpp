@@ -109,6 +109,8 @@ struct conp_fix {
   int row0 = 0, row1 = 0, num_cus = 256;
   std::vector<SkItem> items_h;   // sk_gemm work items of this rank
   std::vector<SkTile> tiles_h;   // (row tile, col tile) pairs of this rank, sorted by col tile
+  std::vector<int> ele_pairs_h;    // (atom index, eleall index) of every owned or ghost electrode atom
+  int n_ele_atoms = 0;
   std::vector<int> ct_ptr_h, seg_ptr_h, rt_owner_h, own_rt_h;   // rt_owner_h: rank that owns each row tile; own_rt_h: this rank's
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
@@ -137,7 +139,7 @@ struct conp_fix {
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_pp_egrid, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_pp_egrid, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -345,6 +347,12 @@ struct conp_fix {
     for (int i = 0; i < nall; ++i)
       if (at->echeck[i]) atom2eleall_h[i] = (at->tag[i] <= idx.maxtag_all) ? idx.tag2eleall[at->tag[i]] : -1;
     d_atom2eleall.upload(atom2eleall_h, stream);
+    ele_pairs_h.clear();                       // (atom, eleall) for every owned or ghost electrode atom: the charge scatter list
+    for (int i = 0; i < nall; ++i)
+      if (atom2eleall_h[i] >= 0) { ele_pairs_h.push_back(i); ele_pairs_h.push_back(atom2eleall_h[i]); }
+    n_ele_atoms = (int)(ele_pairs_h.size() / 2);
+    if (ele_pairs_h.empty()) { ele_pairs_h.push_back(0); ele_pairs_h.push_back(0); }
+    d_ele_pairs.upload(ele_pairs_h, stream);
     d_x.reserve((size_t)nall * 3); d_q.reserve(nall);
   }
 
@@ -954,17 +962,17 @@ struct conp_fix {
       }
       launch_cond_potdiff(stream, ne, d_setzvec.p, d_eleallq, d_slab_part.p, n_slab_part, env.zprd, potdiff, cond_vmult,
                           d_scalars.p + 3);
-      launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
+      launch_charge_finish(stream, ne, n_ele_atoms, d_ele_pairs.p, d_elecheck.p, d_eleallq, d_elesetq.p,
                            args.qinit ? d_eleinitq.p : nullptr, 0.0, d_scalars.p + 3, d_qele.p, d_q_atoms, nullptr);
     } else if (args.conq) {
       // fix conq (fix_conq.cpp:41-90): `potdiff` carries the prescribed charge QR; the potential difference follows from
       // the group-1 sum of S b, all on the device
       launch_left_sum(stream, ne, d_elecheck.p, d_eleallq, d_scalars.p + 1);
       launch_conq_potdiff(stream, d_scalars.p + 1, potdiff, totsetq, env.one_electrode, d_scalars.p + 3);
-      launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
+      launch_charge_finish(stream, ne, n_ele_atoms, d_ele_pairs.p, d_elecheck.p, d_eleallq, d_elesetq.p,
                            args.qinit ? d_eleinitq.p : nullptr, 0.0, d_scalars.p + 3, d_qele.p, d_q_atoms, nullptr);
     } else {
-      launch_charge_finish(stream, ne, nall, d_atom2eleall.p, d_elecheck.p, d_eleallq, d_elesetq.p,
+      launch_charge_finish(stream, ne, n_ele_atoms, d_ele_pairs.p, d_elecheck.p, d_eleallq, d_elesetq.p,
                            args.qinit ? d_eleinitq.p : nullptr, potdiff, nullptr, d_qele.p, d_q_atoms, d_scalars.p + 1);
     }
     prof.end(stream);

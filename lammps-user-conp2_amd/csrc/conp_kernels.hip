@@ -788,11 +788,23 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row
   if ((n & 1) == 0) {
     const double2 *s2 = reinterpret_cast<const double2 *>(srow);
     const double2 *b2 = reinterpret_cast<const double2 *>(b);
-    for (int j = lane; j < n / 2; j += 64) {
+    // 4 row loads in flight per lane; the two accumulator pairs are combined in a fixed order
+    double t0 = 0.0, t1 = 0.0;
+    int j = lane;
+    for (; j + 192 < n / 2; j += 256) {
+      const double2 a0 = s2[j], a1 = s2[j + 64], a2 = s2[j + 128], a3 = s2[j + 192];
+      const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
+      s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
+      t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
+      s0 = fma(a2.x, b2v.x, s0); s1 = fma(a2.y, b2v.y, s1);
+      t0 = fma(a3.x, b3.x, t0); t1 = fma(a3.y, b3.y, t1);
+    }
+    for (; j < n / 2; j += 64) {
       const double2 a = s2[j], bb = b2[j];
       s0 = fma(a.x, bb.x, s0);
       s1 = fma(a.y, bb.y, s1);
     }
+    s0 += t0; s1 += t1;
   } else {
     for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
   }
@@ -807,7 +819,8 @@ void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S,
 
 // fix_conp.cpp:1149-1159 in one launch:
 //   blocks 0 .. nb-2 : q_ele[e] = eleallq[e] + dV * elesetq[e] (+ eleinitq[e]) for e < ne, and the same value written to
-//                      every owned or ghost electrode atom i < nall (atom2eleall[i] >= 0)
+//                      every owned or ghost electrode atom: a compact list of (atom index, eleall index) pairs, so that the
+//                      launch covers the electrode atoms, not all nall atoms
 //   last block       : netcharge_left = sum of eleallq over the group-1 atoms (fixed tree)
 __global__ __launch_bounds__(256) void charge_finish_kernel(int ne, int nall, const int *__restrict__ atom2eleall,
                                                             const int *__restrict__ elecheck, const double *__restrict__ eleallq,
@@ -820,13 +833,26 @@ __global__ __launch_bounds__(256) void charge_finish_kernel(int ne, int nall, co
   if (blockIdx.x == gridDim.x - 1) {
     if (!left_out) return;
     __shared__ double red[4];
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};           // 4 loads in flight per thread; fixed association -> reproducible
-    int i = threadIdx.x;
-    for (; i + 768 < ne; i += 1024) {
+    // this one block is the kernel's critical path: 16 independent loads in flight per thread (Ne = 4096: one round);
+    // fixed association -> reproducible
+    double s16[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s4[u] += (elecheck[i + 256 * u] == 1) ? eleallq[i + 256 * u] : 0.0;
+    for (int u = 0; u < 16; ++u) s16[u] = 0.0;
+    for (int i0 = threadIdx.x; i0 < ne; i0 += 4096) {
+      int ec[16];
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = i0 + 256 * u;
+        ec[u] = i < ne ? elecheck[i] : 0;
+        v[u] = i < ne ? eleallq[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s16[u] += (ec[u] == 1) ? v[u] : 0.0;
     }
-    for (int u = 0; i < ne; i += 256, ++u) s4[u] += (elecheck[i] == 1) ? eleallq[i] : 0.0;
+    double s4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] = (s16[u] + s16[u + 4]) + (s16[u + 8] + s16[u + 12]);
     double s = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -839,13 +865,11 @@ __global__ __launch_bounds__(256) void charge_finish_kernel(int ne, int nall, co
     if (eleinitq) v += eleinitq[i];
     q_ele[i] = v;
   }
-  if (q_atoms && i < nall) {
-    const int e = atom2eleall[i];
-    if (e >= 0) {
-      double v = eleallq[e] + potdiff * elesetq[e];
-      if (eleinitq) v += eleinitq[e];
-      q_atoms[i] = v;
-    }
+  if (q_atoms && i < nall) {               // nall = number of owned + ghost ELECTRODE atoms; atom2eleall = (atom, eleall) pairs
+    const int a = atom2eleall[2 * i], e = atom2eleall[2 * i + 1];
+    double v = eleallq[e] + potdiff * elesetq[e];
+    if (eleinitq) v += eleinitq[e];
+    q_atoms[a] = v;
   }
 }
 
