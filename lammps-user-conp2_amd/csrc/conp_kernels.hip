@@ -133,6 +133,15 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
 #ifndef SK_LATE_MODE
 #define SK_LATE_MODE 2
 #endif
+// raise a kernel's dynamic-LDS limit, only when a launch needs more than it was last given: per-update launches must not
+// pay a runtime call each (the decks' updates are bound by host launch cost)
+template <typename K>
+static void ensure_dyn_lds(K kernel, size_t bytes, size_t &granted) {
+  if (bytes <= granted) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  granted = bytes;
+}
+
 constexpr int SK_J = 16;
 constexpr int SK_LD = SK_J + 1;   // 17 doubles: conflict-free for ds_read2st64_b64 / ds_write_b64 (banks mod 32, 16-lane groups)
 constexpr int SK_NF = 128 + 320;
@@ -347,7 +356,8 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
   if (nwg <= 0) return;
   const size_t lds = (size_t)2 * SK_PANEL * sizeof(double);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t granted = 0;
+  ensure_dyn_lds(sk_gemm_kernel, lds, granted);
   static const int dbg = getenv("CONP_SK_DBG") ? atoi(getenv("CONP_SK_DBG")) : 0;   // ablation switches for experiments
   hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, nl_pad, Xt, Yt, Zs, qc, part, dbg);
 }
@@ -519,7 +529,8 @@ __global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, 
 void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr, const SkTile *tiles, const double *Gwf,
                       const double *Rp, const double *Tz, double *bk_part) {
   const size_t lds = ((size_t)320 * 32 + 16 * 32) * sizeof(double);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(b_project_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t granted = 0;
+  ensure_dyn_lds(b_project_kernel, lds, granted);
   hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 32, 2), dim3(1024), lds, s, pl.C_pad, ne_pad, pl.n_col_tiles, ct_ptr, tiles,
                      Gwf, Rp, Tz, bk_part);
 }
@@ -607,7 +618,8 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
                             const double *Hc, const int *zclass, double *bk_part) {
   const size_t lds = (size_t)(n_own > 0 ? n_own : 1) * 32 * nzc * sizeof(double);      // the host keeps this <= 96 KB (conp_fix.cpp)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(b_zc_dot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t granted = 0;
+  ensure_dyn_lds(b_zc_dot_kernel, lds, granted);
   hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
