@@ -360,6 +360,14 @@ struct conp_fix {
   void post_neighbor(const conp_atoms *at) {
     if (!idx.initialised) throw ConpError(CONP_ERR_STATE, "post_neighbor before setup_post_neighbor");
     if (!have_blist) throw ConpError(CONP_ERR_STATE, "post_neighbor: no neighbor list (init_list not called)");
+    static const bool tren = getenv("CONP_TIME_REN") != nullptr;
+    auto tm0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+      if (!tren) return;
+      const auto t = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "  post_neighbor %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - tm0).count());
+      tm0 = t;
+    };
     bool elyte_grew = false;
     const bool grew = idx.post_neighbor(at->nlocal, at->tag, at->echeck, &elyte_grew);
     const int ne = idx.elenum_all;
@@ -376,8 +384,11 @@ struct conp_fix {
       row0 = (int)((long long)ne * env.rank / env.nranks);
       row1 = (int)((long long)ne * (env.rank + 1) / env.nranks);
     }
+    mark("index maps");
     upload_atoms_static(at);
+    mark("atoms static");
     map_ghosts(at);
+    mark("ghost map");
     // electrolyte atoms that enter the structure factors (km_ewald.cpp:686) -- list fixed until the next re-neighbour
     elyte_idx_h.clear();
     for (int i = 0; i < at->nlocal; ++i) if (at->echeck[i] == 0 && at->q[i] != 0) elyte_idx_h.push_back(i);
@@ -385,18 +396,25 @@ struct conp_fix {
     // atoms are consumed in chunks of 32; the splits want an even share of chunks
     nl_pad = std::max(32, (nl + 31) / 32 * 32);
     d_elyte_idx.upload(elyte_idx_h, stream);
+    mark("electrolyte list");
     build_items();
+    mark("stream-K schedule");
     d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
     d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
+    mark("table reserves");
     // real-space rows of b
     build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
+    mark("b rows build");
     d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
+    mark("b rows + upload");
     build_pf_pairs(blist, at->echeck, pf_i_h, pf_j_h);
     d_pf_i.upload(pf_i_h, stream); d_pf_j.upload(pf_j_h, stream);
     nlocal_cur = at->nlocal;
+    mark("pf pairs + upload");
     sync();
+    mark("sync");
   }
 
   // sk_gemm schedule ("stream-K" over the atom chunks): the work of all tiles of this rank is laid out on one axis,

@@ -2,7 +2,11 @@
 #include "conp_host.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 namespace conp {
@@ -451,38 +455,127 @@ void finish_rows(std::vector<RawPair> &raw, int ne, bool with_col, PairRows &out
 }
 }  // namespace
 
+// Counting sort of the listed pairs by electrode row, called at every re-neighbour with ~3e5 pairs at the decks' size.
+// The row of a pair and its (electrode atom, partner) orientation follow fix_conp.cpp:1326-1350; list order is kept inside a row.
+// The two passes (count, fill) cost ~3.5 ns per pair each on one core (random read-modify-writes), 1.9 ms at il_onelayer --
+// several updates' worth -- so the owners are cut into contiguous ranges, one host thread each: thread t counts its range,
+// the per-row offsets are stacked in thread order (= list order), every thread fills its own slots.  Same output as one thread.
+static int host_threads() {
+  static const int n = [] {
+    if (const char *e = getenv("CONP_HOST_THREADS")) return std::max(1, atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(8u, hw / 2));
+  }();
+  return n;
+}
+
 void build_b_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,
                   PairRows &out) {
-  std::vector<RawPair> raw;
+  const int ne = idx.elenum_all;
+  int nall = 0;
+  size_t nlisted = 0;
   for (int ii = 0; ii < l.inum; ++ii) {
     const int i = l.ilist[ii];
-    const bool ecib = echeck[i] != 0;
+    nall = std::max(nall, i + 1);
     const int *jlist = l.neigh + l.first[i];
     const int jnum = l.numneigh[i];
-    for (int jj = 0; jj < jnum; ++jj) {
-      const int j = jlist[jj] & NEIGHMASK;
-      const bool ecjb = echeck[j] != 0;
-      if ((ecib ^ ecjb) && (newton || ecib || j < nlocal)) {     // fix_conp.cpp:1326-1327
-        if (ecib) raw.push_back({idx.tag2eleall[tag[i]], i, j, 0});           // :1339-1342
-        else if (j < nlocal) raw.push_back({idx.tag2eleall[tag[j]], j, i, 0}); // :1343-1346
-        else if (newton) raw.push_back({idx.tag2eleall[tag[j]], j, i, 0});     // :1347-1350 (newtonbuf row)
-      }
+    nlisted += (size_t)jnum;
+    for (int jj = 0; jj < jnum; ++jj) nall = std::max(nall, (jlist[jj] & NEIGHMASK) + 1);
+  }
+  static thread_local std::vector<int> arow_store, cnt_store;      // capacity survives between re-neighbours
+  arow_store.resize(nall);
+  int *const arow = arow_store.data();                             // arow[j] = eleall row of atom j, -1 for non-electrode atoms
+  for (int i = 0; i < nall; ++i) arow[i] = echeck[i] ? idx.tag2eleall[tag[i]] : -1;
+  // owner ranges of about equal pair counts
+  int T = (nlisted < 20000) ? 1 : host_threads();
+  std::vector<int> start(T + 1, l.inum);
+  start[0] = 0;
+  {
+    size_t acc = 0;
+    int t = 1;
+    for (int ii = 0; ii < l.inum && t < T; ++ii) {
+      acc += (size_t)l.numneigh[l.ilist[ii]];
+      if (acc * T >= nlisted * (size_t)t) start[t++] = ii + 1;
     }
   }
-  finish_rows(raw, idx.elenum_all, false, out);
+  cnt_store.assign((size_t)T * (ne + 1), 0);                       // cnt[t][r] = pairs of row r found by thread t
+  int *const cnt = cnt_store.data();
+  const int nt = newton ? 1 : 0;
+  auto qualifies_row = [&](int i, int ri, int j) {                 // row of the pair (owner i, neighbour j) or -1
+    const int rj = arow[j];
+    if (ri >= 0) return rj < 0 ? ri : -1;                          // :1339-1342
+    return (rj >= 0 && (nt | (j < nlocal))) ? rj : -1;             // :1343-1350
+  };
+  auto count_range = [&](int t) {
+    int *c = cnt + (size_t)t * (ne + 1);
+    for (int ii = start[t]; ii < start[t + 1]; ++ii) {
+      const int i = l.ilist[ii];
+      const int ri = arow[i];
+      const int *jlist = l.neigh + l.first[i];
+      const int jnum = l.numneigh[i];
+      for (int jj = 0; jj < jnum; ++jj) {
+        const int r = qualifies_row(i, ri, jlist[jj] & NEIGHMASK);
+        if (r >= 0) ++c[r];
+      }
+    }
+  };
+  auto run = [&](auto &&fn) {
+    if (T == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (auto &x : th) x.join();
+  };
+  run(count_range);
+  out.row_ptr.assign((size_t)ne + 1, 0);
+  out.col.clear();
+  for (int r = 0; r < ne; ++r) {                                   // stack the threads' counts of a row in thread order
+    int pos = out.row_ptr[r];
+    for (int t = 0; t < T; ++t) { const int c = cnt[(size_t)t * (ne + 1) + r]; cnt[(size_t)t * (ne + 1) + r] = pos; pos += c; }
+    out.row_ptr[r + 1] = pos;
+  }
+  const size_t np = (size_t)out.row_ptr[ne];
+  out.ele_atom.resize(np);
+  out.oth_atom.resize(np);
+  int *const ele = out.ele_atom.data(), *const oth = out.oth_atom.data();
+  auto fill_range = [&](int t) {
+    int *fill = cnt + (size_t)t * (ne + 1);                        // now: next free slot of this thread in each row
+    for (int ii = start[t]; ii < start[t + 1]; ++ii) {
+      const int i = l.ilist[ii];
+      const int ri = arow[i];
+      const int *jlist = l.neigh + l.first[i];
+      const int jnum = l.numneigh[i];
+      for (int jj = 0; jj < jnum; ++jj) {
+        const int j = jlist[jj] & NEIGHMASK;
+        const int r = qualifies_row(i, ri, j);
+        if (r >= 0) {
+          const int pos = fill[r]++;
+          if (ri >= 0) { ele[pos] = i; oth[pos] = j; }
+          else { ele[pos] = j; oth[pos] = i; }
+        }
+      }
+    }
+  };
+  run(fill_range);
 }
 
 void build_pf_pairs(const ListView &l, const int *echeck, std::vector<int> &pi, std::vector<int> &pj) {
-  pi.clear(); pj.clear();
+  size_t cap = 0;
+  for (int ii = 0; ii < l.inum; ++ii) cap += (size_t)l.numneigh[l.ilist[ii]];
+  pi.resize(cap); pj.resize(cap);
+  size_t n = 0;
   for (int ii = 0; ii < l.inum; ++ii) {
     const int i = l.ilist[ii];
     const bool ei = echeck[i] != 0;
     const int *jlist = l.neigh + l.first[i];
-    for (int jj = 0; jj < l.numneigh[i]; ++jj) {
+    const int jnum = l.numneigh[i];
+    for (int jj = 0; jj < jnum; ++jj) {
       const int j = jlist[jj] & NEIGHMASK;
-      if (ei ^ (echeck[j] != 0)) { pi.push_back(i); pj.push_back(j); }
+      pi[n] = i; pj[n] = j;
+      n += (size_t)(ei ^ (echeck[j] != 0));            // exactly one electrode member (fix_conp.cpp:1411)
     }
   }
+  pi.resize(n); pj.resize(n);
 }
 
 void build_a_rows(const ListView &l, int nlocal, const int *tag, const int *echeck, const EleIndex &idx, bool newton,

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Cost of a re-neighbour (conp_fix_post_neighbor: index bookkeeping, electrode-row regrouping of the half list, uploads,
+stream-K schedule) -- LAMMPS calls it every ~10-20 steps, so it is amortised over that many updates.
+usage: python tools/reneighbor_time.py [workload]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lammps-user-conp2_amd"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import bench
+    from conp_amd import FixConp, neighbor
+    wl = sys.argv[1] if len(sys.argv) > 1 else "headline"
+    s = bench.make_workload(wl)
+    t0 = time.perf_counter()
+    at, alist, blist = neighbor.build_lists(s)
+    t1 = time.perf_counter()
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    n = 10
+    t2 = time.perf_counter()
+    for _ in range(n):
+        fx.init_lists(alist, blist)
+        fx.post_neighbor(at)
+    t3 = time.perf_counter()
+    for k in range(n):
+        fx.pre_force(at, k + 1, s.potdiff)
+    t4 = time.perf_counter()
+    print(f"{wl}: nall {at.nall}, blist pairs {blist.npairs}: post_neighbor {(t3 - t2) / n * 1e3:.3f} ms, "
+          f"pre_force (host buffers) {(t4 - t3) / n * 1e3:.3f} ms   [python list build: {t1 - t0:.1f} s, not part of the library]")
+    fx.close()
+
+
+if __name__ == "__main__":
+    main()
