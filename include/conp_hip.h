@@ -139,6 +139,11 @@ double conp_fix_compute_scalar(const conp_fix *fix);                      /* :59
  * (xx,yy,zz,xy,xz,yz).  The reference's arithmetic is kept as written, including `del*forcecoul` and the `eta^2 r^2 < 5.8` gate. */
 int conp_fix_post_force(conp_fix *fix, const conp_atoms *atoms, double *f, double *kspace_energy_add, double *eng_coul_add,
                         double *virial_add /*[6]*/);
+/* The same for a host that can say which step it is in: when `ntimestep` is the step of the last conp_fix_pre_force that wrote
+ * charges and `atoms->x` is the array handed over there, positions and charges are already on the device (nothing moves between
+ * pre_force and post_force of a LAMMPS step) and are not uploaded again.  Any other step (Nevery > 1, a re-neighbour) uploads. */
+int conp_fix_post_force_step(conp_fix *fix, const conp_atoms *atoms, int64_t ntimestep, double *f, double *kspace_energy_add,
+                             double *eng_coul_add, double *virial_add /*[6]*/);
 
 /* finer-grained pieces of the same path (same names as the reference's methods) */
 int conp_fix_linalg_setup(conp_fix *fix, const conp_atoms *atoms);        /* :426-464 a_cal, b_setq_cal, equation_solve, get_setq */

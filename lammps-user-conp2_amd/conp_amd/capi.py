@@ -67,7 +67,7 @@ class conp_info(C.Structure):
 SYMBOLS = [
     "conp_parse_fix_args", "conp_fix_create", "conp_fix_destroy", "conp_last_error", "conp_abi_version",
     "conp_fix_init_list", "conp_fix_setup_post_neighbor", "conp_fix_setup_pre_force", "conp_fix_post_neighbor",
-    "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_post_force", "conp_fix_modify_param", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
+    "conp_fix_pre_force", "conp_fix_compute_scalar", "conp_fix_post_force", "conp_fix_post_force_step", "conp_fix_modify_param", "conp_fix_linalg_setup", "conp_fix_a_cal", "conp_fix_b_cal",
     "conp_fix_equation_solve", "conp_fix_update_charge", "conp_km_conp_setup", "conp_km_a_cal", "conp_km_b_cal",
     "conp_fix_info", "conp_fix_get_ktables", "conp_fix_get_maps", "conp_fix_get_matrix", "conp_fix_set_matrix",
     "conp_fix_get_vectors", "conp_fix_get_sfac", "conp_fix_get_ele_trig", "conp_inv_project", "conp_invert",
@@ -103,6 +103,7 @@ def load_library():
     lib.conp_fix_compute_scalar.argtypes = [vp]
     lib.conp_fix_compute_scalar.restype = C.c_double
     lib.conp_fix_post_force.argtypes = [vp, C.POINTER(conp_atoms), dp, dp, dp, dp]
+    lib.conp_fix_post_force_step.argtypes = [vp, C.POINTER(conp_atoms), C.c_int64, dp, dp, dp, dp]
     lib.conp_fix_modify_param.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), ip]
     lib.conp_fix_equation_solve.argtypes = [vp]
     lib.conp_fix_update_charge.argtypes = [vp, C.POINTER(conp_atoms), C.c_double]
@@ -267,6 +268,12 @@ class FixConp:
     def post_force(self, at):
         f = np.zeros((at.nlocal + at.nghost, 3)); ek = C.c_double(); ec = C.c_double(); vir = np.zeros(6)
         self._check(self.lib.conp_fix_post_force(self.h, C.byref(self.atoms_view(at)), _dptr(f), C.byref(ek), C.byref(ec), _dptr(vir)))
+        return f, ek.value, ec.value, vir
+
+    def post_force_step(self, at, ntimestep):
+        f = np.zeros((at.nlocal + at.nghost, 3)); ek = C.c_double(); ec = C.c_double(); vir = np.zeros(6)
+        self._check(self.lib.conp_fix_post_force_step(self.h, C.byref(self.atoms_view(at)), C.c_int64(ntimestep), _dptr(f),
+                                                      C.byref(ek), C.byref(ec), _dptr(vir)))
         return f, ek.value, ec.value, vir
 
     def compute_scalar(self):

@@ -360,6 +360,7 @@ struct conp_fix {
   void post_neighbor(const conp_atoms *at) {
     if (!idx.initialised) throw ConpError(CONP_ERR_STATE, "post_neighbor before setup_post_neighbor");
     if (!have_blist) throw ConpError(CONP_ERR_STATE, "post_neighbor: no neighbor list (init_list not called)");
+    resident_step = -1;
     static const bool tren = getenv("CONP_TIME_REN") != nullptr;
     auto tm0 = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
@@ -1009,7 +1010,7 @@ struct conp_fix {
   void update_charge(const conp_atoms *at, double potdiff) {
     const int ne = idx.elenum_all;
     if (args.minimizer == CONP_SOLVER_INV) solve_device();
-    scatter_device(nullptr, potdiff);
+    scatter_device(d_q.p, potdiff);          // the device copy of q follows atom->q (post_force of the same step reuses it)
     double *qe = pinned((size_t)ne_pad + 8);
     HIP_TRY(hipMemcpyAsync(qe, d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
     finish_scalar(potdiff);                 // one synchronisation for the charges and the scalars
@@ -1022,20 +1023,27 @@ struct conp_fix {
   }
 
   // fix_conp.cpp:577-580 post_force -> :1163-1201 force_cal + :1368-1444 blist_coul_cal_post_force
-  void post_force(const conp_atoms *at, double *f, double *ek, double *ec, double *vir) {
+  // `ntimestep` >= 0: the host promises that x is what it handed to pre_force at that step (LAMMPS: nothing moves between
+  // pre_force and post_force of a step); the device copy -- positions, and charges incl. the new electrode charges -- is then
+  // reused instead of uploaded again.  Forces and the accumulators come back through the page-locked staging buffer.
+  int64_t resident_step = -1;          // step whose x, q are on the device (host pre_force), -1: none
+  const void *resident_x = nullptr;
+  void post_force(const conp_atoms *at, double *f, double *ek, double *ec, double *vir, int64_t ntimestep = -1) {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
-    upload_xq(at);   // charges were just updated by pre_force on the host side
+    const bool resident = ntimestep >= 0 && ntimestep == resident_step && at->x == resident_x;
+    if (!resident) upload_xq(at);   // charges were just updated by pre_force on the host side
     d_f.reserve((size_t)nall * 3); d_pfacc.reserve(8);
     prof.begin("post_force", stream);
     launch_post_force(stream, (int)pf_i_h.size(), d_pf_i.p, d_pf_j.p, at->nlocal, nall, env.newton_pair != 0, d_x.p, d_q.p, d_type.p,
                       d_atom2eleall.p, real_params(), env.qqrd2e, d_f.p, d_pfacc.p);
     prof.end(stream);
-    std::vector<double> fh((size_t)nall * 3);
-    double acc[8];
-    HIP_TRY(hipMemcpyAsync(fh.data(), d_f.p, fh.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    const size_t nf = (size_t)nall * 3;
+    double *fh = pinned((size_t)ne_pad + 8 + nf + 8) + ne_pad + 8;
+    double *acc = fh + nf;
+    HIP_TRY(hipMemcpyAsync(fh, d_f.p, nf * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(acc, d_pfacc.p, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
-    if (f) for (size_t k = 0; k < fh.size(); ++k) f[k] += fh[k];
+    if (f) for (size_t k = 0; k < nf; ++k) f[k] += fh[k];
     if (ek) *ek = ehgo_active ? env.qqrd2e * 1.0 * acc[7]                                                    // :1198
                               : env.qqrd2e * 1.0 * args.eta * acc[7] / (std::sqrt(2.0) * 1.77245385090551602729);   // :1180
     if (ec) *ec = acc[0];
@@ -1115,9 +1123,11 @@ struct conp_fix {
   void pre_force(const conp_atoms *at, int64_t ntimestep, double potdiff) {
     if (runstage < 2) throw ConpError(CONP_ERR_STATE, "pre_force before setup_pre_force");
     if (ntimestep % args.everynum != 0) return;
+    resident_step = -1;
     b_cal(at);
     if (args.minimizer == CONP_SOLVER_CG) equation_solve();
     update_charge(at, potdiff);
+    resident_step = ntimestep; resident_x = at->x;
   }
 };
 
@@ -1295,6 +1305,14 @@ int conp_fix_post_force(conp_fix *f, const conp_atoms *at, double *fo, double *e
   f->drop_graph();
   if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "post_force before setup");
   f->post_force(at, fo, ek, ec, vir);
+  CONP_GUARD_END
+}
+
+int conp_fix_post_force_step(conp_fix *f, const conp_atoms *at, int64_t ntimestep, double *fo, double *ek, double *ec, double *vir) {
+  CONP_GUARD_BEGIN
+  f->drop_graph();
+  if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "post_force before setup");
+  f->post_force(at, fo, ek, ec, vir, ntimestep);
   CONP_GUARD_END
 }
 

@@ -209,7 +209,7 @@ void FixConpHip::post_force(int) {
   const int nall = atom->nlocal + atom->nghost;
   fbuf.assign(3 * (size_t)nall, 0.0);
   double ek = 0.0, ec = 0.0, vir[6];
-  fail_if(conp_fix_post_force(h, &a, fbuf.data(), &ek, &ec, vir));
+  fail_if(conp_fix_post_force_step(h, &a, (int64_t)update->ntimestep, fbuf.data(), &ek, &ec, vir));   // x, q of this step are resident
   for (int i = 0; i < nall; ++i)
     for (int c = 0; c < 3; ++c) atom->f[i][c] += fbuf[3 * (size_t)i + c];
   if (force->kspace->energy) force->kspace->energy += ek;       // :1165 (the reference adds only when kspace tallied energy)

@@ -584,6 +584,36 @@ def test_post_force_matches_oracle(oracle):
         fx.close(); o.fx.close()
 
 
+def test_post_force_of_the_same_step_reuses_the_device_copy(oracle):
+    """conp_fix_post_force_step: with the step number of the pre_force that just ran, positions and charges are not uploaded
+    again -- same forces as the uploading call; a different step, or moved atoms with Nevery > 1, upload"""
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab")
+    rng = np.random.default_rng(9)
+    ele_idx = np.nonzero(s.echeck != 0)[0]; sol_idx = np.nonzero((s.echeck == 0) & (s.q != 0))[0]
+    for k in range(6):
+        d = rng.normal(size=3); d *= rng.uniform(0.4, 1.1) / np.linalg.norm(d)
+        s.x[sol_idx[k]] = s.x[ele_idx[3 * k]] + d
+    s.x[:, :2] = s.boxlo[:2] + np.mod(s.x[:, :2] - s.boxlo[:2], s.prd[:2])
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    fx.pre_force(at, 1, s.potdiff)
+    ref = fx.post_force(at)                      # always uploads
+    got = fx.post_force_step(at, 1)              # resident: step 1 is the step of the last pre_force
+    assert np.abs(ref[0]).sum() > 0
+    # (the energy / virial accumulators and multiply-hit force entries are f64 atomic sums: equal up to the order of the additions)
+    close = lambda a, b: np.allclose(a, b, rtol=1e-12, atol=1e-12 * np.abs(ref[0]).max())
+    assert close(got[0], ref[0]) and close(got[1], ref[1]) and close(got[2], ref[2]) and close(got[3], ref[3])
+    # atoms move, no pre_force for the new step (Nevery > 1): the stale device copy must not be used
+    at.x[sol_idx[:6]] += 0.05
+    ref2 = fx.post_force(at)
+    got2 = fx.post_force_step(at, 2)
+    assert close(got2[0], ref2[0]) and not close(ref2[0], ref[0])
+    fx.close()
+
+
 @pytest.mark.parametrize("case,extra,okw", [
     ("noslab_zneutr", (), {}),                          # doubled antisymmetric cell, second neutrality constraint (fix_conp.cpp:1027-1060)
     ("qinit", ("qinit",), dict(qinit=True)),           # initial electrode charges kept as an offset (:1107-1114, 1156)
