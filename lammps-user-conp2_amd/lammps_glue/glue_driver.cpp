@@ -251,6 +251,10 @@ int main(int argc, char **argv) {
       for (int k = 0; k < n; ++k) { update.ntimestep += 1; fix.pre_force(0); }
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (n > 0 ? n : 1);
       std::printf("time_pre_force_ms %.6f\n", ms);
+      const auto t1 = std::chrono::steady_clock::now();
+      for (int k = 0; k < n; ++k) { std::fill(fs.begin(), fs.end(), 0.0); fix.post_force(0); }      // same step as the last pre_force
+      const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() / (n > 0 ? n : 1);
+      std::printf("time_post_force_ms %.6f\n", ms2);
     }
   } catch (const std::exception &e) {
     std::printf("ERROR: %s\n", e.what());

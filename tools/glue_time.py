@@ -27,7 +27,7 @@ def main():
         write_case(case, s, at, [alist] if alist is blist else [alist, blist], fix_command_for(s), [(0, s.potdiff, 0, None)])
         p = subprocess.run([DRIVER, case], cwd=d, capture_output=True, text=True, env=dict(os.environ, GLUE_DRIVER_TIME=n))
         for line in p.stdout.splitlines():
-            if line.startswith(("time_pre_force_ms", "ERROR", "scalar")):
+            if line.startswith(("time_pre_force_ms", "time_post_force_ms", "ERROR", "scalar")):
                 print(wl, line)
 
 
