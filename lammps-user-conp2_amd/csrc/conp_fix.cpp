@@ -1026,24 +1026,32 @@ struct conp_fix {
   // `ntimestep` >= 0: the host promises that x is what it handed to pre_force at that step (LAMMPS: nothing moves between
   // pre_force and post_force of a step); the device copy -- positions, and charges incl. the new electrode charges -- is then
   // reused instead of uploaded again.  Forces and the accumulators come back through the page-locked staging buffer.
+  bool pf_f_dirty = true;              // the device force array may hold non-zeros (first use, or the last call had contributions)
   int64_t resident_step = -1;          // step whose x, q are on the device (host pre_force), -1: none
   const void *resident_x = nullptr;
   void post_force(const conp_atoms *at, double *f, double *ek, double *ec, double *vir, int64_t ntimestep = -1) {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
     const bool resident = ntimestep >= 0 && ntimestep == resident_step && at->x == resident_x;
     if (!resident) upload_xq(at);   // charges were just updated by pre_force on the host side
-    d_f.reserve((size_t)nall * 3); d_pfacc.reserve(8);
+    const size_t nf = (size_t)nall * 3;
+    if (d_f.n < nf) pf_f_dirty = true;             // fresh allocation: contents undefined
+    d_f.reserve(nf); d_pfacc.reserve(9);
     prof.begin("post_force", stream);
     launch_post_force(stream, (int)pf_i_h.size(), d_pf_i.p, d_pf_j.p, at->nlocal, nall, env.newton_pair != 0, d_x.p, d_q.p, d_type.p,
-                      d_atom2eleall.p, real_params(), env.qqrd2e, d_f.p, d_pfacc.p);
+                      d_atom2eleall.p, real_params(), env.qqrd2e, d_f.p, d_pfacc.p, pf_f_dirty);
     prof.end(stream);
-    const size_t nf = (size_t)nall * 3;
-    double *fh = pinned((size_t)ne_pad + 8 + nf + 8) + ne_pad + 8;
-    double *acc = fh + nf;
-    HIP_TRY(hipMemcpyAsync(fh, d_f.p, nf * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(acc, d_pfacc.p, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    double *acc = pinned((size_t)ne_pad + 8 + nf + 16) + ne_pad + 8 + nf;
+    HIP_TRY(hipMemcpyAsync(acc, d_pfacc.p, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
-    if (f) for (size_t k = 0; k < nf; ++k) f[k] += fh[k];
+    // the correction only acts where the Gaussians overlap (eta^2 r^2 < 5.8, r < 1.2 A at eta = 1.979): in a normal MD step no
+    // pair is that close, the force array on the device is still all zero and is not brought over
+    pf_f_dirty = acc[8] > 0.0;
+    if (pf_f_dirty) {
+      double *fh = acc - nf;
+      HIP_TRY(hipMemcpyAsync(fh, d_f.p, nf * sizeof(double), hipMemcpyDeviceToHost, stream));
+      sync();
+      if (f) for (size_t k = 0; k < nf; ++k) f[k] += fh[k];
+    }
     if (ek) *ek = ehgo_active ? env.qqrd2e * 1.0 * acc[7]                                                    // :1198
                               : env.qqrd2e * 1.0 * args.eta * acc[7] / (std::sqrt(2.0) * 1.77245385090551602729);   // :1180
     if (ec) *ec = acc[0];

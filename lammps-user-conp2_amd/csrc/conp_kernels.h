@@ -70,7 +70,7 @@ void launch_cond_potdiff(hipStream_t s, int ne, const double *setzvec, const dou
 void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out);
 void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, int nlocal, int nall, int newton, const double *x,
                        const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
-                       double *acc /*[8]: eng_coul, virial[6], sum q^2 of owned electrode atoms*/);
+                       double *acc /*[9]: eng_coul, virial[6], sum q^2 of owned electrode atoms, contributing pairs*/, bool clear_f);
 void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);
 
 // ---- once-per-run matrix work ------------------------------------------------------------------

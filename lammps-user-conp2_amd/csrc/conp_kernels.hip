@@ -959,6 +959,7 @@ __global__ __launch_bounds__(256) void post_force_kernel(int npairs, const int *
   if (!(rsq < rp.cutsq[type[i] * (rp.ntypes + 1) + type[j]])) return;
   const double etarij2 = rp.eta * rp.eta * rsq;
   if (!(etarij2 < 5.8)) return;                                  // :1419 (ERFC_MAX, not its square -- kept as written)
+  atomicAdd(&acc[8], 1.0);                                         // pairs inside the Gaussian overlap range: usually none
   const bool eleilocal = atom2eleall[i] >= 0;
   const double prefactor = qqrd2e * q[i] * q[j];
   double fterm;
@@ -999,9 +1000,9 @@ __global__ __launch_bounds__(1024) void ele_qsq_kernel(int nlocal, const int *__
 
 void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, int nlocal, int nall, int newton, const double *x,
                        const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
-                       double *acc /*[8]: eng_coul, virial[6], qsq*/) {
-  (void)hipMemsetAsync(f, 0, (size_t)nall * 3 * sizeof(double), s);
-  (void)hipMemsetAsync(acc, 0, 8 * sizeof(double), s);
+                       double *acc /*[9]: eng_coul, virial[6], qsq, number of contributing pairs*/, bool clear_f) {
+  if (clear_f) (void)hipMemsetAsync(f, 0, (size_t)nall * 3 * sizeof(double), s);
+  (void)hipMemsetAsync(acc, 0, 9 * sizeof(double), s);
   if (npairs > 0)
     hipLaunchKernelGGL(post_force_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, npairs, pi, pj, nlocal, newton, x, q, type,
                        atom2eleall, rp, qqrd2e, f, acc);

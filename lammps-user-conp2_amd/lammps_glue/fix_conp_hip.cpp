@@ -207,11 +207,10 @@ void FixConpHip::post_force(int) {
   postforceflag = true;
   conp_atoms a = view();
   const int nall = atom->nlocal + atom->nghost;
-  fbuf.assign(3 * (size_t)nall, 0.0);
   double ek = 0.0, ec = 0.0, vir[6];
-  fail_if(conp_fix_post_force_step(h, &a, (int64_t)update->ntimestep, fbuf.data(), &ek, &ec, vir));   // x, q of this step are resident
-  for (int i = 0; i < nall; ++i)
-    for (int c = 0; c < 3; ++c) atom->f[i][c] += fbuf[3 * (size_t)i + c];
+  // atom->f is a contiguous [nmax][3] block like atom->x: the library accumulates into it directly (and touches it only when
+  // some pair is inside the Gaussian overlap range); x, q of this step are already on the device
+  fail_if(conp_fix_post_force_step(h, &a, (int64_t)update->ntimestep, nall ? &atom->f[0][0] : nullptr, &ek, &ec, vir));
   if (force->kspace->energy) force->kspace->energy += ek;       // :1165 (the reference adds only when kspace tallied energy)
   force->pair->eng_coul += ec;                                   // what Pair::ev_tally accumulates (:1436)
   for (int k = 0; k < 6; ++k) force->pair->virial[k] += vir[k];

@@ -49,7 +49,6 @@ class FixConpHip : public Fix {
   class Pair *coulpair;
   FILE *outf;
   bool postforceflag;
-  std::vector<double> fbuf;
   std::vector<std::vector<std::string>> pending_modify;
   std::vector<double> cutsq_flat;
   std::vector<int> echeck, first_a, first_b, neigh_a, neigh_b;
