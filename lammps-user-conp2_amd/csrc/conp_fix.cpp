@@ -128,7 +128,10 @@ struct conp_fix {
   std::string warning;
   double cond_vmult = 0.0;       // fix cond (fix_cond.cpp:58-68)
   bool cond_ready = false;
-  std::vector<int> atom2eleall_h, elyte_idx_h, pf_i_h, pf_j_h;
+  std::vector<int> atom2eleall_h, elyte_idx_h;
+  int bl_inum = 0;                 // owners in the ele-electrolyte list as uploaded for the post-force kernel
+  size_t bl_nneigh = 0;            // length of its flattened neighbour array
+  DevBuf<char> d_rows_scratch;
   int nlocal_cur = 0;
   // device state
   hipStream_t stream = nullptr;
@@ -139,7 +142,7 @@ struct conp_fix {
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_pf_i, d_pf_j, d_pp_egrid, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -356,6 +359,27 @@ struct conp_fix {
     d_x.reserve((size_t)nall * 3); d_q.reserve(nall);
   }
 
+  // real-space rows of b (blist_coul_cal membership, fix_conp.cpp:1326-1350) from the list that is already on the device;
+  // CONP_ROWS_HOST=1 keeps the host counting sort (same output) for comparison
+  int64_t n_b_pairs = 0;
+  void build_b_rows_device(const conp_atoms *at) {
+    const int ne = idx.elenum_all;
+    static const bool on_host = getenv("CONP_ROWS_HOST") != nullptr;
+    if (on_host) {
+      build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
+      d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
+      n_b_pairs = brows.npairs();
+      return;
+    }
+    const size_t sb = b_rows_scratch_bytes(bl_inum, bl_nneigh);
+    d_rows_scratch.reserve(sb);
+    d_b_rowptr.reserve((size_t)ne + 1); d_b_ele.reserve(std::max<size_t>(bl_nneigh, 1)); d_b_oth.reserve(std::max<size_t>(bl_nneigh, 1));
+    n_b_pairs = launch_build_b_rows(stream, bl_inum, bl_nneigh, d_bl_ilist.p, d_bl_numneigh.p, d_bl_first.p, d_bl_neigh.p,
+                                    d_atom2eleall.p, at->nlocal, env.newton_pair != 0, ne, d_rows_scratch.p, sb, d_b_rowptr.p,
+                                    d_b_ele.p, d_b_oth.p);
+    HIP_TRY(hipGetLastError());
+  }
+
   // fix_conp.cpp:468-539 post_neighbor
   void post_neighbor(const conp_atoms *at) {
     if (!idx.initialised) throw ConpError(CONP_ERR_STATE, "post_neighbor before setup_post_neighbor");
@@ -405,15 +429,25 @@ struct conp_fix {
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
     d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
     mark("table reserves");
-    // real-space rows of b
-    build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
-    mark("b rows build");
-    d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
-    mark("b rows + upload");
-    build_pf_pairs(blist, at->echeck, pf_i_h, pf_j_h);
-    d_pf_i.upload(pf_i_h, stream); d_pf_j.upload(pf_j_h, stream);
+    // the flattened half list goes to the device as it is: the post-force kernel walks it (one wavefront per owner), and the
+    // electrode rows of the real-space b are regrouped from it on the device (conp_rows.hip: count, scan, emit, stable sort)
+    {
+      size_t nneigh = 0;
+      for (int ii = 0; ii < blist.inum; ++ii) {
+        const int i = blist.ilist[ii];
+        nneigh = std::max(nneigh, (size_t)blist.first[i] + (size_t)blist.numneigh[i]);
+      }
+      bl_inum = blist.inum;
+      bl_nneigh = nneigh;
+      d_bl_ilist.upload(blist.ilist, (size_t)blist.inum, stream);
+      d_bl_numneigh.upload(blist.numneigh, (size_t)nall, stream);
+      d_bl_first.upload(blist.first, (size_t)nall, stream);
+      d_bl_neigh.upload(blist.neigh, std::max<size_t>(nneigh, 1), stream);
+    }
+    mark("list upload");
+    build_b_rows_device(at);
+    mark("b rows (device)");
     nlocal_cur = at->nlocal;
-    mark("pf pairs + upload");
     sync();
     mark("sync");
   }
@@ -665,8 +699,7 @@ struct conp_fix {
     try { idx.renumber_from_tags(tags, at->nlocal, at->tag, at->echeck); }
     catch (const std::exception &e) { throw ConpError(CONP_ERR_IO, e.what()); }
     upload_atoms_static(at);                                   // atom2eleall follows the new numbering
-    build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
-    d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
+    build_b_rows_device(at);                                   // rows follow the new numbering (the list is on the device)
     HIP_TRY(hipMemcpyAsync(d_A.p, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     km_a_read(at);                                             // kspmod->a_read(): electrode phase tables (:772)
     sync();
@@ -1037,7 +1070,7 @@ struct conp_fix {
     if (d_f.n < nf) pf_f_dirty = true;             // fresh allocation: contents undefined
     d_f.reserve(nf); d_pfacc.reserve(9);
     prof.begin("post_force", stream);
-    launch_post_force(stream, (int)pf_i_h.size(), d_pf_i.p, d_pf_j.p, at->nlocal, nall, env.newton_pair != 0, d_x.p, d_q.p, d_type.p,
+    launch_post_force(stream, bl_inum, d_bl_ilist.p, d_bl_numneigh.p, d_bl_first.p, d_bl_neigh.p, at->nlocal, nall, env.newton_pair != 0, d_x.p, d_q.p, d_type.p,
                       d_atom2eleall.p, real_params(), env.qqrd2e, d_f.p, d_pfacc.p, pf_f_dirty);
     prof.end(stream);
     double *acc = pinned((size_t)ne_pad + 8 + nf + 16) + ne_pad + 8 + nf;
@@ -1399,7 +1432,7 @@ int conp_fix_info(const conp_fix *f, conp_info *o) {
   for (int i = 0; i < 3; ++i) o->unitk[i] = f->kt.unitk[i];
   o->volume = f->kt.volume; o->gsqmx = f->kt.gsqmx; o->ug_tot = f->kt.ug_tot; o->totsetq = f->totsetq;
   o->scalar_output = f->scalar_output; o->totinve = f->totinve; o->slabcorr = f->slabcorr;
-  o->n_blist_pairs = f->brows.npairs(); o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
+  o->n_blist_pairs = f->n_b_pairs; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
   CONP_GUARD_END
 }
 

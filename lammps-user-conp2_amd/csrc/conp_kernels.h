@@ -68,7 +68,12 @@ void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleal
 void launch_cond_potdiff(hipStream_t s, int ne, const double *setzvec, const double *eleallq, const double *slab_part,
                          int n_slab_part, double lz, double rightcharge, double vmult, double *out);
 void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out);
-void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, int nlocal, int nall, int newton, const double *x,
+size_t b_rows_scratch_bytes(int inum, size_t nneigh);
+int64_t launch_build_b_rows(hipStream_t s, int inum, size_t nneigh, const int *ilist, const int *numneigh, const int *first,
+                            const int *neigh, const int *arow, int nlocal, int newton, int ne, void *scratch, size_t scratch_bytes,
+                            int *row_ptr, int *ele, int *oth);
+void launch_post_force(hipStream_t s, int inum, const int *ilist, const int *numneigh, const int *first, const int *neigh, int nlocal,
+                       int nall, int newton, const double *x,
                        const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
                        double *acc /*[9]: eng_coul, virial[6], sum q^2 of owned electrode atoms, contributing pairs*/, bool clear_f);
 void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);

@@ -945,15 +945,12 @@ __device__ __forceinline__ double ferfcr_sqrt_dev(double a2_r2) {
 }
 
 // one thread per listed (owner i, neighbour j) pair with exactly one electrode member; acc[0] eng_coul, acc[1..6] virial
-__global__ __launch_bounds__(256) void post_force_kernel(int npairs, const int *__restrict__ pi, const int *__restrict__ pj,
-                                                         int nlocal, int newton, const double *__restrict__ x,
-                                                         const double *__restrict__ q, const int *__restrict__ type,
-                                                         const int *__restrict__ atom2eleall, RealParams rp, double qqrd2e,
-                                                         double *__restrict__ f, double *__restrict__ acc) {
+__device__ __forceinline__ void post_force_pair(int i, int j, bool ei, int nlocal, int newton, const double *__restrict__ x,
+                                                const double *__restrict__ q, const int *__restrict__ type,
+                                                const int *__restrict__ atom2eleall, const RealParams &rp, double qqrd2e,
+                                                double *__restrict__ f, double *__restrict__ acc) {
 #pragma clang fp contract(off)
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npairs) return;
-  const int i = pi[p], j = pj[p];
+  if (ei == (atom2eleall[j] >= 0)) return;                         // exactly one electrode member
   const double delx = x[3 * i] - x[3 * j], dely = x[3 * i + 1] - x[3 * j + 1], delz = x[3 * i + 2] - x[3 * j + 2];
   const double rsq = delx * delx + dely * dely + delz * delz;
   if (!(rsq < rp.cutsq[type[i] * (rp.ntypes + 1) + type[j]])) return;
@@ -984,6 +981,26 @@ __global__ __launch_bounds__(256) void post_force_kernel(int npairs, const int *
   atomicAdd(&acc[4], w * (delx * dely * fpair)); atomicAdd(&acc[5], w * (delx * delz * fpair)); atomicAdd(&acc[6], w * (dely * delz * fpair));
 }
 
+
+// One wavefront per list owner walks that atom's neighbours straight from the (flattened) LAMMPS half list: every listed pair
+// with exactly one electrode member takes part (blist_coul_cal_post_force has no newton / ghost filter, fix_conp.cpp:1411), so
+// no pair list has to be compacted on the host at a re-neighbour.
+__global__ __launch_bounds__(256) void post_force_kernel(int inum, const int *__restrict__ ilist, const int *__restrict__ numneigh,
+                                                         const int *__restrict__ first, const int *__restrict__ neigh,
+                                                         int nlocal, int newton, const double *__restrict__ x,
+                                                         const double *__restrict__ q, const int *__restrict__ type,
+                                                         const int *__restrict__ atom2eleall, RealParams rp, double qqrd2e,
+                                                         double *__restrict__ f, double *__restrict__ acc) {
+#pragma clang fp contract(off)
+  const int ii = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ii >= inum) return;
+  const int i = ilist[ii];
+  const int *jl = neigh + first[i];
+  const int jn = numneigh[i];
+  const bool ei = atom2eleall[i] >= 0;
+  for (int jj = threadIdx.x & 63; jj < jn; jj += 64) post_force_pair(i, jl[jj] & 0x3FFFFFFF, ei, nlocal, newton, x, q, type, atom2eleall, rp, qqrd2e, f, acc);
+}
+
 // Gaussian self energy sum over owned electrode atoms of q^2 (fix_conp.cpp:1167-1181), one workgroup, fixed tree
 __global__ __launch_bounds__(1024) void ele_qsq_kernel(int nlocal, const int *__restrict__ atom2eleall, const double *__restrict__ q,
                                                        const int *__restrict__ type, const double *__restrict__ u0_i,
@@ -998,14 +1015,15 @@ __global__ __launch_bounds__(1024) void ele_qsq_kernel(int nlocal, const int *__
   if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < 16; ++k) t += red[k]; *out = t; }
 }
 
-void launch_post_force(hipStream_t s, int npairs, const int *pi, const int *pj, int nlocal, int nall, int newton, const double *x,
+void launch_post_force(hipStream_t s, int inum, const int *ilist, const int *numneigh, const int *first, const int *neigh, int nlocal,
+                       int nall, int newton, const double *x,
                        const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
                        double *acc /*[9]: eng_coul, virial[6], qsq, number of contributing pairs*/, bool clear_f) {
   if (clear_f) (void)hipMemsetAsync(f, 0, (size_t)nall * 3 * sizeof(double), s);
   (void)hipMemsetAsync(acc, 0, 9 * sizeof(double), s);
-  if (npairs > 0)
-    hipLaunchKernelGGL(post_force_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, npairs, pi, pj, nlocal, newton, x, q, type,
-                       atom2eleall, rp, qqrd2e, f, acc);
+  if (inum > 0)
+    hipLaunchKernelGGL(post_force_kernel, dim3((inum + 3) / 4), dim3(256), 0, s, inum, ilist, numneigh, first, neigh, nlocal, newton,
+                       x, q, type, atom2eleall, rp, qqrd2e, f, acc);
   hipLaunchKernelGGL(ele_qsq_kernel, dim3(1), dim3(1024), 0, s, nlocal, atom2eleall, q, type, rp.ehgo ? rp.u0_i : nullptr, acc + 7);
 }
 

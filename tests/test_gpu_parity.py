@@ -470,6 +470,27 @@ def test_rank_shards_of_b_add_up_to_the_single_rank_vector(deck, world):
     assert rel_err(total, b1) < 1e-12
 
 
+@pytest.mark.parametrize("deck,newton", [("il_onelayer", False), ("il_onelayer", True), ("dilute", False), ("cond2", False)])
+def test_device_row_regrouping_keeps_the_list_order(deck, newton, monkeypatch):
+    """the electrode rows of the real-space b are regrouped from the half list on the device (count / scan / emit / stable radix
+    sort); the pairs of a row must come out in list order like the host counting sort's -- then both give the same bits"""
+    s = systems.deck(deck, "ffield", etypes=(deck != "dilute"))
+    s.newton = newton
+    at, alist, blist = neighbor.build_lists(s)
+    res = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("CONP_ROWS_HOST", "1")
+        fx = FixConp(s)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.b_cal(at)
+        res.append((fx.vectors()[0].copy(), fx.info().n_blist_pairs))
+        fx.close()
+    assert res[0][1] == res[1][1] > 0
+    assert np.array_equal(res[0][0], res[1][0])
+
+
 def _gpu_shard_worker(rank, world, port, out):
     import os, sys
     import torch
