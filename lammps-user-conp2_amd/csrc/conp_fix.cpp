@@ -137,7 +137,7 @@ struct conp_fix {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
-      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_hist, d_cg_p,
+      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
       d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
@@ -820,40 +820,39 @@ struct conp_fix {
   }
 
   // fix_conp.cpp:864-930 cg
+  // The iterations are enqueued in batches and the convergence flag is read back once per batch (every kernel of an iteration
+  // after convergence returns at once).  The first batch is as long as the last solve needed, so a typical update costs one
+  // read-back: scalars, flag, net charge and the residual history come over in ONE copy into the page-locked staging buffer.
+  int cg_batch = 8;
   void cg() {
     const int ne = idx.elenum_all;
-    d_cg_res.reserve(ne); d_cg_p.reserve(ne); d_cg_ap.reserve(ne); d_cg_scal.reserve(8); d_cg_done.reserve(1); d_cg_hist.reserve(args.maxiter + 1);
+    const int nctl = 16 + args.maxiter + 1;                  // scal[0..8], pad, hist[0..maxiter] at offset 16
+    d_cg_res.reserve(ne); d_cg_p.reserve(ne); d_cg_ap.reserve(ne); d_cg_scal.reserve(nctl); d_cg_done.reserve(1);
     d_cg_done.zero(stream);
+    double *hist_dev = d_cg_scal.p + 16;
     prof.begin("cg", stream);
     launch_cg_init(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_scal.p);
-    int done = 0, iter = 1;
+    double *ctl = pinned((size_t)ne_pad + 8 + nctl) + ne_pad + 8;
+    int done = 0, iter = 1, batch = std::max(2, std::min(16, cg_batch));
     while (iter < args.maxiter && !done) {
-      const int batch_end = std::min(args.maxiter, iter + 8);
+      const int batch_end = std::min(args.maxiter, iter + batch);
       for (; iter < batch_end; ++iter)
         launch_cg_iter(stream, ne, d_A.p, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_ap.p, d_cg_scal.p, args.tolerance,
-                       d_cg_done.p, iter, d_cg_hist.p);
-      HIP_TRY(hipMemcpyAsync(&done, d_cg_done.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+                       d_cg_done.p, iter, hist_dev);
+      HIP_TRY(hipMemcpyAsync(ctl, d_cg_scal.p, (size_t)(16 + iter) * sizeof(double), hipMemcpyDeviceToHost, stream));
       sync();
+      done = ctl[8] != 0.0;
+      batch = 4;
     }
     prof.end(stream);
-    double sc[8];
-    HIP_TRY(hipMemcpyAsync(sc, d_cg_scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
-    sync();
-    cg_iterations = done ? (int)sc[6] : 0;
-    // the log lines of :919-928: one per iteration, the converged one with the net charge (summed in index order like :917-918)
+    cg_iterations = done ? (int)ctl[6] : 0;
+    if (done) cg_batch = cg_iterations;                      // iteration 1..n: n launches reach convergence next time
+    // the log lines of :919-928: one per iteration, the converged one with the net charge
     const int last = done ? cg_iterations : args.maxiter - 1;
-    std::vector<double> hist(last + 1, 0.0), qh(ne);
-    if (last >= 1) HIP_TRY(hipMemcpyAsync(hist.data(), d_cg_hist.p, (last + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(qh.data(), d_eleallq, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
-    sync();
+    const double *hist = ctl + 16;
     for (int it = 1; it <= last; ++it) {
-      if (done && it == last) {
-        double netr = 0.0;
-        for (int i = 0; i < ne; ++i) netr += qh[i];
-        logf("***** Converged at iteration %d. res = %g netcharge = %g\n", it, hist[it], netr);
-      } else {
-        logf("Iteration %d: res = %g\n", it, hist[it]);
-      }
+      if (done && it == last) logf("***** Converged at iteration %d. res = %g netcharge = %g\n", it, hist[it], ctl[7]);
+      else logf("Iteration %d: res = %g\n", it, hist[it]);
     }
   }
 
@@ -977,6 +976,7 @@ struct conp_fix {
     va_start(ap, fmt);
     std::vsnprintf(line, sizeof line, fmt, ap);
     va_end(ap);
+    if (logbuf.size() > (1u << 20)) logbuf.clear();      // a host that never drains (device-resident loops) must not grow it forever
     logbuf += line;
   }
 

@@ -1264,7 +1264,8 @@ void launch_inv_project_apply(hipStream_t s, int n, double *A, const double *ain
 // ================================================================================================
 // 8. conjugate gradient with the neutrality constraint (fix_conp.cpp:864-930).  The matvec is gemv_rows; the
 //    vector updates + scalars run in ONE workgroup so that every reduction has a fixed order.
-//    scal: [0] lresnorm [1] lgamma [2] netr [3] ptap [4] alpha [5] beta [6] converged-iteration
+//    scal: [0] lresnorm [1] lgamma [2] netr [3] ptap [4] alpha [5] beta [6] converged-iteration [7] net charge at
+//          convergence [8] converged flag (0/1), followed in the same buffer by hist[iter] = lresnorm of every iteration
 // ================================================================================================
 __device__ double block_sum_1024(double v, double *red) {
   v = wave_sum(v);
@@ -1286,7 +1287,7 @@ __global__ __launch_bounds__(1024) void cg_init_kernel(int n, const double *__re
   l2 = block_sum_1024(l2, red);
   const double ave = netr / n;
   for (int i = threadIdx.x; i < n; i += 1024) p[i] = res[i] - ave;
-  if (threadIdx.x == 0) { const double lres = l2 - netr * ave; scal[0] = lres; scal[1] = lres; scal[2] = netr; scal[6] = 0.0; }
+  if (threadIdx.x == 0) { const double lres = l2 - netr * ave; scal[0] = lres; scal[1] = lres; scal[2] = netr; scal[6] = 0.0; scal[7] = 0.0; scal[8] = 0.0; }
 }
 
 void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, double *q, double *res, double *p, double *scal) {
@@ -1322,7 +1323,12 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restri
   if (threadIdx.x == 0) {
     scal[0] = lr; scal[1] = lg; scal[2] = netr; scal[3] = ptap; scal[4] = alpha; scal[5] = beta;
     hist[iter] = lr;
-    if (lr / n < tolerance) { *done = 1; scal[6] = (double)iter; }
+  }
+  if (lr / n < tolerance) {                 // block-uniform: every thread holds the same lr
+    double qs = 0.0;                        // net charge of the solution for the "Converged" log line (fix_conp.cpp:917-918)
+    for (int i = threadIdx.x; i < n; i += 1024) qs += q[i];
+    qs = block_sum_1024(qs, red);
+    if (threadIdx.x == 0) { *done = 1; scal[6] = (double)iter; scal[7] = qs; scal[8] = 1.0; }
   }
 }
 
