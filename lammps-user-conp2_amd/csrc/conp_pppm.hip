@@ -223,6 +223,96 @@ __global__ __launch_bounds__(256) void pppm_fft_kernel(int nx, int ny, int nz, i
   }
 }
 
+// ---- x and y transforms of one z-plane in ONE workgroup (the plane, nx * ny complex values, fits in LDS for the decks' meshes):
+// two launches fewer per 3-D transform -- the mesh path of a deck-sized system is bound by its launches.
+// Generic stage: element (t, line) lives at buf[t * st_t + line * st_l]; `t_fast` picks which index runs over adjacent threads
+// (the one with unit stride, so that a wavefront's LDS accesses spread over the banks).
+template <int R>
+__device__ __forceinline__ void fft_stage_g(const double2 *__restrict__ in, double2 *__restrict__ out, const double *__restrict__ tw,
+                                            int n, int Ns, int nlines, int st_t, int st_l, bool t_fast, double sign) {
+  const int nb = n / R;
+  const int tstep = nb / Ns;
+  double wc[R], ws[R];
+#pragma unroll
+  for (int m = 1; m < R; ++m) { wc[m] = tw[2 * m * nb]; ws[m] = sign * tw[2 * m * nb + 1]; }
+  for (int w = threadIdx.x; w < nb * nlines; w += blockDim.x) {
+    const int j = t_fast ? w % nb : w / nlines, lx = t_fast ? w / nb : w % nlines;
+    const int k = j % Ns;
+    const double2 *src = in + lx * st_l;
+    double2 *dst = out + lx * st_l;
+    double2 v[R];
+    v[0] = src[j * st_t];
+    int ti = 0;
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      const double2 x = src[(j + r * nb) * st_t];
+      ti += k * tstep;
+      const double c = tw[2 * ti], sn = sign * tw[2 * ti + 1];
+      v[r] = make_double2(x.x * c - x.y * sn, x.x * sn + x.y * c);
+    }
+    const int j0 = (j - k) * R + k;
+    if (R == 2) {
+      dst[j0 * st_t] = make_double2(v[0].x + v[1].x, v[0].y + v[1].y);
+      dst[(j0 + Ns) * st_t] = make_double2(v[0].x - v[1].x, v[0].y - v[1].y);
+    } else if (R == 4) {
+      const double2 s02 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), d02 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
+      const double2 s13 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y), d13 = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
+      const double2 id13 = make_double2(-sign * d13.y, sign * d13.x);
+      dst[j0 * st_t] = make_double2(s02.x + s13.x, s02.y + s13.y);
+      dst[(j0 + Ns) * st_t] = make_double2(d02.x + id13.x, d02.y + id13.y);
+      dst[(j0 + 2 * Ns) * st_t] = make_double2(s02.x - s13.x, s02.y - s13.y);
+      dst[(j0 + 3 * Ns) * st_t] = make_double2(d02.x - id13.x, d02.y - id13.y);
+    } else {
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        double sr = v[0].x, si = v[0].y;
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+          const int m = (q * r) % R;
+          if (m == 0) { sr += v[r].x; si += v[r].y; }
+          else { sr += v[r].x * wc[m] - v[r].y * ws[m]; si += v[r].x * ws[m] + v[r].y * wc[m]; }
+        }
+        dst[(j0 + q * Ns) * st_t] = make_double2(sr, si);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void fft_axis_g(double2 *&in, double2 *&out, const double *tw, const FftPlan &fp, int n, int nlines,
+                                           int st_t, int st_l, bool t_fast, double sign) {
+  int Ns = 1;
+  for (int st = 0; st < fp.nrad; ++st) {
+    switch (fp.rad[st]) {
+      case 2: fft_stage_g<2>(in, out, tw, n, Ns, nlines, st_t, st_l, t_fast, sign); break;
+      case 3: fft_stage_g<3>(in, out, tw, n, Ns, nlines, st_t, st_l, t_fast, sign); break;
+      case 4: fft_stage_g<4>(in, out, tw, n, Ns, nlines, st_t, st_l, t_fast, sign); break;
+      default: fft_stage_g<5>(in, out, tw, n, Ns, nlines, st_t, st_l, t_fast, sign); break;
+    }
+    __syncthreads();
+    double2 *tmp = in; in = out; out = tmp;
+    Ns *= fp.rad[st];
+  }
+}
+
+// one workgroup per z-plane: x transforms of its ny lines, then y transforms of its nx lines.  real_in: im is not read.
+__global__ __launch_bounds__(256) void pppm_fft_xy_kernel(int nx, int ny, double sign, FftPlan fpx, FftPlan fpy,
+                                                          const double *__restrict__ twx, const double *__restrict__ twy,
+                                                          double *__restrict__ re, double *__restrict__ im, int real_in) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int np = nx * ny;
+  double2 *b0 = reinterpret_cast<double2 *>(smem), *b1 = b0 + np;
+  double *tx = reinterpret_cast<double *>(b1 + np), *ty = tx + 2 * nx;
+  for (int t = threadIdx.x; t < 2 * nx; t += blockDim.x) tx[t] = twx[t];
+  for (int t = threadIdx.x; t < 2 * ny; t += blockDim.x) ty[t] = twy[t];
+  const size_t base = (size_t)blockIdx.x * np;
+  for (int e = threadIdx.x; e < np; e += blockDim.x) b0[e] = make_double2(re[base + e], real_in ? 0.0 : im[base + e]);
+  __syncthreads();
+  double2 *in = b0, *out = b1;
+  fft_axis_g(in, out, tx, fpx, nx, ny, 1, nx, true, sign);      // x: element (t = x, line = y) at [y * nx + x]
+  fft_axis_g(in, out, ty, fpy, ny, nx, nx, 1, false, sign);     // y: element (t = y, line = x)
+  for (int e = threadIdx.x; e < np; e += blockDim.x) { re[base + e] = in[e].x; im[base + e] = in[e].y; }
+}
+
 static bool fft_factor(int n, FftPlan &fp) {
   fp.nrad = 0;
   while (n % 4 == 0 && fp.nrad < 12) { fp.rad[fp.nrad++] = 4; n /= 4; }
@@ -277,7 +367,19 @@ static bool mesh_smooth(const PppmDev &pd) {
 // gscale*greensfn on its last pass; the backward one stores only the real part.
 static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, double *im, bool fused, double gscale) {
   const int dims[3] = {pd.nx, pd.ny, pd.nz};
-  for (int axis = 0; axis < 3; ++axis) {
+  int axis0 = 0;
+  {
+    FftPlan fpx, fpy;
+    const size_t lds = (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double);
+    if (fused && fft_factor(pd.nx, fpx) && fft_factor(pd.ny, fpy) && lds <= 128 * 1024) {
+      // the x and y passes of every z-plane in one workgroup
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pppm_fft_xy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(256), lds, s, pd.nx, pd.ny, sign, fpx, fpy, pd.twid[0], pd.twid[1], re, im,
+                         sign < 0 ? 1 : 0);
+      axis0 = 2;
+    }
+  }
+  for (int axis = axis0; axis < 3; ++axis) {
     const int n = dims[axis];
     FftPlan fp;
     if (fft_factor(n, fp)) {              // 2,3,5-smooth length (every mesh LAMMPS picks): radix FFT
