@@ -2,7 +2,7 @@
 """Per-rank compute time of the sharded update WITHOUT the collectives: one process builds the handle of rank r of N
 (conp_env.rank / nranks) on the single GPU and times b_cal_device + solve_device + scatter_device.  Used to see how the
 k-shard / row-shard scales before an N-GPU node is available; the two 32-KB RCCL collectives come on top.
-usage: python tools/rank_emulation.py [N ...]"""
+usage: python tools/rank_emulation.py [--workload NAME] [N ...]"""
 import os
 import sys
 import time
@@ -18,11 +18,15 @@ def main():
     import torch
     import bench
     from conp_amd import FixConp, neighbor
-    s = bench.make_workload("headline")
+    argv = sys.argv[1:]
+    wl = "headline"
+    if argv and argv[0] == "--workload":
+        wl, argv = argv[1], argv[2:]
+    s = bench.make_workload(wl)
     at, alist, blist = neighbor.build_lists(s)
     d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda()
     d_q = torch.from_numpy(at.q.copy()).cuda()
-    for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    for n in [int(a) for a in argv] or [1, 2, 4, 8]:
         worst = None
         for rank in sorted({0, n - 1, n // 2}):
             fx = FixConp(s, device=0, rank=rank, nranks=n)
@@ -38,16 +42,17 @@ def main():
                 fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())
                 fx.solve_device(s.potdiff)
                 fx.scatter_device(d_q.data_ptr(), s.potdiff)
-            for _ in range(20):
+            reps = 200 if wl != "big" else 10
+            for _ in range(max(2, reps // 10)):
                 step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(200):
+            for _ in range(reps):
                 step()
             torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 200 * 1e3
+            ms = (time.perf_counter() - t0) / reps * 1e3
             fx.profile(True)
-            for _ in range(50):
+            for _ in range(max(3, reps // 4)):
                 step()
             torch.cuda.synchronize()
             prof = {k: round(v[0], 4) for k, v in fx.profile_read().items()}
