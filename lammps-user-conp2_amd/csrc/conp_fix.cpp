@@ -1113,7 +1113,10 @@ struct conp_fix {
   double g_pot = 0.0;
   int g_warm = 0, g_pot_changes = 0;
   bool graph_off = getenv("CONP_GRAPH") == nullptr || atoi(getenv("CONP_GRAPH")) == 0;
+  // called at the top of every C-ABI entry that may touch the device: the handle's device becomes the thread's current one
+  // (a host that drives several GPUs from one thread may have switched), and a captured update graph is dropped
   void drop_graph() {
+    (void)hipSetDevice(env.device);
     if (upd_exec) { (void)hipGraphExecDestroy(upd_exec); upd_exec = nullptr; }
     if (upd_graph) { (void)hipGraphDestroy(upd_graph); upd_graph = nullptr; }
     g_warm = 0;
@@ -1671,6 +1674,7 @@ int conp_fix_scatter_device(conp_fix *f, double *d_q_atoms, double potdiff) {
 int conp_fix_pre_force_device(conp_fix *f, const double *dx, double *dq, double potdiff) {
   CONP_GUARD_BEGIN
   if (f->runstage < 2) throw ConpError(CONP_ERR_STATE, "pre_force_device before setup");
+  (void)hipSetDevice(f->env.device);
   f->update_device(dx, dq, potdiff);
   CONP_GUARD_END
 }
