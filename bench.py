@@ -236,6 +236,19 @@ def main():
                             avg_launch_ms=t_ms,
                             algorithmic_flops_per_launch=flops, survey_count_tflops=2 * ach,
                             note="achieved uses 4 flop per (k, atom); SURVEY 8d's reference-loop count (8 per k) would double it")
+        # composite bound of one update: sum over the kernels of max(algorithmic flops / FP64 peak, algorithmic bytes /
+        # HBM peak), one rank's share; achieved fraction = T_roof / measured time per update
+        HBM_PEAK = 8.0e12
+        n_planar_rows = 2.0 * info.kcount_flat                 # ~ rows of the electrode planar table
+        t_roof = {
+            "structure_factors_mfma": flops / (FP64_PEAK_TFLOPS * 1e12),
+            "b_projection_hbm": 8.0 * n_planar_rows * ne * shard / HBM_PEAK,            # the electrode planar table, streamed once
+            "b_real_space_hbm": info.n_blist_pairs * (8 + 32) / world / HBM_PEAK,       # 2 indices + gathered x, q per pair
+            "gemv_hbm": 8.0 * ne * ne / world / HBM_PEAK,
+        }
+        t_roof_ms = 1e3 * sum(t_roof.values())
+        composite = dict(t_roof_ms=t_roof_ms, frac=t_roof_ms / ms_per_step, parts_ms={k: 1e3 * v for k, v in t_roof.items()},
+                         note="sum of per-kernel max(algorithmic flops / 78.6 TF, algorithmic bytes / 8 TB/s); collectives excluded")
         out = dict(metric="charge-solve updates/sec + ns/day, 4096-atom electrode / 32k electrolyte", value=value,
                    unit="updates/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
@@ -250,7 +263,7 @@ def main():
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),
                    kernels_ms={k: round(v[0], 5) for k, v in prof.items()},
                    ms_per_step_profiled_pass=dt_prof / args.steps * 1e3,
-                   roofline=roofline)
+                   roofline=roofline, composite_roofline=composite)
         if not args.no_cpu_baseline and world == 1:
             S = fx.matrix()
             base = cpu_baseline(s, at, alist, blist, S, args.cpu_threads)
