@@ -790,6 +790,14 @@ void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1
 // ================================================================================================
 // 5. dense solve pieces.  GEMV: one wave per row, 16-byte loads (fix_conp.cpp:1135-1139 ddot_ per row)
 // ================================================================================================
+// the matrix is streamed once per update and is far larger than L2: non-temporal loads keep it from evicting the phase tables
+__device__ __forceinline__ double2 nt_load(const double2 *p) {
+  double2 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row1, const double *__restrict__ S,
                                                         const double *__restrict__ b, double *__restrict__ y) {
   const int row = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row
     double t0 = 0.0, t1 = 0.0;
     int j = lane;
     for (; j + 192 < n / 2; j += 256) {
-      const double2 a0 = s2[j], a1 = s2[j + 64], a2 = s2[j + 128], a3 = s2[j + 192];
+      const double2 a0 = nt_load(s2 + j), a1 = nt_load(s2 + j + 64), a2 = nt_load(s2 + j + 128), a3 = nt_load(s2 + j + 192);
       const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
       s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
       t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
