@@ -914,7 +914,7 @@ struct conp_fix {
     } else {
       prof.begin("elyte_phase", stream);
       launch_elyte_phase(stream, nl, nl_pad, d_elyte_idx.p, dx, dq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
-                         plan.kymax, plan.nz, KPlan::ZSTRIDE, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
+                         plan.kymax, plan.nz, KPlan::ZSTRIDE, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
       prof.end(stream);
       prof.begin("sk_gemm", stream);
       launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,

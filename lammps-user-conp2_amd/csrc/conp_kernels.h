@@ -39,7 +39,7 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
 void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, const int *img, double px, double py, double pz,
                        double *x, double *q);
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
-                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part);

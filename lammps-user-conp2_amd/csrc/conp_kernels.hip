@@ -38,7 +38,7 @@ constexpr int EP_THREADS = 128;
 __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nl, int nl_pad, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double ux, double uy, double uz, int kxmax, int kymax, int nz,
-                                                          int zstride, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
+                                                          int zstride, int nrz, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
                                                           double2 *__restrict__ Zs, double *__restrict__ qc,
                                                           double *__restrict__ slab_part) {
 #pragma clang fp contract(off)
@@ -53,7 +53,10 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nl, int nl_
     }
     const double ang = (c == 0 ? ux : (c == 1 ? uy : uz)) * xc;
     const int nrow = c == 0 ? kxmax + 1 : (c == 1 ? kymax + 1 : nz);
-    double2 *t = (c == 0 ? Xt : (c == 1 ? Yt : Zs)) + j;
+    // tables are blocked by 16 atoms (one sk_gemm chunk): element (row, atom j) at ((j >> 4) * NR + row) * 16 + (j & 15), so that
+    // everything a workgroup loads for a chunk sits in a few contiguous KB instead of one 256-byte piece per 512-KB row
+    const int NR = c == 0 ? kxmax + 2 : (c == 1 ? kymax + 1 : nrz);
+    double2 *t = (c == 0 ? Xt : (c == 1 ? Yt : Zs)) + ((size_t)(j >> 4) * NR) * 16 + (j & 15);
     // X and Y: every row.  Z: row 0 of Zs is the unit step (cos, sin)(uz z); row 1 + s is the seed for m = s*zstride --
     // sk_gemm regenerates the m's in between with the same recurrence, so the values equal the full table's.
     const int stride = (c == 2) ? zstride : 1;
@@ -62,17 +65,17 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nl, int nl_
     const double sc = (c == 0) ? qq : 1.0;
     double c1, s1;
     sincos(ang, &s1, &c1);
-    if (c == 0) Xt[(size_t)(kxmax + 1) * nl_pad + j] = make_double2(0.0, 0.0);   // row for padding planar vectors (no contribution)
+    if (c == 0) t[(size_t)(kxmax + 1) * 16] = make_double2(0.0, 0.0);   // row for padding planar vectors (no contribution)
     if (c == 2) { t[0] = make_double2(c1, s1); qc[j] = qq; qz = qq * xc; }
-    t[(size_t)off * nl_pad] = make_double2(sc, 0.0);
+    t[(size_t)off * 16] = make_double2(sc, 0.0);
     double cm = c1, sm = s1;
-    if (nrow > 1 && stride == 1) t[(size_t)(off + 1) * nl_pad] = make_double2(sc * c1, sc * s1);
+    if (nrow > 1 && stride == 1) t[(size_t)(off + 1) * 16] = make_double2(sc * c1, sc * s1);
     int next = stride > 2 ? stride : 2;   // first stored m >= 2 that is a multiple of stride
     for (int m = 2; m < nrow; ++m) {
       const double cn = cm * c1 - sm * s1;
       const double sn = sm * c1 + cm * s1;
       cm = cn; sm = sn;
-      if (m == next) { t[(size_t)(off + m / stride) * nl_pad] = make_double2(sc * cm, sc * sm); next += stride; }
+      if (m == next) { t[(size_t)(off + m / stride) * 16] = make_double2(sc * cm, sc * sm); next += stride; }
     }
   }
   if (c != 2) return;
@@ -108,12 +111,12 @@ void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, 
 }
 
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
-                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, double2 *Xt,
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part) {
   const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS;
   *n_slab_part = nb;
   hipLaunchKernelGGL(elyte_phase_kernel, dim3(nb, 3), dim3(EP_THREADS), 0, s, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
-                     kymax, nz, zstride, Xt, Yt, Zs, qc, slab_part);
+                     kymax, nz, zstride, nrz, Xt, Yt, Zs, qc, slab_part);
 }
 
 // ================================================================================================
@@ -149,10 +152,11 @@ constexpr int SK_PANEL = SK_NF * SK_LD;   // doubles per buffer
 
 // one step of the angle-addition recurrence without FMA contraction (same arithmetic as elyte_phase_kernel)
 __device__ __forceinline__ double2 zstep(double2 z, double2 st) {
-#pragma clang fp contract(off)
+  // contraction allowed here (2 mul + 2 fma instead of 4 mul + 2 add): at most 4 steps from a seed that elyte_phase computed
+  // with the reference's arithmetic, and FP64 VALU time is MFMA time on this chip (shared pipe)
   double2 r;
-  r.x = z.x * st.x - z.y * st.y;
-  r.y = z.y * st.x + z.x * st.y;
+  r.x = fma(z.x, st.x, -(z.y * st.y));
+  r.y = fma(z.y, st.x, z.x * st.y);
   return r;
 }
 
@@ -164,7 +168,8 @@ struct SkCtx {        // per-thread constants of one work item
   SkItem it;
   int nl_pad, nz;
   int gj, gs;                       // generation role: atom gj of the chunk, sub-index gs 0..31
-  unsigned xoff0, yoff0, xoff1, yoff1, zoff;   // element offsets into the phase tables (< 2^32)
+  unsigned xoff0, yoff0, xoff1, yoff1, zoff;   // row * 16 + gj inside a chunk block of the phase tables
+  unsigned nrx16, nry16, nrz16;                // rows per chunk block * 16 (X, Y, Z tables)
   double sg0, sg1;
   bool zact;
   int a_off, b_off, fr, fk, rh, cg;
@@ -175,22 +180,24 @@ struct SkCtx {        // per-thread constants of one work item
 };
 
 __device__ __forceinline__ void sk_load_raw(const SkCtx &c, int ch, SkRaw &r) {
-  const unsigned jg = (unsigned)ch * SK_J + c.gj;
-  r.X0 = c.Xt[c.xoff0 + jg]; r.Y0 = c.Yt[c.yoff0 + jg];
-  r.X1 = c.Xt[c.xoff1 + jg]; r.Y1 = c.Yt[c.yoff1 + jg];
-  if (c.zact) { r.Zst = c.Zs[jg]; r.Zseed = c.Zs[c.zoff + jg]; }
+  // blocked tables: element (row, atom) of chunk ch at (ch * NR + row) * 16 + (atom & 15); the row offsets already hold row * 16 + gj
+  const unsigned bx = (unsigned)ch * c.nrx16, by = (unsigned)ch * c.nry16, bz = (unsigned)ch * c.nrz16;
+  r.X0 = c.Xt[bx + c.xoff0]; r.Y0 = c.Yt[by + c.yoff0];
+  r.X1 = c.Xt[bx + c.xoff1]; r.Y1 = c.Yt[by + c.yoff1];
+  if (c.zact) { r.Zst = c.Zs[bz + c.gj]; r.Zseed = c.Zs[bz + c.zoff]; }
 }
 
 __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, double *pn) {
   // (kx, sg*ky): q cos = (q cx) cy - (q sx)(sg sy) ; q sin = (q cx)(sg sy) + (q sx) cy   (km_ewald.cpp:739-747); the X table
   // already carries q, padding rows read an all-zero X row
+  // sg is +1 or -1 (0 only on padding rows, whose X row is all zero anyway): a sign flip, not an FP64 multiply
   {
-    const double sy = c.sg0 * r.Y0.y;
+    const double sy = c.sg0 < 0.0 ? -r.Y0.y : r.Y0.y;
     pn[c.gs * SK_LD + c.gj] = r.X0.x * r.Y0.x - r.X0.y * sy;
     pn[(64 + c.gs) * SK_LD + c.gj] = r.X0.x * sy + r.X0.y * r.Y0.x;
   }
   {
-    const double sy = c.sg1 * r.Y1.y;
+    const double sy = c.sg1 < 0.0 ? -r.Y1.y : r.Y1.y;
     pn[(32 + c.gs) * SK_LD + c.gj] = r.X1.x * r.Y1.x - r.X1.y * sy;
     pn[(96 + c.gs) * SK_LD + c.gj] = r.X1.x * sy + r.X1.y * r.Y1.x;
   }
@@ -200,9 +207,10 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
     for (int u = 0; u < 5; ++u) {
       const int ml = 5 * c.gs + u;                        // kz index inside the col tile
       const int feat = 128 + 32 * (ml >> 4) + (ml & 15);
-      const bool ok = c.it.ct * 160 + ml < c.nz;
-      pn[feat * SK_LD + c.gj] = ok ? Z.x : 0.0;
-      pn[(feat + 16) * SK_LD + c.gj] = ok ? Z.y : 0.0;
+      // (kz beyond nz - 1: the seed rows there are never written (zero) or the recurrence just runs on -- finite values in G
+      //  columns that carry zero weight and no listed k; not worth two selects per value)
+      pn[feat * SK_LD + c.gj] = Z.x;
+      pn[(feat + 16) * SK_LD + c.gj] = Z.y;
       Z = zstep(Z, r.Zst);
     }
   }
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   c.a_off = (64 * c.rh + c.fr) * SK_LD + c.fk;
   c.b_off = (128 + 16 * c.cg + c.fr) * SK_LD + c.fk;
   c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
+  c.nrx16 = (unsigned)(pl.kxmax + 2) * 16; c.nry16 = (unsigned)(pl.kymax + 1) * 16; c.nrz16 = (unsigned)(1 + pl.n_col_tiles * 32) * 16;
   const bool late = wave >= 4 && !(dbg & 8);
   const int s0 = seg_ptr[blockIdx.x], s1 = seg_ptr[blockIdx.x + 1];
   for (int sg = s0; sg < s1; ++sg) {
@@ -324,11 +333,11 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     }
     c.fmask = __builtin_amdgcn_readfirstlane(c.fmask);
     const int p0 = c.it.rt * 64 + c.gs, p1 = p0 + 32;
-    c.xoff0 = (unsigned)pl.p_ikx[p0] * nl_pad; c.yoff0 = (unsigned)pl.p_iky[p0] * nl_pad;
-    c.xoff1 = (unsigned)pl.p_ikx[p1] * nl_pad; c.yoff1 = (unsigned)pl.p_iky[p1] * nl_pad;
+    c.xoff0 = (unsigned)pl.p_ikx[p0] * 16 + c.gj; c.yoff0 = (unsigned)pl.p_iky[p0] * 16 + c.gj;
+    c.xoff1 = (unsigned)pl.p_ikx[p1] * 16 + c.gj; c.yoff1 = (unsigned)pl.p_iky[p1] * 16 + c.gj;
     c.sg0 = (double)pl.p_sgn[p0]; c.sg1 = (double)pl.p_sgn[p1];       // 0 marks a padding row
     c.zact = 5 * c.gs < 16 * c.it.nba;                  // this thread's 5 kz values lie in an active block
-    c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * nl_pad;
+    c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * 16 + c.gj;
     double *out = part + (size_t)sg * (128 * 320);
     if (late) {
       switch (nfw) {
