@@ -134,7 +134,7 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
 //    Partial tiles go to part[item][128][320]; sk_reduce sums a tile's splits in a fixed order (deterministic).
 // ================================================================================================
 #ifndef SK_LATE_MODE
-#define SK_LATE_MODE 2
+#define SK_LATE_MODE 1
 #endif
 // raise a kernel's dynamic-LDS limit, only when a launch needs more than it was last given: per-update launches must not
 // pay a runtime call each (the decks' updates are bound by host launch cost)
