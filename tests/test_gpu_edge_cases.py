@@ -99,3 +99,40 @@ def test_one_group_as_both_electrodes(oracle):
     assert rel_err(at.q[ele], o.q[ele]) < 1e-8
     assert fx.compute_scalar() == pytest.approx(o.fx.scalars()["scalar_output"], rel=1e-7, abs=1e-12)
     fx.close(); o.fx.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_seeded_sweep_of_geometries_and_parameters(oracle, seed):
+    """eight seeded draws of box shape, layer count, cut-off, Ewald splitting, accuracy, eta, boundary mode and solver: full
+    chain (k tables bit-exact, b, charges, scalar) against the oracle -- k-table edge cases (kxmax != kymax, several kz column
+    tiles on a tall box, few planar vectors on a narrow one) come out of the draw rather than out of a hand-picked list"""
+    rng = np.random.default_rng(1000 + seed)
+    nx, ny = int(rng.integers(2, 7)), int(rng.integers(1, 4))
+    layers = int(rng.integers(1, 3))
+    lz = float(rng.uniform(45.0, 140.0))
+    mode = ["slab", "ffield"][int(rng.integers(0, 2))]
+    s = systems.synthetic(n_cells_x=nx, n_cells_y=ny, lz=lz, n_elyte=int(rng.integers(5, 40)) * 4, layers=layers,
+                          cutoff=float(rng.uniform(5.0, 9.0)), accuracy_relative=float(10 ** rng.uniform(-6.5, -4.0)),
+                          g_ewald=float(rng.uniform(0.25, 0.5)), mode=mode, seed=seed, min_dist=1.5,
+                          potdiff=float(rng.uniform(0.2, 3.0)), name=f"sweep{seed}")
+    s.eta = float(rng.uniform(1.2, 2.4))
+    cg = bool(rng.integers(0, 2))
+    at, alist, blist = neighbor.build_lists(s)
+    o = OracleRun(oracle, s, at, alist, blist, minimizer=0 if cg else 1)
+    o.setup()
+    o.pre_force(s.potdiff)
+    fx = FixConp(s, extra_args=["cg"] if cg else [])
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    kt = fx.ktables()
+    for name in ("kxvecs", "kyvecs", "kzvecs", "ug"):
+        assert np.array_equal(kt[name], getattr(o.fx.ks, name)), (seed, name)
+    b_o, q_o, sq_o = o.fx.vectors()
+    b_g, q_g, sq_g = fx.vectors()
+    assert rel_err(b_g, b_o) < 1e-10, seed
+    tol = 1e-6 if cg else 1e-8
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < tol, seed
+    assert fx.compute_scalar() == pytest.approx(o.fx.scalars()["scalar_output"], rel=10 * tol, abs=1e-10), seed
+    fx.close(); o.fx.close()
