@@ -142,7 +142,7 @@ struct conp_fix {
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -634,9 +634,32 @@ struct conp_fix {
   // km_ewald.cpp:147-151 + :584-666 : k-space part of A into d_A (strict lower triangle + diagonal + slab on j <= i)
   void km_a_cal_device() {
     const int ne = idx.elenum_all;
+    // kz chunks (16-kz blocks) dealt to nsplit groups of about equal work: heaviest first to the lightest group; a chunk costs
+    // as many row tiles as reach it
+    int nchunk = 0;
+    for (int v : plan.nb_act) nchunk = std::max(nchunk, v);
+    const int nsplit = a_kspace_nsplit(ne_pad, num_cus, nchunk);
+    std::vector<int> group(std::max(nchunk, 1), 0);
+    {
+      std::vector<std::pair<int, int>> cost;
+      for (int c = 0; c < nchunk; ++c) {
+        int n = 0;
+        for (int v : plan.nb_act) n += v > c;
+        cost.push_back({-n, c});
+      }
+      std::stable_sort(cost.begin(), cost.end());
+      std::vector<int> load(nsplit, 0);
+      for (auto &e : cost) {
+        int g = 0;
+        for (int k = 1; k < nsplit; ++k) if (load[k] < load[g]) g = k;
+        group[e.second] = g; load[g] += -e.first;
+      }
+    }
+    d_a_chunk_group.upload(group, stream);
+    d_A.reserve((size_t)nsplit * ne * ne);
     d_A.zero(stream);
     prof.begin("a_kspace", stream);
-    launch_a_kspace(stream, dplan, ne, ne_pad, d_Rp.p, d_Tz.p, d_A.p);
+    launch_a_kspace(stream, dplan, ne, ne_pad, d_Rp.p, d_Tz.p, d_A.p, nsplit, d_a_chunk_group.p);
     prof.end(stream);
   }
 

@@ -79,7 +79,9 @@ void launch_post_force(hipStream_t s, int inum, const int *ilist, const int *num
 void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);
 
 // ---- once-per-run matrix work ------------------------------------------------------------------
-void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A);
+int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk);
+void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A, int nsplit,
+                     const int *chunk_group);
 void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, const double *diag_self_atom /*[ne] or NULL*/,
                         int slab, double pref, const double *ele_z, double *A);
 void launch_a_real(hipStream_t s, int ne, const int *row_ptr, const int *ele_atom, const int *oth_atom, const int *col,

@@ -1082,10 +1082,16 @@ constexpr int AK_LD = 272;         // 256 atoms + 16 pad
 __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_pad, int ne, int ne_pad, int n_row_tiles,
                                                               const int *__restrict__ nb_act, const double *__restrict__ wfull,
                                                               const double *__restrict__ Rp, const double *__restrict__ Tz,
-                                                              double *__restrict__ A) {
+                                                              double *__restrict__ A, int nsplit,
+                                                              const int *__restrict__ chunk_group, size_t part_stride) {
   extern __shared__ __attribute__((aligned(16))) char ak_smem[];
   double *L = reinterpret_cast<double *>(ak_smem);      // [AK_TC][AK_LD]
-  int tidx = blockIdx.x, bi = 0;
+  // unit = (tile, split s): the kz chunks are dealt to `nsplit` groups of about equal work on the host; split s sums its group
+  // into its own copy of the tile (A + s * part_stride), a_parts_sum adds the copies in a fixed order.  More, smaller units:
+  // 528 tiles on 512 workgroup slots (Ne = 4096) leave a 30 % tail otherwise.
+  const int split = blockIdx.x % nsplit;
+  A += (size_t)split * part_stride;
+  int tidx = blockIdx.x / nsplit, bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= tidx) ++bi;
   const int bj = tidx - bi * (bi + 1) / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1102,6 +1108,7 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
   for (int rt = 0; rt < n_row_tiles; ++rt) nchunk = nb_act[rt] > nchunk ? nb_act[rt] : nchunk;
   const double *li = L + fk * AK_LD + wi * 64 + fr, *lj = L + fk * AK_LD + 128 + wj * 64 + fr;
   for (int c = 0; c < nchunk; ++c) {
+    if (chunk_group[c] != split) continue;
     __syncthreads();
     for (int e = threadIdx.x; e < AK_TC * 256; e += 256) {
       const int t = e >> 8, a = e & 255;
@@ -1149,15 +1156,39 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
       }
 }
 
-void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A) {
+// A (strict lower triangle) = fixed-order sum of the split copies: ((A0 + A1) + (A2 + A3)), copies 1.. in `parts`
+__global__ void a_parts_sum_kernel(int ne, int nsplit, double *__restrict__ A, const double *__restrict__ parts) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n2 = (size_t)ne * ne;
+  if (e >= n2) return;
+  const int i = (int)(e / ne), j = (int)(e % ne);
+  if (j >= i) return;
+  double v = A[e];
+  if (nsplit == 2) v += parts[e];
+  else if (nsplit == 4) v = (v + parts[e]) + (parts[n2 + e] + parts[2 * n2 + e]);
+  A[e] = v;
+}
+
+// how many ways the kz chunks of a tile are split: none when there are many more tiles than workgroup slots
+int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk) {
+  const int nb = ne_pad / 128;
+  const long ntiles = (long)nb * (nb + 1) / 2, slots = 2L * num_cus;
+  if (ntiles >= 6 * slots || nchunk < 2) return 1;
+  return nchunk >= 4 ? 4 : 2;
+}
+
+// A must have room for nsplit copies of ne * ne doubles; copy s of a tile goes to A + s * ne * ne, the sum lands in copy 0
+void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A, int nsplit,
+                     const int *chunk_group) {
   const int nb = ne_pad / 128;
   const int ntiles = nb * (nb + 1) / 2;
-  {
-    const size_t lds = (size_t)AK_TC * AK_LD * sizeof(double);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(a_kspace_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(a_kspace_lds_kernel, dim3(ntiles), dim3(256), lds, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.n_row_tiles, pl.nb_act,
-                       pl.wfull, Rp, Tz, A);
-  }
+  const size_t lds = (size_t)AK_TC * AK_LD * sizeof(double);
+  static size_t granted = 0;
+  ensure_dyn_lds(a_kspace_lds_kernel, lds, granted);
+  const size_t n2 = (size_t)ne * ne;
+  hipLaunchKernelGGL(a_kspace_lds_kernel, dim3(ntiles * nsplit), dim3(256), lds, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.n_row_tiles,
+                     pl.nb_act, pl.wfull, Rp, Tz, A, nsplit, chunk_group, n2);
+  if (nsplit > 1) hipLaunchKernelGGL(a_parts_sum_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, ne, nsplit, A, A + n2);
 }
 
 // diagonal ug_tot - 2g/sqrt(pi) + sqrt(2) eta/sqrt(pi) (km_ewald.cpp:631-634, fix_conp.cpp:796-801) and the slab
