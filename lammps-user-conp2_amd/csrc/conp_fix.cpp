@@ -669,8 +669,19 @@ struct conp_fix {
     const int ne = idx.elenum_all;
     logf("A matrix calculating ...\n");                                   // :787
     const auto t_a0 = std::chrono::steady_clock::now();
+    static const bool tt = getenv("CONP_TIME_REN") != nullptr;
+    auto tm = std::chrono::steady_clock::now();
+    auto mk = [&](const char *what) {
+      if (!tt) return;
+      sync();
+      const auto t = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "    a_cal %-20s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tm).count());
+      tm = t;
+    };
     km_a_read(at);
+    mk("electrode tables");
     km_a_cal_device();
+    mk("k-space SYRK");
     const double MY_PIS = 1.77245385090551602729;
     const double diag_k = kt.ug_tot - (2.0 / MY_PIS) * kt.g_ewald;      // km_ewald.cpp:631-634
     const double diag_self = (std::sqrt(2.0) / MY_PIS) * args.eta;      // fix_conp.cpp:796-801
@@ -693,6 +704,7 @@ struct conp_fix {
     launch_a_symmetrise(stream, ne, d_A.p);
     HIP_TRY(hipGetLastError());
     sync();
+    mk("real space + symmetrise");
     runstage = 1;
     if (args.matout) write_matrix_file("amatrix", 0);          // fix_conp.cpp:833-849
     logf("A matrix calculation time  = %g\n",                               // :857
@@ -907,11 +919,24 @@ struct conp_fix {
   // fix_conp.cpp:426-464 linalg_setup
   void linalg_setup(const conp_atoms *at) {
     if (runstage != 0) return;
+    static const bool tt = getenv("CONP_TIME_REN") != nullptr;         // same switch as the re-neighbour breakdown
+    auto t0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+      if (!tt) return;
+      sync();
+      const auto t = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "  linalg_setup %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count());
+      t0 = t;
+    };
     if (args.a_matrix_f == 0) a_cal(at);
     else if (!matrix_loaded) a_read_file(at, args.a_matrix_file);      // fix_conp.cpp:443-446
+    mark("a_cal");
     b_setq_cal(at);
+    mark("b_setq_cal");
     equation_solve();
+    mark("equation_solve");
     get_setq(at);
+    mark("get_setq");
     mesgf("conp output: <d,d> = %.8g\n", -totsetq);                      // :458-461
   }
 

@@ -346,15 +346,21 @@ void electrode_plan_tables(const KTables &kt, const KPlan &plan, int ne, int ne_
     Rp[(size_t)plan.row_a(0) * ne_pad + i] = 1.0;   // origin: cos 0
     Tz[(size_t)plan.col_c(0) * ne_pad + i] = 1.0;   // m = 0
   }
+  // a transpose ([atom][k] -> [k][atom]): atoms in blocks of 8, so that the 8 source rows stay in cache while f runs and every
+  // destination write is one full cache line
+  std::vector<size_t> dst_c(kflat), dst_s(kflat);
+  std::vector<char> is_planar(kflat);
   for (int f = 0; f < kflat; ++f) {
     const int p = plan.flat2p[f];
-    if (p >= 0) {
-      double *ra = Rp.data() + (size_t)plan.row_a(p) * ne_pad, *rb = Rp.data() + (size_t)plan.row_b(p) * ne_pad;
-      for (int i = 0; i < ne; ++i) { ra[i] = csk[(size_t)i * kflat + f]; rb[i] = snk[(size_t)i * kflat + f]; }
-    } else {
-      const int m = f - zoff + 1;
-      double *tc = Tz.data() + (size_t)plan.col_c(m) * ne_pad, *ts = Tz.data() + (size_t)plan.col_s(m) * ne_pad;
-      for (int i = 0; i < ne; ++i) { tc[i] = csk[(size_t)i * kflat + f]; ts[i] = snk[(size_t)i * kflat + f]; }
+    is_planar[f] = p >= 0;
+    if (p >= 0) { dst_c[f] = (size_t)plan.row_a(p) * ne_pad; dst_s[f] = (size_t)plan.row_b(p) * ne_pad; }
+    else { const int m = f - zoff + 1; dst_c[f] = (size_t)plan.col_c(m) * ne_pad; dst_s[f] = (size_t)plan.col_s(m) * ne_pad; }
+  }
+  for (int i0 = 0; i0 < ne; i0 += 8) {
+    const int i1 = std::min(ne, i0 + 8);
+    for (int f = 0; f < kflat; ++f) {
+      double *dc = (is_planar[f] ? Rp.data() : Tz.data()) + dst_c[f], *ds = (is_planar[f] ? Rp.data() : Tz.data()) + dst_s[f];
+      for (int i = i0; i < i1; ++i) { dc[i] = csk[(size_t)i * kflat + f]; ds[i] = snk[(size_t)i * kflat + f]; }
     }
   }
 }
