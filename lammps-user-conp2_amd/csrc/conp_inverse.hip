@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void inv_prep_kernel(int n, int ld, int k0, in
 }
 
 // ---- 5. M -= Cct^T * Wb on the matrix cores: workgroup 128 x 128, wave 64 x 64 (4 x 4 fragments), K = 64 ----------
-__global__ __launch_bounds__(256, 1) void inv_update_kernel(int n, int ld, const double *__restrict__ Cct,
+__global__ __launch_bounds__(256, 2) void inv_update_kernel(int n, int ld, const double *__restrict__ Cct,
                                                             const double *__restrict__ Wb, double *__restrict__ M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
