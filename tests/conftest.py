@@ -11,6 +11,13 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the shared libraries are build artefacts (git-ignored): a tree that was never built gets them here, the way
+    # __graft_entry__.build() makes them (hipcc cross-compiles gfx950 without a GPU; about a minute)
+    lib = os.path.join(ROOT, "lammps-user-conp2_amd", "conp_amd", "libconp_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "lammps-user-conp2_amd", "csrc"), "-j4"],
+                              stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
