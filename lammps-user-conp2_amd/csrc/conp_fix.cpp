@@ -56,6 +56,7 @@ struct DevBuf {
   }
   void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
   void zero(hipStream_t s) { if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
 // per-kernel timing with HIP events on the library's stream (bench.py's roofline leg)
@@ -138,7 +139,7 @@ struct conp_fix {
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
-      d_cg_ap, d_cg_scal, d_inv_work, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
+      d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
@@ -414,21 +415,8 @@ struct conp_fix {
     mark("atoms static");
     map_ghosts(at);
     mark("ghost map");
-    // electrolyte atoms that enter the structure factors (km_ewald.cpp:686) -- list fixed until the next re-neighbour
-    elyte_idx_h.clear();
-    for (int i = 0; i < at->nlocal; ++i) if (at->echeck[i] == 0 && at->q[i] != 0) elyte_idx_h.push_back(i);
-    nl = (int)elyte_idx_h.size();
-    // atoms are consumed in chunks of 32; the splits want an even share of chunks
-    nl_pad = std::max(32, (nl + 31) / 32 * 32);
-    d_elyte_idx.upload(elyte_idx_h, stream);
-    mark("electrolyte list");
-    build_items();
-    mark("stream-K schedule");
-    d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
-    d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
-    d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
-    d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
-    mark("table reserves");
+    build_elyte_list(at);
+    mark("electrolyte list + schedule");
     // the flattened half list goes to the device as it is: the post-force kernel walks it (one wavefront per owner), and the
     // electrode rows of the real-space b are regrouped from it on the device (conp_rows.hip: count, scan, emit, stable sort)
     {
@@ -450,6 +438,35 @@ struct conp_fix {
     nlocal_cur = at->nlocal;
     sync();
     mark("sync");
+  }
+
+  // Electrolyte atoms that enter the structure factors: `electrode_check == 0 && q != 0` (km_ewald.cpp:685-686).  The reference
+  // evaluates that test every step; here the compact list lives on the device between re-neighbourings, and the host-buffer hooks
+  // (which see atom->q) re-check the membership at every update -- elyte_list_stale() -- and rebuild the list when an atom's
+  // charge has switched between zero and non-zero (fix atom/swap, charge-transfer fixes).  Device-resident hosts
+  // (conp_fix_pre_force_device) announce such a change with conp_fix_post_neighbor.
+  void build_elyte_list(const conp_atoms *at) {
+    elyte_idx_h.clear();
+    for (int i = 0; i < at->nlocal; ++i) if (at->echeck[i] == 0 && at->q[i] != 0) elyte_idx_h.push_back(i);
+    nl = (int)elyte_idx_h.size();
+    // atoms are consumed in chunks of 32; the splits want an even share of chunks
+    nl_pad = std::max(32, (nl + 31) / 32 * 32);
+    d_elyte_idx.upload(elyte_idx_h, stream);
+    build_items();
+    d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
+    d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
+    d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
+    d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
+  }
+  bool elyte_list_stale(const conp_atoms *at) const {
+    size_t k = 0;
+    const size_t n = elyte_idx_h.size();
+    for (int i = 0; i < at->nlocal; ++i) {
+      if (at->echeck[i] != 0 || at->q[i] == 0) continue;
+      if (k >= n || elyte_idx_h[k] != i) return true;
+      ++k;
+    }
+    return k != n;
   }
 
   // sk_gemm schedule ("stream-K" over the atom chunks): the work of all tiles of this rank is laid out on one axis,
@@ -834,12 +851,25 @@ struct conp_fix {
   void invert_device(int n, double *A) {
     d_inv_work.reserve(inverse_workspace_doubles(n));
     d_ipiv.reserve(n + 1); d_info.reserve(2);
-    prof.begin("inverse", stream);
-    launch_inverse(stream, n, A, d_inv_work.p, d_ipiv.p, d_info.p);
-    prof.end(stream);
+    // the in-place elimination destroys A: keep a copy while the multi-workgroup panel (grid barriers) is in use, so that a
+    // barrier time-out (info = -7: some workgroup was not resident) can be answered by the one-workgroup panel
+    static const bool single = getenv("CONP_PANEL_SINGLE") != nullptr;
+    if (!single) {
+      d_inv_backup.reserve((size_t)n * n);
+      HIP_TRY(hipMemcpyAsync(d_inv_backup.p, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
     int info = 0;
-    HIP_TRY(hipMemcpyAsync(&info, d_info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-    sync();
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      prof.begin("inverse", stream);
+      const bool multi = launch_inverse(stream, n, A, d_inv_work.p, d_ipiv.p, d_info.p, num_cus, attempt == 0 && !single);
+      prof.end(stream);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&info, d_info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      sync();
+      if (!(multi && info == -7)) break;
+      HIP_TRY(hipMemcpyAsync(A, d_inv_backup.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
+    d_inv_backup.release();
     if (info != 0) throw ConpError(CONP_ERR_NUMERIC, "Inversion failed!");   // fix_conp.cpp:956
   }
 
@@ -1143,6 +1173,7 @@ struct conp_fix {
   void b_cal(const conp_atoms *at) {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
     if (d_Rp.n == 0) km_a_read(at);      // electrode phase tables (kspmod->a_read) not built yet: b_cal before a_cal
+    if (elyte_list_stale(at)) { sync(); build_elyte_list(at); }       // km_ewald.cpp:686 is evaluated every step
     upload_xq(at);
     b_cal_device(d_x.p, d_q.p, true, true);
   }
@@ -1336,8 +1367,8 @@ void conp_fix_destroy(conp_fix *fix) { delete fix; }
 
 int conp_fix_init_list(conp_fix *f, int which, const conp_neighlist *l) {
   CONP_GUARD_BEGIN
-  f->drop_graph();
   if (!f || !l) throw ConpError(CONP_ERR_ARG, "null argument");
+  f->drop_graph();
   ListView v; v.inum = l->inum; v.ilist = l->ilist; v.numneigh = l->numneigh; v.first = l->first; v.neigh = l->neigh;
   if (which == 0 || which == 2) { f->alist = v; f->have_alist = true; }
   if (which == 1 || which == 2) { f->blist = v; f->have_blist = true; }
@@ -1388,6 +1419,9 @@ int conp_fix_modify_param(conp_fix *f, int narg, const char *const *arg, int *co
   CONP_GUARD_BEGIN
   f->drop_graph();
   const int n = f->modify_param(narg, arg);
+  // the reference rebuilds its per-type tables in FixConp::init() of every run (fix_conp.cpp:296-299): a fix_modify that arrives
+  // after the first setup must reach the device tables too
+  if (n > 0 && f->idx.initialised) { f->ehgo_setup_tables(); f->sync(); }
   if (consumed) *consumed = n;
   CONP_GUARD_END
 }
@@ -1463,6 +1497,7 @@ int conp_km_b_cal(conp_fix *f, const conp_atoms *at, double *bbb) {
   f->drop_graph();
   if (f->d_Rp.n == 0) f->km_a_read(at);
   if (at->nlocal + at->nghost != f->nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
+  if (f->elyte_list_stale(at)) { f->sync(); f->build_elyte_list(at); }
   f->upload_xq(at);
   f->b_cal_device(f->d_x.p, f->d_q.p, false);
   HIP_TRY(hipMemcpyAsync(bbb, f->d_b, f->idx.elenum_all * sizeof(double), hipMemcpyDeviceToHost, f->stream));

@@ -5,8 +5,8 @@
 //
 // One block step (NB = 64 columns K = [k0, k0+NB)):
 //   1. LU-factor the panel (rows k0.., columns K) with partial pivoting -> pivots and the factored top 64 x 64 block:
-//      up to 256 cooperating workgroups, rows resident in LDS, one grid barrier per column (1c); a one-workgroup version
-//      (1a + 1b) remains as the fallback when a cooperative launch is not possible
+//      up to 256 workgroups working together, rows resident in LDS, one grid barrier per column (1c); a one-workgroup version
+//      (1a + 1b) remains as the fallback (CONP_PANEL_SINGLE, or when a barrier ever timed out)
 //   2. apply the row swaps to the whole matrix
 //   3. Dinv = (M[K,K])^-1 from the panel's L11, U11 (one workgroup, LDS)
 //   4. Wb = Dinv * M[K,:] with the K columns zeroed;  Cct = M[:,K]^T with the K rows zeroed      (both k-major)
@@ -27,7 +27,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int INV_NB = 64;
 
 // ---- 1a. panel copy: P[(i - k0) * NB + c] = M[i][k0 + c]  for i >= k0 --------------------------------------------
-__global__ void inv_panel_copy_kernel(int n, int k0, int nbw, const double *__restrict__ M, double *__restrict__ P) {
+__global__ void inv_panel_copy_kernel(int n, int k0, int nbw, const double *__restrict__ M, double *__restrict__ P,
+                                      const int *__restrict__ info) {
+  if (*info != 0) return;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t tot = (size_t)(n - k0) * INV_NB;
   if (e >= tot) return;
@@ -39,6 +41,7 @@ __global__ void inv_panel_copy_kernel(int n, int k0, int nbw, const double *__re
 // P is (m x NB) row-major, m = n - k0.  piv[j] = absolute row index swapped with row k0 + j.  info != 0 on a zero pivot.
 __global__ __launch_bounds__(1024) void inv_panel_lu_kernel(int m, int k0, int nbw, double *__restrict__ P, int *__restrict__ piv,
                                                             int *__restrict__ info) {
+  if (*info != 0) return;
   __shared__ double s_val[16];
   __shared__ int s_idx[16];
   __shared__ double s_row[INV_NB];
@@ -65,11 +68,13 @@ __global__ __launch_bounds__(1024) void inv_panel_lu_kernel(int m, int k0, int n
       int p = s_idx[0];
       for (int w = 1; w < 16; ++w)
         if (s_val[w] > b || (s_val[w] == b && s_idx[w] < p)) { b = s_val[w]; p = s_idx[w]; }
-      s_p = p;
-      piv[j] = k0 + p;
-      if (!(b > 0.0)) *info = k0 + j + 1;
+      const bool bad = !(b > 0.0) || !(b <= 1.7976931348623157e308);
+      s_p = bad ? -1 : p;
+      piv[j] = k0 + (bad ? j : p);
+      if (bad) *info = k0 + j + 1;
     }
     __syncthreads();
+    if (s_p < 0) return;                       // zero / non-finite pivot: "Inversion failed!" (fix_conp.cpp:956)
     const int p = s_p;
     // swap rows j and p of the panel, keep the pivot row in LDS
     if (t < INV_NB) {
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int 
   __shared__ double s_best;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = n - k0, G = gridDim.x, wg = blockIdx.x;
+  if (*info != 0) return;                  // an earlier panel failed (uniform: that panel's kernel has completed)
   const int r0 = wg * rpw;
   const int nr = (m - r0 < rpw) ? m - r0 : rpw;
   if (t == 0) s_abort = 0;
@@ -202,13 +208,18 @@ __global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int 
       int pi = s_ri[0], pw = s_ri[4];
       for (int w = 1; w < 4; ++w)
         if (pc_better(s_rv[w], s_ri[w], b, pi)) { b = s_rv[w]; pi = s_ri[w]; pw = s_ri[4 + w]; }
-      s_best = b; s_p = pi; s_win = pw;
+      // no usable pivot in this column (exact zero, or NaN / inf from an earlier column: no candidate is ever "better" than
+      // the initial -1): the reference's dgetrf_ reports it and FixConp::inv aborts with "Inversion failed!" (fix_conp.cpp:956).
+      // Every workgroup sees the same candidates, takes the same decision and leaves before the next barrier.
+      const bool bad = !(b > 0.0) || !(b <= 1.7976931348623157e308) || pi < j || pi >= m;
+      s_best = bad ? -1.0 : b; s_p = bad ? j : pi; s_win = pw;
       if (wg == 0) {
-        piv[j] = k0 + pi;
-        if (!(b > 0.0)) *info = k0 + j + 1;
+        piv[j] = k0 + (bad ? j : pi);
+        if (bad) *info = k0 + j + 1;
       }
     }
     __syncthreads();
+    if (!(s_best > 0.0)) return;
     const int p = s_p;
     if (wave == 0) s_row[lane] = crow[((size_t)par * PC_MAXG + s_win) * INV_NB + lane];
     __syncthreads();
@@ -236,12 +247,16 @@ __global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int 
 }
 
 // ---- 2. row swaps on the whole matrix (each thread owns one column; swaps applied in order) ---------------------
-__global__ void inv_row_swaps_kernel(int n, int k0, int nbw, const int *__restrict__ piv, double *__restrict__ M) {
+// Every kernel downstream of a panel checks *info first: after a failed pivot the remaining pivots of that panel were never
+// written and the matrix content is meaningless -- nothing may be indexed with them (the host reads info once, at the end).
+__global__ void inv_row_swaps_kernel(int n, int k0, int nbw, const int *__restrict__ piv, double *__restrict__ M,
+                                     const int *__restrict__ info) {
+  if (*info != 0) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   for (int j = 0; j < nbw; ++j) {
     const int p = piv[j];
-    if (p != k0 + j) {
+    if (p != k0 + j && p >= 0 && p < n) {
       const double a = M[(size_t)(k0 + j) * n + c], b = M[(size_t)p * n + c];
       M[(size_t)(k0 + j) * n + c] = b;
       M[(size_t)p * n + c] = a;
@@ -250,7 +265,9 @@ __global__ void inv_row_swaps_kernel(int n, int k0, int nbw, const int *__restri
 }
 
 // ---- 3. Dinv = U11^-1 L11^-1 from the factored panel top block (one workgroup, 64 x 64 in LDS) ------------------
-__global__ __launch_bounds__(256) void inv_block_kernel(int nbw, const double *__restrict__ P, double *__restrict__ Dinv) {
+__global__ __launch_bounds__(256) void inv_block_kernel(int nbw, const double *__restrict__ P, double *__restrict__ Dinv,
+                                                        const int *__restrict__ info) {
+  if (*info != 0) return;
   __shared__ double LU[INV_NB][INV_NB];   // strict lower = L11 (unit diagonal implied), upper incl. diagonal = U11
   __shared__ double IV[INV_NB][INV_NB];   // strict lower = L11^-1 (unit diagonal implied), upper incl. diagonal = U11^-1
   const int t = threadIdx.x;
@@ -297,7 +314,8 @@ __global__ __launch_bounds__(256) void inv_block_kernel(int nbw, const double *_
 // 64 x 64 slab of M; the transposed copy Cct goes through LDS so that reads (along k) and writes (along i) both coalesce.
 __global__ __launch_bounds__(256) void inv_prep_kernel(int n, int ld, int k0, int nbw, const double *__restrict__ M,
                                                        const double *__restrict__ Dinv, double *__restrict__ Wb,
-                                                       double *__restrict__ Cct) {
+                                                       double *__restrict__ Cct, const int *__restrict__ info) {
+  if (*info != 0) return;
   extern __shared__ __attribute__((aligned(16))) char inv_smem[];
   double (*D)[INV_NB + 1] = reinterpret_cast<double (*)[INV_NB + 1]>(inv_smem);
   double (*Cc)[INV_NB + 1] = D + INV_NB;
@@ -335,7 +353,9 @@ __global__ __launch_bounds__(256) void inv_prep_kernel(int n, int ld, int k0, in
 
 // ---- 5. M -= Cct^T * Wb on the matrix cores: workgroup 128 x 128, wave 64 x 64 (4 x 4 fragments), K = 64 ----------
 __global__ __launch_bounds__(256, 2) void inv_update_kernel(int n, int ld, const double *__restrict__ Cct,
-                                                            const double *__restrict__ Wb, double *__restrict__ M) {
+                                                            const double *__restrict__ Wb, double *__restrict__ M,
+                                                            const int *__restrict__ info) {
+  if (*info != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   const int i0 = blockIdx.y * 128 + (wave >> 1) * 64, j0 = blockIdx.x * 128 + (wave & 1) * 64;
@@ -372,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void inv_update_kernel(int n, int ld, const
 // written row-wise through LDS;  M[K,j] = Wb[:,j] (j not in K), M[K,K] = Dinv.
 __global__ __launch_bounds__(256) void inv_fixup_kernel(int n, int ld, int k0, int nbw, const double *__restrict__ Dinv,
                                                         const double *__restrict__ Wb, const double *__restrict__ Cct,
-                                                        double *__restrict__ M) {
+                                                        double *__restrict__ M, const int *__restrict__ info) {
+  if (*info != 0) return;
   extern __shared__ __attribute__((aligned(16))) char inv_smem[];
   double (*D)[INV_NB + 1] = reinterpret_cast<double (*)[INV_NB + 1]>(inv_smem);
   double (*Cc)[INV_NB + 1] = D + INV_NB;
@@ -408,13 +429,14 @@ __global__ __launch_bounds__(256) void inv_fixup_kernel(int n, int ld, int k0, i
 }
 
 // ---- final: undo the row swaps as column swaps in reverse order (thread per row) ---------------------------------
-__global__ void inv_col_swaps_kernel(int n, const int *__restrict__ piv_all, double *__restrict__ M) {
+__global__ void inv_col_swaps_kernel(int n, const int *__restrict__ piv_all, double *__restrict__ M, const int *__restrict__ info) {
+  if (*info != 0) return;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   double *row = M + (size_t)r * n;
   for (int k = n - 1; k >= 0; --k) {
     const int p = piv_all[k];
-    if (p != k) { const double a = row[k]; row[k] = row[p]; row[p] = a; }
+    if (p != k && p >= 0 && p < n) { const double a = row[k]; row[k] = row[p]; row[p] = a; }
   }
 }
 
@@ -426,7 +448,14 @@ size_t inverse_workspace_doubles(int n) {
   return (size_t)n * INV_NB + 2 * INV_NB * ld + INV_NB * INV_NB + coop;
 }
 
-void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/) {
+// The multi-workgroup panel is an ordinary launch of G <= (number of CUs) workgroups of 256 threads with up to 150 KB of
+// LDS each: one per CU, all resident at once on a device whose earlier work on this stream has drained -- what the agent-scope
+// barrier needs.  (hipLaunchCooperativeKernel, which the first version used, makes the HIP runtime create a second,
+// "cooperative" HSA queue; that queue's teardown inside exit() faults under rocprofv3 -- tools/exit_probe.sh, DESIGN.md.)
+// Should a workgroup ever not become resident, the bounded spin ends every wave and sets info = -7; the caller then restores
+// the matrix and repeats with multi_wg = false.
+bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/, int num_cus,
+                    bool multi_wg) {
   const int ld = (n + 127) / 128 * 128;
   double *P = work;
   double *Wb = P + (size_t)n * INV_NB;
@@ -439,57 +468,48 @@ void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
   unsigned *counters = reinterpret_cast<unsigned *>(cidx + 2 * PC_MAXG);   // one per panel
   const int npanels = (n + INV_NB - 1) / INV_NB;
   (void)hipMemsetAsync(info, 0, sizeof(int), s);
+  (void)hipMemsetAsync(piv_all, 0, (size_t)n * sizeof(int), s);
   (void)hipMemsetAsync(counters, 0, (size_t)npanels * sizeof(unsigned), s);
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 1;
-  }
+  const int ncu = num_cus > 0 ? num_cus : 1;
   const size_t lds_prep = 2 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double), lds_fix = 3 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fix);
-  // test / fallback switches, read per call: CONP_PANEL_SINGLE = old one-workgroup panel, CONP_PANEL_MAXG = cap on workgroups
-  bool coop = getenv("CONP_PANEL_SINGLE") == nullptr;
+  // test / fallback switches, read per call: CONP_PANEL_SINGLE = one-workgroup panel, CONP_PANEL_MAXG = cap on workgroups
+  bool multi = multi_wg && getenv("CONP_PANEL_SINGLE") == nullptr;
   const int maxg_env = getenv("CONP_PANEL_MAXG") ? atoi(getenv("CONP_PANEL_MAXG")) : PC_MAXG;
+  bool used_multi = false;
   for (int k0 = 0; k0 < n; k0 += INV_NB) {
     const int nbw = (n - k0 < INV_NB) ? n - k0 : INV_NB;
     const int m = n - k0;
-    if (coop) {
+    bool panel_done = false;
+    if (multi) {
       int maxg = ncu < PC_MAXG ? ncu : PC_MAXG;
       if (maxg_env >= 1 && maxg_env < maxg) maxg = maxg_env;
       int rpw = (m + maxg - 1) / maxg;
       rpw = rpw < 64 ? 64 : (rpw + 15) / 16 * 16;
       const int G = (m + rpw - 1) / rpw;
       const size_t lds = ((size_t)rpw * PC_LD + INV_NB + 4) * sizeof(double) + 8 * sizeof(int);
-      if (lds > 150 * 1024) coop = false;
-      else {
+      if (lds <= 150 * 1024 && G <= ncu) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_panel_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int a_n = n, a_k0 = k0, a_nbw = nbw, a_rpw = rpw;
-        const double *a_M = M;
-        double *a_P = P;
-        int *a_piv = piv_all + k0, *a_info = info;
-        unsigned *a_cnt = counters + k0 / INV_NB;
-        void *kargs[] = {&a_n, &a_k0, &a_nbw, &a_rpw, &a_M, &a_P, &a_piv, &a_info, &cval, &cidx, &crow, &rowj, &a_cnt};
-        if (hipLaunchCooperativeKernel(reinterpret_cast<const void *>(inv_panel_coop_kernel), dim3(G), dim3(256), kargs, lds, s) !=
-            hipSuccess) {
-          (void)hipGetLastError();
-          coop = false;          // not co-resident / not supported: the single-workgroup panel below
-        }
+        hipLaunchKernelGGL(inv_panel_coop_kernel, dim3(G), dim3(256), lds, s, n, k0, nbw, rpw, (const double *)M, P, piv_all + k0, info,
+                           cval, cidx, crow, rowj, counters + k0 / INV_NB);
+        panel_done = true;
+        used_multi = true;
       }
     }
-    if (!coop) {
+    if (!panel_done) {
       const size_t tot = (size_t)m * INV_NB;
-      hipLaunchKernelGGL(inv_panel_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, k0, nbw, M, P);
+      hipLaunchKernelGGL(inv_panel_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, k0, nbw, M, P, info);
       hipLaunchKernelGGL(inv_panel_lu_kernel, dim3(1), dim3(1024), 0, s, m, k0, nbw, P, piv_all + k0, info);
     }
-    hipLaunchKernelGGL(inv_row_swaps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, k0, nbw, piv_all + k0, M);
-    hipLaunchKernelGGL(inv_block_kernel, dim3(1), dim3(256), 0, s, nbw, P, Dinv);
-    hipLaunchKernelGGL(inv_prep_kernel, dim3(ld / INV_NB), dim3(256), lds_prep, s, n, ld, k0, nbw, M, Dinv, Wb, Cct);
-    hipLaunchKernelGGL(inv_update_kernel, dim3(ld / 128, ld / 128), dim3(256), 0, s, n, ld, Cct, Wb, M);
-    hipLaunchKernelGGL(inv_fixup_kernel, dim3((n + INV_NB - 1) / INV_NB), dim3(256), lds_fix, s, n, ld, k0, nbw, Dinv, Wb, Cct, M);
+    hipLaunchKernelGGL(inv_row_swaps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, k0, nbw, piv_all + k0, M, info);
+    hipLaunchKernelGGL(inv_block_kernel, dim3(1), dim3(256), 0, s, nbw, P, Dinv, info);
+    hipLaunchKernelGGL(inv_prep_kernel, dim3(ld / INV_NB), dim3(256), lds_prep, s, n, ld, k0, nbw, M, Dinv, Wb, Cct, info);
+    hipLaunchKernelGGL(inv_update_kernel, dim3(ld / 128, ld / 128), dim3(256), 0, s, n, ld, Cct, Wb, M, info);
+    hipLaunchKernelGGL(inv_fixup_kernel, dim3((n + INV_NB - 1) / INV_NB), dim3(256), lds_fix, s, n, ld, k0, nbw, Dinv, Wb, Cct, M, info);
   }
-  hipLaunchKernelGGL(inv_col_swaps_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, piv_all, M);
+  hipLaunchKernelGGL(inv_col_swaps_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, piv_all, M, info);
+  return used_multi;
 }
 
 }  // namespace conp

@@ -92,7 +92,10 @@ void launch_inv_project(hipStream_t s, int n, double *A, int use_mask, const uns
 void launch_inv_project_apply(hipStream_t s, int n, double *A, const double *ainve, const double *totinve);
 // in-place inverse (conp_inverse.hip): blocked Gauss-Jordan with partial pivoting; *info != 0 -> singular
 size_t inverse_workspace_doubles(int n);
-void launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/);
+// returns true when the multi-workgroup panel was used (then info == -7 means "a grid barrier timed out": restore M, repeat
+// with multi_wg = false)
+bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/, int num_cus,
+                    bool multi_wg);
 // CG (fix_conp.cpp:864-930): state vectors on device; returns via *d_done
 void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, double *q, double *res, double *p,
                     double *scal /*[8]*/);

@@ -11,6 +11,7 @@
 //   C/D: register r of lane l is C[row = (l >> 4) + 4 r][col = l & 15].
 #include "conp_kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace conp {
@@ -138,11 +139,18 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
 #endif
 // raise a kernel's dynamic-LDS limit, only when a launch needs more than it was last given: per-update launches must not
 // pay a runtime call each (the decks' updates are bound by host launch cost)
+// The attribute is per device: the cache is indexed by the calling thread's current device (handles on several GPUs in one
+// process are supported, conp_env.device), and atomic because hosts may drive handles from different threads (a lost race
+// only sets the attribute twice).
+struct DynLdsCache { std::atomic<size_t> granted[64]; };
 template <typename K>
-static void ensure_dyn_lds(K kernel, size_t bytes, size_t &granted) {
-  if (bytes <= granted) return;
+static void ensure_dyn_lds(K kernel, size_t bytes, DynLdsCache &cache) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<size_t> &g = cache.granted[dev & 63];
+  if (bytes <= g.load(std::memory_order_relaxed)) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  granted = bytes;
+  g.store(bytes, std::memory_order_relaxed);
 }
 
 constexpr int SK_J = 16;
@@ -365,7 +373,7 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
   if (nwg <= 0) return;
   const size_t lds = (size_t)2 * SK_PANEL * sizeof(double);
-  static size_t granted = 0;
+  static DynLdsCache granted{};
   ensure_dyn_lds(sk_gemm_kernel, lds, granted);
   static const int dbg = getenv("CONP_SK_DBG") ? atoi(getenv("CONP_SK_DBG")) : 0;   // ablation switches for experiments
   hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, nl_pad, Xt, Yt, Zs, qc, part, dbg);
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, 
 void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr, const SkTile *tiles, const double *Gwf,
                       const double *Rp, const double *Tz, double *bk_part) {
   const size_t lds = ((size_t)320 * 32 + 16 * 32) * sizeof(double);
-  static size_t granted = 0;
+  static DynLdsCache granted{};
   ensure_dyn_lds(b_project_kernel, lds, granted);
   hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 32, 2), dim3(1024), lds, s, pl.C_pad, ne_pad, pl.n_col_tiles, ct_ptr, tiles,
                      Gwf, Rp, Tz, bk_part);
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
                             const double *Hc, const int *zclass, double *bk_part) {
   const size_t lds = (size_t)(n_own > 0 ? n_own : 1) * 32 * nzc * sizeof(double);      // the host keeps this <= 96 KB (conp_fix.cpp)
-  static size_t granted = 0;
+  static DynLdsCache granted{};
   ensure_dyn_lds(b_zc_dot_kernel, lds, granted);
   hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
@@ -1183,7 +1191,7 @@ void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const
   const int nb = ne_pad / 128;
   const int ntiles = nb * (nb + 1) / 2;
   const size_t lds = (size_t)AK_TC * AK_LD * sizeof(double);
-  static size_t granted = 0;
+  static DynLdsCache granted{};
   ensure_dyn_lds(a_kspace_lds_kernel, lds, granted);
   const size_t n2 = (size_t)ne * ne;
   hipLaunchKernelGGL(a_kspace_lds_kernel, dim3(ntiles * nsplit), dim3(256), lds, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.n_row_tiles,

@@ -136,3 +136,31 @@ def test_seeded_sweep_of_geometries_and_parameters(oracle, seed):
     assert rel_err(at.q[ele], o.q[ele]) < tol, seed
     assert fx.compute_scalar() == pytest.approx(o.fx.scalars()["scalar_output"], rel=10 * tol, abs=1e-10), seed
     fx.close(); o.fx.close()
+
+
+def test_charge_switched_on_between_reneighbourings(oracle):
+    """km_ewald.cpp:685-686 tests `q != 0` at EVERY step: an electrolyte atom whose charge goes from exactly 0 to non-zero (and
+    another one back to 0) without a re-neighbour must enter / leave the structure factors at once.  The library keeps a compact
+    list on the device; the host-buffer hooks re-check it against atom->q at every update."""
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab")
+    sol = np.nonzero((s.echeck == 0) & (s.q != 0))[0]
+    saved = s.q[sol[:4]].copy()
+    s.q[sol[:4]] = 0.0                                  # four neutral atoms at setup ...
+    at, o, fx = _run_both(oracle, s)
+    n0 = fx.info().n_elyte_charged
+    loc = {int(t): i for i, t in enumerate(at.tag[:at.nlocal])}
+    for a, qv in zip(sol[:4], saved):                   # ... that carry charge from the next step on (owned copies and ghosts)
+        for arr in (at.q, o.q):
+            arr[at.tag == s.tag[a]] = qv
+    for a in sol[4:6]:                                  # and two that lose theirs
+        for arr in (at.q, o.q):
+            arr[at.tag == s.tag[a]] = 0.0
+    o.pre_force(s.potdiff)
+    fx.pre_force(at, 1, s.potdiff)
+    assert fx.info().n_elyte_charged == n0 + 4 - 2
+    b_o, q_o, _ = o.fx.vectors()
+    b_g, q_g, _ = fx.vectors()
+    assert np.abs(b_g - b_o).max() <= 1e-10 * np.abs(b_o).max()
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < 1e-8
+    fx.close(); o.fx.close()

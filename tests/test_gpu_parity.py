@@ -201,6 +201,32 @@ def test_inverse_matches_numpy():
     with pytest.raises(ConpError) as e:
         fx.invert(sing)
     assert "Inversion failed" in str(e.value) and e.value.code == -4
+    # an exact zero pivot BEFORE the last column (a zero row is pivoted to the end and never gets there): a zero column, and
+    # duplicated electrode atoms (two equal rows and columns) -- in the multi-workgroup panel, past the first panel, and in the
+    # one-workgroup panel.  All must end in the reference's error, never in an out-of-range row swap.
+    for n, col in ((80, 17), (200, 130), (700, 333)):
+        zc = rng.normal(size=(n, n)); zc[:, col] = 0.0
+        with pytest.raises(ConpError) as e:
+            fx.invert(zc)
+        assert "Inversion failed" in str(e.value) and e.value.code == -4, (n, col)
+    import os
+    os.environ["CONP_PANEL_SINGLE"] = "1"
+    try:
+        zc = rng.normal(size=(200, 200)); zc[:, 130] = 0.0
+        with pytest.raises(ConpError):
+            fx.invert(zc)
+    finally:
+        del os.environ["CONP_PANEL_SINGLE"]
+    m = rng.normal(size=(150, 150)); dup = m @ m.T + 150 * np.eye(150)
+    dup[40] = dup[7]; dup[:, 40] = dup[:, 7]; dup[40, 40] = dup[7, 7]            # atom 40 is a copy of atom 7
+    with pytest.raises(ConpError) as e:
+        fx.invert(dup)
+    assert e.value.code == -4
+    nanm = rng.normal(size=(100, 100)); nanm[3, 5] = np.nan
+    with pytest.raises(ConpError):
+        fx.invert(nanm)
+    good = rng.normal(size=(90, 90))                       # the handle is still usable afterwards
+    assert np.abs(fx.invert(good) @ good - np.eye(90)).max() < 1e-8 * max(1.0, np.linalg.cond(good) / 1e4)
     fx.close()
 
 

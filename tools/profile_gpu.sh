@@ -9,17 +9,17 @@ mkdir -p $OUT
 STEPS=${STEPS:-50}
 ARGS="bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-profile ${BENCH_ARGS:-}"
 echo "== kernel trace" >&2
-# (rocprofv3's tool library sometimes faults in its own atexit teardown AFTER writing the CSVs: judge the pass by its output)
-have() { find "$1" -name "$2" | grep -q .; }
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || have $OUT/trace "*kernel_stats.csv" || { tail -5 $OUT/trace.log; exit 1; }
+# Every pass must EXIT CLEANLY.  (Round 1 masked a SIGSEGV inside exit() here; its cause was the HIP runtime's cooperative-launch
+# queue, created by hipLaunchCooperativeKernel in the inverse, whose teardown faults under rocprofv3 -- tools/exit_probe.sh.)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 echo "== pmc SQ pass" >&2
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1 || have $OUT/pmc_sq "*counter_collection.csv" || { tail -5 $OUT/pmc_sq.log; exit 1; }
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1 || { tail -5 $OUT/pmc_sq.log; exit 1; }
 echo "== pmc SQ pass 2" >&2
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/pmc_sq2.log 2>&1 || { tail -5 $OUT/pmc_sq2.log; }
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/pmc_sq2.log 2>&1 || { tail -5 $OUT/pmc_sq2.log; exit 1; }
 echo "== pmc FETCH pass" >&2
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || have $OUT/pmc_fetch "*counter_collection.csv" || { tail -5 $OUT/pmc_fetch.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 echo "== pmc WRITE pass" >&2
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || have $OUT/pmc_write "*counter_collection.csv" || { tail -5 $OUT/pmc_write.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
 find $OUT -name "*.csv" | head -40 >&2
 python3 tools/collect_profiles.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
