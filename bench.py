@@ -6,7 +6,9 @@ FP64 matrix cores, projection on the electrode atoms, real-space electrode-elect
 inverse GEMV) + charge write, with atoms, neighbour rows and S resident in HBM.  Workload at every N: the synthetic
 graphene-electrode / ionic-liquid box the metric is quoted on (4096 electrode / 32768 electrolyte atoms).
 N > 1: k-vectors (planar row tiles) and electrode rows are sharded over the ranks; one all-reduce of b (Ne doubles) and
-one all-gather of q (Ne doubles) per update over RCCL -> "strong" scaling.
+one all-gather of q (Ne doubles) per update, made INSIDE the library on its own RCCL communicator (conp_fix_comm_init_rccl);
+the once-per-run A build is sharded by tiles and summed over RCCL, every rank keeps only its rows of the projected inverse
+-> "strong" scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|big|il_onelayer|il_twolayer|dilute|cond2] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -118,10 +120,13 @@ def main():
     at, alist, blist = neighbor.build_lists(s)
     fx = FixConp(s, device=dev_index, rank=rank, nranks=world, extra_args=["pppm"] if args.pppm else [],
                  pppm_mesh=tuple(args.pppm) if args.pppm else None)
-    # multi-rank: the library shares torch's current stream with the RCCL collectives (stream order = data dependence).
-    # One rank: the library keeps its own stream (fences below are device-wide), which lets it replay the update as a HIP graph.
-    if world > 1:
+    # multi-rank: the library makes its own RCCL communicator (rank 0's unique id travels through torch.distributed) and runs
+    # the collectives on its own stream, in order with its kernels.  The rehearsal on a one-GPU box cannot (RCCL refuses two
+    # ranks on one device): it keeps the Python choreography over gloo.
+    if world > 1 and rehearse:
         fx.set_stream(torch.cuda.current_stream().cuda_stream)
+    elif world > 1:
+        fx.comm_init_rccl()
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
     t_a0 = time.perf_counter()
@@ -135,7 +140,8 @@ def main():
     d_q = torch.from_numpy(at.q.copy()).cuda()
     d_b = torch.zeros(ne, dtype=torch.float64, device="cuda")
     d_sol = torch.zeros(ne, dtype=torch.float64, device="cuda")
-    fx.bind_device_buffers(d_b.data_ptr(), d_sol.data_ptr())
+    if world == 1 or rehearse:
+        fx.bind_device_buffers(d_b.data_ptr(), d_sol.data_ptr())
     row0, row1 = fx.row_range()
     potdiff = s.potdiff
 
@@ -160,8 +166,8 @@ def main():
     backend = HipBackend()
 
     def step():
-        if world == 1:
-            fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), potdiff)
+        if world == 1 or not rehearse:
+            fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), potdiff)      # N > 1: all-reduce(b) / all-gather(q) inside, on RCCL
         else:
             sharded_update(backend, ne, rank, world)
 
@@ -257,7 +263,7 @@ def main():
                                accuracy_relative=s.accuracy_relative, mode="ffield" if s.ff_flag == 1 else "slab",
                                solver="inv", kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
                                blist_pairs=int(info.n_blist_pairs),
-                               parallelism=f"k-shard+row-shard x{world}"),
+                               parallelism=f"k-shard+row-shard x{world}" + (", RCCL inside libconp_hip" if world > 1 and not rehearse else "")),
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
                    ms_per_step_host_buffers_pcie=host_ms,
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),

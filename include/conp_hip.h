@@ -77,7 +77,7 @@ typedef struct {
   const double *cutsq;                            /* coulpair->cutsq flattened [(ntypes+1)*(ntypes+1)] (fix_conp.cpp:1235) */
   double cut_coul;                                /* *coulpair->extract("cut_coul") (fix_conp.cpp:1237) */
   int one_electrode;                              /* groupbit == jgroupbit (fix_conp.cpp:295) */
-  int device;                                     /* HIP device ordinal of this rank */
+  int device;                                     /* HIP device ordinal of this rank; -1: rank modulo the visible devices */
   int rank, nranks;                               /* shard id for the multi-GPU path (section "sharding") */
   /* `pppm` keyword (fix_conp.cpp:162, 401-404): mesh and stencil order of the pppm/conp kspace style, i.e. LAMMPS PPPM's
    * nx_pppm, ny_pppm, nz_pppm, order (pppm_conp.cpp:242, 206); ignored without the keyword */
@@ -152,6 +152,39 @@ int conp_fix_b_cal(conp_fix *fix, const conp_atoms *atoms);               /* :67
 int conp_fix_equation_solve(conp_fix *fix);                               /* :698-718 */
 int conp_fix_update_charge(conp_fix *fix, const conp_atoms *atoms, double potdiff); /* :1120-1161 */
 
+/* ---- several MPI ranks (LAMMPS spatial decomposition) ------------------------------------------------------------------
+ * The reference runs on N ranks: every rank owns the atoms of its sub-domain, and FixConp / KSpaceModuleEwald exchange through
+ * MPI_Allreduce (maxtag fix_conp.cpp:415, newtonbuf :1356, structure factors km_ewald.cpp:784-785, sum q^2 :77),
+ * MPI_Allgather / MPI_Allgatherv (elenum_list :492, eleall2tag :523, elebuf2eleall :535, b_comm :643, A rows :822).
+ * The library makes the same exchanges through callbacks the host supplies (the glue implements them with MPI on `world`,
+ * lammps_glue/fix_conp_hip.cpp), so that it needs no MPI itself.  After conp_fix_set_comm the atoms and lists handed to the
+ * hooks are THIS RANK's (owned + ghost); the library
+ *   - numbers the electrode atoms globally like post_neighbor does (rank-major, :492-525),
+ *   - all-gathers the charged electrolyte atoms' (x, q) every update and computes its shard of the k-vectors for ALL electrode
+ *     rows, adds its own real-space rows, all-reduces b, solves its rows, all-gathers q,
+ *   - shards the once-per-run A build by tiles and all-reduces the matrix before the (replicated, :947-949) inverse.
+ * Every callback returns 0 on success.  All ranks must enter every hook together (as with the reference's collectives). */
+typedef struct {
+  void *ctx;
+  int rank, nranks;
+  int (*allreduce_sum)(void *ctx, double *buf, int64_t n);                      /* in place, MPI_SUM, MPI_DOUBLE */
+  int (*allreduce_max_int)(void *ctx, int *buf, int n);                         /* in place, MPI_MAX, MPI_INT */
+  int (*allgather_int)(void *ctx, int value, int *out /*[nranks]*/);            /* MPI_Allgather of one int */
+  /* MPI_Allgatherv of bytes: rank r contributes counts[r] bytes, stored at recv + displs[r] */
+  int (*allgatherv)(void *ctx, const void *send, int64_t nbytes, void *recv, const int64_t *counts, const int64_t *displs);
+} conp_comm;
+/* call between conp_fix_create and conp_fix_setup_post_neighbor; overrides conp_env.rank / nranks */
+int conp_fix_set_comm(conp_fix *fix, const conp_comm *comm);
+
+/* Data plane on RCCL (one rank per GPU): the all-reduce of b and the all-gather of q of a device-resident update, and the
+ * all-reduce of the sharded A build, run inside the library on its own stream over xGMI.  Rank 0 makes an id with
+ * conp_rccl_unique_id, the host distributes the 128 bytes (MPI_Bcast, torch.distributed ...), every rank calls
+ * conp_fix_comm_init_rccl before setup.  Without it a multi-rank handle uses the conp_comm callbacks (host buffers), or leaves
+ * the two collectives to the caller (conp_fix_b_cal_device / _solve_device / _scatter_device). */
+#define CONP_RCCL_ID_BYTES 128
+int conp_rccl_unique_id(void *id_out /*[CONP_RCCL_ID_BYTES]*/);
+int conp_fix_comm_init_rccl(conp_fix *fix, const void *id /*[CONP_RCCL_ID_BYTES]*/);
+
 /* ---- KSpaceModule provider surface (kspacemodule.h:30-40), Ewald provider (km_ewald.cpp) ---- */
 int conp_km_conp_setup(conp_fix *fix, double qsqsum, int64_t natoms);     /* km_ewald.cpp:63-132 (qsqsum: Allreduce'd sum q^2 :72-78) */
 int conp_km_a_cal(conp_fix *fix, const conp_atoms *atoms, double *aaa /*[Ne*Ne], host, overwritten: k-space part only*/); /* :147-151 */
@@ -223,6 +256,7 @@ int64_t conp_host_pair_rows(int which, const conp_neighlist *list, const conp_at
  * With nranks == 1 conp_fix_pre_force_device runs all three back to back. */
 int conp_fix_set_stream(conp_fix *fix, void *hip_stream);
 int conp_fix_bind_device_buffers(conp_fix *fix, double *d_b /*[Ne]*/, double *d_q /*[Ne]*/);
+/* this rank's electrode rows: blocks of ceil(Ne / nranks) rows, so that rank r's rows start at r * ceil(Ne / nranks) */
 int conp_fix_row_range(const conp_fix *fix, int *row0, int *row1);
 int conp_fix_b_cal_device(conp_fix *fix, const double *d_x, const double *d_q);
 int conp_fix_solve_device(conp_fix *fix, double potdiff);

@@ -21,7 +21,8 @@ class ConpError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "libconp_hip.so")
+    # CONP_LIB: a diagnostic build of the same ABI (tools/sk_stamp.py loads the s_memtime-stamped one); never set in tests / bench
+    return os.environ.get("CONP_LIB") or os.path.join(HERE, "libconp_hip.so")
 
 
 class conp_fix_args(C.Structure):
@@ -53,6 +54,17 @@ class conp_neighlist(C.Structure):
                 ("first", C.POINTER(C.c_int)), ("neigh", C.POINTER(C.c_int)), ("nneigh", C.c_int64)]
 
 
+_CB_SUM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+_CB_MAXI = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int)
+_CB_GATHER_INT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int))
+_CB_GATHERV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
+class conp_comm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int), ("allreduce_sum", _CB_SUM),
+                ("allreduce_max_int", _CB_MAXI), ("allgather_int", _CB_GATHER_INT), ("allgatherv", _CB_GATHERV)]
+
+
 class conp_info(C.Structure):
     _fields_ = [("elenum", C.c_int), ("elenum_all", C.c_int), ("elytenum", C.c_int), ("maxtag_all", C.c_int),
                 ("runstage", C.c_int), ("kcount", C.c_int), ("kcount_flat", C.c_int), ("kcount_expand", C.c_int),
@@ -76,6 +88,7 @@ SYMBOLS = [
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
     "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
+    "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl",
 ]
 
 
@@ -141,6 +154,9 @@ def load_library():
     lib.conp_fix_log_drain.restype = C.c_char_p
     lib.conp_fix_mesg_drain.argtypes = [vp]
     lib.conp_fix_mesg_drain.restype = C.c_char_p
+    lib.conp_fix_set_comm.argtypes = [vp, C.POINTER(conp_comm)]
+    lib.conp_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.conp_fix_comm_init_rccl.argtypes = [vp, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -365,6 +381,61 @@ class FixConp:
         self._check(self.lib.conp_invert(self.h, a.shape[0], _dptr(a)))
         return a
 
+    # -- several ranks ---------------------------------------------------------------------------
+    def set_comm_torch(self, group=None):
+        """conp_fix_set_comm with callbacks on torch.distributed (any backend that moves CPU tensors, e.g. gloo): the atoms and
+        lists handed to the hooks from now on are THIS RANK's sub-domain -- the role MPI plays for the LAMMPS glue"""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def cb_sum(_ctx, buf, n):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+
+        def cb_maxi(_ctx, buf, n):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            return 0
+
+        def cb_gather_int(_ctx, v, out):
+            t = torch.tensor([v], dtype=torch.int32)
+            outs = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(outs, t, group=group)
+            for r in range(world):
+                out[r] = int(outs[r][0])
+            return 0
+
+        def cb_gatherv(_ctx, send, nbytes, recv, counts, displs):
+            mine = torch.from_numpy(np.frombuffer((C.c_char * nbytes).from_address(send), dtype=np.uint8).copy()) if nbytes else torch.zeros(0, dtype=torch.uint8)
+            outs = [torch.zeros(int(counts[r]), dtype=torch.uint8) for r in range(world)]
+            dist.all_gather(outs, mine, group=group) if len({int(counts[r]) for r in range(world)}) == 1 else _uneven_all_gather(outs, mine, group, world)
+            for r in range(world):
+                n = int(counts[r])
+                if n:
+                    C.memmove(recv + int(displs[r]), outs[r].numpy().ctypes.data, n)
+            return 0
+
+        self._comm_cbs = (_CB_SUM(cb_sum), _CB_MAXI(cb_maxi), _CB_GATHER_INT(cb_gather_int), _CB_GATHERV(cb_gatherv))
+        self._comm = conp_comm(ctx=None, rank=rank, nranks=world, allreduce_sum=self._comm_cbs[0], allreduce_max_int=self._comm_cbs[1],
+                               allgather_int=self._comm_cbs[2], allgatherv=self._comm_cbs[3])
+        self._check(self.lib.conp_fix_set_comm(self.h, C.byref(self._comm)))
+
+    def comm_init_rccl(self, group=None):
+        """one RCCL communicator inside the library (one rank per GPU): rank 0 makes the id, torch.distributed carries its 128 bytes"""
+        import torch
+        import torch.distributed as dist
+        buf = (C.c_char * 128)()
+        if dist.get_rank(group) == 0:
+            self._check(self.lib.conp_rccl_unique_id(buf))
+        obj = [bytes(buf.raw)]
+        dist.broadcast_object_list(obj, src=0, group=group)
+        idb = (C.c_char * 128).from_buffer_copy(obj[0])
+        self._check(self.lib.conp_fix_comm_init_rccl(self.h, idb))
+
     # -- device-resident path --------------------------------------------------------------------
     def set_stream(self, stream_ptr: int):
         self._check(self.lib.conp_fix_set_stream(self.h, C.c_void_p(stream_ptr)))
@@ -422,6 +493,19 @@ class FixConp:
             self.close()
         except Exception:
             pass
+
+
+def _uneven_all_gather(outs, mine, group, world):
+    """all_gather with different lengths per rank: pad to the longest (the collectives want equal sizes), trim after"""
+    import torch
+    import torch.distributed as dist
+    nmax = max(o.numel() for o in outs)
+    pad = torch.zeros(nmax, dtype=torch.uint8)
+    pad[: mine.numel()] = mine
+    bufs = [torch.zeros(nmax, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    for r in range(world):
+        outs[r].copy_(bufs[r][: outs[r].numel()])
 
 
 # ---- host-only helpers (no GPU needed) -----------------------------------------------------------------------------

@@ -15,8 +15,10 @@ import torch.distributed as dist
 
 
 def row_range(ne: int, rank: int, world: int):
-    """contiguous electrode-row shard; must match conp_fix.cpp (row0 = ne*rank/world)"""
-    return ne * rank // world, ne * (rank + 1) // world
+    """contiguous electrode-row shard in blocks of ceil(ne / world) rows; must match conp_fix.cpp (post_neighbor: rows_per)"""
+    per = (ne + world - 1) // world
+    r0 = min(ne, rank * per)
+    return r0, min(ne, r0 + per)
 
 
 def my_row_tiles(n_row_tiles: int, rank: int, world: int, costs=None):

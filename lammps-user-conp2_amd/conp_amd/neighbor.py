@@ -141,3 +141,53 @@ def build_lists(sys_, order_seed: int | None = 1, special_frac: float = 0.0):
     pb = _half_pairs(at, e_idx, l_idx, r, sys_.newton)
     blist = _csr(at, pb, np.arange(at.nlocal), rng, special_frac)
     return at, alist, blist
+
+
+def build_lists_decomposed(sys_, nranks: int, axis: int = 0, order_seed: int | None = 1):
+    """LAMMPS' spatial decomposition into `nranks` slabs along `axis`: per rank (atoms, alist, blist).  A rank owns the atoms of
+    its slab; its ghosts are every image -- periodic copies AND the unshifted atoms of other ranks -- within cutoff + skin of the
+    slab.  Half lists, newton off: an owned-ghost pair is in the list of each owner."""
+    cutneigh = sys_.cutoff + sys_.skin
+    prd = sys_.prd
+    shifts = []
+    for c in range(3):
+        if sys_.periodic[c]:
+            m = int(np.ceil(cutneigh / prd[c]))
+            shifts.append(range(-m, m + 1))
+        else:
+            shifts.append(range(0, 1))
+    edges = sys_.boxlo[axis] + prd[axis] * np.arange(nranks + 1) / nranks
+    which = np.clip(np.searchsorted(edges, sys_.x[:, axis], side="right") - 1, 0, nranks - 1)
+    out = []
+    for r in range(nranks):
+        own = np.nonzero(which == r)[0]
+        lo, hi = sys_.boxlo - cutneigh, sys_.boxhi + cutneigh
+        lo = lo.copy(); hi = hi.copy()
+        lo[axis], hi[axis] = edges[r] - cutneigh, edges[r + 1] + cutneigh
+        xs, src = [sys_.x[own]], [own]
+        for s in itertools.product(*shifts):
+            xi = sys_.x + np.array(s) * prd
+            keep = np.all((xi >= lo) & (xi < hi), axis=1)
+            if s == (0, 0, 0):
+                keep &= which != r
+            if keep.any():
+                xs.append(xi[keep]); src.append(np.nonzero(keep)[0])
+        src = np.concatenate(src)
+        nlocal = len(own)
+        loc_of = {int(g): i for i, g in enumerate(own)}
+        owner = np.array([loc_of.get(int(g), -1) for g in src], dtype=np.int32)
+        at = Atoms(nlocal=nlocal, nghost=len(src) - nlocal, x=np.ascontiguousarray(np.concatenate(xs)), q=sys_.q[src].copy(),
+                   type=sys_.type[src].copy(), tag=sys_.tag[src].copy(), echeck=sys_.echeck[src].copy(), owner=owner)
+        rng = np.random.default_rng(order_seed + r) if order_seed is not None else None
+        allidx = np.arange(at.nall, dtype=np.int64)
+        if sys_.eletypes is None:
+            pairs = _half_pairs(at, allidx, None, cutneigh, sys_.newton)
+            lst = _csr(at, pairs, np.arange(at.nlocal), rng)
+            out.append((at, lst, lst))
+            continue
+        is_e = np.isin(at.type, np.array(sys_.eletypes))
+        e_idx, l_idx = allidx[is_e], allidx[~is_e]
+        alist = _csr(at, _half_pairs(at, e_idx, None, cutneigh, sys_.newton), np.nonzero(is_e[:at.nlocal])[0], rng)
+        blist = _csr(at, _half_pairs(at, e_idx, l_idx, cutneigh, sys_.newton), np.arange(at.nlocal), rng)
+        out.append((at, alist, blist))
+    return out

@@ -2,6 +2,8 @@
 // Method names mirror FixConp / KSpaceModuleEwald (fix_conp.h:37-74, kspacemodule.h:30-40); citations are
 // file:line in /root/reference.  There is no CPU fallback: every compute entry point needs the HIP device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the entry points are resolved with dlopen when a communicator is asked for
 
 #include <algorithm>
 #include <cmath>
@@ -88,6 +90,73 @@ struct Profiler {
   void reset() { collect(); acc.clear(); order.clear(); }
 };
 
+// ---- ranks: the host's conp_comm callbacks behind the RankOps interface of conp_host.hpp ----------------------------------
+struct RankComm : conp::RankOps {
+  conp_comm c{};
+  bool have = false;            // callbacks present: the atoms handed to the hooks are this rank's sub-domain
+  int rank_ = 0, nranks_ = 1;
+  int nranks() const override { return nranks_; }
+  int rank() const override { return rank_; }
+  bool active() const { return have && nranks_ > 1; }
+  static void check(int rc, const char *what) {
+    if (rc != 0) throw ConpError(CONP_ERR_STATE, std::string("conp_comm callback failed: ") + what);
+  }
+  void allreduce_max_int(int *v, int n) override { if (active()) check(c.allreduce_max_int(c.ctx, v, n), "allreduce_max_int"); }
+  void allgather_int(int v, int *out) override {
+    if (active()) check(c.allgather_int(c.ctx, v, out), "allgather_int"); else out[0] = v;
+  }
+  void allgatherv_int(const int *send, int n, int *recv, const int *counts, const int *displs) override {
+    if (!active()) { for (int i = 0; i < n; ++i) recv[i] = send[i]; return; }
+    std::vector<int64_t> cb(nranks_), db(nranks_);
+    for (int r = 0; r < nranks_; ++r) { cb[r] = (int64_t)counts[r] * sizeof(int); db[r] = (int64_t)displs[r] * sizeof(int); }
+    check(c.allgatherv(c.ctx, send, (int64_t)n * sizeof(int), recv, cb.data(), db.data()), "allgatherv");
+  }
+  void sum(double *b, int64_t n) { if (active() && n > 0) check(c.allreduce_sum(c.ctx, b, n), "allreduce_sum"); }
+  // rank r contributes counts[r] doubles (w values per item); recv holds them rank-major
+  void gatherv(const double *send, const std::vector<int> &items, int w, double *recv) {
+    if (!active()) { std::memcpy(recv, send, (size_t)items[0] * w * sizeof(double)); return; }
+    std::vector<int64_t> cb(nranks_), db(nranks_);
+    int64_t off = 0;
+    for (int r = 0; r < nranks_; ++r) { cb[r] = (int64_t)items[r] * w * sizeof(double); db[r] = off; off += cb[r]; }
+    check(c.allgatherv(c.ctx, send, cb[rank_], recv, cb.data(), db.data()), "allgatherv");
+  }
+};
+
+// ---- RCCL, resolved at run time (the library stays loadable where no RCCL is installed; torch's bundled copy and the
+// system's share a soname, whichever the process loaded first serves both) -------------------------------------------------
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  void load() {
+    if (lib) return;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) throw ConpError(CONP_ERR_NO_DEVICE, std::string("cannot load librccl: ") + dlerror());
+    auto sym = [&](const char *n) {
+      void *p = dlsym(lib, n);
+      if (!p) throw ConpError(CONP_ERR_NO_DEVICE, std::string("librccl lacks ") + n);
+      return p;
+    };
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+  }
+  void ok(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) throw ConpError(CONP_ERR_NO_DEVICE, std::string("RCCL error in ") + what + ": " + (GetErrorString ? GetErrorString(r) : "?"));
+  }
+};
+Rccl g_rccl;   // plain pointers, no destructor: nothing of it runs at exit
+
 }  // namespace
 
 using namespace conp;
@@ -107,7 +176,15 @@ struct conp_fix {
   bool have_alist = false, have_blist = false, kspace_ready = false, matrix_loaded = false;
   int runstage = 0;          // fix_conp.cpp:181-183
   int ne_pad = 0, nl = 0, nl_pad = 0, nall = 0;
-  int row0 = 0, row1 = 0, num_cus = 256;
+  int row0 = 0, row1 = 0, rows_per = 0, num_cus = 256;
+  // several ranks: host callbacks (spatially decomposed atoms) and / or an RCCL communicator (device-resident collectives)
+  RankComm rc;
+  bool decomposed = false;       // conp_fix_set_comm was called: atoms and lists are this rank's sub-domain
+  ncclComm_t nccl = nullptr;
+  bool s_sharded = false;        // the projected inverse is stored by rows [row0, row1) only (d_Srows)
+  std::vector<int> elyte_counts;   // decomposed: charged electrolyte atoms per rank (gather layout of d_xg / d_qg)
+  int nl_local = 0;
+  std::vector<double> xq_pack, xq_all;
   std::vector<SkItem> items_h;   // sk_gemm work items of this rank
   std::vector<SkTile> tiles_h;   // (row tile, col tile) pairs of this rank, sorted by col tile
   std::vector<int> ele_pairs_h;    // (atom index, eleall index) of every owned or ghost electrode atom
@@ -138,12 +215,12 @@ struct conp_fix {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
-      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p,
+      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p, d_Srows, d_xg, d_qg,
       d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -157,6 +234,7 @@ struct conp_fix {
   ~conp_fix() {
     prof.collect();
     drop_graph();
+    if (nccl) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(nccl); nccl = nullptr; }
     if (h_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_pin); }
     for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -180,7 +258,8 @@ struct conp_fix {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw ConpError(CONP_ERR_NO_DEVICE, "no HIP device visible: libconp_hip has no CPU fallback");
-    if (env.device < 0 || env.device >= ndev) throw ConpError(CONP_ERR_NO_DEVICE, "device ordinal out of range");
+    if (env.device < 0) env.device = env.rank % ndev;      // "this rank's GPU": ranks of a node spread over its devices
+    if (env.device >= ndev) throw ConpError(CONP_ERR_NO_DEVICE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(env.device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, env.device));
@@ -336,12 +415,13 @@ struct conp_fix {
       dpppm.rho_coeff = d_pp_coeff.p; dpppm.greensfn = d_pp_green.p;
       dpppm.twid[0] = d_pp_tw0.p; dpppm.twid[1] = d_pp_tw1.p; dpppm.twid[2] = d_pp_tw2.p;
     }
-    double qsqsum = 0.0;                                   // km_ewald.cpp:72-78 (one rank)
-    for (int i = 0; i < at->nlocal; i++) qsqsum += at->q[i] * at->q[i];
-    km_conp_setup(qsqsum, (int64_t)at->nlocal);
+    double qn[2] = {0.0, (double)at->nlocal};              // km_ewald.cpp:72-78: sum q^2 over the owned atoms, Allreduce :77
+    for (int i = 0; i < at->nlocal; i++) qn[0] += at->q[i] * at->q[i];
+    rc.sum(qn, 2);                                         // (natoms = atom->natoms: the owned atoms of all ranks)
+    km_conp_setup(qn[0], (int64_t)std::llround(qn[1]));
     evscale = env.qe2f / env.qqr2e;                        // :412
     ehgo_setup_tables();                                   // FixConp::init :296-299
-    idx.linalg_init(at->nlocal, at->tag);
+    idx.linalg_init(at->nlocal, at->tag, &rc);
   }
 
   void upload_atoms_static(const conp_atoms *at) {
@@ -395,20 +475,24 @@ struct conp_fix {
       tm0 = t;
     };
     bool elyte_grew = false;
-    const bool grew = idx.post_neighbor(at->nlocal, at->tag, at->echeck, &elyte_grew);
+    const bool grew = idx.post_neighbor(at->nlocal, at->tag, at->echeck, &elyte_grew, &rc);
     const int ne = idx.elenum_all;
     if (grew) {
       ne_pad = (ne + 127) / 128 * 128;
       d_A.reserve((size_t)ne * ne);
-      d_bk.reserve(4 * (size_t)ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(ne_pad); d_eleallq_own.reserve(ne_pad); d_qele.reserve(ne_pad);
+      // electrode rows in blocks of ceil(Ne / nranks): rank r's rows start at r * rows_per, so that an all-gather of rows_per
+      // values per rank lands every row at its own index (the buffers hold nranks * rows_per >= Ne entries)
+      rows_per = (ne + env.nranks - 1) / env.nranks;
+      const size_t nvec = std::max<size_t>(ne_pad, (size_t)rows_per * env.nranks);
+      d_bk.reserve(4 * (size_t)ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(nvec); d_eleallq_own.reserve(nvec); d_qele.reserve(ne_pad);
       d_elesetq.reserve(ne_pad); d_eleinitq.reserve(ne_pad); d_ele_z.reserve(ne_pad); d_elecheck.reserve(ne_pad);
       d_ainve.reserve(ne_pad);
       d_bk.zero(stream); d_breal.zero(stream); d_b_own.zero(stream); d_eleallq_own.zero(stream); d_qele.zero(stream);
       d_elesetq.zero(stream); d_eleinitq.zero(stream);
       if (!d_b) d_b = d_b_own.p;
       if (!d_eleallq) d_eleallq = d_eleallq_own.p;
-      row0 = (int)((long long)ne * env.rank / env.nranks);
-      row1 = (int)((long long)ne * (env.rank + 1) / env.nranks);
+      row0 = std::min(ne, env.rank * rows_per);
+      row1 = std::min(ne, row0 + rows_per);
     }
     mark("index maps");
     upload_atoms_static(at);
@@ -448,7 +532,19 @@ struct conp_fix {
   void build_elyte_list(const conp_atoms *at) {
     elyte_idx_h.clear();
     for (int i = 0; i < at->nlocal; ++i) if (at->echeck[i] == 0 && at->q[i] != 0) elyte_idx_h.push_back(i);
-    nl = (int)elyte_idx_h.size();
+    nl_local = nl = (int)elyte_idx_h.size();
+    if (decomposed) {
+      // every rank's charged electrolyte atoms enter every rank's structure factors: their (x, q) are all-gathered at each
+      // update (b_cal) into d_xg / d_qg, rank-major; the phase kernel then walks that compact array
+      elyte_counts.assign(env.nranks, 0);
+      rc.allgather_int(nl_local, elyte_counts.data());
+      nl = 0;
+      for (int v : elyte_counts) nl += v;
+      std::vector<int> iota(std::max(nl, 1));
+      for (int i = 0; i < nl; ++i) iota[i] = i;
+      d_iota.upload(iota, stream);
+      d_xg.reserve((size_t)std::max(nl, 1) * 3); d_qg.reserve(std::max(nl, 1));
+    }
     // atoms are consumed in chunks of 32; the splits want an even share of chunks
     nl_pad = std::max(32, (nl + 31) / 32 * 32);
     d_elyte_idx.upload(elyte_idx_h, stream);
@@ -458,15 +554,51 @@ struct conp_fix {
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
     d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
   }
-  bool elyte_list_stale(const conp_atoms *at) const {
+  bool elyte_list_stale(const conp_atoms *at) {
     size_t k = 0;
     const size_t n = elyte_idx_h.size();
-    for (int i = 0; i < at->nlocal; ++i) {
+    int stale = 0;
+    for (int i = 0; i < at->nlocal && !stale; ++i) {
       if (at->echeck[i] != 0 || at->q[i] == 0) continue;
-      if (k >= n || elyte_idx_h[k] != i) return true;
+      if (k >= n || elyte_idx_h[k] != i) stale = 1;
       ++k;
     }
-    return k != n;
+    if (!stale && k != n) stale = 1;
+    rc.allreduce_max_int(&stale, 1);       // decomposed: the gather layout is common to all ranks, so is the decision
+    return stale != 0;
+  }
+  // decomposed runs: this rank's charged electrolyte atoms -> everybody (MPI_Allgatherv), then onto the device
+  void gather_elyte(const conp_atoms *at) {
+    xq_pack.resize((size_t)nl_local * 4);
+    for (int k = 0; k < nl_local; ++k) {
+      const int i = elyte_idx_h[k];
+      xq_pack[4 * (size_t)k] = at->x[3 * (size_t)i]; xq_pack[4 * (size_t)k + 1] = at->x[3 * (size_t)i + 1];
+      xq_pack[4 * (size_t)k + 2] = at->x[3 * (size_t)i + 2]; xq_pack[4 * (size_t)k + 3] = at->q[i];
+    }
+    xq_all.resize((size_t)std::max(nl, 1) * 4);
+    rc.gatherv(xq_pack.data(), elyte_counts, 4, xq_all.data());
+    // de-interleave into the layouts the kernels read: x [nl][3], q [nl]
+    double *st = pinned((size_t)ne_pad + 8 + (size_t)nl * 4) + ne_pad + 8;
+    sync();
+    for (int k = 0; k < nl; ++k) {
+      st[3 * (size_t)k] = xq_all[4 * (size_t)k]; st[3 * (size_t)k + 1] = xq_all[4 * (size_t)k + 1];
+      st[3 * (size_t)k + 2] = xq_all[4 * (size_t)k + 2]; st[3 * (size_t)nl + k] = xq_all[4 * (size_t)k + 3];
+    }
+    if (nl > 0) {
+      HIP_TRY(hipMemcpyAsync(d_xg.p, st, (size_t)nl * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(d_qg.p, st + 3 * (size_t)nl, (size_t)nl * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
+  }
+
+  // FixConp::b_comm (fix_conp.cpp:641-648) for w values per atom: rows of the owned electrode atoms, in `ele` order, from every
+  // rank (MPI_Allgatherv with elenum_list / displs) land at their permanent index through elebuf2eleall
+  std::vector<double> ele_comm_buf;
+  void ele_comm(const double *send /*[elenum][w]*/, int w, double *recv /*[Ne][w]*/) {
+    const int ne = idx.elenum_all;
+    ele_comm_buf.resize((size_t)std::max(ne, 1) * w);
+    rc.gatherv(send, idx.elenum_list, w, ele_comm_buf.data());
+    for (int iall = 0; iall < ne; ++iall)
+      for (int c = 0; c < w; ++c) recv[(size_t)idx.elebuf2eleall[iall] * w + c] = ele_comm_buf[(size_t)iall * w + c];
   }
 
   // sk_gemm schedule ("stream-K" over the atom chunks): the work of all tiles of this rank is laid out on one axis,
@@ -534,10 +666,12 @@ struct conp_fix {
   void gather_xele(const conp_atoms *at) {
     const int ne = idx.elenum_all;
     xele_h.assign((size_t)ne * 3, 0.0);
+    std::vector<double> mine((size_t)std::max(idx.elenum, 1) * 3);
     for (int i = 0; i < idx.elenum; ++i) {
       const int iloc = idx.tag2local[idx.ele2tag[i]];
-      for (int c = 0; c < 3; ++c) xele_h[3 * (size_t)idx.ele2eleall[i] + c] = at->x[3 * (size_t)iloc + c];
+      for (int c = 0; c < 3; ++c) mine[3 * (size_t)i + c] = at->x[3 * (size_t)iloc + c];
     }
+    ele_comm(mine.data(), 3, xele_h.data());           // km_ewald.cpp:510-531 gathers the electrode tables the same way
   }
 
   // km_ewald.cpp:134-145 a_read: electrode phase tables (electrodes are immobile: filled once, appendix D)
@@ -649,13 +783,32 @@ struct conp_fix {
   }
 
   // km_ewald.cpp:147-151 + :584-666 : k-space part of A into d_A (strict lower triangle + diagonal + slab on j <= i)
+  // several ranks with a way to sum matrices (RCCL or the host callbacks): the tiles are dealt to the ranks
+  // (an RCCL communicator of ONE rank takes the same path: that is how the call sites are tested on a one-GPU box)
+  bool setup_sharded() const { return nccl != nullptr || (env.nranks > 1 && rc.active()); }
+  // sum of the ranks' zero-initialised partial matrices (fix_conp.cpp:816-822 gathers rows instead; every element here is
+  // written by one rank's k-space tile and at most one rank's real-space row, so the sum does not depend on the order)
+  void allreduce_matrix(double *A, size_t n) {
+    if (!setup_sharded()) return;
+    if (nccl) {
+      g_rccl.ok(g_rccl.AllReduce(A, A, n, ncclDouble, ncclSum, nccl, stream), "all-reduce(A)");
+      return;
+    }
+    std::vector<double> h(n);
+    HIP_TRY(hipMemcpyAsync(h.data(), A, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    rc.sum(h.data(), (int64_t)n);
+    HIP_TRY(hipMemcpyAsync(A, h.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+    sync();
+  }
   void km_a_cal_device() {
     const int ne = idx.elenum_all;
+    const int trank = setup_sharded() ? env.rank : 0, tranks = setup_sharded() ? env.nranks : 1;
     // kz chunks (16-kz blocks) dealt to nsplit groups of about equal work: heaviest first to the lightest group; a chunk costs
     // as many row tiles as reach it
     int nchunk = 0;
     for (int v : plan.nb_act) nchunk = std::max(nchunk, v);
-    const int nsplit = a_kspace_nsplit(ne_pad, num_cus, nchunk);
+    const int nsplit = a_kspace_nsplit(ne_pad, num_cus, nchunk, tranks);
     std::vector<int> group(std::max(nchunk, 1), 0);
     {
       std::vector<std::pair<int, int>> cost;
@@ -676,7 +829,7 @@ struct conp_fix {
     d_A.reserve((size_t)nsplit * ne * ne);
     d_A.zero(stream);
     prof.begin("a_kspace", stream);
-    launch_a_kspace(stream, dplan, ne, ne_pad, d_Rp.p, d_Tz.p, d_A.p, nsplit, d_a_chunk_group.p);
+    launch_a_kspace(stream, dplan, ne, ne_pad, d_Rp.p, d_Tz.p, d_A.p, nsplit, d_a_chunk_group.p, trank, tranks);
     prof.end(stream);
   }
 
@@ -705,19 +858,27 @@ struct conp_fix {
     const double pref = 12.56637061435917295384 / kt.volume;            // MY_4PI/volume km_ewald.cpp:648
     const double *diag_atom = nullptr;
     if (ehgo_active) {            // :803-810: u0 of the atom's type on the diagonal
-      std::vector<double> da(ne_pad, 0.0);
-      for (int i = 0; i < idx.elenum; ++i) da[idx.ele2eleall[i]] = u0_i_h[at->type[idx.tag2local[idx.ele2tag[i]]]];
+      std::vector<double> da(ne_pad, 0.0), mine(std::max(idx.elenum, 1));
+      for (int i = 0; i < idx.elenum; ++i) mine[i] = u0_i_h[at->type[idx.tag2local[idx.ele2tag[i]]]];
+      ele_comm(mine.data(), 1, da.data());
       d_diag_atom.upload(da, stream);
       diag_atom = d_diag_atom.p;
     }
-    launch_a_diag_slab(stream, ne, diag_k, diag_self, diag_atom, kt.slabflag == 1, pref, d_ele_z.p, d_A.p);
+    const bool sharded = setup_sharded();
+    if (!sharded || env.rank == 0)         // diagonal and slab term once (they overwrite / add on the whole lower triangle)
+      launch_a_diag_slab(stream, ne, diag_k, diag_self, diag_atom, kt.slabflag == 1, pref, d_ele_z.p, d_A.p);
     build_a_rows(alist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, arows);
     d_a_rowptr.upload(arows.row_ptr, stream); d_a_ele.upload(arows.ele_atom, stream);
     d_a_oth.upload(arows.oth_atom, stream); d_a_col.upload(arows.col, stream);
     upload_xq(at);
     prof.begin("a_real", stream);
-    launch_a_real(stream, ne, d_a_rowptr.p, d_a_ele.p, d_a_oth.p, d_a_col.p, d_x.p, d_type.p, real_params(), d_A.p);
+    // real-space rows: a sub-domain's list only holds the rows of its own electrode atoms (fix_conp.cpp:1242-1276); with
+    // replicated atoms the rows are split by the row range
+    const bool by_range = sharded && !decomposed;
+    launch_a_real(stream, ne, by_range ? row0 : 0, by_range ? row1 : ne, d_a_rowptr.p, d_a_ele.p, d_a_oth.p, d_a_col.p, d_x.p,
+                  d_type.p, real_params(), d_A.p);
     prof.end(stream);
+    allreduce_matrix(d_A.p, (size_t)ne * ne);
     launch_a_symmetrise(stream, ne, d_A.p);
     HIP_TRY(hipGetLastError());
     sync();
@@ -748,7 +909,7 @@ struct conp_fix {
     std::fclose(fp);
     if (too_many) throw ConpError(CONP_ERR_IO, "Too many entries in A matrix file");        // :737
     if (count != need) throw ConpError(CONP_ERR_IO, "Too few entries in A matrix file");     // :746
-    try { idx.renumber_from_tags(tags, at->nlocal, at->tag, at->echeck); }
+    try { idx.renumber_from_tags(tags, at->nlocal, at->tag, at->echeck, &rc); }
     catch (const std::exception &e) { throw ConpError(CONP_ERR_IO, e.what()); }
     upload_atoms_static(at);                                   // atom2eleall follows the new numbering
     build_b_rows_device(at);                                   // rows follow the new numbering (the list is on the device)
@@ -762,6 +923,7 @@ struct conp_fix {
   // fix_conp.cpp:833-849 (amatrix) and :960-977 (inv_a_matrix)
   void write_matrix_file(const char *path, int which) {
     const int ne = idx.elenum_all;
+    unshard_rows();
     std::vector<double> a((size_t)ne * ne);
     HIP_TRY(hipMemcpyAsync(a.data(), d_A.p, a.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
@@ -794,8 +956,8 @@ struct conp_fix {
     const double zprd = env.zprd, zhalf = 0.5 * env.zprd + env.boxlo_z;
     d_vec_h.assign(ne_pad, 0.0);
     std::fill(idx.elecheck_eleall.begin(), idx.elecheck_eleall.end(), 0);
+    std::vector<double> mine((size_t)std::max(idx.elenum, 1) * 2), all((size_t)std::max(ne, 1) * 2);
     for (int iloc = 0; iloc < idx.elenum; ++iloc) {
-      const int iall = idx.ele2eleall[iloc];
       const int i = idx.tag2local[idx.ele2tag[iloc]];
       const int eci = at->echeck[i];
       const double z = at->x[3 * (size_t)i + 2];
@@ -804,9 +966,10 @@ struct conp_fix {
         if (eci == 1 && z < zhalf) v = -evscale * (z / zprd + 1);
         else v = -evscale * z / zprd;
       } else v = -0.5 * evscale * eci;
-      d_vec_h[idx.elebuf2eleall[iloc]] = v;   // b_comm with one rank
-      idx.elecheck_eleall[iall] = eci;
+      mine[2 * (size_t)iloc] = v; mine[2 * (size_t)iloc + 1] = (double)eci;
     }
+    ele_comm(mine.data(), 2, all.data());            // b_comm(bbb, bbb_all) :634 and the Allreduce of elecheck_eleall :633
+    for (int i = 0; i < ne; ++i) { d_vec_h[i] = all[2 * (size_t)i]; idx.elecheck_eleall[i] = (int)all[2 * (size_t)i + 1]; }
     std::vector<int> ec(ne_pad, 0);
     for (int i = 0; i < ne; ++i) ec[i] = idx.elecheck_eleall[i];
     d_elecheck.upload(ec, stream);
@@ -938,8 +1101,9 @@ struct conp_fix {
     launch_left_sum(stream, ne, d_elecheck.p, d_elesetq.p, d_scalars.p + 0);
     HIP_TRY(hipMemcpyAsync(&totsetq, d_scalars.p + 0, sizeof(double), hipMemcpyDeviceToHost, stream));
     if (args.qinit) {
-      std::vector<double> qi(ne_pad, 0.0);
-      for (int iloc = 0; iloc < idx.elenum; ++iloc) qi[idx.elebuf2eleall[iloc]] = at->q[idx.tag2local[idx.ele2tag[iloc]]];
+      std::vector<double> qi(ne_pad, 0.0), mine(std::max(idx.elenum, 1));
+      for (int iloc = 0; iloc < idx.elenum; ++iloc) mine[iloc] = at->q[idx.tag2local[idx.ele2tag[iloc]]];
+      ele_comm(mine.data(), 1, qi.data());
       d_eleinitq.upload(qi, stream);
     }
     sync();
@@ -972,8 +1136,12 @@ struct conp_fix {
 
   // ---- per-step device path -------------------------------------------------------------------
   // km_ewald.cpp:153-167 b_cal + fix_conp.cpp:1281-1365 blist_coul_cal, this rank's shard, into d_b
+  // dx / dq: this rank's atom arrays (real-space rows, charge write).  The structure factors read the charged electrolyte atoms
+  // through an index list: the owned ones out of dx / dq, or -- decomposed runs -- every rank's, gathered into d_xg / d_qg.
   void b_cal_device(const double *dx, const double *dq, bool coulyes, bool timed = false) {
     const int ne = idx.elenum_all;
+    const double *ex = decomposed ? d_xg.p : dx, *eq = decomposed ? d_qg.p : dq;
+    const int *eidx = decomposed ? d_iota.p : d_elyte_idx.p;
     if (!kspace_ready || d_Rp.n == 0 || d_b == nullptr)
       throw ConpError(CONP_ERR_STATE, "b_cal before the k tables / electrode phase tables exist (setup_post_neighbor, a_cal)");
     if (timed) {
@@ -984,14 +1152,14 @@ struct conp_fix {
       // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
       prof.begin("pppm_b", stream);
       if (env.rank == 0)
-        launch_pppm_b(stream, dpppm, nl, d_elyte_idx.p, dx, dq, ne, ne_pad, d_pp_egrid.p, d_pp_ew.p, d_pp_re.p, d_pp_im.p,
+        launch_pppm_b(stream, dpppm, nl, eidx, ex, eq, ne, ne_pad, d_pp_egrid.p, d_pp_ew.p, d_pp_re.p, d_pp_im.p,
                       d_slab_part.p, &n_slab_part, d_bk.p);
       else
         d_bk.zero(stream);
       prof.end(stream);
     } else {
       prof.begin("elyte_phase", stream);
-      launch_elyte_phase(stream, nl, nl_pad, d_elyte_idx.p, dx, dq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
+      launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                          plan.kymax, plan.nz, KPlan::ZSTRIDE, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
       prof.end(stream);
       prof.begin("sk_gemm", stream);
@@ -1020,7 +1188,9 @@ struct conp_fix {
     if (timed) HIP_TRY(hipEventRecord(ev_b[1], stream));
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     prof.begin("b_real_combine", stream);
-    launch_b_real_combine(stream, ne, ne_pad, coulyes ? row0 : 0, coulyes ? row1 : 0, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
+    // real-space rows: with replicated atoms this rank's row range; a sub-domain's list holds its own electrode atoms' rows only
+    const int rr0 = !coulyes ? 0 : (decomposed ? 0 : row0), rr1 = !coulyes ? 0 : (decomposed ? ne : row1);
+    launch_b_real_combine(stream, ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
                           d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
                           4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
     prof.end(stream);
@@ -1058,17 +1228,94 @@ struct conp_fix {
     logbuf += line;
   }
 
+  // the matrix the GEMV streams: the full projected inverse, or -- several ranks -- this rank's rows of it (row r at base + r * Ne)
+  const double *s_base() const { return s_sharded ? d_Srows.p - (size_t)row0 * idx.elenum_all : d_A.p; }
+  // several ranks: after the setup only the rows [row0, row1) of S are ever read (fix_conp.cpp:1135-1139 does the same row-local
+  // ddot_).  Keep those, release the Ne x Ne buffer: 2.1 GB -> 268 MB per rank at Ne = 16384 on 8 ranks.
+  void shard_rows() {
+    if (s_sharded || !setup_sharded() || args.minimizer != CONP_SOLVER_INV || runstage < 3) return;
+    const size_t ne = idx.elenum_all, nr = (size_t)(row1 - row0);
+    d_Srows.reserve(std::max<size_t>(nr * ne, 1));
+    if (nr) HIP_TRY(hipMemcpyAsync(d_Srows.p, d_A.p + (size_t)row0 * ne, nr * ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    sync();
+    d_A.release();
+    s_sharded = true;
+  }
+  // the whole matrix back in d_A (read-back entry points, `matout`): all-gather of the row blocks
+  void unshard_rows() {
+    if (!s_sharded) return;
+    const size_t ne = idx.elenum_all, nr = (size_t)(row1 - row0);
+    d_A.reserve(std::max<size_t>((size_t)rows_per * env.nranks, ne) * ne);
+    if (nccl) {
+      if (nr) HIP_TRY(hipMemcpyAsync(d_A.p + (size_t)env.rank * rows_per * ne, d_Srows.p, nr * ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      g_rccl.ok(g_rccl.AllGather(d_A.p + (size_t)env.rank * rows_per * ne, d_A.p, (size_t)rows_per * ne, ncclDouble, nccl, stream), "all-gather(S)");
+    } else {
+      std::vector<double> mine(std::max<size_t>(nr * ne, 1)), all(ne * ne);
+      if (nr) HIP_TRY(hipMemcpyAsync(mine.data(), d_Srows.p, nr * ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+      sync();
+      std::vector<int> rows(env.nranks);
+      for (int r = 0; r < env.nranks; ++r) rows[r] = std::min<int>((int)ne, (r + 1) * rows_per) - std::min<int>((int)ne, r * rows_per);
+      rc.gatherv(mine.data(), rows, (int)ne, all.data());
+      HIP_TRY(hipMemcpyAsync(d_A.p, all.data(), ne * ne * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
+    sync();
+    d_Srows.release();
+    s_sharded = false;
+  }
+
   // fix_conp.cpp:1135-1139: rows [row0,row1) of eleallq = S b (inverse solver), or the CG solve
   void solve_device() {
     const int ne = idx.elenum_all;
     if (args.minimizer == CONP_SOLVER_INV) {
       if (runstage < 3) throw ConpError(CONP_ERR_STATE, "solve before the inverse exists");
+      if (!s_sharded && setup_sharded()) shard_rows();          // first update after the setup
       prof.begin("gemv", stream);
-      launch_gemv_rows(stream, ne, row0, row1, d_A.p, d_b, d_eleallq);
+      launch_gemv_rows(stream, ne, row0, row1, s_base(), d_b, d_eleallq);
       prof.end(stream);
     } else {
       cg();
     }
+  }
+
+  // ---- the two exchanges of an update: all-reduce(b), all-gather(q) ---------------------------------------------
+  // RCCL on the library's stream when a communicator exists (one rank per GPU), else the host's callbacks through the
+  // page-locked staging buffer (ranks that share a GPU, the LAMMPS glue's default).  MPI_Allgatherv + MPI_Allreduce of the
+  // reference: fix_conp.cpp:643 (b_comm of b and of q), :1356 (newtonbuf).
+  void allreduce_b() {
+    if (env.nranks <= 1 && !nccl) return;
+    const int ne = idx.elenum_all;
+    prof.begin("allreduce_b", stream);
+    if (nccl) g_rccl.ok(g_rccl.AllReduce(d_b, d_b, (size_t)ne, ncclDouble, ncclSum, nccl, stream), "all-reduce(b)");
+    else if (rc.active()) {
+      double *h = pinned((size_t)ne_pad + 8);
+      HIP_TRY(hipMemcpyAsync(h, d_b, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+      sync();
+      rc.sum(h, ne);
+      HIP_TRY(hipMemcpyAsync(d_b, h, ne * sizeof(double), hipMemcpyHostToDevice, stream));
+    } else if (getenv("CONP_RANK_EMULATION")) {
+      // tools/rank_emulation.py: one rank's compute time measured on a box that has no partner ranks
+    } else throw ConpError(CONP_ERR_STATE, "an update on several ranks needs conp_fix_comm_init_rccl or conp_fix_set_comm (or do the "
+                                           "two collectives yourself between conp_fix_b_cal_device / _solve_device / _scatter_device)");
+    prof.end(stream);
+  }
+  void allgather_q() {
+    if ((env.nranks <= 1 && !nccl) || args.minimizer != CONP_SOLVER_INV) return;    // CG solves all rows on every rank, like the reference
+    const int ne = idx.elenum_all;
+    prof.begin("allgather_q", stream);
+    if (nccl) {
+      double *mine = d_eleallq + (size_t)env.rank * rows_per;
+      g_rccl.ok(g_rccl.AllGather(mine, d_eleallq, (size_t)rows_per, ncclDouble, nccl, stream), "all-gather(q)");
+    } else if (rc.active()) {
+      double *h = pinned((size_t)ne_pad + 8 + (size_t)ne + rows_per) + ne_pad + 8;
+      const int nr = row1 - row0;
+      if (nr) HIP_TRY(hipMemcpyAsync(h + ne, d_eleallq + row0, nr * sizeof(double), hipMemcpyDeviceToHost, stream));
+      sync();
+      std::vector<int> rows(env.nranks);
+      for (int r = 0; r < env.nranks; ++r) rows[r] = std::min(ne, (r + 1) * rows_per) - std::min(ne, r * rows_per);
+      rc.gatherv(h + ne, rows, 1, h);
+      HIP_TRY(hipMemcpyAsync(d_eleallq, h, ne * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
+    prof.end(stream);
   }
 
   // fix_conp.cpp:1149-1159: charges for owned + ghost electrode atoms, scalar output
@@ -1120,7 +1367,7 @@ struct conp_fix {
   // fix_conp.cpp:1120-1161 update_charge (host-buffer flavour)
   void update_charge(const conp_atoms *at, double potdiff) {
     const int ne = idx.elenum_all;
-    if (args.minimizer == CONP_SOLVER_INV) solve_device();
+    if (args.minimizer == CONP_SOLVER_INV) { solve_device(); allgather_q(); }
     scatter_device(d_q.p, potdiff);          // the device copy of q follows atom->q (post_force of the same step reuses it)
     double *qe = pinned((size_t)ne_pad + 8);
     HIP_TRY(hipMemcpyAsync(qe, d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1157,6 +1404,7 @@ struct conp_fix {
     // the correction only acts where the Gaussians overlap (eta^2 r^2 < 5.8, r < 1.2 A at eta = 1.979): in a normal MD step no
     // pair is that close, the force array on the device is still all zero and is not brought over
     pf_f_dirty = acc[8] > 0.0;
+    if (decomposed) rc.sum(acc + 7, 1);            // MPI_Allreduce of the electrode sum q^2 (fix_conp.cpp:1176, :1193)
     if (pf_f_dirty) {
       double *fh = acc - nf;
       HIP_TRY(hipMemcpyAsync(fh, d_f.p, nf * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1175,7 +1423,9 @@ struct conp_fix {
     if (d_Rp.n == 0) km_a_read(at);      // electrode phase tables (kspmod->a_read) not built yet: b_cal before a_cal
     if (elyte_list_stale(at)) { sync(); build_elyte_list(at); }       // km_ewald.cpp:686 is evaluated every step
     upload_xq(at);
+    if (decomposed) gather_elyte(at);
     b_cal_device(d_x.p, d_q.p, true, true);
+    allreduce_b();
   }
 
   // ---- one device-resident update as a HIP graph ------------------------------------------------
@@ -1201,14 +1451,18 @@ struct conp_fix {
     g_warm = 0;
   }
   void update_direct(const double *dx, double *dq, double potdiff) {
+    if (decomposed) throw ConpError(CONP_ERR_STATE, "device-resident updates take replicated atoms (conp_env.rank / nranks); "
+                                                    "spatially decomposed runs use the host-buffer hooks");
     b_cal_device(dx, dq, true);
+    allreduce_b();
     solve_device();
+    allgather_q();
     scatter_device(dq, potdiff);
   }
   void update_device(const double *dx, double *dq, double potdiff) {
     // (the legacy default stream cannot be captured)
     const bool can = !graph_off && stream != nullptr && !prof.on && args.minimizer == CONP_SOLVER_INV && runstage >= 3 &&
-                     (!args.cond || cond_ready);
+                     (!args.cond || cond_ready) && env.nranks == 1;
     if (can && upd_exec && potdiff != g_pot && ++g_pot_changes > 2) graph_off = true;     // variable potential: stay direct
     if (!can || graph_off) { if (upd_exec) drop_graph(); update_direct(dx, dq, potdiff); return; }
     if (upd_exec && (dx != g_dx || dq != g_dq || potdiff != g_pot)) drop_graph();
@@ -1485,8 +1739,10 @@ int conp_km_a_cal(conp_fix *f, const conp_atoms *at, double *aaa) {
   f->km_a_read(at);
   f->km_a_cal_device();
   const double MY_PIS = 1.77245385090551602729;
-  launch_a_diag_slab(f->stream, ne, f->kt.ug_tot - (2.0 / MY_PIS) * f->kt.g_ewald, 0.0, nullptr, f->kt.slabflag == 1,
-                     12.56637061435917295384 / f->kt.volume, f->d_ele_z.p, f->d_A.p);
+  if (!f->setup_sharded() || f->env.rank == 0)
+    launch_a_diag_slab(f->stream, ne, f->kt.ug_tot - (2.0 / MY_PIS) * f->kt.g_ewald, 0.0, nullptr, f->kt.slabflag == 1,
+                       12.56637061435917295384 / f->kt.volume, f->d_ele_z.p, f->d_A.p);
+  f->allreduce_matrix(f->d_A.p, (size_t)ne * ne);
   HIP_TRY(hipMemcpyAsync(aaa, f->d_A.p, (size_t)ne * ne * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();
   CONP_GUARD_END
@@ -1499,7 +1755,9 @@ int conp_km_b_cal(conp_fix *f, const conp_atoms *at, double *bbb) {
   if (at->nlocal + at->nghost != f->nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
   if (f->elyte_list_stale(at)) { f->sync(); f->build_elyte_list(at); }
   f->upload_xq(at);
+  if (f->decomposed) f->gather_elyte(at);
   f->b_cal_device(f->d_x.p, f->d_q.p, false);
+  if (f->nccl || f->rc.active()) f->allreduce_b();
   HIP_TRY(hipMemcpyAsync(bbb, f->d_b, f->idx.elenum_all * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();
   CONP_GUARD_END
@@ -1548,6 +1806,7 @@ int conp_fix_get_maps(const conp_fix *f, int *ele2tag, int *ele2eleall, int *ele
 int conp_fix_get_matrix(conp_fix *f, double *aaa) {
   CONP_GUARD_BEGIN
   f->drop_graph();
+  f->unshard_rows();             // several ranks keep only their rows of S after the setup: collective re-assembly
   const size_t ne = f->idx.elenum_all;
   HIP_TRY(hipMemcpyAsync(aaa, f->d_A.p, ne * ne * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   f->sync();
@@ -1557,6 +1816,7 @@ int conp_fix_get_matrix(conp_fix *f, double *aaa) {
 int conp_fix_set_matrix(conp_fix *f, const double *aaa, int runstage) {
   CONP_GUARD_BEGIN
   f->drop_graph();
+  if (f->s_sharded) { f->d_Srows.release(); f->s_sharded = false; }
   const size_t ne = f->idx.elenum_all;
   f->d_A.reserve(ne * ne);
   HIP_TRY(hipMemcpyAsync(f->d_A.p, aaa, ne * ne * sizeof(double), hipMemcpyHostToDevice, f->stream));
@@ -1706,6 +1966,44 @@ int64_t conp_host_pair_rows(int which, const conp_neighlist *l, const conp_atoms
   } catch (const std::exception &e) { g_last_error = e.what(); return -1; }
 }
 
+int conp_fix_set_comm(conp_fix *f, const conp_comm *comm) {
+  CONP_GUARD_BEGIN
+  if (!f || !comm) throw ConpError(CONP_ERR_ARG, "null argument");
+  if (f->idx.initialised) throw ConpError(CONP_ERR_STATE, "conp_fix_set_comm after setup_post_neighbor");
+  if (comm->nranks < 1 || comm->rank < 0 || comm->rank >= comm->nranks) throw ConpError(CONP_ERR_ARG, "bad rank/nranks");
+  if (comm->nranks > 1 && (!comm->allreduce_sum || !comm->allreduce_max_int || !comm->allgather_int || !comm->allgatherv))
+    throw ConpError(CONP_ERR_ARG, "conp_comm: every callback is needed with more than one rank");
+  f->rc.c = *comm; f->rc.have = true; f->rc.rank_ = comm->rank; f->rc.nranks_ = comm->nranks;
+  f->env.rank = comm->rank; f->env.nranks = comm->nranks;
+  f->decomposed = true;
+  CONP_GUARD_END
+}
+
+int conp_rccl_unique_id(void *id_out) {
+  CONP_GUARD_BEGIN
+  if (!id_out) throw ConpError(CONP_ERR_ARG, "null argument");
+  static_assert(sizeof(ncclUniqueId) == CONP_RCCL_ID_BYTES, "ncclUniqueId size");
+  g_rccl.load();
+  ncclUniqueId id;
+  g_rccl.ok(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(id_out, &id, sizeof(id));
+  CONP_GUARD_END
+}
+
+int conp_fix_comm_init_rccl(conp_fix *f, const void *id_in) {
+  CONP_GUARD_BEGIN
+  if (!f || !id_in) throw ConpError(CONP_ERR_ARG, "null argument");
+  if (f->nccl) throw ConpError(CONP_ERR_STATE, "RCCL communicator already initialised");
+  f->drop_graph();
+  g_rccl.load();
+  ncclUniqueId id;
+  std::memcpy(&id, id_in, sizeof(id));
+  g_rccl.ok(g_rccl.CommInitRank(&f->nccl, f->env.nranks, id, f->env.rank), "ncclCommInitRank");
+  // results of the in-library collectives land in the library's own vectors
+  f->d_b = f->d_b_own.p; f->d_eleallq = f->d_eleallq_own.p;
+  CONP_GUARD_END
+}
+
 int conp_fix_set_stream(conp_fix *f, void *s) {
   CONP_GUARD_BEGIN
   f->drop_graph();
@@ -1719,6 +2017,8 @@ int conp_fix_bind_device_buffers(conp_fix *f, double *d_b, double *d_q) {
   CONP_GUARD_BEGIN
   f->drop_graph();
   f->sync();
+  if (f->nccl && d_q) throw ConpError(CONP_ERR_STATE, "with an RCCL communicator the library gathers q into its own buffer "
+                                                      "(nranks * ceil(Ne / nranks) entries); read it with conp_fix_get_vectors");
   const size_t nb = f->idx.elenum_all * sizeof(double);
   if (d_b) { if (f->d_b && nb) HIP_TRY(hipMemcpy(d_b, f->d_b, nb, hipMemcpyDeviceToDevice)); f->d_b = d_b; }
   if (d_q) { if (f->d_eleallq && nb) HIP_TRY(hipMemcpy(d_q, f->d_eleallq, nb, hipMemcpyDeviceToDevice)); f->d_eleallq = d_q; }

@@ -368,9 +368,10 @@ void electrode_plan_tables(const KTables &kt, const KPlan &plan, int ne, int ne_
 // ------------------------------------------------------------------------------------------------
 // EleIndex
 // ------------------------------------------------------------------------------------------------
-void EleIndex::linalg_init(int nlocal, const int *tag) {   // fix_conp.cpp:413-416 (one rank: Allreduce MAX is the local max)
+void EleIndex::linalg_init(int nlocal, const int *tag, RankOps *ops) {   // fix_conp.cpp:413-416
   int maxtag = 0;
   for (int i = 0; i < nlocal; ++i) maxtag = std::max(tag[i], maxtag);
+  if (ops) ops->allreduce_max_int(&maxtag, 1);                            // MPI_Allreduce MAX :415
   maxtag_all = maxtag;
   tag2eleall.assign((size_t)maxtag_all + 1, 0);
   elenum = elenum_all = elytenum = 0;
@@ -384,8 +385,11 @@ void EleIndex::map_atoms(int nlocal, const int *tag) {
   for (int i = 0; i < nlocal; ++i) tag2local[tag[i]] = i;
 }
 
-bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool *elyte_grew) {
+bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool *elyte_grew, RankOps *ops) {
   if (!initialised) throw std::logic_error("post_neighbor before linalg_init");
+  RankOps one;
+  if (!ops) ops = &one;
+  const int nprocs = ops->nranks();
   const int elytenum_old = elytenum, elenum_all_old = elenum_all;
   int n = 0;
   for (int i = 0; i < nlocal; ++i) if (echeck[i]) ++n;            // :480-484
@@ -395,10 +399,14 @@ bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool
   ele2eleall.resize(elenum);
   int j = 0;
   for (int i = 0; i < nlocal; ++i) if (echeck[i]) ele2tag[j++] = tag[i];   // :493-498
-  elenum_all = elenum;                                           // one rank: sum of elenum_list
+  elenum_list.assign(nprocs, 0); displs.assign(nprocs, 0);
+  ops->allgather_int(elenum, elenum_list.data());                // MPI_Allgather :492
+  elenum_all = 0;
+  for (int r = 0; r < nprocs; ++r) { displs[r] = elenum_all; elenum_all += elenum_list[r]; }   // :499-506
   const bool grew = elenum_all > elenum_all_old;
   if (grew) {                                                    // :510-525
-    eleall2tag.assign(ele2tag.begin(), ele2tag.end());           // Allgatherv of one rank
+    eleall2tag.assign(elenum_all, 0);
+    ops->allgatherv_int(ele2tag.data(), elenum, eleall2tag.data(), elenum_list.data(), displs.data());   // :523
     elecheck_eleall.assign(elenum_all, 0);
     eleall2ele.assign((size_t)elenum_all + 1, -1);
     elebuf2eleall.assign(elenum_all, 0);
@@ -414,13 +422,13 @@ bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool
       eleall2ele[ele2eleall[j]] = j;
       ++j;
     }
-  for (int i = 0; i < elenum; ++i) elebuf2eleall[i] = ele2eleall[i];  // Allgatherv :535
+  ops->allgatherv_int(ele2eleall.data(), elenum, elebuf2eleall.data(), elenum_list.data(), displs.data());   // :535
   if (elyte_grew) *elyte_grew = elytenum > elytenum_old;
   map_atoms(nlocal, tag);
   return grew;
 }
 
-void EleIndex::renumber_from_tags(const std::vector<int> &file_tags, int nlocal, const int *tag, const int *echeck) {
+void EleIndex::renumber_from_tags(const std::vector<int> &file_tags, int nlocal, const int *tag, const int *echeck, RankOps *ops) {
   if ((int)file_tags.size() != elenum_all) throw std::invalid_argument("matrix file tag row does not match the electrode count");
   eleall2tag = file_tags;
   for (int i = 0; i < elenum_all; ++i) {                 // :755-759
@@ -436,7 +444,9 @@ void EleIndex::renumber_from_tags(const std::vector<int> &file_tags, int nlocal,
       eleall2ele[ele2eleall[j]] = j;
       ++j;
     }
-  for (int i = 0; i < elenum; ++i) elebuf2eleall[i] = ele2eleall[i];
+  RankOps one;
+  if (!ops) ops = &one;
+  ops->allgatherv_int(ele2eleall.data(), elenum, elebuf2eleall.data(), elenum_list.data(), displs.data());
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -100,20 +100,36 @@ void electrode_plan_tables(const KTables &kt, const KPlan &plan, int ne, int ne_
                            const std::vector<double> &snk, std::vector<double> &Rp, std::vector<double> &Tz);
 
 // ------------------------------------------------------------------------------------------------
-// EleIndex: FixConp::post_neighbor (fix_conp.cpp:468-539) + linalg_init's tag2eleall sizing (:413-416), one rank.
+// RankOps: the collectives FixConp::post_neighbor / linalg_init make on `world` (fix_conp.cpp:415, 492, 523, 535).  The default
+// is one rank; conp_fix.cpp implements it on the host's conp_comm callbacks for spatially decomposed runs.
+// ------------------------------------------------------------------------------------------------
+struct RankOps {
+  virtual ~RankOps() {}
+  virtual int nranks() const { return 1; }
+  virtual int rank() const { return 0; }
+  virtual void allreduce_max_int(int *, int) {}
+  virtual void allgather_int(int v, int *out) { out[0] = v; }
+  virtual void allgatherv_int(const int *send, int n, int *recv, const int * /*counts*/, const int * /*displs*/) {
+    for (int i = 0; i < n; ++i) recv[i] = send[i];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// EleIndex: FixConp::post_neighbor (fix_conp.cpp:468-539) + linalg_init's tag2eleall sizing (:413-416).
 // ------------------------------------------------------------------------------------------------
 struct EleIndex {
   int elenum = 0, elenum_all = 0, elytenum = 0, maxtag_all = -1;
   std::vector<int> ele2tag, ele2eleall, tag2eleall, eleall2tag, eleall2ele, elecheck_eleall, elebuf2eleall;
+  std::vector<int> elenum_list, displs;   // per rank: owned electrode atoms and their offsets in gathered buffers (:492-506)
   std::vector<int> tag2local;   // atom->map(tag) for owned atoms
   bool initialised = false;
 
-  void linalg_init(int nlocal, const int *tag);
+  void linalg_init(int nlocal, const int *tag, RankOps *ops = nullptr);
   // returns true when elenum_all grew (the reference then reallocates A, b, q ... :510-525)
-  bool post_neighbor(int nlocal, const int *tag, const int *echeck, bool *elyte_grew);
+  bool post_neighbor(int nlocal, const int *tag, const int *echeck, bool *elyte_grew, RankOps *ops = nullptr);
   void map_atoms(int nlocal, const int *tag);
   // FixConp::a_read (fix_conp.cpp:753-772): the matrix file's tag row becomes the permanent numbering
-  void renumber_from_tags(const std::vector<int> &file_tags, int nlocal, const int *tag, const int *echeck);
+  void renumber_from_tags(const std::vector<int> &file_tags, int nlocal, const int *tag, const int *echeck, RankOps *ops = nullptr);
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -79,13 +79,14 @@ void launch_post_force(hipStream_t s, int inum, const int *ilist, const int *num
 void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);
 
 // ---- once-per-run matrix work ------------------------------------------------------------------
-int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk);
+int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk, int nranks);
+// rank r of nranks computes the lower-triangle tiles r, r + nranks, ... into its zero-initialised A
 void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A, int nsplit,
-                     const int *chunk_group);
+                     const int *chunk_group, int rank, int nranks);
 void launch_a_diag_slab(hipStream_t s, int ne, double diag_k, double diag_self, const double *diag_self_atom /*[ne] or NULL*/,
                         int slab, double pref, const double *ele_z, double *A);
-void launch_a_real(hipStream_t s, int ne, const int *row_ptr, const int *ele_atom, const int *oth_atom, const int *col,
-                   const double *x, const int *type, RealParams rp, double *A);
+void launch_a_real(hipStream_t s, int ne, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
+                   const int *col, const double *x, const int *type, RealParams rp, double *A);
 void launch_a_symmetrise(hipStream_t s, int ne, double *A);
 void launch_inv_project(hipStream_t s, int n, double *A, int use_mask, const unsigned char *mask, double *ainve,
                         double *totinve /*device scalar*/, int apply);

@@ -248,6 +248,23 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const double *cur,
   }
 }
 
+// ---- diagnostic build only (-DSK_STAMP, `make stamp`, tools/sk_stamp.py): s_memtime stamps around the phases of a chunk,
+// summed per wave in scalar registers and stored once per segment into a buffer nothing else reads.  In the product build no
+// stamp executes.  Its fences forbid overlaps the real kernel has: read the SHARES, never the length (guide, "In-kernel stamps").
+#ifdef SK_STAMP
+__device__ unsigned long long sk_stamp_buf[1024 * 8 * 8];   // [workgroup][wave][prologue, load issue, mfma, build, barrier, epilogue, chunks, late]
+#define SK_STAMP_T(t)                                                          \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");  \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+#define SK_STAMP_ADD(sum, a, b) sum += (b) - (a)
+#else
+#define SK_STAMP_T(t) do { } while (0)
+#define SK_STAMP_ADD(sum, a, b) do { } while (0)
+#endif
+
 // One segment = (tile, chunk range).  Between two barriers the workgroup multiplies chunk c (panel buffer c&1) and
 // builds chunk c+1 (other buffer).  The two waves of a SIMD (w and w+4) do this in OPPOSITE order -- waves 0-3
 // multiply first, waves 4-7 build first -- so one wave's operand generation overlaps its partner's MFMAs.
@@ -259,24 +276,37 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *o
 #pragma unroll
     for (int g = 0; g < (NFW > 0 ? NFW : 1); ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
   SkRaw raw;
+#ifdef SK_STAMP
+  unsigned long long st_a = 0, st_b = 0, s_pro = 0, s_load = 0, s_mfma = 0, s_build = 0, s_bar = 0, s_epi = 0;
+#endif
+  SK_STAMP_T(st_a);
   sk_load_raw(c, c.it.c0, raw);
   sk_build_panel(c, raw, panel);
   if (late && c.it.c0 + 1 < c.it.c1) sk_load_raw(c, c.it.c0 + 1, raw);
   __syncthreads();
+  SK_STAMP_T(st_b); SK_STAMP_ADD(s_pro, st_a, st_b);
   for (int ch = c.it.c0; ch < c.it.c1; ++ch) {
     const double *cur = panel + ((ch - c.it.c0) & 1) * SK_PANEL;
     double *nxt = panel + (((ch - c.it.c0) & 1) ^ 1) * SK_PANEL;
     const bool more = ch + 1 < c.it.c1;
     if (!late) {
+      SK_STAMP_T(st_a);
       if (more && !(c.dbg & 4)) sk_load_raw(c, ch + 1, raw);
+      SK_STAMP_T(st_b); SK_STAMP_ADD(s_load, st_a, st_b);
       if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
+      SK_STAMP_T(st_a); SK_STAMP_ADD(s_mfma, st_b, st_a);
       if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
+      SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
     } else {
 #if SK_LATE_MODE == 1
       // full stagger: build first, multiply second
+      SK_STAMP_T(st_a);
       if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
+      SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
       if (ch + 2 < c.it.c1 && !(c.dbg & 4)) sk_load_raw(c, ch + 2, raw);
+      SK_STAMP_T(st_a); SK_STAMP_ADD(s_load, st_b, st_a);
       if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
+      SK_STAMP_T(st_b); SK_STAMP_ADD(s_mfma, st_a, st_b);
 #else
       // half stagger: the partner (early) wave multiplies all 4 k-steps first; this wave multiplies 2, builds, multiplies 2 --
       // k-steps 0-1 of both waves overlap (LDS latency hidden behind the partner's MFMAs), each wave's build overlaps the
@@ -288,9 +318,11 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *o
 #endif
     }
     __syncthreads();
+    SK_STAMP_T(st_a); SK_STAMP_ADD(s_bar, st_b, st_a);
   }
   // ---- partial tile out: part[segment][128][320] (only the active fragments)
   if (c.dbg & 16) return;
+  SK_STAMP_T(st_a);
 #pragma unroll
   for (int g = 0; g < NFW; ++g)
 #pragma unroll
@@ -301,6 +333,14 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *o
         const int col = 16 * (4 * g + c.cg) + c.fr;
         out[row * 320 + col] = acc[f][g][r];
       }
+#ifdef SK_STAMP
+  SK_STAMP_T(st_b); SK_STAMP_ADD(s_epi, st_a, st_b);
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
+    unsigned long long *o = sk_stamp_buf + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;
+    o[0] += s_pro; o[1] += s_load; o[2] += s_mfma; o[3] += s_build; o[4] += s_bar; o[5] += s_epi;
+    o[6] += (unsigned long long)(c.it.c1 - c.it.c0); o[7] = late ? 1 : 0;
+  }
+#endif
 }
 
 // Persistent-style launch: workgroup w runs the segments seg_ptr[w] .. seg_ptr[w+1]-1 (host: equal cost per workgroup,
@@ -368,6 +408,17 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     }
   }
 }
+
+#ifdef SK_STAMP
+extern "C" int conp_debug_sk_stamps(unsigned long long *out /*[1024*8*8]*/, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_stamp_buf), sizeof(unsigned long long) * 1024 * 8 * 8) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long zeros[1024 * 8 * 8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sk_stamp_buf), zeros, sizeof(zeros)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
@@ -1091,7 +1142,8 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
                                                               const int *__restrict__ nb_act, const double *__restrict__ wfull,
                                                               const double *__restrict__ Rp, const double *__restrict__ Tz,
                                                               double *__restrict__ A, int nsplit,
-                                                              const int *__restrict__ chunk_group, size_t part_stride) {
+                                                              const int *__restrict__ chunk_group, size_t part_stride,
+                                                              int tile_first, int tile_stride) {
   extern __shared__ __attribute__((aligned(16))) char ak_smem[];
   double *L = reinterpret_cast<double *>(ak_smem);      // [AK_TC][AK_LD]
   // unit = (tile, split s): the kz chunks are dealt to `nsplit` groups of about equal work on the host; split s sums its group
@@ -1099,7 +1151,9 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
   // 528 tiles on 512 workgroup slots (Ne = 4096) leave a 30 % tail otherwise.
   const int split = blockIdx.x % nsplit;
   A += (size_t)split * part_stride;
-  int tidx = blockIdx.x / nsplit, bi = 0;
+  // several ranks: the lower-triangle tiles are dealt cyclically (rank r takes tiles r, r + nranks, ...; equal cost apart from
+  // the half-empty diagonal tiles), everybody's zero-initialised matrix is then summed (conp_fix.cpp allreduce_matrix)
+  int tidx = (blockIdx.x / nsplit) * tile_stride + tile_first, bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= tidx) ++bi;
   const int bj = tidx - bi * (bi + 1) / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1178,24 +1232,26 @@ __global__ void a_parts_sum_kernel(int ne, int nsplit, double *__restrict__ A, c
 }
 
 // how many ways the kz chunks of a tile are split: none when there are many more tiles than workgroup slots
-int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk) {
+int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk, int nranks) {
   const int nb = ne_pad / 128;
-  const long ntiles = (long)nb * (nb + 1) / 2, slots = 2L * num_cus;
+  const long ntiles = ((long)nb * (nb + 1) / 2 + nranks - 1) / nranks, slots = 2L * num_cus;
   if (ntiles >= 6 * slots || nchunk < 2) return 1;
   return nchunk >= 4 ? 4 : 2;
 }
 
 // A must have room for nsplit copies of ne * ne doubles; copy s of a tile goes to A + s * ne * ne, the sum lands in copy 0
 void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A, int nsplit,
-                     const int *chunk_group) {
+                     const int *chunk_group, int rank, int nranks) {
   const int nb = ne_pad / 128;
-  const int ntiles = nb * (nb + 1) / 2;
+  const int ntiles_all = nb * (nb + 1) / 2;
+  const int ntiles = ntiles_all > rank ? (ntiles_all - rank + nranks - 1) / nranks : 0;
   const size_t lds = (size_t)AK_TC * AK_LD * sizeof(double);
   static DynLdsCache granted{};
   ensure_dyn_lds(a_kspace_lds_kernel, lds, granted);
   const size_t n2 = (size_t)ne * ne;
-  hipLaunchKernelGGL(a_kspace_lds_kernel, dim3(ntiles * nsplit), dim3(256), lds, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.n_row_tiles,
-                     pl.nb_act, pl.wfull, Rp, Tz, A, nsplit, chunk_group, n2);
+  if (ntiles > 0)
+    hipLaunchKernelGGL(a_kspace_lds_kernel, dim3(ntiles * nsplit), dim3(256), lds, s, pl.R_pad, pl.C_pad, ne, ne_pad, pl.n_row_tiles,
+                       pl.nb_act, pl.wfull, Rp, Tz, A, nsplit, chunk_group, n2, rank, nranks);
   if (nsplit > 1) hipLaunchKernelGGL(a_parts_sum_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, ne, nsplit, A, A + n2);
 }
 
@@ -1217,12 +1273,12 @@ __global__ void a_diag_slab_kernel(int ne, double diag_k, double diag_self, cons
 
 // one thread per electrode row, pairs in list order (deterministic): A[row][col] += [erfc(g r) - erfc(eta r / sqrt 2)] / r
 // (fix_conp.cpp:1242-1276, eta_potential_A :1467-1470)
-__global__ void a_real_kernel(int ne, const int *__restrict__ row_ptr, const int *__restrict__ ele_atom,
+__global__ void a_real_kernel(int ne, int row0, int row1, const int *__restrict__ row_ptr, const int *__restrict__ ele_atom,
                               const int *__restrict__ oth_atom, const int *__restrict__ col, const double *__restrict__ x,
                               const int *__restrict__ type, RealParams rp, double *__restrict__ A) {
 #pragma clang fp contract(off)
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= ne) return;
+  const int row = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= row1 || row >= ne) return;
   const int nt1 = rp.ntypes + 1;
   for (int p = row_ptr[row]; p < row_ptr[row + 1]; ++p) {
     const int ie = ele_atom[p], jo = oth_atom[p];
@@ -1236,9 +1292,11 @@ __global__ void a_real_kernel(int ne, const int *__restrict__ row_ptr, const int
   }
 }
 
-void launch_a_real(hipStream_t s, int ne, const int *row_ptr, const int *ele_atom, const int *oth_atom, const int *col,
-                   const double *x, const int *type, RealParams rp, double *A) {
-  hipLaunchKernelGGL(a_real_kernel, dim3((ne + 63) / 64), dim3(64), 0, s, ne, row_ptr, ele_atom, oth_atom, col, x, type, rp, A);
+void launch_a_real(hipStream_t s, int ne, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
+                   const int *col, const double *x, const int *type, RealParams rp, double *A) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(a_real_kernel, dim3((row1 - row0 + 63) / 64), dim3(64), 0, s, ne, row0, row1, row_ptr, ele_atom, oth_atom, col,
+                     x, type, rp, A);
 }
 
 // a_ij += a_ji ; a_ji = a_ij  for i > j   (fix_conp.cpp:826-831)

@@ -3,6 +3,12 @@
 
 #include <cstring>
 
+#ifdef CONP_GLUE_MOCK
+#include "mock_lammps/mpi_mock.h"
+#else
+#include <mpi.h>
+#endif
+
 #ifndef CONP_GLUE_MOCK
 #include "atom.h"
 #include "comm.h"
@@ -24,6 +30,26 @@
 using namespace LAMMPS_NS;
 using namespace FixConst;
 
+// ---- conp_comm on MPI: the collectives FixConp makes on `world` (fix_conp.cpp:415, 492, 523, 535, 643, 822, 1356;
+// km_ewald.cpp:77, 784), handed to the library as callbacks.  ctx = &world.
+static int cb_allreduce_sum(void *ctx, double *buf, int64_t n) {
+  return MPI_Allreduce(MPI_IN_PLACE, buf, (int)n, MPI_DOUBLE, MPI_SUM, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
+}
+static int cb_allreduce_max_int(void *ctx, int *buf, int n) {
+  return MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_INT, MPI_MAX, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
+}
+static int cb_allgather_int(void *ctx, int value, int *out) {
+  return MPI_Allgather(&value, 1, MPI_INT, out, 1, MPI_INT, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
+}
+static int cb_allgatherv(void *ctx, const void *send, int64_t nbytes, void *recv, const int64_t *counts, const int64_t *displs) {
+  MPI_Comm w = *static_cast<MPI_Comm *>(ctx);
+  int n = 1;
+  MPI_Comm_size(w, &n);
+  std::vector<int> c(n), d(n);
+  for (int r = 0; r < n; ++r) { c[r] = (int)counts[r]; d[r] = (int)displs[r]; }
+  return MPI_Allgatherv(send, (int)nbytes, MPI_BYTE, recv, c.data(), d.data(), MPI_BYTE, w) != MPI_SUCCESS;
+}
+
 void FixConpHip::fail_if(int status) {
   if (status != CONP_OK) error->all(FLERR, conp_last_error());
 }
@@ -36,8 +62,6 @@ FixConpHip::FixConpHip(LAMMPS *lmp, int narg, char **arg)
   if (jgroup == -1) error->all(FLERR, "Fix conp group ID does not exist");  // :106-107
   jgroupbit = group->bitmask[jgroup];
   outf = fopen(args.logfile, "w");                                         // :119
-  if (comm->nprocs > 1)
-    error->all(FLERR, "fix conp/hip: one MPI rank per fix in this release (multi-GPU runs shard inside the library)");
   scalar_flag = 1; extscalar = 0; global_freq = 1;                         // :177-179
 }
 
@@ -88,9 +112,20 @@ void FixConpHip::init() {
     env.ntypes = atom->ntypes; env.cutsq = cutsq_flat.data();
     env.cut_coul = *(double *)coulpair->extract("cut_coul", itmp);
     env.one_electrode = (groupbit == jgroupbit);                           // :295
-    env.device = 0; env.rank = 0; env.nranks = 1;
-    env.ghost_images = 1;     // LAMMPS ghosts are images of owned atoms kept current by forward communication
+    // several MPI ranks (spatial decomposition): every rank drives its own handle on its own atoms and lists; device -1 lets the
+    // library take GPU (rank mod visible devices), so that ranks of a node spread over its GPUs or share one
+    env.device = comm->nprocs > 1 ? -1 : 0; env.rank = comm->me; env.nranks = comm->nprocs;
+    // ghosts that are periodic images of owned atoms are rebuilt on the device; a rank whose ghosts belong to other ranks fails
+    // the library's check at post_neighbor and uploads them as they are
+    env.ghost_images = 1;
     fail_if(conp_fix_create(&args, &env, &h));
+    if (comm->nprocs > 1) {
+      conp_comm cc;
+      cc.ctx = &world; cc.rank = comm->me; cc.nranks = comm->nprocs;
+      cc.allreduce_sum = cb_allreduce_sum; cc.allreduce_max_int = cb_allreduce_max_int;
+      cc.allgather_int = cb_allgather_int; cc.allgatherv = cb_allgatherv;
+      fail_if(conp_fix_set_comm(h, &cc));
+    }
     for (auto &toks : pending_modify) {
       std::vector<const char *> ptrs;
       for (auto &tk : toks) ptrs.push_back(tk.c_str());

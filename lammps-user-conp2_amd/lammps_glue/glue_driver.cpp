@@ -1,13 +1,20 @@
 // glue_driver -- a miniature host that drives FixConpHip the way LAMMPS does, on top of the interface mock.
 // It exists to EXECUTE the C++ glue (constructor / init / init_list / setup_* / post_neighbor / pre_force / post_force /
-// compute_scalar / modify_param, log-file writing, error->all propagation) against libconp_hip.so on a real GPU; the numerical
-// content is checked by tests/test_gpu_glue.py against the ctypes path through the same library.
+// compute_scalar / modify_param, log-file writing, error->all propagation, and the MPI-backed conp_comm callbacks) against
+// libconp_hip.so on a real GPU; the numerical content is checked by tests/test_gpu_glue.py against the ctypes path through the
+// same library.
 //
-// usage: glue_driver CASEFILE [provider]   (whitespace-separated tokens, written by the test)
-//   with `provider`: INTEGRATION.md mode B instead -- a handle is set up through the C ABI the way FixConp::init /
-//   setup_post_neighbor would, then KSpaceModuleHip::{conp_setup, a_cal, b_cal} run with the fix's public maps and the result
-//   is printed as "a I J VALUE" (local row I, global column J) and "b I VALUE".
-//   ntypes nlocal nghost
+// usage: glue_driver CASEFILE                      one rank, FixConpHip (INTEGRATION.md mode A)
+//        glue_driver CASEFILE provider             mode B: the reference's FixConp keeps its loops, only `kspmod` is replaced:
+//                                                  a stand-in for the fix's public members is registered with KSpaceModuleHip
+//                                                  (register_fix, fix_conp.cpp:409) and conp_setup / conp_post_neighbor / a_cal /
+//                                                  b_cal run; output "a I J VALUE" (local row I, global column J), "b I VALUE"
+//        glue_driver ranks N CASE_0 .. CASE_N-1 [provider]
+//                                                  N rank THREADS, one per sub-domain case file (LAMMPS' spatial decomposition:
+//                                                  owned atoms + ghosts + lists of that rank), collectives through the MPI mock;
+//                                                  every output line is prefixed "rank R "
+// case file (whitespace-separated tokens, written by the test):
+//   ntypes nlocal nghost natoms
 //   xprd yprd zprd boxlo_x boxlo_y boxlo_z
 //   g_ewald accuracy slab_volfactor slabflag nx_pppm ny_pppm nz_pppm order      (mesh 0 0 0 0 = not a PPPM style)
 //   qqrd2e qqr2e qe2f dielectric newton_pair cut_coul
@@ -19,8 +26,9 @@
 //   nmodify { ntok tok... } ...                          fix_modify lines
 //   narg tok...                                          the fix command
 //   nsteps { ntimestep potdiff_value reneighbor(0/1) has_x(0/1) [x y z per atom] } ...
-// output (stdout): "scalar STEP VALUE", "q STEP TAG VALUE" for electrode atoms, "f STEP ..." sums, "ERROR: msg" + exit 2.
+// output (stdout): "scalar STEP VALUE", "q STEP TAG VALUE" for owned electrode atoms, "f STEP ..." sums, "ERROR: msg" + exit 2.
 #include <chrono>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +36,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define CONP_GLUE_MOCK 1
@@ -36,25 +45,41 @@
 
 using namespace LAMMPS_NS;
 
-int main(int argc, char **argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: glue_driver CASEFILE\n"); return 1; }
-  std::ifstream in(argv[1]);
-  if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
+namespace {
+
+struct Out {
+  std::string text;
+  void f(const char *fmt, ...) {
+    char line[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    text += line;
+  }
+};
+
+// one rank: its own mock LAMMPS instance, atoms and lists from its case file
+int run_case(const char *path, bool provider, int me, int nprocs, MockCommRank *world, Out &out) {
+  std::ifstream in(path);
+  if (!in) { out.f("ERROR: cannot open %s\n", path); return 1; }
 
   LAMMPS lmp{};
   Memory memory; Error error; Atom atom{}; Force force{}; Domain domain{}; Update update{}; Comm comm{}; Group group{};
   Variable variable; Input input{}; Neighbor neighbor{}; Modify modify; KSpace kspace{}; Pair pair{};
+  lmp.world = world;
   lmp.memory = &memory; lmp.error = &error; lmp.atom = &atom; lmp.force = &force; lmp.domain = &domain; lmp.update = &update;
   lmp.comm = &comm; lmp.group = &group; lmp.input = &input; lmp.neighbor = &neighbor; lmp.modify = &modify;
-  lmp.screen = stdout; lmp.logfile = nullptr;
+  lmp.screen = me == 0 ? stdout : nullptr; lmp.logfile = nullptr;
   input.variable = &variable;
   force.kspace = &kspace; force.pair = &pair;
-  comm.me = 0; comm.nprocs = 1;
+  comm.me = me; comm.nprocs = nprocs;
   char style[] = "verlet";
   update.integrate_style = style;
 
   int ntypes, nlocal, nghost;
-  in >> ntypes >> nlocal >> nghost;
+  long natoms;
+  in >> ntypes >> nlocal >> nghost >> natoms;
   const int nall = nlocal + nghost;
   in >> domain.xprd >> domain.yprd >> domain.zprd >> domain.boxlo[0] >> domain.boxlo[1] >> domain.boxlo[2];
   domain.zprd_half = 0.5 * domain.zprd;
@@ -89,7 +114,7 @@ int main(int argc, char **argv) {
   }
   std::vector<int> map_array(maxtag + 1, -1);
   for (int i = nall - 1; i >= 0; --i) map_array[tag[i]] = i;      // owned atoms win over their ghosts, like Atom::map
-  atom.nlocal = nlocal; atom.nghost = nghost; atom.ntypes = ntypes; atom.natoms = nlocal;
+  atom.nlocal = nlocal; atom.nghost = nghost; atom.ntypes = ntypes; atom.natoms = natoms;
   atom.x = xrows.data(); atom.f = frows.data(); atom.q = q.data(); atom.type = type.data(); atom.mask = mask.data();
   atom.tag = tag.data(); atom.map_array = map_array.data(); atom.map_size = maxtag + 1;
 
@@ -133,132 +158,188 @@ int main(int argc, char **argv) {
   std::vector<NeighRequest *> requests(8, nullptr);
   neighbor.requests = requests.data();
 
-  if (argc > 2 && std::string(argv[2]) == "provider") {
-    try {
-      auto must = [&](int rc) { if (rc != CONP_OK) throw std::runtime_error(conp_last_error()); };
-      conp_fix_args fa;
-      std::vector<const char *> cargv;
-      for (auto &t : toks) cargv.push_back(t.c_str());
-      must(conp_parse_fix_args(narg, cargv.data(), ntypes, &fa));
-      const int gb = bitmask[group.find(toks[1])], jgb = bitmask[group.find(toks[4])];
-      conp_env env;
-      std::memset(&env, 0, sizeof(env));
-      env.qqrd2e = force.qqrd2e; env.qqr2e = force.qqr2e; env.qe2f = force.qe2f; env.dielectric = force.dielectric;
-      env.newton_pair = force.newton_pair; env.g_ewald = kspace.g_ewald; env.accuracy = kspace.accuracy;
-      env.slab_volfactor = kspace.slab_volfactor; env.slabflag = kspace.slabflag;
-      env.xprd = domain.xprd; env.yprd = domain.yprd; env.zprd = domain.zprd;
-      env.boxlo_x = domain.boxlo[0]; env.boxlo_y = domain.boxlo[1]; env.boxlo_z = domain.boxlo[2];
-      env.ntypes = ntypes; env.cutsq = cutsq_store.data(); env.cut_coul = pair.cut_coul; env.nranks = 1;
-      conp_fix *h = nullptr;
-      must(conp_fix_create(&fa, &env, &h));
-      std::vector<std::vector<int>> firsts(nlists);
-      for (int l = 0; l < nlists; ++l) {
-        ListStore &L = lists[l];
-        firsts[l].assign(L.first.begin(), L.first.end());
-        conp_neighlist v;
-        v.inum = L.nl.inum; v.ilist = L.ilist.data(); v.numneigh = L.numneigh.data(); v.first = firsts[l].data();
-        v.neigh = L.neigh.data(); v.nneigh = (int64_t)L.neigh.size();
-        must(conp_fix_init_list(h, nlists == 1 ? 2 : l, &v));
-      }
-      std::vector<int> ec(nall);
-      for (int i = 0; i < nall; ++i) ec[i] = (mask[i] & gb) ? 1 : ((mask[i] & jgb) ? -1 : 0);
-      conp_atoms a;
-      a.nlocal = nlocal; a.nghost = nghost; a.x = xs.data(); a.q = q.data(); a.type = type.data(); a.tag = tag.data();
-      a.echeck = ec.data();
-      must(conp_fix_setup_post_neighbor(h, &a));
-      conp_info info;
-      must(conp_fix_info(h, &info));
-      int elenum = info.elenum, elenum_all = info.elenum_all;
-      std::vector<int> ele2tag(elenum), ele2eleall(elenum), eleall2tag(elenum_all), eleall2ele(elenum_all + 1), echk(elenum_all),
-          ebuf(elenum_all), tag2eleall(info.maxtag_all + 1);
-      must(conp_fix_get_maps(h, ele2tag.data(), ele2eleall.data(), eleall2tag.data(), eleall2ele.data(), echk.data(), ebuf.data(),
-                             tag2eleall.data()));
-      const int *e2ea = ele2eleall.data();
-      KSpaceModuleHip km(&lmp, h, gb, jgb, &e2ea, &elenum, &elenum_all);
-      km.conp_setup(true);
-      km.conp_post_neighbor(true, true);
-      km.a_read();
-      std::vector<double> aaa((size_t)elenum * elenum_all, 0.0), bbb(elenum, 0.0);
-      km.a_cal(aaa.data());
-      km.b_cal(bbb.data());
-      for (int i = 0; i < elenum; ++i) {
-        std::printf("b %d %.17g\n", i, bbb[i]);
-        for (int j = 0; j < elenum_all; ++j) std::printf("a %d %d %.17g\n", i, j, aaa[(size_t)i * elenum_all + j]);
-      }
-      for (int i = 0; i < elenum; ++i) std::printf("m %d %d\n", i, ele2eleall[i]);
-      conp_fix_destroy(h);
-    } catch (const std::exception &e) {
-      std::printf("ERROR: %s\n", e.what());
-      return 2;
+  if (provider) {
+    // Mode B.  What FixConp::linalg_init / post_neighbor do around the provider (fix_conp.cpp:401-416, 468-539), with a stand-in
+    // that carries the fix's PUBLIC members: the index maps are made the way the fix makes them (one more handle serves as the
+    // fix's bookkeeping here; in a LAMMPS tree the reference's own FixConp fills them).
+    auto must = [&](int rc) { if (rc != CONP_OK) throw std::runtime_error(conp_last_error()); };
+    conp_fix_args fa;
+    std::vector<const char *> cargv;
+    for (auto &t : toks) cargv.push_back(t.c_str());
+    must(conp_parse_fix_args(narg, cargv.data(), ntypes, &fa));
+    const int gb = bitmask[group.find(toks[1])], jgb = bitmask[group.find(toks[4])];
+    FixConp fixstub;
+    fixstub.eta = fa.eta;
+    fixstub.check = [&](int i) { return (mask[i] & gb) ? 1 : ((mask[i] & jgb) ? -1 : 0); };
+    // the fix's own maps: FixConp::post_neighbor's algorithm (conp_host_index restates it bit-exactly; one rank here -- in the
+    // `ranks` mode the stand-in's numbering comes from a bookkeeping handle that talks to the other ranks)
+    conp_env env;
+    std::memset(&env, 0, sizeof(env));
+    env.qqrd2e = force.qqrd2e; env.qqr2e = force.qqr2e; env.qe2f = force.qe2f; env.dielectric = force.dielectric;
+    env.newton_pair = force.newton_pair; env.g_ewald = kspace.g_ewald; env.accuracy = kspace.accuracy;
+    env.slab_volfactor = kspace.slab_volfactor; env.slabflag = kspace.slabflag;
+    env.xprd = domain.xprd; env.yprd = domain.yprd; env.zprd = domain.zprd;
+    env.boxlo_x = domain.boxlo[0]; env.boxlo_y = domain.boxlo[1]; env.boxlo_z = domain.boxlo[2];
+    env.ntypes = ntypes; env.cutsq = cutsq_store.data(); env.cut_coul = pair.cut_coul; env.nranks = nprocs; env.rank = me;
+    conp_fix *book = nullptr;
+    must(conp_fix_create(&fa, &env, &book));
+    // (the bookkeeping handle of a multi-rank run would need the comm too; the provider test with ranks uses FixConpHip instead)
+    std::vector<std::vector<int>> firsts(nlists);
+    for (int l = 0; l < nlists; ++l) {
+      ListStore &L = lists[l];
+      firsts[l].assign(L.first.begin(), L.first.end());
+      conp_neighlist v;
+      v.inum = L.nl.inum; v.ilist = L.ilist.data(); v.numneigh = L.numneigh.data(); v.first = firsts[l].data();
+      v.neigh = L.neigh.data(); v.nneigh = (int64_t)L.neigh.size();
+      must(conp_fix_init_list(book, nlists == 1 ? 2 : l, &v));
     }
+    std::vector<int> ec(nall);
+    for (int i = 0; i < nall; ++i) ec[i] = fixstub.check(i);
+    conp_atoms a;
+    a.nlocal = nlocal; a.nghost = nghost; a.x = xs.data(); a.q = q.data(); a.type = type.data(); a.tag = tag.data();
+    a.echeck = ec.data();
+    must(conp_fix_setup_post_neighbor(book, &a));
+    conp_info info;
+    must(conp_fix_info(book, &info));
+    std::vector<int> ele2tag(info.elenum), ele2eleall(info.elenum), eleall2tag(info.elenum_all), eleall2ele(info.elenum_all + 1),
+        echk(info.elenum_all), ebuf(info.elenum_all), tag2eleall(info.maxtag_all + 1);
+    must(conp_fix_get_maps(book, ele2tag.data(), ele2eleall.data(), eleall2tag.data(), eleall2ele.data(), echk.data(), ebuf.data(),
+                           tag2eleall.data()));
+    conp_fix_destroy(book);
+    fixstub.elenum = info.elenum; fixstub.elenum_all = info.elenum_all; fixstub.elytenum = info.elytenum;
+    fixstub.ele2tag = ele2tag.data(); fixstub.ele2eleall = ele2eleall.data(); fixstub.eleall2tag = eleall2tag.data();
+    fixstub.tag2eleall = tag2eleall.data();
+    // fix_conp.cpp:408-410: kspmod = new ...(lmp); kspmod->register_fix(this); kspmod->conp_setup(lowmemflag);
+    KSpaceModule *kspmod = new KSpaceModuleHip(&lmp);
+    fixstub.kspmod = kspmod;
+    kspmod->register_fix(&fixstub);
+    kspmod->conp_setup(true);
+    kspmod->conp_post_neighbor(true, true);        // fix_conp.cpp:538
+    kspmod->a_read();                              // km_ewald.cpp:147-151 a_cal calls a_read first
+    std::vector<double> aaa((size_t)info.elenum * info.elenum_all, 0.0), bbb(info.elenum, 0.0);
+    kspmod->a_cal(aaa.data());
+    kspmod->b_cal(bbb.data());
+    for (int i = 0; i < info.elenum; ++i) {
+      out.f("b %d %.17g\n", i, bbb[i]);
+      for (int j = 0; j < info.elenum_all; ++j) out.f("a %d %d %.17g\n", i, j, aaa[(size_t)i * info.elenum_all + j]);
+    }
+    for (int i = 0; i < info.elenum; ++i) out.f("m %d %d\n", i, ele2eleall[i]);
+    delete kspmod;                                 // fix_conp.cpp:207: the fix deletes its Ewald provider; the handle goes with it
     return 0;
   }
 
-  try {
-    FixConpHip fix(&lmp, narg, fargv.data());
-    for (auto &ml : modify_lines) {                    // fix_modify arrives before init(), as in an input script
-      std::vector<char *> margv;
-      for (auto &t : ml) margv.push_back(const_cast<char *>(t.c_str()));
-      const int used = fix.modify_param((int)margv.size(), margv.data());
-      if (used == 0) throw std::runtime_error("Illegal fix_modify command");
+  FixConpHip fix(&lmp, narg, fargv.data());
+  for (auto &ml : modify_lines) {                    // fix_modify arrives before init(), as in an input script
+    std::vector<char *> margv;
+    for (auto &t : ml) margv.push_back(const_cast<char *>(t.c_str()));
+    const int used = fix.modify_param((int)margv.size(), margv.data());
+    if (used == 0) throw std::runtime_error("Illegal fix_modify command");
+  }
+  fix.init();
+  // Neighbor::init hands every request its list (Neighbor::init -> Fix::init_list); an occasional skip list is the
+  // ele-ele list (list 0), the perpetual one the ele-electrolyte list (last list)
+  for (int r = 0; r < neighbor.nrequest; ++r) {
+    const bool occasional = requests[r]->occasional != 0;
+    ListStore &L = (neighbor.nrequest == 1 || occasional) ? lists.front() : lists.back();
+    L.nl.index = r; L.nl.occasional = requests[r]->occasional;
+    fix.init_list(0, &L.nl);
+  }
+  update.ntimestep = 0;
+  int nsteps;
+  in >> nsteps;
+  // Verlet::setup order: modify->setup_post_neighbor(), then modify->setup_pre_force()
+  bool first = true;
+  for (int s = 0; s < nsteps; ++s) {
+    long ts; double pd; int reneigh, has_x;
+    in >> ts >> pd >> reneigh >> has_x;
+    if (has_x) for (size_t k = 0; k < xs.size(); ++k) in >> xs[k];
+    update.ntimestep = ts; update.laststep = -1;
+    if (s == nsteps - 1) update.laststep = ts;
+    variable.value = pd;
+    if (first) {
+      fix.setup_post_neighbor();
+      fix.setup_pre_force(0);
+      first = false;
+    } else {
+      if (reneigh) fix.post_neighbor();
+      fix.pre_force(0);
     }
-    fix.init();
-    // Neighbor::init hands every request its list (Neighbor::init -> Fix::init_list); an occasional skip list is the
-    // ele-ele list (list 0), the perpetual one the ele-electrolyte list (last list)
-    for (int r = 0; r < neighbor.nrequest; ++r) {
-      const bool occasional = requests[r]->occasional != 0;
-      ListStore &L = (neighbor.nrequest == 1 || occasional) ? lists.front() : lists.back();
-      L.nl.index = r; L.nl.occasional = requests[r]->occasional;
-      fix.init_list(0, &L.nl);
-    }
-    update.ntimestep = 0;
-    int nsteps;
-    in >> nsteps;
-    std::vector<long> step_no(nsteps);
-    // Verlet::setup order: modify->setup_post_neighbor(), then modify->setup_pre_force()
-    bool first = true;
-    for (int s = 0; s < nsteps; ++s) {
-      long ts; double pd; int reneigh, has_x;
-      in >> ts >> pd >> reneigh >> has_x;
-      if (has_x) for (size_t k = 0; k < xs.size(); ++k) in >> xs[k];
-      update.ntimestep = ts; update.laststep = -1;
-      if (s == nsteps - 1) update.laststep = ts;
-      variable.value = pd;
-      if (first) {
-        fix.setup_post_neighbor();
-        fix.setup_pre_force(0);
-        first = false;
-      } else {
-        if (reneigh) fix.post_neighbor();
-        fix.pre_force(0);
-      }
-      std::fill(fs.begin(), fs.end(), 0.0);
-      if (fix.setmask() & FixConst::POST_FORCE) fix.post_force(0);
-      fix.end_of_step();
-      std::printf("scalar %ld %.17g\n", ts, fix.compute_scalar());
-      for (int i = 0; i < nlocal; ++i)
-        if (mask[i] & (fix.groupbit | bitmask[group.find(toks[4])])) std::printf("q %ld %d %.17g\n", ts, tag[i], q[i]);
-      double fsum[3] = {0, 0, 0}, fabs_ = 0;
-      for (int i = 0; i < nlocal; ++i) for (int c = 0; c < 3; ++c) { fsum[c] += fs[3 * (size_t)i + c]; fabs_ += std::abs(fs[3 * (size_t)i + c]); }
-      std::printf("f %ld %.17g %.17g %.17g %.17g eng_coul %.17g kspace_energy %.17g\n", ts, fsum[0], fsum[1], fsum[2], fabs_,
-                  pair.eng_coul, kspace.energy);
-    }
-    // GLUE_DRIVER_TIME=N: wall time of N more pre_force calls -- the PCIe-inclusive rate a LAMMPS run would see through the glue
-    if (const char *tn = std::getenv("GLUE_DRIVER_TIME")) {
-      const int n = std::atoi(tn);
-      for (int k = 0; k < 3; ++k) { update.ntimestep += 1; fix.pre_force(0); }
-      const auto t0 = std::chrono::steady_clock::now();
-      for (int k = 0; k < n; ++k) { update.ntimestep += 1; fix.pre_force(0); }
-      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (n > 0 ? n : 1);
-      std::printf("time_pre_force_ms %.6f\n", ms);
-      const auto t1 = std::chrono::steady_clock::now();
-      for (int k = 0; k < n; ++k) { std::fill(fs.begin(), fs.end(), 0.0); fix.post_force(0); }      // same step as the last pre_force
-      const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() / (n > 0 ? n : 1);
-      std::printf("time_post_force_ms %.6f\n", ms2);
-    }
-  } catch (const std::exception &e) {
-    std::printf("ERROR: %s\n", e.what());
-    return 2;
+    std::fill(fs.begin(), fs.end(), 0.0);
+    if (fix.setmask() & FixConst::POST_FORCE) fix.post_force(0);
+    fix.end_of_step();
+    out.f("scalar %ld %.17g\n", ts, fix.compute_scalar());
+    for (int i = 0; i < nlocal; ++i)
+      if (mask[i] & (fix.groupbit | bitmask[group.find(toks[4])])) out.f("q %ld %d %.17g\n", ts, tag[i], q[i]);
+    double fsum[3] = {0, 0, 0}, fabs_ = 0;
+    for (int i = 0; i < nlocal; ++i) for (int c = 0; c < 3; ++c) { fsum[c] += fs[3 * (size_t)i + c]; fabs_ += std::abs(fs[3 * (size_t)i + c]); }
+    out.f("f %ld %.17g %.17g %.17g %.17g eng_coul %.17g kspace_energy %.17g\n", ts, fsum[0], fsum[1], fsum[2], fabs_,
+          pair.eng_coul, kspace.energy);
+  }
+  // GLUE_DRIVER_TIME=N: wall time of N more pre_force calls -- the PCIe-inclusive rate a LAMMPS run would see through the glue
+  if (const char *tn = std::getenv("GLUE_DRIVER_TIME")) {
+    const int n = std::atoi(tn);
+    for (int k = 0; k < 3; ++k) { update.ntimestep += 1; fix.pre_force(0); }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < n; ++k) { update.ntimestep += 1; fix.pre_force(0); }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (n > 0 ? n : 1);
+    out.f("time_pre_force_ms %.6f\n", ms);
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int k = 0; k < n; ++k) { std::fill(fs.begin(), fs.end(), 0.0); fix.post_force(0); }      // same step as the last pre_force
+    const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() / (n > 0 ? n : 1);
+    out.f("time_post_force_ms %.6f\n", ms2);
   }
   return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: glue_driver CASEFILE [provider] | glue_driver ranks N CASE_0 .. CASE_N-1\n"); return 1; }
+  if (std::string(argv[1]) == "ranks") {
+    const int n = argc > 2 ? std::atoi(argv[2]) : 0;
+    if (n < 1 || argc < 3 + n) { std::fprintf(stderr, "glue_driver ranks N needs N case files\n"); return 1; }
+    const bool provider = argc > 3 + n && std::string(argv[3 + n]) == "provider";
+    MockWorld world(n);
+    std::vector<MockCommRank> ranks(n);
+    std::vector<Out> outs(n);
+    std::vector<int> rcs(n, 0);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < n; ++r) {
+      ranks[r] = MockCommRank{&world, r};
+      threads.emplace_back([&, r] {
+        try {
+          rcs[r] = run_case(argv[3 + r], provider, r, n, &ranks[r], outs[r]);
+        } catch (const std::exception &e) {
+          outs[r].f("ERROR: %s\n", e.what());
+          rcs[r] = 2;
+          world.fail();                      // the other ranks sit in a collective: wake them, they fail too
+        }
+      });
+    }
+    for (auto &t : threads) t.join();
+    int rc = 0;
+    for (int r = 0; r < n; ++r) {
+      size_t pos = 0;
+      while (pos < outs[r].text.size()) {
+        const size_t e = outs[r].text.find('\n', pos);
+        const std::string line = outs[r].text.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        std::printf("rank %d %s\n", r, line.c_str());
+        if (e == std::string::npos) break;
+        pos = e + 1;
+      }
+      if (rcs[r]) rc = rcs[r];
+    }
+    return rc;
+  }
+  Out out;
+  int rc = 0;
+  try {
+    MockCommRank *single = nullptr;
+    rc = run_case(argv[1], argc > 2 && std::string(argv[2]) == "provider", 0, 1, single, out);
+  } catch (const std::exception &e) {
+    out.f("ERROR: %s\n", e.what());
+    rc = 2;
+  }
+  std::fputs(out.text.c_str(), stdout);
+  return rc;
 }

@@ -1,56 +1,47 @@
 /* KSpaceModuleHip -- the Ewald k-space provider of USER-CONP2 (km_ewald.h:27-80) served by libconp_hip.so.
- * It implements the reference's provider interface (kspacemodule.h:26-45): a maintainer who keeps the reference's
- * FixConp unchanged replaces `new KSpaceModuleEwald(lmp)` (fix_conp.cpp:408) by `new KSpaceModuleHip(lmp, handle)`.
- * FixConpHip (fix_conp_hip.h) uses the fused hooks instead and does not need this class. */
+ * It IS a KSpaceModule of the reference (kspacemodule.h:26-45): a maintainer who keeps the reference's FixConp replaces
+ *     else kspmod = new KSpaceModuleEwald(lmp);          (fix_conp.cpp:408)
+ * by  else kspmod = new KSpaceModuleHip(lmp);
+ * and nothing else -- `kspmod->register_fix(this)` (:409) hands the fix over, and the provider reads the fix's public members
+ * (elenum, elenum_all, ele2tag, eleall2tag, eta, electrode_check(): fix_conp.h:58-89) exactly as KSpaceModuleEwald does.
+ * Ownership: the provider creates its own conp_fix handle in conp_setup() and destroys it in its destructor; FixConp deletes its
+ * Ewald provider in ~FixConp (fix_conp.cpp:207), so the handle's life is the fix's.  FixConpHip (fix_conp_hip.h) replaces the
+ * whole fix instead and does not use this class. */
 #ifndef LMP_FIXCONP_KM_HIP_H
 #define LMP_FIXCONP_KM_HIP_H
 
+#include <vector>
+
 #include "conp_hip.h"
 #ifdef CONP_GLUE_MOCK
-#include "mock_lammps/lammps_mock.h"
+#include "mock_lammps/conp2_mock.h"
 #else
+#include "kspacemodule.h" /* the reference's header: KSpaceModule, FixConp */
 #include "pointers.h"
 #endif
 
 namespace LAMMPS_NS {
 
-/* same virtual surface as the reference's KSpaceModule (kspacemodule.h:30-40) */
-class KSpaceModuleIface {
+class KSpaceModuleHip : public KSpaceModule, protected Pointers {
  public:
-  virtual ~KSpaceModuleIface() {}
-  virtual void conp_setup(bool) {}
-  virtual void conp_post_neighbor(bool, bool) {}
-  virtual void conp_pre_force() {}
-  virtual void a_cal(double *) {}
-  virtual void a_read() {}
-  virtual void b_cal(double *) {}
-  virtual void update_charge() {}
-  virtual double compute_particle_potential(int) { return 0.; }
-  virtual void compute_group_potential(int, double *) {}
-  virtual double return_qsum() { return 0.; }
-};
-
-class KSpaceModuleHip : public KSpaceModuleIface, protected Pointers {
- public:
-  /* ele2eleall / elenum: the owning fix's public maps (fix_conp.h:58-66), read each call like the reference does */
-  KSpaceModuleHip(LAMMPS *lmp, conp_fix *handle, int groupbit, int jgroupbit, const int *const *ele2eleall, const int *elenum,
-                  const int *elenum_all);
-  void conp_setup(bool lowmem) override;                 /* km_ewald.cpp:63-132 */
-  void a_cal(double *aaa) override;                      /* km_ewald.cpp:147-151 : aaa[elenum][elenum_all], k-space part */
-  void b_cal(double *bbb) override;                      /* km_ewald.cpp:153-167 : bbb[elenum], local electrode order */
-  /* km_ewald.cpp:232-275 / :134-145 only (re)allocate and fill the provider's phase tables; the library sizes its device
-   * tables from the atoms handed to a_cal / b_cal, so these two hooks have nothing left to do.  update_charge,
-   * compute_particle_potential, compute_group_potential and return_qsum keep the base-class defaults, as in KSpaceModuleEwald. */
-  void conp_post_neighbor(bool, bool) override {}
-  void a_read() override {}
+  explicit KSpaceModuleHip(LAMMPS *lmp);
+  ~KSpaceModuleHip() override;
+  void conp_setup(bool lowmem) override;                 /* km_ewald.cpp:63-132: handle creation + k tables */
+  void conp_post_neighbor(bool, bool) override;          /* km_ewald.cpp:232-275: the handle follows the fix's atoms */
+  void a_cal(double *aaa) override;                      /* km_ewald.cpp:147-151 : aaa[elenum][elenum_all] +=, k-space part */
+  void a_read() override {}                              /* km_ewald.cpp:134-145: the phase tables are built inside a_cal / b_cal */
+  void b_cal(double *bbb) override;                      /* km_ewald.cpp:153-167 : bbb[elenum] =, local electrode order */
+  /* update_charge, conp_pre_force, compute_particle_potential, compute_group_potential and return_qsum keep the base-class
+   * defaults, as in KSpaceModuleEwald (the Ewald provider has no mesh potential; `pppm/conp/hip` has: pppm_conp_hip.h). */
 
  private:
   conp_fix *h;
-  int groupbit, jgroupbit;
-  const int *const *ele2eleall;
-  const int *elenum, *elenum_all;
+  bool first;
+  std::vector<int> echeck, lib_tag2eleall, nolist;
+  std::vector<double> xflat, cutsq0;
   void fail_if(int status);
-  void fill_atoms(conp_atoms &at, int *&echeck_buf, double *&x_buf);
+  conp_atoms view();
+  void refresh_maps();
 };
 
 }  // namespace LAMMPS_NS

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <string>
 
+#include "mpi_mock.h"
+
 #define FLERR __FILE__, __LINE__
 #define NEIGHMASK 0x3FFFFFFF
 
@@ -35,17 +37,17 @@ class NeighList { public: int index, inum, occasional; int *ilist, *numneigh, **
 class Neighbor { public: NeighRequest **requests; int nrequest = 0; int request(void *, int instance = 0); void build(int); void build_one(NeighList *, int preflag = 0); };
 class Modify { public: int find_fix(const std::string &); };
 
-class LAMMPS { public: Memory *memory; Error *error; Atom *atom; Force *force; Domain *domain; Update *update; Comm *comm; Group *group; Input *input; Neighbor *neighbor; Modify *modify; FILE *screen, *logfile; };
+class LAMMPS { public: MPI_Comm world = nullptr; Memory *memory; Error *error; Atom *atom; Force *force; Domain *domain; Update *update; Comm *comm; Group *group; Input *input; Neighbor *neighbor; Modify *modify; FILE *screen, *logfile; };
 
 class Pointers {
  public:
   explicit Pointers(LAMMPS *ptr)
-      : lmp(ptr), memory(ptr->memory), error(ptr->error), atom(ptr->atom), force(ptr->force), domain(ptr->domain),
+      : lmp(ptr), world(ptr->world), memory(ptr->memory), error(ptr->error), atom(ptr->atom), force(ptr->force), domain(ptr->domain),
         update(ptr->update), comm(ptr->comm), group(ptr->group), input(ptr->input), neighbor(ptr->neighbor),
         modify(ptr->modify), screen(ptr->screen), logfile(ptr->logfile) {}
   virtual ~Pointers() {}
  protected:
-  LAMMPS *lmp; Memory *&memory; Error *&error; Atom *&atom; Force *&force; Domain *&domain; Update *&update; Comm *&comm;
+  LAMMPS *lmp; MPI_Comm &world; Memory *&memory; Error *&error; Atom *&atom; Force *&force; Domain *&domain; Update *&update; Comm *&comm;
   Group *&group; Input *&input; Neighbor *&neighbor; Modify *&modify; FILE *&screen; FILE *&logfile;
 };
 

@@ -6,6 +6,72 @@
 
 #include "lammps_mock.h"
 
+// ---- the MPI mock: rank threads of one process meet at a generation barrier; a collective = publish, barrier, read, barrier
+void MockWorld::barrier() {
+  std::unique_lock<std::mutex> lk(m);
+  if (failed) throw std::runtime_error("another rank failed");
+  const long gen = generation;
+  if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); return; }
+  cv.wait(lk, [&] { return generation != gen || failed; });
+  if (failed && generation == gen) throw std::runtime_error("another rank failed");
+}
+void MockWorld::fail() {
+  std::lock_guard<std::mutex> lk(m);
+  failed = true;
+  cv.notify_all();
+}
+
+static size_t mock_size(MPI_Datatype t) { return t == MPI_DOUBLE ? sizeof(double) : (t == MPI_INT ? sizeof(int) : 1); }
+
+int MPI_Comm_rank(MPI_Comm c, int *r) { *r = c ? c->rank : 0; return MPI_SUCCESS; }
+int MPI_Comm_size(MPI_Comm c, int *n) { *n = c ? c->w->n : 1; return MPI_SUCCESS; }
+int MPI_Barrier(MPI_Comm c) { if (c && c->w->n > 1) c->w->barrier(); return MPI_SUCCESS; }
+
+int MPI_Allreduce(const void *send, void *recv, int count, MPI_Datatype t, MPI_Op op, MPI_Comm c) {
+  const size_t bytes = (size_t)count * mock_size(t);
+  if (!c || c->w->n == 1) { if (send != MPI_IN_PLACE) std::memcpy(recv, send, bytes); return MPI_SUCCESS; }
+  MockWorld *w = c->w;
+  std::vector<char> mine(bytes), res(bytes);
+  std::memcpy(mine.data(), send == MPI_IN_PLACE ? recv : send, bytes);
+  w->ptr[c->rank] = mine.data();
+  w->barrier();
+  for (int k = 0; k < count; ++k) {          // fixed rank order: every rank forms the same bits
+    if (t == MPI_DOUBLE) {
+      double a = static_cast<const double *>(w->ptr[0])[k];
+      for (int r = 1; r < w->n; ++r) { const double b = static_cast<const double *>(w->ptr[r])[k]; a = op == MPI_SUM ? a + b : (b > a ? b : a); }
+      reinterpret_cast<double *>(res.data())[k] = a;
+    } else {
+      int a = static_cast<const int *>(w->ptr[0])[k];
+      for (int r = 1; r < w->n; ++r) { const int b = static_cast<const int *>(w->ptr[r])[k]; a = op == MPI_SUM ? a + b : (b > a ? b : a); }
+      reinterpret_cast<int *>(res.data())[k] = a;
+    }
+  }
+  w->barrier();
+  std::memcpy(recv, res.data(), bytes);
+  return MPI_SUCCESS;
+}
+
+int MPI_Allgatherv(const void *send, int scount, MPI_Datatype t, void *recv, const int *rcounts, const int *displs, MPI_Datatype, MPI_Comm c) {
+  const size_t sz = mock_size(t);
+  if (!c || c->w->n == 1) { std::memcpy(static_cast<char *>(recv) + (size_t)displs[0] * sz, send, (size_t)scount * sz); return MPI_SUCCESS; }
+  MockWorld *w = c->w;
+  w->ptr[c->rank] = send;
+  w->len[c->rank] = scount;
+  w->barrier();
+  for (int r = 0; r < w->n; ++r)
+    if (rcounts[r] > 0) std::memcpy(static_cast<char *>(recv) + (size_t)displs[r] * sz, w->ptr[r], (size_t)rcounts[r] * sz);
+  w->barrier();
+  return MPI_SUCCESS;
+}
+
+int MPI_Allgather(const void *send, int scount, MPI_Datatype t, void *recv, int rcount, MPI_Datatype rt, MPI_Comm c) {
+  int n = 1;
+  MPI_Comm_size(c, &n);
+  std::vector<int> counts(n, rcount), displs(n);
+  for (int r = 0; r < n; ++r) displs[r] = r * rcount;
+  return MPI_Allgatherv(send, scount, t, recv, counts.data(), displs.data(), rt, c);
+}
+
 namespace LAMMPS_NS {
 
 void Error::all(const char *file, int line, const std::string &msg) {

@@ -22,7 +22,7 @@ BIT = {"all": 1, "eleleft": 2, "eleright": 4}
 def write_case(path, s, at, lists, tokens, steps, variable=("-", 0.0), modify=(), mesh=(0, 0, 0, 0)):
     out = []
     w = lambda *a: out.append(" ".join(repr(float(v)) if isinstance(v, (float, np.floating)) else str(v) for v in a))
-    w(s.ntypes, at.nlocal, at.nghost)
+    w(s.ntypes, at.nlocal, at.nghost, s.natoms)
     w(*[float(v) for v in s.prd], *[float(v) for v in s.boxlo])
     w(float(s.g_ewald), float(s.accuracy), float(s.slab_volfactor), int(s.slabflag), *mesh)
     w(systems.QQRD2E, systems.QQR2E, systems.QE2F, 1.0, int(s.newton), float(s.cutoff))
@@ -50,12 +50,20 @@ def write_case(path, s, at, lists, tokens, steps, variable=("-", 0.0), modify=()
 
 
 def run_driver(case, cwd, *extra):
+    """case: one case file, or a list of them = one per rank thread (`glue_driver ranks N ...`)"""
     if not os.path.exists(DRIVER):            # normally built by __graft_entry__.build(); g++ is on the GPU box too
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "driver"])
-    p = subprocess.run([DRIVER, case, *extra], cwd=cwd, capture_output=True, text=True, timeout=300)
-    res = {"scalar": {}, "q": {}, "f": {}, "error": None, "screen": [], "rc": p.returncode}
+    cmd = [DRIVER, case, *extra] if isinstance(case, str) else [DRIVER, "ranks", str(len(case)), *case, *extra]
+    p = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=300)
+    res = {"scalar": {}, "q": {}, "f": {}, "error": None, "screen": [], "rc": p.returncode, "scalar_by_rank": {}}
     for line in p.stdout.splitlines():
+        rank = 0
+        if line.startswith("rank "):                 # several ranks: "rank R <line>"; the charges of all ranks form one table
+            _, r, line = line.split(" ", 2)
+            rank = int(r)
         t = line.split()
+        if line.startswith("scalar "):
+            res["scalar_by_rank"].setdefault(rank, {})[int(t[1])] = float(t[2])
         if line.startswith("scalar "):
             res["scalar"][int(t[1])] = float(t[2])
         elif line.startswith("q "):
@@ -213,3 +221,53 @@ def test_pppm_keyword_takes_the_mesh_from_the_kspace_style(tmp_path):
     # the mesh spread uses f64 atomics: equal up to the order of the additions
     assert np.abs(got - at.q[ele]).max() <= 1e-12 * np.abs(at.q[ele]).max()
     fx.close()
+
+
+@pytest.mark.parametrize("name,axis,nranks", [("small_slab", 0, 2), ("dilute_ffield_etypes", 2, 2), ("small_ffield", 1, 3)])
+def test_several_mpi_ranks_match_one_rank(tmp_path, name, axis, nranks):
+    """FixConpHip on a spatially decomposed system (fix_conp.cpp:409, 641-648; km_ewald.cpp:782-786 are the reference's multi-rank
+    sites): N rank threads, each with the owned atoms, ghosts and half lists of its slab, the collectives through the glue's
+    MPI-backed conp_comm callbacks (here the MPI mock).  Charges per tag, and the fix scalar on every rank, equal the one-rank run."""
+    s = {"small_slab": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab"),
+         "small_ffield": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0),
+         "dilute_ffield_etypes": lambda: systems.deck("dilute", "ffield", etypes=True)}[name]()
+    rng = np.random.default_rng(5)
+    disp = np.where((s.echeck == 0)[:, None], rng.normal(scale=0.02, size=s.x.shape), 0.0)     # per ATOM (by tag - 1)
+    tag2row = {int(t): i for i, t in enumerate(s.tag)}
+
+    def moved(at):
+        return at.x + disp[[tag2row[int(t)] for t in at.tag]]
+
+    # one rank, ctypes path
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    ref = {0: ({int(t): q for t, q in zip(at.tag[:at.nlocal], at.q[:at.nlocal])}, fx.compute_scalar())}
+    at.x[:] = moved(at)
+    fx.pre_force(at, 1, 0.7)
+    ref[1] = ({int(t): q for t, q in zip(at.tag[:at.nlocal], at.q[:at.nlocal])}, fx.compute_scalar())
+    fx.post_neighbor(at)
+    fx.pre_force(at, 2, 0.7)
+    ref[2] = ({int(t): q for t, q in zip(at.tag[:at.nlocal], at.q[:at.nlocal])}, fx.compute_scalar())
+    fx.close()
+
+    parts = neighbor.build_lists_decomposed(s, nranks, axis=axis)
+    assert all(p[0].nlocal > 0 for p in parts)
+    cases = []
+    for r, (atr, al, bl) in enumerate(parts):
+        case = str(tmp_path / f"case{r}.txt")
+        steps = [(0, s.potdiff, 0, None), (1, 0.7, 0, moved(atr)), (2, 0.7, 1, None)]
+        write_case(case, s, atr, [al] if al is bl else [al, bl], fix_command_for(s), steps)
+        cases.append(case)
+    res, proc = run_driver(cases, str(tmp_path))
+    assert res["rc"] == 0 and res["error"] is None, proc.stdout[-3000:] + proc.stderr[-2000:]
+    ele_tags = [int(t) for t, e in zip(s.tag, s.echeck) if e != 0]
+    for ts in (0, 1, 2):
+        qref, sc = ref[ts]
+        scale = max(abs(qref[t]) for t in ele_tags)
+        assert sorted(res["q"][ts]) == sorted(ele_tags)                       # every electrode atom reported by exactly its owner
+        assert max(abs(res["q"][ts][t] - qref[t]) for t in ele_tags) < 1e-9 * scale, ts
+        for r in range(nranks):
+            assert res["scalar_by_rank"][r][ts] == pytest.approx(sc, rel=1e-9, abs=1e-12)

@@ -1,0 +1,136 @@
+"""-m gpu: several ranks.  (1) spatially decomposed atoms with the conp_comm callbacks (the LAMMPS-MPI route; here two / three
+processes share cuda:0 and the callbacks run on torch.distributed gloo) against the one-rank result; (2) the RCCL data plane
+inside the library -- a one-rank communicator exercises every RCCL call site (all-reduce of b and of the sharded A build,
+in-place all-gather of q, row-sharded S and its re-assembly) on the one GPU this box has; several GPUs are the driver's bench."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conp_amd import FixConp, neighbor, systems
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make(name):
+    return {"small_slab": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab"),
+            "dilute_ffield": lambda: systems.deck("dilute", "ffield", etypes=True),
+            "dilute_slab_generic": lambda: systems.deck("dilute", "slab", etypes=False)}[name]()
+
+
+def _decomposed_worker(rank, world, port, name, axis, solver, out):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "lammps-user-conp2_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = _make(name)
+    at, alist, blist = neighbor.build_lists_decomposed(s, world, axis=axis)[rank]
+    fx = FixConp(s, device=0, rank=rank, nranks=world, extra_args=["cg"] if solver == "cg" else [])
+    fx.set_comm_torch()
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    q0 = {int(t): float(q) for t, q, e in zip(at.tag[:at.nlocal], at.q[:at.nlocal], at.echeck[:at.nlocal]) if e}
+    sc0 = fx.compute_scalar()
+    # a second update with changed electrolyte charges (the per-step gather), and the post-force correction
+    sol = at.echeck == 0
+    at.q[sol] *= 1.25
+    fx.pre_force(at, 1, 0.4)
+    q1 = {int(t): float(q) for t, q, e in zip(at.tag[:at.nlocal], at.q[:at.nlocal], at.echeck[:at.nlocal]) if e}
+    f, ek, ec, vir = fx.post_force(at)
+    S = fx.matrix() if solver == "inv" else None            # collective: the row-sharded inverse is re-assembled
+    m = fx.maps()
+    out[rank] = dict(q0=q0, q1=q1, sc0=sc0, sc1=fx.compute_scalar(), ek=ek, S=S, eleall2tag=m["eleall2tag"].copy(),
+                     info=(fx.info().elenum, fx.info().elenum_all, fx.info().n_elyte_charged))
+    fx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,axis,world,solver", [("small_slab", 0, 2, "inv"), ("dilute_ffield", 2, 2, "inv"),
+                                                    ("dilute_slab_generic", 1, 3, "inv"), ("small_slab", 1, 2, "cg")])
+def test_decomposed_ranks_match_one_rank(name, axis, world, solver):
+    import torch.multiprocessing as mp
+    s = _make(name)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s, extra_args=["cg"] if solver == "cg" else [])
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    ele = at.echeck[:at.nlocal] != 0
+    q0 = {int(t): float(q) for t, q in zip(at.tag[:at.nlocal][ele], at.q[:at.nlocal][ele])}
+    sc0 = fx.compute_scalar()
+    at.q[at.echeck == 0] *= 1.25
+    fx.pre_force(at, 1, 0.4)
+    q1 = {int(t): float(q) for t, q in zip(at.tag[:at.nlocal][ele], at.q[:at.nlocal][ele])}
+    sc1 = fx.compute_scalar()
+    _, ek, _, _ = fx.post_force(at)
+    S1 = fx.matrix()
+    tags1 = fx.maps()["eleall2tag"]
+    n_charged = fx.info().n_elyte_charged
+    fx.close()
+    mgr = mp.Manager(); out = mgr.dict()
+    port = 29600 + (os.getpid() + 7 * axis + world) % 300
+    mp.spawn(_decomposed_worker, args=(world, port, name, axis, solver, out), nprocs=world, join=True)
+    tol = 1e-6 if solver == "cg" else 1e-9
+    allq0, allq1 = {}, {}
+    for r in range(world):
+        o = out[r]
+        assert not (set(o["q0"]) & set(allq0))                      # every electrode atom has one owner
+        allq0.update(o["q0"]); allq1.update(o["q1"])
+        assert o["info"][1] == len(q0) and o["info"][2] == n_charged
+        assert o["sc0"] == pytest.approx(sc0, rel=tol, abs=1e-12) and o["sc1"] == pytest.approx(sc1, rel=tol, abs=1e-12)
+        assert o["ek"] == pytest.approx(ek, rel=1e-9)                # self energy: sum over the electrode atoms of ALL ranks
+    assert sorted(allq0) == sorted(q0)
+    scale = max(abs(v) for v in q0.values())
+    assert max(abs(allq0[t] - q0[t]) for t in q0) < tol * scale
+    assert max(abs(allq1[t] - q1[t]) for t in q1) < tol * scale
+    if solver == "inv":
+        # the projected inverse in the ranks' own (rank-major) numbering == the one-rank matrix permuted by tag
+        pos1 = {int(t): i for i, t in enumerate(tags1)}
+        perm = np.array([pos1[int(t)] for t in out[0]["eleall2tag"]])
+        for r in range(world):
+            assert np.array_equal(out[r]["eleall2tag"], out[0]["eleall2tag"])
+            assert rel_err(out[r]["S"], S1[np.ix_(perm, perm)]) < 1e-8
+
+
+def _rccl_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "lammps-user-conp2_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = systems.deck("il_onelayer", "ffield")
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s, device=0, rank=rank, nranks=world)
+    fx.comm_init_rccl()                                        # ncclGetUniqueId on rank 0, 128 bytes broadcast, ncclCommInitRank
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.linalg_setup(at)                                        # tiles dealt to the ranks, all-reduce(A) on RCCL
+    d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda(); d_q = torch.from_numpy(at.q.copy()).cuda()
+    for _ in range(3):
+        fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)     # all-reduce(b), rows of S b, all-gather(q) inside
+    torch.cuda.synchronize()
+    b, q, _ = fx.vectors()
+    out[rank] = (b, q, d_q.cpu().numpy(), fx.matrix())
+    fx.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_data_plane_one_rank_communicator():
+    import torch.multiprocessing as mp
+    s = systems.deck("il_onelayer", "ffield")
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist); fx.setup_post_neighbor(at); fx.setup_pre_force(at, 0, s.potdiff)
+    b1, q1, _ = fx.vectors()
+    S1 = fx.matrix()
+    fx.close()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, 29950 + os.getpid() % 40, out), nprocs=1, join=True)
+    b, q, q_atoms, S = out[0]
+    assert rel_err(b, b1) < 1e-12 and rel_err(q, q1) < 1e-11 and rel_err(S, S1) < 1e-12
+    ele = at.echeck != 0
+    assert rel_err(q_atoms[ele], at.q[ele]) < 1e-11

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Where a chunk of sk_gemm spends its cycles: runs the headline workload on the DIAGNOSTIC build of the library
+(`make -C lammps-user-conp2_amd/csrc stamp`: s_memtime stamps around load issue / MFMA / panel build / barrier, summed per wave)
+and prints the shares per wave role.  The stamped kernel is slower than the real one (its fences forbid overlaps): shares only.
+
+    python3 tools/sk_stamp.py [workload] [updates]
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lammps-user-conp2_amd"))
+sys.path.insert(0, ROOT)
+os.environ["CONP_LIB"] = os.path.join(ROOT, "lammps-user-conp2_amd", "conp_amd", "libconp_hip_stamp.so")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.cuda.init()
+import bench  # noqa: E402
+from conp_amd import FixConp, capi, neighbor  # noqa: E402
+
+s = bench.make_workload(sys.argv[1] if len(sys.argv) > 1 else "headline")
+nupd = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+at, alist, blist = neighbor.build_lists(s)
+fx = FixConp(s)
+fx.init_lists(alist, blist); fx.setup_post_neighbor(at); fx.linalg_setup(at)
+d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda(); d_q = torch.from_numpy(at.q.copy()).cuda()
+lib = capi.load_library()
+buf = np.zeros(1024 * 8 * 8, dtype=np.uint64)
+for _ in range(3):
+    fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)
+torch.cuda.synchronize()
+lib.conp_debug_sk_stamps(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 1)
+for _ in range(nupd):
+    fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)
+torch.cuda.synchronize()
+lib.conp_debug_sk_stamps(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 0)
+t = buf.reshape(1024, 8, 8).astype(np.float64)
+used = t[:, :, 6].sum(axis=1) > 0
+t = t[used]
+names = ["prologue", "load issue", "mfma", "build", "barrier", "epilogue"]
+print(f"workgroups with work: {t.shape[0]}, updates {nupd}")
+for role, sel in (("early waves 0-3 (multiply, then build)", slice(0, 4)), ("late waves 4-7 (build, then multiply)", slice(4, 8))):
+    w = t[:, sel, :]
+    tot = w[:, :, :6].sum()
+    print(f"  {role}: cycles per wave per update {tot / (w.shape[0] * 4 * nupd):.0f}, chunks per wave {w[:, :, 6].sum() / (w.shape[0] * 4 * nupd):.1f}")
+    for k, n in enumerate(names):
+        print(f"      {n:11s} {100 * w[:, :, k].sum() / tot:5.1f} %   ({w[:, :, k].sum() / max(w[:, :, 6].sum(), 1):8.0f} cycles per chunk)")
+per_wave = t[:, :, :6].sum(axis=2) / nupd
+print("  per-wave total cycles: min %.0f  median %.0f  max %.0f" % (per_wave.min(), np.median(per_wave), per_wave.max()))
+for wv in range(8):
+    w = t[:, wv, :]
+    print(f"  wave {wv}: mfma {w[:, 2].sum() / w[:, 6].sum():7.0f}  build {w[:, 3].sum() / w[:, 6].sum():6.0f}  barrier {w[:, 4].sum() / w[:, 6].sum():6.0f}  load {w[:, 1].sum() / w[:, 6].sum():5.0f} cycles per chunk")
+fx.close()
