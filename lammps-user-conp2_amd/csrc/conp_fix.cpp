@@ -1425,7 +1425,8 @@ struct conp_fix {
     upload_xq(at);
     if (decomposed) gather_elyte(at);
     b_cal_device(d_x.p, d_q.p, true, true);
-    allreduce_b();
+    // (a handle that is rank r of N WITHOUT a communicator leaves this rank's shard in b: the caller sums the shards itself)
+    if (nccl || rc.active()) allreduce_b();
   }
 
   // ---- one device-resident update as a HIP graph ------------------------------------------------

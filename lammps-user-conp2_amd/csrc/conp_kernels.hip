@@ -154,9 +154,17 @@ static void ensure_dyn_lds(K kernel, size_t bytes, DynLdsCache &cache) {
 }
 
 constexpr int SK_J = 16;
-constexpr int SK_LD = SK_J + 1;   // 17 doubles: conflict-free for ds_read2st64_b64 / ds_write_b64 (banks mod 32, 16-lane groups)
+// LDS operand panel: panel[feature][16 atoms], NO padding -- the atom column is XOR-swizzled with the low four bits of the
+// feature index: element (feature, atom j) lives at feature * 16 + (j ^ (feature & 15)).  An MFMA fragment read (16 consecutive
+// features x the 2 atoms 4 ks + fk of a 32-lane group) then touches all 64 banks exactly once as ds_read_b64 AND all 32 banks
+// once per 16-lane group should the compiler pair two reads into ds_read2st64_b64; the 16 atoms of one feature a 16-lane group
+// writes are a permutation of one 128-byte row: conflict-free ds_write_b64.  (The first version padded rows to 17 doubles:
+// clean for the paired form only -- every single ds_read_b64 had a 2-way conflict, SQ_LDS_BANK_CONFLICT ~ 1 per LDS instruction.)
+constexpr int SK_LD = SK_J;
 constexpr int SK_NF = 128 + 320;
-constexpr int SK_PANEL = SK_NF * SK_LD;   // doubles per buffer
+constexpr int SK_PANEL = SK_NF * SK_LD;          // doubles per buffer (57,344 bytes)
+constexpr unsigned SK_BUF1 = 65536;              // byte offset of the second buffer: switching buffers is one XOR of a byte address
+constexpr size_t SK_LDS_BYTES = SK_BUF1 + (size_t)SK_PANEL * sizeof(double);
 
 // one step of the angle-addition recurrence without FMA contraction (same arithmetic as elyte_phase_kernel)
 __device__ __forceinline__ double2 zstep(double2 z, double2 st) {
@@ -180,8 +188,12 @@ struct SkCtx {        // per-thread constants of one work item
   unsigned nrx16, nry16, nrz16;                // rows per chunk block * 16 (X, Y, Z tables)
   double sg0, sg1;
   bool zact;
-  int a_off, b_off, fr, fk, rh, cg;
-  unsigned fmask;                   // bit 5 f + g: column fragment g of this wave is inside the sphere for row fragment f
+  int fr, fk, rh, cg;
+  unsigned wa;                      // generation: doubles offset of (feature gs, atom gj) in a panel (swizzled)
+  // MFMA fragments: this lane's element of A / B fragment 0 at k-step ks sits at byte  base + ((ks ^ p) << 5),  p = fr >> 2
+  // (atom 4 ks + fk, swizzled by the row: (4 ks + fk) ^ fr = ((ks ^ p) << 2) | ((fk ^ fr) & 3))
+  unsigned base_a, base_b, pq;      // pq = p << 5
+  int f0;                           // row fragments f >= f0 skip the wave's last column fragment (sphere culling), wave-uniform
   const double2 *Xt, *Yt, *Zs;
   const double *qc;
   int dbg;
@@ -199,15 +211,16 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
   // (kx, sg*ky): q cos = (q cx) cy - (q sx)(sg sy) ; q sin = (q cx)(sg sy) + (q sx) cy   (km_ewald.cpp:739-747); the X table
   // already carries q, padding rows read an all-zero X row
   // sg is +1 or -1 (0 only on padding rows, whose X row is all zero anyway): a sign flip, not an FP64 multiply
+  // features gs, 32 + gs, 64 + gs, 96 + gs share their low four bits: one swizzled column for all four
   {
     const double sy = c.sg0 < 0.0 ? -r.Y0.y : r.Y0.y;
-    pn[c.gs * SK_LD + c.gj] = r.X0.x * r.Y0.x - r.X0.y * sy;
-    pn[(64 + c.gs) * SK_LD + c.gj] = r.X0.x * sy + r.X0.y * r.Y0.x;
+    pn[c.wa] = r.X0.x * r.Y0.x - r.X0.y * sy;
+    pn[c.wa + 64 * SK_LD] = r.X0.x * sy + r.X0.y * r.Y0.x;
   }
   {
     const double sy = c.sg1 < 0.0 ? -r.Y1.y : r.Y1.y;
-    pn[(32 + c.gs) * SK_LD + c.gj] = r.X1.x * r.Y1.x - r.X1.y * sy;
-    pn[(96 + c.gs) * SK_LD + c.gj] = r.X1.x * sy + r.X1.y * r.Y1.x;
+    pn[c.wa + 32 * SK_LD] = r.X1.x * r.Y1.x - r.X1.y * sy;
+    pn[c.wa + 96 * SK_LD] = r.X1.x * sy + r.X1.y * r.Y1.x;
   }
   if (c.zact) {
     double2 Z = r.Zseed;
@@ -215,35 +228,57 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
     for (int u = 0; u < 5; ++u) {
       const int ml = 5 * c.gs + u;                        // kz index inside the col tile
       const int feat = 128 + 32 * (ml >> 4) + (ml & 15);
+      const int at = feat * SK_LD + (c.gj ^ (ml & 15));   // (feat and feat + 16 have the same low bits)
       // (kz beyond nz - 1: the seed rows there are never written (zero) or the recurrence just runs on -- finite values in G
       //  columns that carry zero weight and no listed k; not worth two selects per value)
-      pn[feat * SK_LD + c.gj] = Z.x;
-      pn[(feat + 16) * SK_LD + c.gj] = Z.y;
+      pn[at] = Z.x;
+      pn[at + 16 * SK_LD] = Z.y;
       Z = zstep(Z, r.Zst);
     }
   }
 }
 
-// MFMA phase of one chunk for a wave that owns NFW column fragments (fi = 4 g + cg, g < NFW)
+// MFMA phase of one chunk for a wave that owns NFW column fragments (fi = 4 g + cg, g < NFW) x 4 row fragments f.
+// Row-fragment-major.  Fragment registers: the NFW B values of the current k-step, one A value in use and the NEXT A value
+// already on its way (issued before the <= NFW MFMAs of the current row fragment); during the last row fragment of a k-step
+// every B value is re-read for the next k-step right after its last use.  So each LDS read has about NFW MFMAs (64 cycles
+// apiece) between issue and first use, with 2 NFW + 4 fragment registers instead of 2 NFW + 8 -- a wave that multiplies alone
+// (its SIMD partner is building the next panel) no longer stalls on LDS at the top of every k-step (tools/sk_stamp.py: that
+// was ~1900 of the ~7900 cycles of a chunk).  After the last k-step the "next" reads wrap to k-step 0 of the same buffer:
+// six reads nobody uses instead of a branch.
+// Sphere culling: row fragments f >= f0 skip the wave's LAST column fragment (the host orders planar vectors by |k_p|, so the
+// kz cut never grows with f; a fragment whose cut is shorter still than NFW - 1 multiplies a few zero-weight columns: G entries
+// no listed k reads).  One wave-uniform branch per row fragment instead of one per MFMA.
+#define SK_LDS_F64(byte_addr) (*reinterpret_cast<const double *>(smem + (byte_addr)))
 template <int NFW>
-__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const double *cur, d4 (&acc)[4][NFW > 0 ? NFW : 1], int ks0 = 0,
-                                              int ks1 = SK_J / 4) {
-  if (NFW > 0) {
-    const double *ap = cur + c.a_off, *bp = cur + c.b_off;
-    // not unrolled on purpose: 160 of the 256 VGPRs are accumulators; hoisting the LDS reads of several k-steps spills,
-    // and the SIMD partner wave covers the LDS latency (measured: explicit double-buffering of the fragments gave nothing)
+__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
+  if constexpr (NFW > 0) {
+    constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;        // bytes between row fragments / between this wave's column fragments
+    const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
+    double bf[NFW], a0, a1;
+    unsigned q = c.pq;                                                  // (ks ^ p) << 5 for ks = 0: the 32-byte group of k-step 0
+#pragma unroll
+    for (int g = 0; g < NFW; ++g) bf[g] = SK_LDS_F64(bb + q + g * FB);
+    a0 = SK_LDS_F64(ba + q);
 #pragma unroll 1
-    for (int ks = ks0; ks < ks1; ++ks) {
-      double af[4], bf[NFW > 0 ? NFW : 1];
+    for (int ks = 0; ks < SK_J / 4; ++ks) {
+      const unsigned qn = (unsigned)(((ks + 1) & 3) << 5) ^ c.pq;       // the group of the next k-step (wraps after the last)
+      const unsigned an = ba + qn, bn = bb + qn, ac = ba + q;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) af[f] = ap[(16 * f) * SK_LD + 4 * ks];
+      for (int f = 0; f < 4; ++f) {
+        a1 = f < 3 ? SK_LDS_F64(ac + (f + 1) * FA) : SK_LDS_F64(an);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < NFW; ++g) bf[g] = bp[(64 * g) * SK_LD + 4 * ks];
-#pragma unroll
-      for (int g = 0; g < NFW; ++g)
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-          if (c.fmask & (1u << (5 * f + g))) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);   // wave-uniform skip
+        for (int g = 0; g + 1 < NFW; ++g) {
+          acc[f][g] = MFMA_F64(a0, bf[g], acc[f][g]);
+          if (f == 3) { bf[g] = SK_LDS_F64(bn + g * FB); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if (f < c.f0) acc[f][NFW - 1] = MFMA_F64(a0, bf[NFW - 1], acc[f][NFW - 1]);      // wave-uniform
+        if (f == 3) bf[NFW - 1] = SK_LDS_F64(bn + (NFW - 1) * FB);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = a1;
+      }
+      q = qn;
     }
   }
 }
@@ -269,7 +304,7 @@ __device__ unsigned long long sk_stamp_buf[1024 * 8 * 8];   // [workgroup][wave]
 // builds chunk c+1 (other buffer).  The two waves of a SIMD (w and w+4) do this in OPPOSITE order -- waves 0-3
 // multiply first, waves 4-7 build first -- so one wave's operand generation overlaps its partner's MFMAs.
 template <int NFW, bool late>
-__device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *out) {
+__device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out) {
   d4 acc[4][NFW > 0 ? NFW : 1];
 #pragma unroll
   for (int f = 0; f < 4; ++f)
@@ -281,19 +316,19 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *o
 #endif
   SK_STAMP_T(st_a);
   sk_load_raw(c, c.it.c0, raw);
-  sk_build_panel(c, raw, panel);
+  sk_build_panel(c, raw, reinterpret_cast<double *>(smem));
   if (late && c.it.c0 + 1 < c.it.c1) sk_load_raw(c, c.it.c0 + 1, raw);
   __syncthreads();
   SK_STAMP_T(st_b); SK_STAMP_ADD(s_pro, st_a, st_b);
-  for (int ch = c.it.c0; ch < c.it.c1; ++ch) {
-    const double *cur = panel + ((ch - c.it.c0) & 1) * SK_PANEL;
-    double *nxt = panel + (((ch - c.it.c0) & 1) ^ 1) * SK_PANEL;
+  unsigned buf = 0;                                    // byte offset of the panel being multiplied: 0 or SK_BUF1
+  for (int ch = c.it.c0; ch < c.it.c1; ++ch, buf ^= SK_BUF1) {
+    double *nxt = reinterpret_cast<double *>(smem + (buf ^ SK_BUF1));
     const bool more = ch + 1 < c.it.c1;
     if (!late) {
       SK_STAMP_T(st_a);
       if (more && !(c.dbg & 4)) sk_load_raw(c, ch + 1, raw);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_load, st_a, st_b);
-      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
+      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, smem, buf, acc);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_mfma, st_b, st_a);
       if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
@@ -305,16 +340,10 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, double *panel, double *o
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
       if (ch + 2 < c.it.c1 && !(c.dbg & 4)) sk_load_raw(c, ch + 2, raw);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_load, st_b, st_a);
-      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc);
+      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, smem, buf, acc);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_mfma, st_a, st_b);
 #else
-      // half stagger: the partner (early) wave multiplies all 4 k-steps first; this wave multiplies 2, builds, multiplies 2 --
-      // k-steps 0-1 of both waves overlap (LDS latency hidden behind the partner's MFMAs), each wave's build overlaps the
-      // other's k-steps 2-3
-      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc, 0, SK_J / 8);
-      if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
-      if (ch + 2 < c.it.c1 && !(c.dbg & 4)) sk_load_raw(c, ch + 2, raw);
-      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, cur, acc, SK_J / 8, SK_J / 4);
+#error "only the full stagger (SK_LATE_MODE 1) is kept: half stagger measured 264 vs 260 us (DESIGN.md)"
 #endif
     }
     __syncthreads();
@@ -350,8 +379,7 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
                                                          double *__restrict__ part, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *panel = reinterpret_cast<double *>(smem);   // [2][SK_NF][SK_LD]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // panel buffer 0 at byte 0, buffer 1 at byte SK_BUF1
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   SkCtx c;
@@ -360,8 +388,10 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   c.rh = wave & 1; c.cg = wave >> 1;
   c.gj = t & 15; c.gs = t >> 4;
   c.fr = lane & 15; c.fk = lane >> 4;
-  c.a_off = (64 * c.rh + c.fr) * SK_LD + c.fk;
-  c.b_off = (128 + 16 * c.cg + c.fr) * SK_LD + c.fk;
+  c.wa = (unsigned)(c.gs * SK_LD + (c.gj ^ (c.gs & 15)));
+  c.base_a = ((unsigned)(64 * c.rh + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
+  c.base_b = ((unsigned)(128 + 16 * c.cg + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
+  c.pq = (unsigned)(c.fr >> 2) << 5;
   c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
   c.nrx16 = (unsigned)(pl.kxmax + 2) * 16; c.nry16 = (unsigned)(pl.kymax + 1) * 16; c.nrz16 = (unsigned)(1 + pl.n_col_tiles * 32) * 16;
   const bool late = wave >= 4 && !(dbg & 8);
@@ -371,15 +401,24 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     const int nfrag = 2 * c.it.nba;                     // active column fragments of this tile
     const int nfw = (nfrag - c.cg + 3) >> 2;            // fragments of this wave: fi = 4 g + cg < nfrag   (wave-uniform)
     // per row fragment f (16 planar vectors) only the leading nbf_f <= nba kz blocks are inside the cut-off sphere
-    c.fmask = 0;
+    // f0 = the first row fragment whose cut leaves out this wave's last column fragment (4: none)
+    int f0 = 4;
+#pragma unroll
+    for (int f = 3; f >= 0; --f) {
+      const int nff = 2 * (int)((c.it.nbf >> (8 * f)) & 255u);
+      const int n = (nff - c.cg + 3) >> 2;
+      if (n < nfw) f0 = f;
+    }
+    // (never-increasing counts are the host's ordering; if a later fragment had MORE columns than an earlier one, f0 would
+    //  point at the earlier one and the later would lose its last column: guard by taking the cut of the LAST offender only when
+    //  all following fragments are short too -- which the loop above does: f0 is the smallest f with a short cut, so any longer
+    //  cut behind it would be wrong; fall back to no culling then)
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int nff = 2 * (int)((c.it.nbf >> (8 * f)) & 255u);
-      int n = (nff - c.cg + 3) >> 2;
-      n = n < 0 ? 0 : n;
-      c.fmask |= ((1u << n) - 1u) << (5 * f);
+      if (f >= f0 && ((nff - c.cg + 3) >> 2) >= nfw) f0 = 4;
     }
-    c.fmask = __builtin_amdgcn_readfirstlane(c.fmask);
+    c.f0 = __builtin_amdgcn_readfirstlane(f0);
     const int p0 = c.it.rt * 64 + c.gs, p1 = p0 + 32;
     c.xoff0 = (unsigned)pl.p_ikx[p0] * 16 + c.gj; c.yoff0 = (unsigned)pl.p_iky[p0] * 16 + c.gj;
     c.xoff1 = (unsigned)pl.p_ikx[p1] * 16 + c.gj; c.yoff1 = (unsigned)pl.p_iky[p1] * 16 + c.gj;
@@ -389,21 +428,21 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     double *out = part + (size_t)sg * (128 * 320);
     if (late) {
       switch (nfw) {
-        case 5: sk_body<5, true>(c, panel, out); break;
-        case 4: sk_body<4, true>(c, panel, out); break;
-        case 3: sk_body<3, true>(c, panel, out); break;
-        case 2: sk_body<2, true>(c, panel, out); break;
-        case 1: sk_body<1, true>(c, panel, out); break;
-        default: sk_body<0, true>(c, panel, out); break;
+        case 5: sk_body<5, true>(c, smem, out); break;
+        case 4: sk_body<4, true>(c, smem, out); break;
+        case 3: sk_body<3, true>(c, smem, out); break;
+        case 2: sk_body<2, true>(c, smem, out); break;
+        case 1: sk_body<1, true>(c, smem, out); break;
+        default: sk_body<0, true>(c, smem, out); break;
       }
     } else {
       switch (nfw) {
-        case 5: sk_body<5, false>(c, panel, out); break;
-        case 4: sk_body<4, false>(c, panel, out); break;
-        case 3: sk_body<3, false>(c, panel, out); break;
-        case 2: sk_body<2, false>(c, panel, out); break;
-        case 1: sk_body<1, false>(c, panel, out); break;
-        default: sk_body<0, false>(c, panel, out); break;
+        case 5: sk_body<5, false>(c, smem, out); break;
+        case 4: sk_body<4, false>(c, smem, out); break;
+        case 3: sk_body<3, false>(c, smem, out); break;
+        case 2: sk_body<2, false>(c, smem, out); break;
+        case 1: sk_body<1, false>(c, smem, out); break;
+        default: sk_body<0, false>(c, smem, out); break;
       }
     }
   }
@@ -423,7 +462,7 @@ extern "C" int conp_debug_sk_stamps(unsigned long long *out /*[1024*8*8]*/, int 
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
   if (nwg <= 0) return;
-  const size_t lds = (size_t)2 * SK_PANEL * sizeof(double);
+  const size_t lds = SK_LDS_BYTES;
   static DynLdsCache granted{};
   ensure_dyn_lds(sk_gemm_kernel, lds, granted);
   static const int dbg = getenv("CONP_SK_DBG") ? atoi(getenv("CONP_SK_DBG")) : 0;   // ablation switches for experiments

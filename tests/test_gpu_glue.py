@@ -259,7 +259,9 @@ def test_several_mpi_ranks_match_one_rank(tmp_path, name, axis, nranks):
     for r, (atr, al, bl) in enumerate(parts):
         case = str(tmp_path / f"case{r}.txt")
         steps = [(0, s.potdiff, 0, None), (1, 0.7, 0, moved(atr)), (2, 0.7, 1, None)]
-        write_case(case, s, atr, [al] if al is bl else [al, bl], fix_command_for(s), steps)
+        tokens = fix_command_for(s)
+        tokens[6] = "v_dv"                               # the potential difference changes from step to step: an equal-style variable
+        write_case(case, s, atr, [al] if al is bl else [al, bl], tokens, steps, variable=("dv", s.potdiff))
         cases.append(case)
     res, proc = run_driver(cases, str(tmp_path))
     assert res["rc"] == 0 and res["error"] is None, proc.stdout[-3000:] + proc.stderr[-2000:]
