@@ -190,6 +190,33 @@ int conp_km_conp_setup(conp_fix *fix, double qsqsum, int64_t natoms);     /* km_
 int conp_km_a_cal(conp_fix *fix, const conp_atoms *atoms, double *aaa /*[Ne*Ne], host, overwritten: k-space part only*/); /* :147-151 */
 int conp_km_b_cal(conp_fix *fix, const conp_atoms *atoms, double *bbb /*[Ne] eleall order, host*/);                          /* :153-167 */
 
+/* ---- PPPMCONP beyond the b vector (`pppm` keyword; pppm_conp.cpp:385-534), SURVEY 8f-2 --------------------------------------
+ * All three take the atoms as they are NOW (after pre_force wrote the electrode charges) and work on the handle's mesh
+ * (conp_env.pppm_*).  Mesh arrays are [nz][ny][nx], periodic (one rank: LAMMPS' ghost planes folded in).
+ *   conp_pppm_make_rho            : ele_make_rho (:385-426) + the make_rho override (:434-450): density = electrolyte brick +
+ *                                   electrode brick, what PPPMCONP hands to PPPM::compute instead of re-spreading every atom.
+ *                                   Any output may be NULL.
+ *   conp_pppm_compute_group_potential (:487-534): recv[i] = - sum over the order^3 stencil of w * u_brick for owned atoms with
+ *                                   sel[i] != 0.  u_brick is what PPPM::compute leaves there when per-atom energies are
+ *                                   tallied (ComputePotentialAtom insists on that step, compute_potential_atom.cpp:128-130):
+ *                                   the mesh potential of the TOTAL density; the library forms it from the same bricks.
+ *   conp_pppm_compute_particle_potential (:452-485): the same for atom i, plus 2 g_ewald q_i / sqrt(pi). */
+int conp_pppm_make_rho(conp_fix *fix, const conp_atoms *atoms, double *density, double *ele_density, double *elyte_density);
+int conp_pppm_compute_group_potential(conp_fix *fix, const conp_atoms *atoms, const int *sel /*[nlocal]*/, double *recv /*[nlocal]*/);
+int conp_pppm_compute_particle_potential(conp_fix *fix, const conp_atoms *atoms, int i, double *u);
+
+/* ---- `compute potential/atom` (compute_potential_atom.cpp:120-345), SURVEY 8f-4 --------------------------------------------
+ * per-atom electrostatic potential in volts: pair part over the pair style's half list (:223-308, optional Gaussian `eta`
+ * correction for atoms with etasel != 0 = eta_check :313-318), k-space part through the PPPM provider (:165-175 -> the
+ * particle potential above), slab correction (:323-345), times qqr2e / qe2f (:214).
+ * sel[i] = mask[i] & groupbit for i < nlocal + nghost; potential has nlocal (+ nghost when newton_pair) entries. */
+typedef struct {
+  int pairflag, kspaceflag, qsumflag;   /* `pair` / `kspace` / not `noqsum` (:59-88) */
+  double eta;                           /* 0: no `eta` keyword */
+} conp_potential_args;
+int conp_compute_potential_atom(conp_fix *fix, const conp_atoms *atoms, const conp_neighlist *pairlist, const int *sel,
+                                const int *etasel /*NULL without eta*/, const conp_potential_args *args, double *potential);
+
 /* ---- state read-back for parity tests and for the glue (public members fix_conp.h:58-85) ---- */
 typedef struct {
   int elenum, elenum_all, elytenum, maxtag_all, runstage;

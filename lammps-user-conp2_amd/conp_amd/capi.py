@@ -65,6 +65,10 @@ class conp_comm(C.Structure):
                 ("allreduce_max_int", _CB_MAXI), ("allgather_int", _CB_GATHER_INT), ("allgatherv", _CB_GATHERV)]
 
 
+class conp_potential_args(C.Structure):
+    _fields_ = [("pairflag", C.c_int), ("kspaceflag", C.c_int), ("qsumflag", C.c_int), ("eta", C.c_double)]
+
+
 class conp_info(C.Structure):
     _fields_ = [("elenum", C.c_int), ("elenum_all", C.c_int), ("elytenum", C.c_int), ("maxtag_all", C.c_int),
                 ("runstage", C.c_int), ("kcount", C.c_int), ("kcount_flat", C.c_int), ("kcount_expand", C.c_int),
@@ -89,6 +93,8 @@ SYMBOLS = [
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
     "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
     "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl",
+    "conp_pppm_make_rho", "conp_pppm_compute_group_potential", "conp_pppm_compute_particle_potential",
+    "conp_compute_potential_atom",
 ]
 
 
@@ -154,6 +160,11 @@ def load_library():
     lib.conp_fix_log_drain.restype = C.c_char_p
     lib.conp_fix_mesg_drain.argtypes = [vp]
     lib.conp_fix_mesg_drain.restype = C.c_char_p
+    lib.conp_pppm_make_rho.argtypes = [vp, C.POINTER(conp_atoms), dp, dp, dp]
+    lib.conp_pppm_compute_group_potential.argtypes = [vp, C.POINTER(conp_atoms), ip, dp]
+    lib.conp_pppm_compute_particle_potential.argtypes = [vp, C.POINTER(conp_atoms), C.c_int, dp]
+    lib.conp_compute_potential_atom.argtypes = [vp, C.POINTER(conp_atoms), C.POINTER(conp_neighlist), ip, ip,
+                                                C.POINTER(conp_potential_args), dp]
     lib.conp_fix_set_comm.argtypes = [vp, C.POINTER(conp_comm)]
     lib.conp_rccl_unique_id.argtypes = [C.c_void_p]
     lib.conp_fix_comm_init_rccl.argtypes = [vp, C.c_void_p]
@@ -380,6 +391,35 @@ class FixConp:
         a = np.ascontiguousarray(a, dtype=np.float64).copy()
         self._check(self.lib.conp_invert(self.h, a.shape[0], _dptr(a)))
         return a
+
+    # -- PPPM coupling beyond b, compute potential/atom ---------------------------------------------
+    def pppm_make_rho(self, at, nfft):
+        d, e, l = np.zeros(nfft), np.zeros(nfft), np.zeros(nfft)
+        self._check(self.lib.conp_pppm_make_rho(self.h, C.byref(self.atoms_view(at)), _dptr(d), _dptr(e), _dptr(l)))
+        return d, e, l
+
+    def pppm_group_potential(self, at, sel):
+        sel = np.ascontiguousarray(sel, np.int32)
+        out = np.zeros(at.nlocal)
+        self._check(self.lib.conp_pppm_compute_group_potential(self.h, C.byref(self.atoms_view(at)), _iptr(sel), _dptr(out)))
+        return out
+
+    def pppm_particle_potential(self, at, i):
+        u = C.c_double()
+        self._check(self.lib.conp_pppm_compute_particle_potential(self.h, C.byref(self.atoms_view(at)), int(i), C.byref(u)))
+        return u.value
+
+    def compute_potential_atom(self, at, pairlist, sel, etasel=None, eta=0.0, pair=True, kspace=True, qsum=True):
+        sel = np.ascontiguousarray(sel, np.int32)
+        es = None if etasel is None else np.ascontiguousarray(etasel, np.int32)
+        pot = np.zeros(at.nlocal + at.nghost)
+        pa = conp_potential_args(pairflag=int(pair), kspaceflag=int(kspace), qsumflag=int(qsum), eta=float(eta))
+        neigh = pairlist.neigh if pairlist.neigh.size else np.zeros(1, np.int32)
+        lv = conp_neighlist(inum=pairlist.inum, ilist=_iptr(pairlist.ilist), numneigh=_iptr(pairlist.numneigh),
+                            first=_iptr(pairlist.first), neigh=_iptr(neigh), nneigh=int(pairlist.neigh.size))
+        self._check(self.lib.conp_compute_potential_atom(self.h, C.byref(self.atoms_view(at)), C.byref(lv), _iptr(sel),
+                                                         _iptr(es) if es is not None else C.POINTER(C.c_int)(), C.byref(pa), _dptr(pot)))
+        return pot
 
     # -- several ranks ---------------------------------------------------------------------------
     def set_comm_torch(self, group=None):

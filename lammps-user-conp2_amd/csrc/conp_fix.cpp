@@ -215,12 +215,13 @@ struct conp_fix {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
-      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p, d_Srows, d_xg, d_qg,
+      d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p, d_Srows, d_xg, d_qg, d_pp_ele, d_pp_scratch,
       d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of;
+  DevBuf<unsigned> d_ticket, d_row_tickets;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -271,6 +272,8 @@ struct conp_fix {
     d_cutsq.upload(cutsq_h, stream);
     d_scalars.reserve(16);
     d_scalars.zero(stream);
+    d_ticket.reserve(4);
+    d_ticket.zero(stream);
   }
 
   // FixConp::modify_param (fix_conp.cpp:1482-1515)
@@ -435,6 +438,15 @@ struct conp_fix {
     for (int i = 0; i < nall; ++i)
       if (atom2eleall_h[i] >= 0) { ele_pairs_h.push_back(i); ele_pairs_h.push_back(atom2eleall_h[i]); }
     n_ele_atoms = (int)(ele_pairs_h.size() / 2);
+    {   // the same list by electrode row (CSR): the fused GEMV + charge write scatters row by row
+      const int ne = idx.elenum_all;
+      std::vector<int> ptr((size_t)ne + 1, 0), of(std::max(n_ele_atoms, 1), 0);
+      for (int k = 0; k < n_ele_atoms; ++k) ++ptr[ele_pairs_h[2 * (size_t)k + 1] + 1];
+      for (int r = 0; r < ne; ++r) ptr[r + 1] += ptr[r];
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+      for (int k = 0; k < n_ele_atoms; ++k) of[fill[ele_pairs_h[2 * (size_t)k + 1]]++] = ele_pairs_h[2 * (size_t)k];
+      d_ele_csr_ptr.upload(ptr, stream); d_ele_csr_of.upload(of, stream);
+    }
     if (ele_pairs_h.empty()) { ele_pairs_h.push_back(0); ele_pairs_h.push_back(0); }
     d_ele_pairs.upload(ele_pairs_h, stream);
     d_x.reserve((size_t)nall * 3); d_q.reserve(nall);
@@ -487,6 +499,7 @@ struct conp_fix {
       d_bk.reserve(4 * (size_t)ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(nvec); d_eleallq_own.reserve(nvec); d_qele.reserve(ne_pad);
       d_elesetq.reserve(ne_pad); d_eleinitq.reserve(ne_pad); d_ele_z.reserve(ne_pad); d_elecheck.reserve(ne_pad);
       d_ainve.reserve(ne_pad);
+      d_row_tickets.reserve(ne_pad / 64 + 1); d_row_tickets.zero(stream);
       d_bk.zero(stream); d_breal.zero(stream); d_b_own.zero(stream); d_eleallq_own.zero(stream); d_qele.zero(stream);
       d_elesetq.zero(stream); d_eleinitq.zero(stream);
       if (!d_b) d_b = d_b_own.p;
@@ -1148,6 +1161,16 @@ struct conp_fix {
       for (auto &e : ev_b) if (!e) HIP_TRY(hipEventCreate(&e));
       HIP_TRY(hipEventRecord(ev_b[0], stream));
     }
+    // what the last step (one electrode row of b = k-space partials + slab + real-space pairs) needs, for whichever kernel does it
+    const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
+    // real-space rows: with replicated atoms this rank's row range; a sub-domain's list holds its own electrode atoms' rows only
+    const int rr0 = !coulyes ? 0 : (decomposed ? 0 : row0), rr1 = !coulyes ? 0 : (decomposed ? ne : row1);
+    const BRowArgs brow = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 1,
+                                    d_bk.p, slab, d_ele_z.p, d_slab_part.p, 0 /*set below*/, 4.0 * 3.14159265358979323846 / kt.volume,
+                                    d_b, d_scalars.p + 2);
+    bool combined = false;              // the z-class dot kernel's last-arriving blocks did the row assembly
+    // (the timed host-buffer hooks keep the two halves in separate launches: Ktime / Ctime are measured around them)
+    const bool fuse_rows = !no_fuse && !timed;
     if (args.pppm) {
       // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
       prof.begin("pppm_b", stream);
@@ -1166,34 +1189,38 @@ struct conp_fix {
       launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                      d_Gpart.p);
       prof.end(stream);
+      BRowArgs fr = brow;
+      fr.n_slab_part = n_slab_part;
       if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
-        // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot
+        // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)
         prof.begin("reduce_project", stream);
         launch_reduce_project_zclass(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, ne_pad,
-                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p);
+                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p,
+                                     fuse_rows ? &fr : nullptr, d_row_tickets.p);
         prof.end(stream);
+        combined = fuse_rows;
       } else {
         prof.begin("sk_reduce", stream);
         launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, d_Gw.p);
         prof.end(stream);
         prof.begin("b_project", stream);
-        if (nzc > 0)
+        if (nzc > 0) {
           launch_b_project_zclass(stream, dplan, ne_pad, d_rt_mine.p, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Gw.p, d_Tzc.p, d_Rp.p,
-                                  d_zclass.p, d_Hc.p, d_bk.p);
-        else
+                                  d_zclass.p, d_Hc.p, d_bk.p, fuse_rows ? &fr : nullptr, d_row_tickets.p);
+          combined = fuse_rows;
+        } else
           launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
         prof.end(stream);
       }
     }
     if (timed) HIP_TRY(hipEventRecord(ev_b[1], stream));
-    const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
-    prof.begin("b_real_combine", stream);
-    // real-space rows: with replicated atoms this rank's row range; a sub-domain's list holds its own electrode atoms' rows only
-    const int rr0 = !coulyes ? 0 : (decomposed ? 0 : row0), rr1 = !coulyes ? 0 : (decomposed ? ne : row1);
-    launch_b_real_combine(stream, ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
-                          d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
-                          4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
-    prof.end(stream);
+    if (!combined) {
+      prof.begin("b_real_combine", stream);
+      launch_b_real_combine(stream, ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
+                            d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
+                            4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
+      prof.end(stream);
+    }
     if (timed) { HIP_TRY(hipEventRecord(ev_b[2], stream)); ev_pending = true; }
     HIP_TRY(hipGetLastError());   // a refused launch (bad grid / LDS size) must not pass silently
   }
@@ -1318,6 +1345,21 @@ struct conp_fix {
     prof.end(stream);
   }
 
+  // plain `fix conp` on one rank with the inverse solver: GEMV and charge write in one launch (gemv_finish_kernel)
+  bool can_fuse_solve() const {
+    static const bool off = getenv("CONP_NO_FUSE") != nullptr;
+    return !off && args.minimizer == CONP_SOLVER_INV && !args.conq && !args.cond && env.nranks == 1 && !nccl && !s_sharded &&
+           runstage >= 3;
+  }
+  void solve_scatter_fused(double *d_q_atoms, double potdiff) {
+    const int ne = idx.elenum_all;
+    prof.begin("gemv_charge", stream);
+    launch_gemv_finish(stream, ne, d_A.p, d_b, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr, potdiff, d_ele_csr_ptr.p,
+                       d_ele_csr_of.p, d_elecheck.p, d_qele.p, d_q_atoms, d_scalars.p + 1, d_ticket.p);
+    prof.end(stream);
+    HIP_TRY(hipGetLastError());
+  }
+
   // fix_conp.cpp:1149-1159: charges for owned + ghost electrode atoms, scalar output
   void scatter_device(double *d_q_atoms, double potdiff) {
     const int ne = idx.elenum_all;
@@ -1367,8 +1409,11 @@ struct conp_fix {
   // fix_conp.cpp:1120-1161 update_charge (host-buffer flavour)
   void update_charge(const conp_atoms *at, double potdiff) {
     const int ne = idx.elenum_all;
-    if (args.minimizer == CONP_SOLVER_INV) { solve_device(); allgather_q(); }
-    scatter_device(d_q.p, potdiff);          // the device copy of q follows atom->q (post_force of the same step reuses it)
+    if (can_fuse_solve()) solve_scatter_fused(d_q.p, potdiff);
+    else {
+      if (args.minimizer == CONP_SOLVER_INV) { solve_device(); allgather_q(); }
+      scatter_device(d_q.p, potdiff);        // the device copy of q follows atom->q (post_force of the same step reuses it)
+    }
     double *qe = pinned((size_t)ne_pad + 8);
     HIP_TRY(hipMemcpyAsync(qe, d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
     finish_scalar(potdiff);                 // one synchronisation for the charges and the scalars
@@ -1455,6 +1500,7 @@ struct conp_fix {
     if (decomposed) throw ConpError(CONP_ERR_STATE, "device-resident updates take replicated atoms (conp_env.rank / nranks); "
                                                     "spatially decomposed runs use the host-buffer hooks");
     b_cal_device(dx, dq, true);
+    if (can_fuse_solve()) { solve_scatter_fused(dq, potdiff); return; }
     allreduce_b();
     solve_device();
     allgather_q();
@@ -1965,6 +2011,188 @@ int64_t conp_host_pair_rows(int which, const conp_neighlist *l, const conp_atoms
     cp(row_ptr, r.row_ptr); cp(ele_atom, r.ele_atom); cp(oth_atom, r.oth_atom); cp(col, r.col);
     return r.npairs();
   } catch (const std::exception &e) { g_last_error = e.what(); return -1; }
+}
+
+// ---- PPPM coupling beyond b, compute potential/atom --------------------------------------------------------------------------
+namespace {
+void need_pppm(conp_fix *f) {
+  if (!f->args.pppm || f->dpppm.nfft <= 0)
+    throw ConpError(CONP_ERR_STATE, "Compute requires a compatible KSpace provider like pppm/conp");   // compute_potential_atom.cpp:110
+  if (f->decomposed) throw ConpError(CONP_ERR_STATE, "the PPPM mesh is not sharded: one rank");
+}
+// index lists of the owned atoms that carry charge, by kind (0 electrolyte, 1 electrode, 2 all), and x, q on the device
+int pppm_list(conp_fix *f, const conp_atoms *at, int kind, DevBuf<int> &d_idx) {
+  std::vector<int> idx;
+  for (int i = 0; i < at->nlocal; ++i) {
+    if (at->q[i] == 0) continue;
+    if (kind == 0 && at->echeck[i] != 0) continue;
+    if (kind == 1 && at->echeck[i] == 0) continue;
+    idx.push_back(i);
+  }
+  const int n = (int)idx.size();
+  if (idx.empty()) idx.push_back(0);
+  d_idx.upload(idx, f->stream);
+  return n;
+}
+void pppm_upload(conp_fix *f, const conp_atoms *at) {
+  if (at->nlocal + at->nghost != f->nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
+  f->resident_step = -1;
+  f->upload_xq_n(at, f->nall);
+}
+// u_brick of the total density into d_pp_re
+void pppm_total_potential(conp_fix *f, const conp_atoms *at) {
+  DevBuf<int> d_idx;
+  pppm_upload(f, at);
+  const int n = pppm_list(f, at, 2, d_idx);
+  f->d_pp_scratch.reserve(2048);
+  launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+  launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p);
+  HIP_TRY(hipGetLastError());
+  f->sync();                       // d_idx goes out of scope
+}
+}  // namespace
+
+int conp_pppm_make_rho(conp_fix *f, const conp_atoms *at, double *density, double *ele_density, double *elyte_density) {
+  CONP_GUARD_BEGIN
+  f->drop_graph();
+  need_pppm(f);
+  pppm_upload(f, at);
+  const size_t nf = (size_t)f->dpppm.nfft;
+  f->d_pp_scratch.reserve(2048);
+  f->d_pp_ele.reserve(nf);
+  std::vector<double> e(nf), l(nf);
+  {
+    DevBuf<int> d_idx;
+    const int n = pppm_list(f, at, 1, d_idx);          // ele_make_rho (pppm_conp.cpp:385-426)
+    launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_ele.p, f->d_pp_scratch.p);
+    HIP_TRY(hipMemcpyAsync(e.data(), f->d_pp_ele.p, nf * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    f->sync();
+  }
+  {
+    DevBuf<int> d_idx;
+    const int n = pppm_list(f, at, 0, d_idx);          // elyte_make_rho (:172-228)
+    launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    HIP_TRY(hipMemcpyAsync(l.data(), f->d_pp_re.p, nf * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    f->sync();
+  }
+  if (ele_density) std::memcpy(ele_density, e.data(), nf * sizeof(double));
+  if (elyte_density) std::memcpy(elyte_density, l.data(), nf * sizeof(double));
+  if (density) for (size_t k = 0; k < nf; ++k) density[k] = l[k] + e[k];        // make_rho override :434-450
+  CONP_GUARD_END
+}
+
+int conp_pppm_compute_group_potential(conp_fix *f, const conp_atoms *at, const int *sel, double *recv) {
+  CONP_GUARD_BEGIN
+  f->drop_graph();
+  need_pppm(f);
+  if (!sel || !recv) throw ConpError(CONP_ERR_ARG, "null argument");
+  pppm_total_potential(f, at);
+  std::vector<int> idx;
+  for (int i = 0; i < at->nlocal; ++i) if (sel[i]) idx.push_back(i);
+  if (idx.empty()) return CONP_OK;
+  DevBuf<int> d_idx;
+  DevBuf<double> d_out;
+  d_idx.upload(idx, f->stream);
+  d_out.reserve(at->nlocal);
+  launch_pppm_probe(f->stream, f->dpppm, (int)idx.size(), d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, 0.0, d_out.p);
+  std::vector<double> out(at->nlocal);
+  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, (size_t)at->nlocal * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  for (int i : idx) recv[i] = out[i];
+  CONP_GUARD_END
+}
+
+int conp_pppm_compute_particle_potential(conp_fix *f, const conp_atoms *at, int i, double *u) {
+  CONP_GUARD_BEGIN
+  f->drop_graph();
+  need_pppm(f);
+  if (!u || i < 0 || i >= at->nlocal) throw ConpError(CONP_ERR_ARG, "atom index out of range");
+  pppm_total_potential(f, at);
+  std::vector<int> idx(1, i);
+  DevBuf<int> d_idx;
+  DevBuf<double> d_out;
+  d_idx.upload(idx, f->stream);
+  d_out.reserve(at->nlocal);
+  launch_pppm_probe(f->stream, f->dpppm, 1, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p,
+                    2.0 * f->env.g_ewald / 1.77245385090551602729, d_out.p);
+  HIP_TRY(hipMemcpyAsync(u, d_out.p + i, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  CONP_GUARD_END
+}
+
+int conp_compute_potential_atom(conp_fix *f, const conp_atoms *at, const conp_neighlist *pl, const int *sel, const int *etasel,
+                                const conp_potential_args *pa, double *potential) {
+  CONP_GUARD_BEGIN
+  f->drop_graph();
+  if (!at || !sel || !pa || !potential) throw ConpError(CONP_ERR_ARG, "null argument");
+  if (pa->eta != 0.0 && !etasel) throw ConpError(CONP_ERR_ARG, "eta needs the eta_check selection");
+  if (pa->kspaceflag) need_pppm(f);
+  const int nall = at->nlocal + at->nghost;
+  const int ntotal = at->nlocal + (f->env.newton_pair ? at->nghost : 0);
+  pppm_upload(f, at);
+  DevBuf<double> d_pot;
+  DevBuf<int> d_sel, d_eta, d_il, d_nn, d_first, d_neigh, d_idx;
+  d_pot.reserve(nall); d_pot.zero(f->stream);
+  d_sel.upload(sel, nall, f->stream);
+  std::vector<int> ez(nall, 0);
+  d_eta.upload(etasel ? etasel : ez.data(), nall, f->stream);
+  if (pa->pairflag) {
+    if (!pl) throw ConpError(CONP_ERR_ARG, "the pair part needs the pair style's neighbor list");
+    size_t nneigh = 0;
+    for (int ii = 0; ii < pl->inum; ++ii) nneigh = std::max(nneigh, (size_t)pl->first[pl->ilist[ii]] + (size_t)pl->numneigh[pl->ilist[ii]]);
+    d_il.upload(pl->ilist, (size_t)pl->inum, f->stream); d_nn.upload(pl->numneigh, nall, f->stream);
+    d_first.upload(pl->first, nall, f->stream); d_neigh.upload(pl->neigh, std::max<size_t>(nneigh, 1), f->stream);
+    launch_potential_pair(f->stream, pl->inum, d_il.p, d_nn.p, d_first.p, d_neigh.p, at->nlocal, f->env.newton_pair, f->d_x.p,
+                          f->d_q.p, f->d_type.p, d_sel.p, d_eta.p, f->env.ntypes, f->d_cutsq.p, f->real_params().cut_coulsq,
+                          f->env.g_ewald, pa->eta, d_pot.p);
+  }
+  std::vector<double> pot(nall, 0.0), uk(at->nlocal, 0.0);
+  if (pa->kspaceflag) {
+    std::vector<int> all;
+    for (int i = 0; i < at->nlocal; ++i) if (at->q[i] != 0) all.push_back(i);
+    const int n = (int)all.size();
+    if (all.empty()) all.push_back(0);
+    d_idx.upload(all, f->stream);
+    f->d_pp_scratch.reserve(2048);
+    launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p);
+    std::vector<int> idx;
+    for (int i = 0; i < at->nlocal; ++i) if (sel[i]) idx.push_back(i);
+    DevBuf<int> d_pidx;
+    DevBuf<double> d_uk;
+    d_uk.reserve(std::max(at->nlocal, 1));
+    if (!idx.empty()) {
+      d_pidx.upload(idx, f->stream);
+      launch_pppm_probe(f->stream, f->dpppm, (int)idx.size(), d_pidx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p,
+                        2.0 * f->env.g_ewald / 1.77245385090551602729, d_uk.p);
+      HIP_TRY(hipMemcpyAsync(uk.data(), d_uk.p, (size_t)at->nlocal * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(pot.data(), d_pot.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    f->sync();
+    const double MY_PIS = 1.77245385090551602729;
+    for (int i : idx) {                                                           // :165-175
+      pot[i] -= uk[i];
+      if (pa->eta != 0.0 && etasel[i]) pot[i] += pa->eta * at->q[i] * std::sqrt(2.0) / MY_PIS;
+    }
+    if (f->env.slabflag) {                                                        // slabcorr :323-345
+      const double volume = f->env.xprd * f->env.yprd * f->env.zprd * f->env.slab_volfactor;
+      const double pi2vol = 2 * 3.14159265358979323846 / volume;
+      double slabcorr = 0.0, qsum = 0.0;
+      for (int i = 0; i < at->nlocal; ++i) { slabcorr += 2 * pi2vol * at->q[i] * at->x[3 * (size_t)i + 2]; qsum += at->q[i]; }
+      for (int i = 0; i < at->nlocal; ++i)
+        if (sel[i]) {
+          const double z = at->x[3 * (size_t)i + 2];
+          pot[i] += z * slabcorr;
+          if (pa->qsumflag) pot[i] -= pi2vol * qsum * z * z;
+        }
+    }
+  } else {
+    HIP_TRY(hipMemcpyAsync(pot.data(), d_pot.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    f->sync();
+  }
+  const double evs = f->env.qqr2e / f->env.qe2f;                                  // :99, :214
+  for (int i = 0; i < ntotal; ++i) potential[i] = pot[i] * evs;
+  CONP_GUARD_END
 }
 
 int conp_fix_set_comm(conp_fix *f, const conp_comm *comm) {

@@ -25,6 +25,33 @@ struct RealParams {           // real-space pair kernels
   const double *u0_i;                 // [ntypes+1] (post-force self energy :1182-1199)
 };
 
+// everything one electrode row of b needs besides the k-space partials' origin (b_real_combine_kernel; the fused tail of
+// b_zc_dot_kernel): real-space rows [row0, row1), the four k-space partial slots, the slab term
+struct BRowArgs {
+  int ne, ne_pad, row0, row1;
+  const int *row_ptr, *ele_atom, *oth_atom;
+  const double *x, *q;
+  const int *type;
+  RealParams rp;
+  int add_k;
+  const double *bk;
+  int slab;
+  const double *ele_z, *slab_part;
+  int n_slab_part;
+  double slab_pref;
+  double *b_out, *slab_out;
+};
+inline BRowArgs make_brow(int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
+                          const double *x, const double *q, const int *type, RealParams rp, int add_k, const double *bk, int slab,
+                          const double *ele_z, const double *slab_part, int n_slab_part, double slab_pref, double *b_out,
+                          double *slab_out) {
+  BRowArgs a;
+  a.ne = ne; a.ne_pad = ne_pad; a.row0 = row0; a.row1 = row1; a.row_ptr = row_ptr; a.ele_atom = ele_atom; a.oth_atom = oth_atom;
+  a.x = x; a.q = q; a.type = type; a.rp = rp; a.add_k = add_k; a.bk = bk; a.slab = slab; a.ele_z = ele_z; a.slab_part = slab_part;
+  a.n_slab_part = n_slab_part; a.slab_pref = slab_pref; a.b_out = b_out; a.slab_out = slab_out;
+  return a;
+}
+
 struct PppmDev {              // device view of PppmPlan
   int nx, ny, nz, order, nlower, nfft;
   double shift, shiftone, delinv[3], delvolinv, boxlo[3];
@@ -34,6 +61,17 @@ struct PppmDev {              // device view of PppmPlan
 void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_idx, const double *x, const double *q, int ne,
                    int ne_pad, const int *egrid, const double *ew, double *re, double *im, double *slab_part, int *n_slab_part,
                    double *bk);
+
+// PPPM coupling beyond b (pppm_conp.cpp:385-534) and the pair part of compute potential/atom (compute_potential_atom.cpp:223-308)
+void launch_pppm_density(hipStream_t s, const PppmDev &pd, int n, const int *idx, const double *x, const double *q, double *rho,
+                         double *slab_scratch /*[>= 1025]*/);
+void launch_pppm_poisson(hipStream_t s, const PppmDev &pd, double *re /*rho in, u_brick out*/, double *im);
+void launch_pppm_probe(hipStream_t s, const PppmDev &pd, int n, const int *idx, const double *x, const double *q, const double *u,
+                       double self, double *out /*indexed by atom*/);
+void launch_potential_pair(hipStream_t s, int inum, const int *ilist, const int *numneigh, const int *first, const int *neigh,
+                           int nlocal, int newton, const double *x, const double *q, const int *type, const int *sel,
+                           const int *etasel, int ntypes, const double *cutsq, double cut_coulsq, double g_ewald, double eta,
+                           double *potential);
 
 // ---- per-step electrolyte path -----------------------------------------------------------------
 void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, const int *img, double px, double py, double pz,
@@ -52,16 +90,21 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
 // planar-electrode fast path of the projection (<= 64 distinct electrode z values)
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part);
+                                  const int *zclass, double *Hc, double *bk_part, const BRowArgs *fuse /*NULL: b_real_combine is a
+                                  launch of its own*/, unsigned *tickets /*[ne_pad / 64], zero*/);
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
                              const double *Tzc /*[C_pad][64]*/, const double *Rp, const int *zclass /*[ne_pad]*/,
-                             double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/);
+                             double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/, const BRowArgs *fuse, unsigned *tickets);
 // this rank's contribution to b in one launch: k-space halves + slab (rank 0) + real-space rows row0..row1
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
                            const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,
                            const double *bk, int slab, const double *ele_z, const double *slab_part, int n_slab_part,
                            double slab_pref, double *b_out, double *slab_out);
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);
+// all rows + the charge write of plain `fix conp` in one launch (atoms_ptr / atoms_of: electrode row -> its owned and ghost atoms)
+void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, double *y, const double *elesetq,
+                        const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of, const int *elecheck,
+                        double *q_ele, double *q_atoms, double *left_out, unsigned *ticket /*device, zero*/);
 void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleall, const int *elecheck, const double *eleallq,
                           const double *elesetq, const double *eleinitq, double potdiff, const double *d_potdiff, double *q_ele,
                           double *q_atoms, double *left_out);

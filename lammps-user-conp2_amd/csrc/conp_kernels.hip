@@ -250,6 +250,33 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
 // kz cut never grows with f; a fragment whose cut is shorter still than NFW - 1 multiplies a few zero-weight columns: G entries
 // no listed k reads).  One wave-uniform branch per row fragment instead of one per MFMA.
 #define SK_LDS_F64(byte_addr) (*reinterpret_cast<const double *>(smem + (byte_addr)))
+#ifndef SK_MFMA_PREFETCH
+#define SK_MFMA_PREFETCH 1
+#endif
+#if !SK_MFMA_PREFETCH
+// comparison build (-DSK_MFMA_PREFETCH=0): all fragment reads of a k-step at its top, column-major MFMAs -- the first version's order
+template <int NFW>
+__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
+  if constexpr (NFW > 0) {
+    constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
+    const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
+#pragma unroll 1
+    for (int ks = 0; ks < SK_J / 4; ++ks) {
+      const unsigned q = (unsigned)(ks << 5) ^ c.pq;
+      double af[4], bf[NFW];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) af[f] = SK_LDS_F64(ba + q + f * FA);
+#pragma unroll
+      for (int g = 0; g < NFW; ++g) bf[g] = SK_LDS_F64(bb + q + g * FB);
+#pragma unroll
+      for (int g = 0; g < NFW; ++g)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          if (g + 1 < NFW || f < c.f0) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+    }
+  }
+}
+#else
 template <int NFW>
 __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
   if constexpr (NFW > 0) {
@@ -282,12 +309,14 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, 
     }
   }
 }
+#endif
 
 // ---- diagnostic build only (-DSK_STAMP, `make stamp`, tools/sk_stamp.py): s_memtime stamps around the phases of a chunk,
 // summed per wave in scalar registers and stored once per segment into a buffer nothing else reads.  In the product build no
 // stamp executes.  Its fences forbid overlaps the real kernel has: read the SHARES, never the length (guide, "In-kernel stamps").
 #ifdef SK_STAMP
 __device__ unsigned long long sk_stamp_buf[1024 * 8 * 8];   // [workgroup][wave][prologue, load issue, mfma, build, barrier, epilogue, chunks, late]
+__device__ unsigned long long sk_clock_buf[1024 * 4];       // [workgroup][s_memtime start, end, s_memrealtime (100 MHz) start, end]
 #define SK_STAMP_T(t)                                                          \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
@@ -352,16 +381,19 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
   // ---- partial tile out: part[segment][128][320] (only the active fragments)
   if (c.dbg & 16) return;
   SK_STAMP_T(st_a);
+  {
+    // one lane-dependent offset, made opaque per segment: left to itself the compiler hoists all 80 store addresses out of the
+    // segment loop and spills them (600 bytes of scratch, reloaded at every tile write)
+    unsigned lane_off = (unsigned)((64 * c.rh + c.fk) * 320 + 16 * c.cg + c.fr);
+    asm volatile("" : "+v"(lane_off));
+    double *o = out + lane_off;
 #pragma unroll
-  for (int g = 0; g < NFW; ++g)
+    for (int g = 0; g < NFW; ++g)
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 64 * c.rh + 16 * f + c.fk + 4 * r;
-        const int col = 16 * (4 * g + c.cg) + c.fr;
-        out[row * 320 + col] = acc[f][g][r];
-      }
+        for (int r = 0; r < 4; ++r) o[(16 * f + 4 * r) * 320 + 64 * g] = acc[f][g][r];
+  }
 #ifdef SK_STAMP
   SK_STAMP_T(st_b); SK_STAMP_ADD(s_epi, st_a, st_b);
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
@@ -395,6 +427,9 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
   c.nrx16 = (unsigned)(pl.kxmax + 2) * 16; c.nry16 = (unsigned)(pl.kymax + 1) * 16; c.nrz16 = (unsigned)(1 + pl.n_col_tiles * 32) * 16;
   const bool late = wave >= 4 && !(dbg & 8);
+#ifdef SK_STAMP
+  unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int s0 = seg_ptr[blockIdx.x], s1 = seg_ptr[blockIdx.x + 1];
   for (int sg = s0; sg < s1; ++sg) {
     c.it = items[sg];
@@ -446,9 +481,18 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
       }
     }
   }
+#ifdef SK_STAMP
+  if (t == 0 && blockIdx.x < 1024) {
+    unsigned long long *o = sk_clock_buf + (size_t)blockIdx.x * 4;
+    o[0] = ck0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = rt0; o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 #ifdef SK_STAMP
+extern "C" int conp_debug_sk_clock(unsigned long long *out /*[1024*4]*/) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_clock_buf), sizeof(unsigned long long) * 1024 * 4) == hipSuccess ? 0 : -1;
+}
 extern "C" int conp_debug_sk_stamps(unsigned long long *out /*[1024*8*8]*/, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_stamp_buf), sizeof(unsigned long long) * 1024 * 8 * 8) != hipSuccess) return -1;
   if (reset) {
@@ -674,12 +718,89 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
   for (int r = 0; r < 4; ++r) out[(size_t)(16 * rf + fk + 4 * r) * 64 + 16 * wave + fr] = acc[r];
 }
 
+// ---- erfc(x)/r through the reference's 5-term polynomial (fix_conp.cpp:53-60, 1446-1454) and the pair potentials -------------
+__device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
+#pragma clang fp contract(off)
+  if (a2_r2 < 5.8 * 5.8) {
+    const double a_r = sqrt(a2_r2);
+    const double expm2 = exp(-a2_r2);
+    const double t = 1.0 / (1.0 + 0.3275911 * a_r);
+    return t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2 / a_r;
+  }
+  return 0.0;
+}
+
+// pair_potential of the reference (fix_conp.cpp:1467-1475 eta_potential_A / eta_potential, :1561-1566 ehgo_potential)
+__device__ __forceinline__ double pair_potential_dev(const RealParams &rp, double rsq, int ti, int tj, bool for_a) {
+#pragma clang fp contract(off)
+  if (rp.ehgo) {
+    const double etaij = rp.eta_ij[ti * (rp.ntypes + 1) + tj], foij = rp.fo_ij[ti * (rp.ntypes + 1) + tj];
+    const double etarij2 = etaij * etaij * rsq;
+    return foij * exp(-0.5 * etarij2) - erfcr_sqrt_dev(etarij2) * etaij;
+  }
+  if (for_a) {
+    const double etarij2 = rp.eta * rp.eta * rsq / 2;
+    return -erfcr_sqrt_dev(etarij2) * rp.eta / sqrt(2.0);
+  }
+  return -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
+}
+
+// One electrode row of b, by one wave (all 64 lanes return the same values):
+//   b[row] = (bk0 + bk1) + (bk2 + bk3)                           (k-space shard, km_ewald.cpp:789-825)
+//          - z_row * sum_j 4 pi q_j z_j / V                      (slab, km_ewald.cpp:827-847; rank 0 only)
+//          - sum_pairs q_j [erfc(g r) - erfc(eta r)] / r         (rows row0..row1 only; fix_conp.cpp:1313-1353)
+__device__ __forceinline__ double b_slab_scalar(const BRowArgs &a, int lane) {
+#pragma clang fp contract(off)
+  double sp = 0.0;
+  for (int k = lane; k < a.n_slab_part; k += 64) sp += a.slab_part[k];
+  sp = wave_sum(sp);
+  return a.slab_pref * __shfl(sp, 0, 64);
+}
+__device__ __forceinline__ void b_row(const BRowArgs &a, int row, int lane, double sc, bool bk_volatile) {
+#pragma clang fp contract(off)
+  const int nt1 = a.rp.ntypes + 1;
+  double sum = 0.0;
+  if (row >= a.row0 && row < a.row1) {
+    for (int p = a.row_ptr[row] + lane; p < a.row_ptr[row + 1]; p += 64) {
+      const int ie = a.ele_atom[p], jo = a.oth_atom[p];
+      const double dx = a.x[3 * ie] - a.x[3 * jo], dy = a.x[3 * ie + 1] - a.x[3 * jo + 1], dz = a.x[3 * ie + 2] - a.x[3 * jo + 2];
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq < a.rp.cutsq[a.type[ie] * nt1 + a.type[jo]] && rsq < a.rp.cut_coulsq) {
+        double dudq = erfcr_sqrt_dev(a.rp.g_ewald * a.rp.g_ewald * rsq) * a.rp.g_ewald;
+        dudq += pair_potential_dev(a.rp, rsq, a.type[ie], a.type[jo], false);
+        sum -= a.q[jo] * dudq;
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) {
+    double v = 0.0;
+    if (a.add_k) {
+      double k0, k1, k2, k3;
+      if (bk_volatile) {      // written by other workgroups of the SAME launch (the fused kernel's last-arriver): bypass stale lines
+        k0 = __hip_atomic_load(a.bk + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k1 = __hip_atomic_load(a.bk + a.ne_pad + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k2 = __hip_atomic_load(a.bk + 2 * (size_t)a.ne_pad + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k3 = __hip_atomic_load(a.bk + 3 * (size_t)a.ne_pad + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        k0 = a.bk[row]; k1 = a.bk[a.ne_pad + row]; k2 = a.bk[2 * (size_t)a.ne_pad + row]; k3 = a.bk[3 * (size_t)a.ne_pad + row];
+      }
+      v = (k0 + k1) + (k2 + k3);
+    }
+    if (a.slab) v -= a.ele_z[row] * sc;
+    v += sum;
+    a.b_out[row] = v;
+    if (a.slab && row == 0 && a.slab_out) *a.slab_out = sc;
+  }
+}
+
 // grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16.
 // The block first sums the 4 k-quarter slots of Hc for ITS rows and the nzc classes in use into LDS (one pass of coalesced
 // loads) -- reading them per thread and per row from global cost more than the 42 MB Rp stream itself (20 -> 11 us).
 __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
                                                         const double *__restrict__ Rp, const double *__restrict__ Hc4,
-                                                        const int *__restrict__ zclass, double *__restrict__ bk) {
+                                                        const int *__restrict__ zclass, double *__restrict__ bk,
+                                                        BRowArgs ra, unsigned *__restrict__ tickets) {
   extern __shared__ __attribute__((aligned(16))) char zc_smem[];
   double *H = reinterpret_cast<double *>(zc_smem);          // [n_own * 32][nzc]
   __shared__ double red[16][64];
@@ -718,16 +839,38 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
     double tot = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) tot += red[k][a];
-    bk[(size_t)blockIdx.y * ne_pad + i] = -tot;
+    // write-through (sc1) store: the block that assembles these rows may sit on another XCD, whose L2 is not coherent with ours
+    __hip_atomic_store(bk + (size_t)blockIdx.y * ne_pad + i, -tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the store has left before this workgroup takes its ticket
+  }
+  if (!tickets) return;
+  // ---- fused tail: the LAST of the four row-quarter blocks of this atom block assembles b for its 64 rows (k-space quarters in
+  // the fixed order, slab term, real-space pairs) -- what b_real_combine_kernel does in a launch of its own otherwise.
+  // Hand-off without fences (an agent-scope fence writes back / invalidates whole caches: measured 4.5x on this kernel): sc1
+  // stores, the storing wave's vmcnt(0), workgroup barrier, ONE agent-scope ticket add; the last arriver reads the partials
+  // with sc1 loads only (MI355X_MICROARCH.md, inter-workgroup visibility).
+  __shared__ unsigned s_ticket;
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_ticket != 3u) return;
+  if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next update
+  const double sc = ra.slab ? b_slab_scalar(ra, a) : 0.0;
+  for (int k = 0; k < 4; ++k) {
+    const int row = blockIdx.x * 64 + w + 16 * k;
+    if (row < ra.ne) b_row(ra, row, a, sc, true);
   }
 }
 
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
-                            const double *Hc, const int *zclass, double *bk_part) {
+                            const double *Hc, const int *zclass, double *bk_part, const BRowArgs *fuse, unsigned *tickets) {
   const size_t lds = (size_t)(n_own > 0 ? n_own : 1) * 32 * nzc * sizeof(double);      // the host keeps this <= 96 KB (conp_fix.cpp)
   static DynLdsCache granted{};
   ensure_dyn_lds(b_zc_dot_kernel, lds, granted);
-  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  BRowArgs ra{};
+  if (fuse) ra = *fuse;
+  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part,
+                     ra, fuse ? tickets : nullptr);
 }
 
 // Planar electrodes with one column tile (nz <= 160): the last partial-tile sum and the Hc product in ONE kernel -- a block
@@ -787,7 +930,7 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
 // sk_reduce (+ level 1 when tiles are heavily split) with the Hc product fused in, then the per-atom dot
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part) {
+                                  const int *zclass, double *Hc, double *bk_part, const BRowArgs *fuse, unsigned *tickets) {
   if (ntiles <= 0) return;
   const int nzc16 = (nzc + 15) / 16;
   int level = 0;
@@ -798,100 +941,40 @@ void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile
   }
   hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
                      nzc16, level);
-  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, fuse, tickets);
 }
 
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
-                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part) {
+                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fuse,
+                             unsigned *tickets) {
   const int nzc16 = (nzc + 15) / 16;
   hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
-  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, fuse, tickets);
 }
 
 // ================================================================================================
 // 4. real-space kernels.  erfc(x)/r through the reference's 5-term polynomial (fix_conp.cpp:53-60, 1446-1454)
 // ================================================================================================
-__device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
-#pragma clang fp contract(off)
-  if (a2_r2 < 5.8 * 5.8) {
-    const double a_r = sqrt(a2_r2);
-    const double expm2 = exp(-a2_r2);
-    const double t = 1.0 / (1.0 + 0.3275911 * a_r);
-    return t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2 / a_r;
-  }
-  return 0.0;
-}
-
-// pair_potential of the reference (fix_conp.cpp:1467-1475 eta_potential_A / eta_potential, :1561-1566 ehgo_potential)
-__device__ __forceinline__ double pair_potential_dev(const RealParams &rp, double rsq, int ti, int tj, bool for_a) {
-#pragma clang fp contract(off)
-  if (rp.ehgo) {
-    const double etaij = rp.eta_ij[ti * (rp.ntypes + 1) + tj], foij = rp.fo_ij[ti * (rp.ntypes + 1) + tj];
-    const double etarij2 = etaij * etaij * rsq;
-    return foij * exp(-0.5 * etarij2) - erfcr_sqrt_dev(etarij2) * etaij;
-  }
-  if (for_a) {
-    const double etarij2 = rp.eta * rp.eta * rsq / 2;
-    return -erfcr_sqrt_dev(etarij2) * rp.eta / sqrt(2.0);
-  }
-  return -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
-}
-
 // one wave per electrode row (global eleall index), fused with the assembly of this rank's b contribution:
 //   b[row] = bk_half0[row] + bk_half1[row]                       (k-space shard, km_ewald.cpp:789-825)
 //          - z_row * sum_j 4 pi q_j z_j / V                      (slab, km_ewald.cpp:827-847; rank 0 only)
 //          - sum_pairs q_j [erfc(g r) - erfc(eta r)] / r         (rows row0..row1 only; fix_conp.cpp:1313-1353)
-__global__ __launch_bounds__(256) void b_real_combine_kernel(int ne, int ne_pad, int row0, int row1,
-                                                             const int *__restrict__ row_ptr, const int *__restrict__ ele_atom,
-                                                             const int *__restrict__ oth_atom, const double *__restrict__ x,
-                                                             const double *__restrict__ q, const int *__restrict__ type,
-                                                             RealParams rp, int add_k, const double *__restrict__ bk, int slab,
-                                                             const double *__restrict__ ele_z,
-                                                             const double *__restrict__ slab_part, int n_slab_part,
-                                                             double slab_pref, double *__restrict__ b_out,
-                                                             double *__restrict__ slab_out) {
-#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void b_real_combine_kernel(BRowArgs a) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= ne) return;
+  if (row >= a.ne) return;
   const int lane = threadIdx.x & 63;
-  const int nt1 = rp.ntypes + 1;
-  double sum = 0.0;
-  if (row >= row0 && row < row1) {
-    for (int p = row_ptr[row] + lane; p < row_ptr[row + 1]; p += 64) {
-      const int ie = ele_atom[p], jo = oth_atom[p];
-      const double dx = x[3 * ie] - x[3 * jo], dy = x[3 * ie + 1] - x[3 * jo + 1], dz = x[3 * ie + 2] - x[3 * jo + 2];
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq < rp.cutsq[type[ie] * nt1 + type[jo]] && rsq < rp.cut_coulsq) {
-        double dudq = erfcr_sqrt_dev(rp.g_ewald * rp.g_ewald * rsq) * rp.g_ewald;
-        dudq += pair_potential_dev(rp, rsq, type[ie], type[jo], false);
-        sum -= q[jo] * dudq;
-      }
-    }
-  }
-  sum = wave_sum(sum);
-  double sc = 0.0;
-  if (slab) {   // every wave derives the same scalar with the same summation tree
-    double sp = 0.0;
-    for (int k = lane; k < n_slab_part; k += 64) sp += slab_part[k];
-    sp = wave_sum(sp);
-    sc = slab_pref * __shfl(sp, 0, 64);
-  }
-  if (lane == 0) {
-    double v = add_k ? (bk[row] + bk[ne_pad + row]) + (bk[2 * (size_t)ne_pad + row] + bk[3 * (size_t)ne_pad + row]) : 0.0;
-    if (slab) v -= ele_z[row] * sc;
-    v += sum;
-    b_out[row] = v;
-    if (slab && row == 0 && slab_out) *slab_out = sc;
-  }
+  const double sc = a.slab ? b_slab_scalar(a, lane) : 0.0;     // every wave derives the same scalar with the same summation tree
+  b_row(a, row, lane, sc, false);
 }
 
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
                            const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,
                            const double *bk, int slab, const double *ele_z, const double *slab_part, int n_slab_part,
                            double slab_pref, double *b_out, double *slab_out) {
-  hipLaunchKernelGGL(b_real_combine_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, ne, ne_pad, row0, row1, row_ptr, ele_atom,
-                     oth_atom, x, q, type, rp, add_k, bk, slab, ele_z, slab_part, n_slab_part, slab_pref, b_out, slab_out);
+  hipLaunchKernelGGL(b_real_combine_kernel, dim3((ne + 3) / 4), dim3(256), 0, s,
+                     make_brow(ne, ne_pad, row0, row1, row_ptr, ele_atom, oth_atom, x, q, type, rp, add_k, bk, slab, ele_z, slab_part,
+                               n_slab_part, slab_pref, b_out, slab_out));
 }
 
 // ================================================================================================
@@ -937,6 +1020,104 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row
   }
   const double r = wave_sum(s0 + s1);
   if (lane == 0) y[row] = r;
+}
+
+// GEMV with the charge write in its tail (fix_conp.cpp:1135-1159 in ONE launch; plain `fix conp`, all rows on this rank):
+//   every wave: y[row] = S[row,:] . b  (same loop, same association as gemv_rows_kernel), then q = y + dV * setq (+ qinit) into
+//   q_ele[row] and into every owned / ghost copy of that electrode atom (CSR row -> atoms);
+//   the LAST block to finish (agent-scope ticket) forms the group-1 sum of y with charge_finish_kernel's fixed tree.
+// Bit-identical to gemv_rows_kernel + charge_finish_kernel; one launch and one dependent-launch gap fewer per update.
+__global__ __launch_bounds__(256) void gemv_finish_kernel(int n, const double *__restrict__ S, const double *__restrict__ b,
+                                                          double *__restrict__ y, const double *__restrict__ elesetq,
+                                                          const double *__restrict__ eleinitq, double potdiff,
+                                                          const int *__restrict__ atoms_ptr, const int *__restrict__ atoms_of,
+                                                          const int *__restrict__ elecheck, double *__restrict__ q_ele,
+                                                          double *__restrict__ q_atoms, double *__restrict__ left_out,
+                                                          unsigned *__restrict__ ticket) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row < n) {
+    const double *srow = S + (size_t)row * n;
+    double s0 = 0.0, s1 = 0.0;
+    if ((n & 1) == 0) {
+      const double2 *s2 = reinterpret_cast<const double2 *>(srow);
+      const double2 *b2 = reinterpret_cast<const double2 *>(b);
+      double t0 = 0.0, t1 = 0.0;
+      int j = lane;
+      for (; j + 192 < n / 2; j += 256) {
+        const double2 a0 = nt_load(s2 + j), a1 = nt_load(s2 + j + 64), a2 = nt_load(s2 + j + 128), a3 = nt_load(s2 + j + 192);
+        const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
+        s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
+        t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
+        s0 = fma(a2.x, b2v.x, s0); s1 = fma(a2.y, b2v.y, s1);
+        t0 = fma(a3.x, b3.x, t0); t1 = fma(a3.y, b3.y, t1);
+      }
+      for (; j < n / 2; j += 64) {
+        const double2 a = s2[j], bb = b2[j];
+        s0 = fma(a.x, bb.x, s0);
+        s1 = fma(a.y, bb.y, s1);
+      }
+      s0 += t0; s1 += t1;
+    } else {
+      for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
+    }
+    double r = wave_sum(s0 + s1);
+    r = __shfl(r, 0, 64);
+    double v;
+    {
+#pragma clang fp contract(off)
+      v = r + potdiff * elesetq[row];
+      if (eleinitq) v += eleinitq[row];
+    }
+    if (lane == 0) {
+      __hip_atomic_store(y + row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: read by the last block, maybe on another XCD
+      q_ele[row] = v;
+    }
+    if (q_atoms)
+      for (int k = atoms_ptr[row] + lane; k < atoms_ptr[row + 1]; k += 64) q_atoms[atoms_of[k]] = v;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // ---- last block: netcharge_left = sum of y over the group-1 atoms.  Fence-free hand-off: sc1 stores above, every storing
+  // wave's vmcnt(0), workgroup barrier, one agent-scope ticket add; sc1 loads below.
+  __shared__ unsigned s_ticket;
+  __shared__ double red[4];
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+  double s16[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) s16[u] = 0.0;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4096) {
+    int ec[16];
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + 256 * u;
+      ec[u] = i < n ? elecheck[i] : 0;
+      v[u] = i < n ? __hip_atomic_load(y + (i < n ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s16[u] += (ec[u] == 1) ? v[u] : 0.0;
+  }
+  double s4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s4[u] = (s16[u] + s16[u + 4]) + (s16[u + 8] + s16[u + 12]);
+  double sum = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *left_out = (red[0] + red[1]) + (red[2] + red[3]);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next update
+  }
+}
+
+void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, double *y, const double *elesetq,
+                        const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of, const int *elecheck,
+                        double *q_ele, double *q_atoms, double *left_out, unsigned *ticket) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gemv_finish_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, S, b, y, elesetq, eleinitq, potdiff, atoms_ptr,
+                     atoms_of, elecheck, q_ele, q_atoms, left_out, ticket);
 }
 
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y) {

@@ -429,4 +429,126 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
   hipLaunchKernelGGL(pppm_gather_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, pd, ne, ne_pad, egrid, ew, re, bk);
 }
 
+// ---- PPPM coupling beyond b (pppm_conp.cpp:385-534) ---------------------------------------------------------------------------
+// density brick of the atoms in `idx` (ele_make_rho :385-426 for the electrode atoms, elyte_make_rho for the electrolyte; their
+// sum is what the make_rho override hands to PPPM::compute, :434-450).  rho is zeroed here.
+void launch_pppm_density(hipStream_t s, const PppmDev &pd, int n, const int *idx, const double *x, const double *q, double *rho,
+                         double *slab_scratch) {
+  hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, rho);
+  if (n <= 0) return;
+  const int apb = 256 / (pd.order * pd.order);
+  const int ngroups = (n + apb - 1) / apb;
+  const int npass = (ngroups + 1023) / 1024;
+  const int nb = (ngroups + npass - 1) / npass;
+  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, n, idx, x, q, rho, slab_scratch, npass);
+}
+
+// rho (in `re`) -> u_brick (in `re`): forward transform, greensfn / N, backward transform (elyte_poisson :230-267; the same
+// arithmetic PPPM::poisson leaves in u_brick for per-atom energies)
+void launch_pppm_poisson(hipStream_t s, const PppmDev &pd, double *re, double *im) {
+  const bool fused = mesh_smooth(pd);
+  const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
+  if (!fused) hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, im);
+  dft3(s, pd, -1.0, re, im, fused, gscale);
+  if (!fused)
+    hipLaunchKernelGGL(pppm_greens_kernel, dim3((pd.nfft + 255) / 256), dim3(256), 0, s, pd.nfft, gscale, pd.greensfn, re, im);
+  dft3(s, pd, +1.0, re, im, fused, gscale);
+}
+
+// compute_group_potential / compute_particle_potential (:452-534): out[idx[k]] = - sum over the order^3 stencil of w u_brick
+// (+ self * q_i: the 2 g / sqrt(pi) q_i of the particle flavour); stencil weights from the atom's current position
+// (particle_map + compute_rho1d), one wavefront per atom
+__global__ __launch_bounds__(256) void pppm_probe_kernel(PppmDev pd, int n, const int *__restrict__ idx, const double *__restrict__ x,
+                                                         const double *__restrict__ q, const double *__restrict__ u, double self,
+                                                         double *__restrict__ out) {
+  __shared__ double coeff[64];
+  if (threadIdx.x < pd.order * pd.order) coeff[threadIdx.x] = pd.rho_coeff[threadIdx.x];
+  __syncthreads();
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= n) return;
+  const int i = idx[k];
+  int g[3];
+  double w[3][8];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double xs = (x[3 * i + c] - pd.boxlo[c]) * pd.delinv[c];
+    g[c] = static_cast<int>(xs + pd.shift) - 16384;
+    rho1d_dev(coeff, pd.order, g[c] + pd.shiftone - xs, w[c]);
+  }
+  const int o2 = pd.order * pd.order;
+  double acc = 0.0;
+  for (int row = lane; row < o2; row += 64) {
+    const int nn = row / pd.order, m = row - nn * pd.order;
+    const int mz = pwrap(nn + pd.nlower + g[2], pd.nz), my = pwrap(m + pd.nlower + g[1], pd.ny);
+    const double y0 = w[2][nn] * w[1][m];
+    const double *line = u + ((size_t)mz * pd.ny + my) * pd.nx;
+    for (int l = 0; l < pd.order; ++l) acc -= (y0 * w[0][l]) * line[pwrap(l + pd.nlower + g[0], pd.nx)];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) out[i] = acc + self * q[i];
+}
+
+void launch_pppm_probe(hipStream_t s, const PppmDev &pd, int n, const int *idx, const double *x, const double *q, const double *u,
+                       double self, double *out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(pppm_probe_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pd, n, idx, x, q, u, self, out);
+}
+
+// ---- compute potential/atom, pair part (compute_potential_atom.cpp:223-308): one wavefront per list owner -------------------
+__global__ __launch_bounds__(256) void potential_pair_kernel(int inum, const int *__restrict__ ilist, const int *__restrict__ numneigh,
+                                                             const int *__restrict__ first, const int *__restrict__ neigh, int nlocal,
+                                                             int newton, const double *__restrict__ x, const double *__restrict__ q,
+                                                             const int *__restrict__ type, const int *__restrict__ sel,
+                                                             const int *__restrict__ etasel, int ntypes,
+                                                             const double *__restrict__ cutsq, double cut_coulsq, double g_ewald,
+                                                             double eta, double *__restrict__ potential) {
+#pragma clang fp contract(off)
+  const int ii = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ii >= inum) return;
+  const int i = ilist[ii];
+  const int gci = sel[i];
+  const double qi = q[i];
+  double mine = 0.0;
+  for (int jj = lane; jj < numneigh[i]; jj += 64) {
+    const int j = neigh[first[i] + jj] & 0x3FFFFFFF;
+    const int gcj = sel[j];
+    if (!((gci || gcj) && (qi != 0.0 || q[j] != 0.0) && (newton || gci || j < nlocal))) continue;
+    const double delx = x[3 * i] - x[3 * j], dely = x[3 * i + 1] - x[3 * j + 1], delz = x[3 * i + 2] - x[3 * j + 2];
+    double rsq = delx * delx + dely * dely + delz * delz;
+    if (rsq < 1e-10) rsq = 1e-10;
+    if (!(rsq < cutsq[type[i] * (ntypes + 1) + type[j]] && rsq < cut_coulsq)) continue;
+    const double r = sqrt(rsq), grij = g_ewald * r;
+    double expm2 = exp(-grij * grij), t = 1.0 / (1.0 + 0.3275911 * grij);
+    double erfc_ = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2;
+    double dudq = erfc_ / r;
+    if (eta != 0.0) {
+      const int ne2 = etasel[i] + etasel[j];
+      if (ne2) {
+        const double etarij = ne2 == 2 ? eta * r / sqrt(2.0) : eta * r;
+        if (etarij < 5.8) {
+          expm2 = exp(-etarij * etarij);
+          t = 1.0 / (1.0 + 0.3275911 * etarij);
+          erfc_ = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2;
+          dudq -= erfc_ / r;
+        }
+      }
+    }
+    if (gci) mine += q[j] * dudq;
+    if (j < nlocal || newton) atomicAdd(&potential[j], qi * dudq);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if (lane == 0 && gci) atomicAdd(&potential[i], mine);
+}
+
+void launch_potential_pair(hipStream_t s, int inum, const int *ilist, const int *numneigh, const int *first, const int *neigh,
+                           int nlocal, int newton, const double *x, const double *q, const int *type, const int *sel,
+                           const int *etasel, int ntypes, const double *cutsq, double cut_coulsq, double g_ewald, double eta,
+                           double *potential) {
+  if (inum <= 0) return;
+  hipLaunchKernelGGL(potential_pair_kernel, dim3((inum + 3) / 4), dim3(256), 0, s, inum, ilist, numneigh, first, neigh, nlocal, newton,
+                     x, q, type, sel, etasel, ntypes, cutsq, cut_coulsq, g_ewald, eta, potential);
+}
+
 }  // namespace conp

@@ -1557,3 +1557,170 @@ void orc_pppm_b_cal(const orc_pppm *p, int nlocal, const double *x, const double
   if (p->slabflag == 1) for (i = 0; i < ne; ++i) bbb[i] -= xele[3 * i + 2] * slabcorr;
   free(rho); free(im);
 }
+
+/* =============================================================================================
+ * PPPM coupling beyond b and `compute potential/atom` (8f-4), one rank.  PARITY UNPINNED like the section above.
+ * ===========================================================================================*/
+
+/* the stencil spread of one atom set: sel == NULL -> every atom; which = 0 electrolyte (echeck == 0), 1 electrode (echeck != 0),
+ * 2 both.  q == 0 atoms add nothing.  rho is accumulated (the caller zeroes it). */
+static void orc_pppm_spread(const orc_pppm *p, int n, const double *x, const double *q, const int *echeck, int which, double *rho) {
+  const int order = p->order, nx = p->nx, ny = p->ny, nz = p->nz;
+  double w[3][ORC_PPPM_MAXORDER];
+  int i, c, l, m, k;
+  for (i = 0; i < n; ++i) {
+    int g[3];
+    double z0;
+    if (which == 0 && echeck[i] != 0) continue;
+    if (which == 1 && echeck[i] == 0) continue;
+    if (q[i] == 0) continue;
+    for (c = 0; c < 3; ++c) {
+      const double xs = (x[3 * i + c] - p->boxlo[c]) * p->delinv[c];
+      g[c] = (int)(xs + p->shift) - ORC_PPPM_OFFSET;
+      orc_pppm_rho1d(p, g[c] + p->shiftone - xs, w[c]);
+    }
+    z0 = p->delvolinv * q[i];
+    for (k = 0; k < order; k++) {
+      const int mz = orc_wrap(k + p->nlower + g[2], nz);
+      const double y0 = z0 * w[2][k];
+      for (m = 0; m < order; m++) {
+        const int my = orc_wrap(m + p->nlower + g[1], ny);
+        const double x0 = y0 * w[1][m];
+        for (l = 0; l < order; l++) rho[((size_t)mz * ny + my) * nx + orc_wrap(l + p->nlower + g[0], nx)] += x0 * w[0][l];
+      }
+    }
+  }
+}
+
+/* PPPMCONP::ele_make_rho (pppm_conp.cpp:385-426) and the make_rho override (:434-450): density_brick = elyte_density_brick +
+ * ele_density_brick on the periodic mesh (one rank: ghost planes folded).  Any output may be NULL. */
+void orc_pppm_make_rho(const orc_pppm *p, int nlocal, const double *x, const double *q, const int *echeck, double *density,
+                       double *ele_density, double *elyte_density) {
+  double *e = (double *)calloc(p->nfft, sizeof(double)), *l = (double *)calloc(p->nfft, sizeof(double));
+  int i;
+  orc_pppm_spread(p, nlocal, x, q, echeck, 1, e);
+  orc_pppm_spread(p, nlocal, x, q, echeck, 0, l);
+  if (ele_density) memcpy(ele_density, e, sizeof(double) * p->nfft);
+  if (elyte_density) memcpy(elyte_density, l, sizeof(double) * p->nfft);
+  if (density) for (i = 0; i < p->nfft; ++i) density[i] = l[i] + e[i];
+  free(e); free(l);
+}
+
+/* u_brick as PPPM::compute leaves it when per-atom energies are tallied (what ComputePotentialAtom requires,
+ * compute_potential_atom.cpp:128-130): inverse transform of greensfn / N times the transform of the TOTAL density */
+void orc_pppm_u_brick(const orc_pppm *p, int nlocal, const double *x, const double *q, const int *echeck, double *u) {
+  double *im = (double *)calloc(p->nfft, sizeof(double));
+  const double scaleinv = 1.0 / ((double)p->nx * p->ny * p->nz);
+  int i, c;
+  memset(u, 0, sizeof(double) * p->nfft);
+  orc_pppm_spread(p, nlocal, x, q, echeck, 2, u);
+  for (c = 0; c < 3; ++c) orc_dft_axis(u, im, p->nx, p->ny, p->nz, c, -1);
+  for (i = 0; i < p->nfft; ++i) { u[i] *= scaleinv * p->greensfn[i]; im[i] *= scaleinv * p->greensfn[i]; }
+  for (c = 0; c < 3; ++c) orc_dft_axis(u, im, p->nx, p->ny, p->nz, c, +1);
+  free(im);
+}
+
+/* the stencil sum of PPPMCONP::compute_group_potential / compute_particle_potential (pppm_conp.cpp:452-534): u = - sum w u_brick */
+static double orc_pppm_probe(const orc_pppm *p, const double *xi, const double *u) {
+  const int order = p->order;
+  double w[3][ORC_PPPM_MAXORDER], acc = 0.0;
+  int g[3], c, l, m, n;
+  for (c = 0; c < 3; ++c) {
+    const double xs = (xi[c] - p->boxlo[c]) * p->delinv[c];
+    g[c] = (int)(xs + p->shift) - ORC_PPPM_OFFSET;                       /* part2grid, PPPM::particle_map */
+    orc_pppm_rho1d(p, g[c] + p->shiftone - xs, w[c]);
+  }
+  for (n = 0; n < order; n++) {
+    const int mz = orc_wrap(n + p->nlower + g[2], p->nz);
+    const double z0 = w[2][n];
+    for (m = 0; m < order; m++) {
+      const int my = orc_wrap(m + p->nlower + g[1], p->ny);
+      const double y0 = z0 * w[1][m];
+      for (l = 0; l < order; l++) acc -= (y0 * w[0][l]) * u[((size_t)mz * p->ny + my) * p->nx + orc_wrap(l + p->nlower + g[0], p->nx)];
+    }
+  }
+  return acc;
+}
+
+/* :487-534: recv[i] for the selected owned atoms.  particle != 0 adds the + 2 g q_i / sqrt(pi) of compute_particle_potential (:483). */
+void orc_pppm_group_potential(const orc_pppm *p, int nlocal, const double *x, const double *q, const int *echeck, const int *sel,
+                              int particle, double *recv) {
+  double *u = (double *)malloc(sizeof(double) * p->nfft);
+  int i;
+  orc_pppm_u_brick(p, nlocal, x, q, echeck, u);
+  for (i = 0; i < nlocal; ++i) {
+    if (!sel[i]) continue;
+    recv[i] = orc_pppm_probe(p, x + 3 * i, u);
+    if (particle) recv[i] += 2 * p->g_ewald * q[i] / 1.77245385090551602729;
+  }
+  free(u);
+}
+
+/* ComputePotentialAtom::compute_peratom (compute_potential_atom.cpp:120-218) for one rank: pair part (:223-308) over the pair
+ * style's half list, k-space part through the provider (:165-175), slab correction (:323-345), scaled by qqr2e / qe2f.
+ * sel = mask & groupbit, etasel = eta_check (molecule id is molidL or molidR); potential has nlocal entries (+ nghost with newton). */
+void orc_compute_potential_atom(const orc_pppm *p, int nlocal, int nghost, const double *x, const double *q, const int *type,
+                                const int *echeck, const int *sel, const int *etasel, int inum, const int *ilist, const int *numneigh,
+                                const int *first, const int *neigh, int newton, int ntypes, const double *cutsq, double cut_coul,
+                                double g_ewald, double eta, int pairflag, int kspaceflag, int slabflag, int qsumflag, double volume,
+                                double evscale, double *potential) {
+  const int ntotal = nlocal + (newton ? nghost : 0);
+  int i, ii, jj;
+  for (i = 0; i < ntotal; ++i) potential[i] = 0.0;
+  if (pairflag) {
+    double cut_coulsq = cut_coul * cut_coul;
+    const double cut_erfc = 5.8 * 5.8 / (g_ewald * g_ewald);
+    if (cut_coulsq > cut_erfc) cut_coulsq = cut_erfc;
+    for (ii = 0; ii < inum; ++ii) {
+      const int a = ilist[ii];
+      const int gcib = sel[a];
+      for (jj = 0; jj < numneigh[a]; ++jj) {
+        const int j = neigh[first[a] + jj] & 0x3FFFFFFF;
+        const int gcjb = sel[j];
+        if ((gcib || gcjb) && (q[a] != 0 || q[j] != 0) && (newton || gcib || j < nlocal)) {
+          const double delx = x[3 * a] - x[3 * j], dely = x[3 * a + 1] - x[3 * j + 1], delz = x[3 * a + 2] - x[3 * j + 2];
+          double rsq = delx * delx + dely * dely + delz * delz;
+          if (rsq < 1e-10) rsq = 1e-10;
+          if (rsq < cutsq[type[a] * (ntypes + 1) + type[j]] && rsq < cut_coulsq) {
+            const double r = sqrt(rsq), grij = g_ewald * r;
+            double expm2 = exp(-grij * grij), t = 1.0 / (1.0 + 0.3275911 * grij);
+            double erfc_ = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2;
+            double dudq = erfc_ / r;
+            if (eta != 0. && etasel[a] + etasel[j]) {
+              const double etarij = (etasel[a] + etasel[j] == 2) ? eta * r / sqrt(2) : eta * r;
+              if (etarij < 5.8) {
+                expm2 = exp(-etarij * etarij);
+                t = 1.0 / (1.0 + 0.3275911 * etarij);
+                erfc_ = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2;
+                dudq -= erfc_ / r;
+              }
+            }
+            if (gcib) potential[a] += q[j] * dudq;
+            if (j < nlocal || newton) potential[j] += q[a] * dudq;
+          }
+        }
+      }
+    }
+  }
+  if (kspaceflag) {
+    double *u = (double *)malloc(sizeof(double) * p->nfft);
+    orc_pppm_u_brick(p, nlocal, x, q, echeck, u);
+    for (i = 0; i < nlocal; ++i)
+      if (sel[i]) {
+        potential[i] -= orc_pppm_probe(p, x + 3 * i, u) + 2 * g_ewald * q[i] / 1.77245385090551602729;
+        if (eta != 0. && etasel[i]) potential[i] += eta * q[i] * sqrt(2) / 1.77245385090551602729;
+      }
+    free(u);
+    if (slabflag) {                                                     /* :323-345 */
+      double qsum = 0.0, slabcorr = 0.0;
+      const double pi2vol = 2 * ORC_PI / volume;
+      for (i = 0; i < nlocal; ++i) { slabcorr += 2 * pi2vol * q[i] * x[3 * i + 2]; qsum += q[i]; }
+      for (i = 0; i < nlocal; ++i)
+        if (sel[i]) {
+          potential[i] += x[3 * i + 2] * slabcorr;
+          if (qsumflag) potential[i] -= pi2vol * qsum * x[3 * i + 2] * x[3 * i + 2];
+        }
+    }
+  }
+  for (i = 0; i < ntotal; ++i) potential[i] *= evscale;
+}

@@ -263,6 +263,42 @@ class Pppm:
                                 np.ascontiguousarray(echeck, np.int32), len(xele), np.ascontiguousarray(xele), b, None)
         return b
 
+    # ---- PPPM coupling beyond b (pppm_conp.cpp:385-534) and compute potential/atom (compute_potential_atom.cpp:120-345)
+    def _nfft(self, mesh):
+        return int(mesh[0]) * int(mesh[1]) * int(mesh[2])
+
+    def make_rho(self, mesh, x, q, echeck, nlocal):
+        n = self._nfft(mesh)
+        d, e, l = np.zeros(n), np.zeros(n), np.zeros(n)
+        self.lib.orc_pppm_make_rho.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, _dp, _dp]
+        self.lib.orc_pppm_make_rho(self.h, nlocal, np.ascontiguousarray(x), np.ascontiguousarray(q),
+                                   np.ascontiguousarray(echeck, np.int32), d, e, l)
+        return d, e, l
+
+    def group_potential(self, x, q, echeck, nlocal, sel, particle=False):
+        out = np.zeros(nlocal)
+        self.lib.orc_pppm_group_potential.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _ip, C.c_int, _dp]
+        self.lib.orc_pppm_group_potential(self.h, nlocal, np.ascontiguousarray(x), np.ascontiguousarray(q),
+                                          np.ascontiguousarray(echeck, np.int32), np.ascontiguousarray(sel, np.int32), int(particle), out)
+        return out
+
+    def compute_potential_atom(self, s, at, lst, sel, etasel, eta=0.0, pair=True, kspace=True, qsum=True):
+        nall = at.nlocal + at.nghost
+        pot = np.zeros(nall)
+        neigh = lst.neigh if lst.neigh.size else np.zeros(1, np.int32)
+        self.lib.orc_compute_potential_atom.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _ip, _ip, C.c_int, _ip, _ip, _ip,
+                                                        _ip, C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                                        C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+        vol = float(s.prd[0] * s.prd[1] * s.prd[2] * s.slab_volfactor)
+        from conp_amd import systems as _sy
+        self.lib.orc_compute_potential_atom(self.h, at.nlocal, at.nghost, np.ascontiguousarray(at.x), np.ascontiguousarray(at.q),
+                                            np.ascontiguousarray(at.type, np.int32), np.ascontiguousarray(at.echeck, np.int32),
+                                            np.ascontiguousarray(sel, np.int32), np.ascontiguousarray(etasel, np.int32), lst.inum,
+                                            lst.ilist, lst.numneigh, lst.first, neigh, int(s.newton), s.ntypes,
+                                            np.ascontiguousarray(s.cutsq_table().ravel()), float(s.cutoff), float(s.g_ewald), float(eta),
+                                            int(pair), int(kspace), int(s.slabflag), int(qsum), vol, _sy.QQR2E / _sy.QE2F, pot)
+        return pot
+
     def close(self):
         if self.h:
             self.lib.orc_pppm_destroy(self.h); self.h = None

@@ -71,3 +71,95 @@ def test_pppm_keyword_without_mesh_is_the_reference_error():
         fx.setup_post_neighbor(at)
     assert "couldn't detect a pppm/conp kspace style" in str(e.value)      # fix_conp.cpp:404
     fx.close()
+
+
+def _pppm_handle(deck, mode, mesh, order):
+    s = systems.deck(deck, mode, etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s, extra_args=["pppm"], pppm_mesh=mesh, pppm_order=order)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)               # electrode atoms carry their solved charges from here on
+    return s, at, alist, blist, fx
+
+
+@pytest.mark.parametrize("deck,mode,mesh,order", [("dilute", "ffield", (27, 24, 144), 5), ("il_onelayer", "ffield", (36, 40, 150), 4)])
+def test_pppm_density_bricks_match_oracle(oracle, deck, mode, mesh, order):
+    """ele_make_rho (pppm_conp.cpp:385-426) and the make_rho override (:434-450): electrode brick, electrolyte brick, their sum"""
+    s, at, alist, blist, fx = _pppm_handle(deck, mode, mesh, order)
+    n = mesh[0] * mesh[1] * mesh[2]
+    d, e, l = fx.pppm_make_rho(at, n)
+    pp = oracle_py.Pppm(oracle, s, mesh, order)
+    d_o, e_o, l_o = pp.make_rho(mesh, at.x, at.q, at.echeck, at.nlocal)
+    assert np.abs(e_o).max() > 0 and np.abs(l_o).max() > 0
+    assert rel_err(e, e_o) < 1e-12 and rel_err(l, l_o) < 1e-12 and rel_err(d, d_o) < 1e-12
+    dv = (s.prd[0] / mesh[0]) * (s.prd[1] / mesh[1]) * (s.prd[2] * s.slab_volfactor / mesh[2])
+    ele = at.echeck[:at.nlocal] != 0
+    assert e.sum() * dv == pytest.approx(at.q[:at.nlocal][ele].sum(), abs=1e-10)         # the stencil weights sum to one
+    assert l.sum() * dv == pytest.approx(at.q[:at.nlocal][~ele].sum(), abs=1e-10)
+    pp.close(); fx.close()
+
+
+@pytest.mark.parametrize("deck,mode,mesh,order,acc", [("dilute", "ffield", (27, 24, 144), 5, 2e-4),
+                                                      ("dilute", "slab", (27, 24, 432), 5, 2e-4),
+                                                      ("il_onelayer", "ffield", (40, 45, 180), 5, 2e-4)])
+def test_pppm_potentials_match_oracle_and_ewald(oracle, deck, mode, mesh, order, acc):
+    """compute_group_potential / compute_particle_potential (pppm_conp.cpp:452-534) against the oracle's restatement, and against
+    the k-space potential summed directly over the reference's k list with the structure factor of ALL charges (mesh accuracy)"""
+    s, at, alist, blist, fx = _pppm_handle(deck, mode, mesh, order)
+    n = at.nlocal
+    rng = np.random.default_rng(4)
+    sel = (rng.random(n) < 0.3).astype(np.int32)
+    sel[np.nonzero(at.echeck[:n] != 0)[0][:5]] = 1                      # some electrode atoms among the probes
+    got = fx.pppm_group_potential(at, sel)
+    pp = oracle_py.Pppm(oracle, s, mesh, order)
+    want = pp.group_potential(at.x, at.q, at.echeck, n, sel)
+    pick = sel != 0
+    assert rel_err(got[pick], want[pick]) < 1e-10
+    i0 = int(np.nonzero(pick)[0][3])
+    up = fx.pppm_particle_potential(at, i0)
+    assert up == pytest.approx(pp.group_potential(at.x, at.q, at.echeck, n, sel, particle=True)[i0], rel=1e-10)
+    assert up - got[i0] == pytest.approx(2 * s.g_ewald * at.q[i0] / np.sqrt(np.pi), rel=1e-9, abs=1e-14)
+    # direct k sum: - sum_k 2 ug_k [cos(k r_i) Re S + sin(k r_i) Im S],  S over every charged atom (electrodes included)
+    kt = fx.ktables()
+    info = fx.info()
+    uk = np.array(info.unitk)
+    kv = np.stack([kt["kxvecs"], kt["kyvecs"], kt["kzvecs"]], 1) * uk
+    ph = at.x[:n] @ kv.T
+    S = (at.q[:n, None] * np.exp(1j * ph)).sum(axis=0)
+    probes = np.nonzero(pick)[0]
+    ew = -(2 * kt["ug"] * (np.cos(ph[probes]) * S.real + np.sin(ph[probes]) * S.imag)).sum(axis=1)
+    assert rel_err(got[probes], ew) < acc
+    pp.close(); fx.close()
+
+
+@pytest.mark.parametrize("deck,mode,mesh,eta", [("dilute", "ffield", (27, 24, 144), 0.0), ("dilute", "slab", (27, 24, 432), 1.979),
+                                                ("il_onelayer", "ffield", (36, 40, 150), 1.979)])
+def test_compute_potential_atom_matches_oracle(oracle, deck, mode, mesh, eta):
+    """`compute potential/atom` (compute_potential_atom.cpp:120-345): pair part over the pair style's half list (with and without
+    the Gaussian `eta` correction), k-space part through the PPPM provider, slab correction, volts"""
+    order = 5 if mesh[0] != 36 else 4
+    s, at, alist, blist, fx = _pppm_handle(deck, mode, mesh, order)
+    s_gen = systems.deck(deck, mode, etypes=False)                      # the pair style's own list: generic half list
+    at_g, plist, _ = neighbor.build_lists(s_gen)
+    assert at_g.nlocal == at.nlocal and np.array_equal(at_g.tag, at.tag)
+    nall = at.nlocal + at.nghost
+    rng = np.random.default_rng(8)
+    sel = (rng.random(nall) < 0.5).astype(np.int32)
+    sel[at.nlocal:] = sel[at.owner[at.nlocal:]]                          # ghosts carry their owner's group membership
+    etasel = (at.echeck != 0).astype(np.int32)                           # eta_check: the electrode molecules
+    pp = oracle_py.Pppm(oracle, s, mesh, order)
+    for kw in (dict(pair=True, kspace=True, qsum=True), dict(pair=True, kspace=False, qsum=True), dict(pair=False, kspace=True, qsum=False)):
+        got = fx.compute_potential_atom(at, plist, sel, etasel, eta=eta, **kw)
+        want = pp.compute_potential_atom(s, at, plist, sel, etasel, eta=eta, **kw)
+        assert np.abs(want[:at.nlocal]).max() > 0
+        assert rel_err(got[:at.nlocal], want[:at.nlocal]) < 1e-10, kw
+    # the constant-potential property seen by the diagnostic: with the eta correction the potential on the electrode atoms of one
+    # electrode is flat (that is what the charges were solved for), up to the mesh accuracy
+    if eta:
+        sel_all = np.ones(nall, np.int32)
+        pot = fx.compute_potential_atom(at, plist, sel_all, etasel, eta=eta)
+        for sign in (1, -1):
+            v = pot[:at.nlocal][at.echeck[:at.nlocal] == sign]
+            assert v.std() < 5e-3 * max(abs(v.mean()), s.potdiff)
+    pp.close(); fx.close()

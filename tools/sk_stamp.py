@@ -52,4 +52,11 @@ print("  per-wave total cycles: min %.0f  median %.0f  max %.0f" % (per_wave.min
 for wv in range(8):
     w = t[:, wv, :]
     print(f"  wave {wv}: mfma {w[:, 2].sum() / w[:, 6].sum():7.0f}  build {w[:, 3].sum() / w[:, 6].sum():6.0f}  barrier {w[:, 4].sum() / w[:, 6].sum():6.0f}  load {w[:, 1].sum() / w[:, 6].sum():5.0f} cycles per chunk")
+ck = np.zeros(1024 * 4, dtype=np.uint64)
+if hasattr(lib, "conp_debug_sk_clock") and lib.conp_debug_sk_clock(ck.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0:
+    ck = ck.reshape(1024, 4).astype(np.float64)[:t.shape[0]]
+    dc, dr = ck[:, 1] - ck[:, 0], ck[:, 3] - ck[:, 2]
+    ok = dr > 0
+    print("  shader clock during the (stamped) kernel: median %.0f MHz (s_memtime ticks per 100-MHz s_memrealtime tick); "
+          "kernel length per workgroup: median %.1f us" % (np.median(dc[ok] / dr[ok]) * 100.0, np.median(dr[ok]) / 100.0))
 fx.close()
