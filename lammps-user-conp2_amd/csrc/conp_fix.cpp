@@ -221,7 +221,8 @@ struct conp_fix {
   DevBuf<double2> d_Xt, d_Yt, d_Zt;
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
       d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of;
-  DevBuf<unsigned> d_ticket, d_row_tickets;
+  bool left_stale = false;          // the fused GEMV + charge write leaves the fix scalar's group-1 sum to refresh_scalar()
+  double left_potdiff = 0.0;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
@@ -272,8 +273,7 @@ struct conp_fix {
     d_cutsq.upload(cutsq_h, stream);
     d_scalars.reserve(16);
     d_scalars.zero(stream);
-    d_ticket.reserve(4);
-    d_ticket.zero(stream);
+
   }
 
   // FixConp::modify_param (fix_conp.cpp:1482-1515)
@@ -499,7 +499,6 @@ struct conp_fix {
       d_bk.reserve(4 * (size_t)ne_pad); d_breal.reserve(ne_pad); d_b_own.reserve(nvec); d_eleallq_own.reserve(nvec); d_qele.reserve(ne_pad);
       d_elesetq.reserve(ne_pad); d_eleinitq.reserve(ne_pad); d_ele_z.reserve(ne_pad); d_elecheck.reserve(ne_pad);
       d_ainve.reserve(ne_pad);
-      d_row_tickets.reserve(ne_pad / 64 + 1); d_row_tickets.zero(stream);
       d_bk.zero(stream); d_breal.zero(stream); d_b_own.zero(stream); d_eleallq_own.zero(stream); d_qele.zero(stream);
       d_elesetq.zero(stream); d_eleinitq.zero(stream);
       if (!d_b) d_b = d_b_own.p;
@@ -1161,16 +1160,9 @@ struct conp_fix {
       for (auto &e : ev_b) if (!e) HIP_TRY(hipEventCreate(&e));
       HIP_TRY(hipEventRecord(ev_b[0], stream));
     }
-    // what the last step (one electrode row of b = k-space partials + slab + real-space pairs) needs, for whichever kernel does it
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     // real-space rows: with replicated atoms this rank's row range; a sub-domain's list holds its own electrode atoms' rows only
     const int rr0 = !coulyes ? 0 : (decomposed ? 0 : row0), rr1 = !coulyes ? 0 : (decomposed ? ne : row1);
-    const BRowArgs brow = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 1,
-                                    d_bk.p, slab, d_ele_z.p, d_slab_part.p, 0 /*set below*/, 4.0 * 3.14159265358979323846 / kt.volume,
-                                    d_b, d_scalars.p + 2);
-    bool combined = false;              // the z-class dot kernel's last-arriving blocks did the row assembly
-    // (the timed host-buffer hooks keep the two halves in separate launches: Ktime / Ctime are measured around them)
-    const bool fuse_rows = !no_fuse && !timed;
     if (args.pppm) {
       // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
       prof.begin("pppm_b", stream);
@@ -1189,38 +1181,31 @@ struct conp_fix {
       launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                      d_Gpart.p);
       prof.end(stream);
-      BRowArgs fr = brow;
-      fr.n_slab_part = n_slab_part;
       if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
         // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)
         prof.begin("reduce_project", stream);
         launch_reduce_project_zclass(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, ne_pad,
-                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p,
-                                     fuse_rows ? &fr : nullptr, d_row_tickets.p);
+                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p);
         prof.end(stream);
-        combined = fuse_rows;
       } else {
         prof.begin("sk_reduce", stream);
         launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, d_Gw.p);
         prof.end(stream);
         prof.begin("b_project", stream);
-        if (nzc > 0) {
+        if (nzc > 0)
           launch_b_project_zclass(stream, dplan, ne_pad, d_rt_mine.p, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Gw.p, d_Tzc.p, d_Rp.p,
-                                  d_zclass.p, d_Hc.p, d_bk.p, fuse_rows ? &fr : nullptr, d_row_tickets.p);
-          combined = fuse_rows;
-        } else
+                                  d_zclass.p, d_Hc.p, d_bk.p);
+        else
           launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
         prof.end(stream);
       }
     }
     if (timed) HIP_TRY(hipEventRecord(ev_b[1], stream));
-    if (!combined) {
-      prof.begin("b_real_combine", stream);
-      launch_b_real_combine(stream, ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
-                            d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
-                            4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
-      prof.end(stream);
-    }
+    prof.begin("b_real_combine", stream);
+    launch_b_real_combine(stream, ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
+                          d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
+                          4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
+    prof.end(stream);
     if (timed) { HIP_TRY(hipEventRecord(ev_b[2], stream)); ev_pending = true; }
     HIP_TRY(hipGetLastError());   // a refused launch (bad grid / LDS size) must not pass silently
   }
@@ -1355,8 +1340,9 @@ struct conp_fix {
     const int ne = idx.elenum_all;
     prof.begin("gemv_charge", stream);
     launch_gemv_finish(stream, ne, d_A.p, d_b, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr, potdiff, d_ele_csr_ptr.p,
-                       d_ele_csr_of.p, d_elecheck.p, d_qele.p, d_q_atoms, d_scalars.p + 1, d_ticket.p);
+                       d_ele_csr_of.p, d_qele.p, d_q_atoms);
     prof.end(stream);
+    left_stale = true; left_potdiff = potdiff;        // the fix scalar's group-1 sum is formed on demand (refresh_scalar)
     HIP_TRY(hipGetLastError());
   }
 
@@ -1399,6 +1385,7 @@ struct conp_fix {
   }
 
   void finish_scalar(double potdiff) {
+    if (left_stale) { launch_left_sum(stream, idx.elenum_all, d_elecheck.p, d_eleallq, d_scalars.p + 1); left_stale = false; }
     double *h = pinned((size_t)ne_pad + 8) + ne_pad;
     HIP_TRY(hipMemcpyAsync(h, d_scalars.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
@@ -1660,6 +1647,12 @@ int conp_fix_create(const conp_fix_args *args, const conp_env *env, conp_fix **o
   f->cutsq_h.assign(env->cutsq, env->cutsq + nc);
   f->env.cutsq = nullptr;
   f->init_device();
+  // `himem` (fix_conp.cpp:168 -> lowmemflag = false) makes KSpaceModuleEwald keep pre-scaled csk / snk[Ne][K] tables instead of
+  // expanding them per atom (km_ewald.cpp:263-268, 498-506): a memory / time trade of the CPU provider.  This provider has ONE
+  // formulation (phases regenerated on the matrix cores, nothing of size Ne x K stored), so the keyword selects nothing -- said
+  // once where the reference prints its own notes (utils::logmesg), not silently.
+  if (!args->lowmem)
+    f->mesgf("conp/hip: keyword himem has no effect: the HIP provider keeps no Ne x K phase table in either mode\n");
   *out = f.release();
   CONP_GUARD_END
 }
@@ -1714,7 +1707,13 @@ int conp_fix_pre_force(conp_fix *f, const conp_atoms *at, int64_t ntimestep, dou
   CONP_GUARD_END
 }
 
-double conp_fix_compute_scalar(const conp_fix *f) { return f->scalar_output; }
+double conp_fix_compute_scalar(const conp_fix *cf) {
+  conp_fix *f = const_cast<conp_fix *>(cf);
+  if (f->left_stale) {          // device-resident updates do not bring the scalar over every step: form and fetch it now
+    try { (void)hipSetDevice(f->env.device); f->finish_scalar(f->left_potdiff); } catch (...) {}
+  }
+  return f->scalar_output;
+}
 
 int conp_fix_modify_param(conp_fix *f, int narg, const char *const *arg, int *consumed) {
   CONP_GUARD_BEGIN

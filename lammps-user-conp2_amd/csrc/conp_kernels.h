@@ -90,11 +90,10 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
 // planar-electrode fast path of the projection (<= 64 distinct electrode z values)
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part, const BRowArgs *fuse /*NULL: b_real_combine is a
-                                  launch of its own*/, unsigned *tickets /*[ne_pad / 64], zero*/);
+                                  const int *zclass, double *Hc, double *bk_part);
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
                              const double *Tzc /*[C_pad][64]*/, const double *Rp, const int *zclass /*[ne_pad]*/,
-                             double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/, const BRowArgs *fuse, unsigned *tickets);
+                             double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/);
 // this rank's contribution to b in one launch: k-space halves + slab (rank 0) + real-space rows row0..row1
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
                            const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,
@@ -103,8 +102,8 @@ void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);
 // all rows + the charge write of plain `fix conp` in one launch (atoms_ptr / atoms_of: electrode row -> its owned and ghost atoms)
 void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, double *y, const double *elesetq,
-                        const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of, const int *elecheck,
-                        double *q_ele, double *q_atoms, double *left_out, unsigned *ticket /*device, zero*/);
+                        const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of, double *q_ele,
+                        double *q_atoms);
 void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleall, const int *elecheck, const double *eleallq,
                           const double *elesetq, const double *eleinitq, double potdiff, const double *d_potdiff, double *q_ele,
                           double *q_atoms, double *left_out);

@@ -756,7 +756,7 @@ __device__ __forceinline__ double b_slab_scalar(const BRowArgs &a, int lane) {
   sp = wave_sum(sp);
   return a.slab_pref * __shfl(sp, 0, 64);
 }
-__device__ __forceinline__ void b_row(const BRowArgs &a, int row, int lane, double sc, bool bk_volatile) {
+__device__ __forceinline__ void b_row(const BRowArgs &a, int row, int lane, double sc) {
 #pragma clang fp contract(off)
   const int nt1 = a.rp.ntypes + 1;
   double sum = 0.0;
@@ -776,15 +776,7 @@ __device__ __forceinline__ void b_row(const BRowArgs &a, int row, int lane, doub
   if (lane == 0) {
     double v = 0.0;
     if (a.add_k) {
-      double k0, k1, k2, k3;
-      if (bk_volatile) {      // written by other workgroups of the SAME launch (the fused kernel's last-arriver): bypass stale lines
-        k0 = __hip_atomic_load(a.bk + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k1 = __hip_atomic_load(a.bk + a.ne_pad + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k2 = __hip_atomic_load(a.bk + 2 * (size_t)a.ne_pad + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k3 = __hip_atomic_load(a.bk + 3 * (size_t)a.ne_pad + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        k0 = a.bk[row]; k1 = a.bk[a.ne_pad + row]; k2 = a.bk[2 * (size_t)a.ne_pad + row]; k3 = a.bk[3 * (size_t)a.ne_pad + row];
-      }
+      const double k0 = a.bk[row], k1 = a.bk[a.ne_pad + row], k2 = a.bk[2 * (size_t)a.ne_pad + row], k3 = a.bk[3 * (size_t)a.ne_pad + row];
       v = (k0 + k1) + (k2 + k3);
     }
     if (a.slab) v -= a.ele_z[row] * sc;
@@ -799,8 +791,7 @@ __device__ __forceinline__ void b_row(const BRowArgs &a, int row, int lane, doub
 // loads) -- reading them per thread and per row from global cost more than the 42 MB Rp stream itself (20 -> 11 us).
 __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
                                                         const double *__restrict__ Rp, const double *__restrict__ Hc4,
-                                                        const int *__restrict__ zclass, double *__restrict__ bk,
-                                                        BRowArgs ra, unsigned *__restrict__ tickets) {
+                                                        const int *__restrict__ zclass, double *__restrict__ bk) {
   extern __shared__ __attribute__((aligned(16))) char zc_smem[];
   double *H = reinterpret_cast<double *>(zc_smem);          // [n_own * 32][nzc]
   __shared__ double red[16][64];
@@ -839,38 +830,19 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
     double tot = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) tot += red[k][a];
-    // write-through (sc1) store: the block that assembles these rows may sit on another XCD, whose L2 is not coherent with ours
-    __hip_atomic_store(bk + (size_t)blockIdx.y * ne_pad + i, -tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the store has left before this workgroup takes its ticket
-  }
-  if (!tickets) return;
-  // ---- fused tail: the LAST of the four row-quarter blocks of this atom block assembles b for its 64 rows (k-space quarters in
-  // the fixed order, slab term, real-space pairs) -- what b_real_combine_kernel does in a launch of its own otherwise.
-  // Hand-off without fences (an agent-scope fence writes back / invalidates whole caches: measured 4.5x on this kernel): sc1
-  // stores, the storing wave's vmcnt(0), workgroup barrier, ONE agent-scope ticket add; the last arriver reads the partials
-  // with sc1 loads only (MI355X_MICROARCH.md, inter-workgroup visibility).
-  __shared__ unsigned s_ticket;
-  __syncthreads();
-  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (s_ticket != 3u) return;
-  if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next update
-  const double sc = ra.slab ? b_slab_scalar(ra, a) : 0.0;
-  for (int k = 0; k < 4; ++k) {
-    const int row = blockIdx.x * 64 + w + 16 * k;
-    if (row < ra.ne) b_row(ra, row, a, sc, true);
+    bk[(size_t)blockIdx.y * ne_pad + i] = -tot;
   }
 }
 
+// (The four row-quarter partials of an atom are added, with the slab and real-space terms, by b_real_combine_kernel.  Letting the
+//  last-arriving quarter block of each atom block do that here -- sc1 hand-off, ticket -- was measured: 32 -> 47 us for the pair
+//  at the headline size, 22 -> 33 us on il_onelayer: 64 late workgroups do serially what 4096 waves of their own launch do at once.)
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
-                            const double *Hc, const int *zclass, double *bk_part, const BRowArgs *fuse, unsigned *tickets) {
+                            const double *Hc, const int *zclass, double *bk_part) {
   const size_t lds = (size_t)(n_own > 0 ? n_own : 1) * 32 * nzc * sizeof(double);      // the host keeps this <= 96 KB (conp_fix.cpp)
   static DynLdsCache granted{};
   ensure_dyn_lds(b_zc_dot_kernel, lds, granted);
-  BRowArgs ra{};
-  if (fuse) ra = *fuse;
-  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part,
-                     ra, fuse ? tickets : nullptr);
+  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 // Planar electrodes with one column tile (nz <= 160): the last partial-tile sum and the Hc product in ONE kernel -- a block
@@ -930,7 +902,7 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
 // sk_reduce (+ level 1 when tiles are heavily split) with the Hc product fused in, then the per-atom dot
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part, const BRowArgs *fuse, unsigned *tickets) {
+                                  const int *zclass, double *Hc, double *bk_part) {
   if (ntiles <= 0) return;
   const int nzc16 = (nzc + 15) / 16;
   int level = 0;
@@ -941,16 +913,15 @@ void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile
   }
   hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
                      nzc16, level);
-  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, fuse, tickets);
+  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
-                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fuse,
-                             unsigned *tickets) {
+                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part) {
   const int nzc16 = (nzc + 15) / 16;
   hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
-  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, fuse, tickets);
+  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 // ================================================================================================
@@ -965,7 +936,7 @@ __global__ __launch_bounds__(256) void b_real_combine_kernel(BRowArgs a) {
   if (row >= a.ne) return;
   const int lane = threadIdx.x & 63;
   const double sc = a.slab ? b_slab_scalar(a, lane) : 0.0;     // every wave derives the same scalar with the same summation tree
-  b_row(a, row, lane, sc, false);
+  b_row(a, row, lane, sc);
 }
 
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
@@ -1022,102 +993,64 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row
   if (lane == 0) y[row] = r;
 }
 
-// GEMV with the charge write in its tail (fix_conp.cpp:1135-1159 in ONE launch; plain `fix conp`, all rows on this rank):
+// GEMV with the charge write in its tail (fix_conp.cpp:1135-1158 in ONE launch; plain `fix conp`, all rows on this rank):
 //   every wave: y[row] = S[row,:] . b  (same loop, same association as gemv_rows_kernel), then q = y + dV * setq (+ qinit) into
-//   q_ele[row] and into every owned / ghost copy of that electrode atom (CSR row -> atoms);
-//   the LAST block to finish (agent-scope ticket) forms the group-1 sum of y with charge_finish_kernel's fixed tree.
-// Bit-identical to gemv_rows_kernel + charge_finish_kernel; one launch and one dependent-launch gap fewer per update.
+//   q_ele[row] and into every owned / ghost copy of that electrode atom (CSR row -> atoms).
+// Bit-identical to gemv_rows_kernel + charge_finish_kernel's charge part; one launch and one dependent-launch gap fewer per
+// update.  The fix scalar's group-1 sum of y (:1150, :1159) is formed when somebody asks for it (left_sum_kernel): a first
+// version made the last block to finish compute it in this launch -- 1024 ticket adds on one address plus the fences cost
+// more than the launch they saved (gemv 23 + finish 7 us -> 38 us fused).
 __global__ __launch_bounds__(256) void gemv_finish_kernel(int n, const double *__restrict__ S, const double *__restrict__ b,
                                                           double *__restrict__ y, const double *__restrict__ elesetq,
                                                           const double *__restrict__ eleinitq, double potdiff,
                                                           const int *__restrict__ atoms_ptr, const int *__restrict__ atoms_of,
-                                                          const int *__restrict__ elecheck, double *__restrict__ q_ele,
-                                                          double *__restrict__ q_atoms, double *__restrict__ left_out,
-                                                          unsigned *__restrict__ ticket) {
+                                                          double *__restrict__ q_ele, double *__restrict__ q_atoms) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row < n) {
-    const double *srow = S + (size_t)row * n;
-    double s0 = 0.0, s1 = 0.0;
-    if ((n & 1) == 0) {
-      const double2 *s2 = reinterpret_cast<const double2 *>(srow);
-      const double2 *b2 = reinterpret_cast<const double2 *>(b);
-      double t0 = 0.0, t1 = 0.0;
-      int j = lane;
-      for (; j + 192 < n / 2; j += 256) {
-        const double2 a0 = nt_load(s2 + j), a1 = nt_load(s2 + j + 64), a2 = nt_load(s2 + j + 128), a3 = nt_load(s2 + j + 192);
-        const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
-        s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
-        t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
-        s0 = fma(a2.x, b2v.x, s0); s1 = fma(a2.y, b2v.y, s1);
-        t0 = fma(a3.x, b3.x, t0); t1 = fma(a3.y, b3.y, t1);
-      }
-      for (; j < n / 2; j += 64) {
-        const double2 a = s2[j], bb = b2[j];
-        s0 = fma(a.x, bb.x, s0);
-        s1 = fma(a.y, bb.y, s1);
-      }
-      s0 += t0; s1 += t1;
-    } else {
-      for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
+  if (row >= n) return;
+  const double *srow = S + (size_t)row * n;
+  double s0 = 0.0, s1 = 0.0;
+  if ((n & 1) == 0) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(srow);
+    const double2 *b2 = reinterpret_cast<const double2 *>(b);
+    double t0 = 0.0, t1 = 0.0;
+    int j = lane;
+    for (; j + 192 < n / 2; j += 256) {
+      const double2 a0 = nt_load(s2 + j), a1 = nt_load(s2 + j + 64), a2 = nt_load(s2 + j + 128), a3 = nt_load(s2 + j + 192);
+      const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
+      s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
+      t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
+      s0 = fma(a2.x, b2v.x, s0); s1 = fma(a2.y, b2v.y, s1);
+      t0 = fma(a3.x, b3.x, t0); t1 = fma(a3.y, b3.y, t1);
     }
-    double r = wave_sum(s0 + s1);
-    r = __shfl(r, 0, 64);
-    double v;
-    {
+    for (; j < n / 2; j += 64) {
+      const double2 a = s2[j], bb = b2[j];
+      s0 = fma(a.x, bb.x, s0);
+      s1 = fma(a.y, bb.y, s1);
+    }
+    s0 += t0; s1 += t1;
+  } else {
+    for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
+  }
+  double r = wave_sum(s0 + s1);
+  r = __shfl(r, 0, 64);
+  double v;
+  {
 #pragma clang fp contract(off)
-      v = r + potdiff * elesetq[row];
-      if (eleinitq) v += eleinitq[row];
-    }
-    if (lane == 0) {
-      __hip_atomic_store(y + row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: read by the last block, maybe on another XCD
-      q_ele[row] = v;
-    }
-    if (q_atoms)
-      for (int k = atoms_ptr[row] + lane; k < atoms_ptr[row + 1]; k += 64) q_atoms[atoms_of[k]] = v;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    v = r + potdiff * elesetq[row];
+    if (eleinitq) v += eleinitq[row];
   }
-  // ---- last block: netcharge_left = sum of y over the group-1 atoms.  Fence-free hand-off: sc1 stores above, every storing
-  // wave's vmcnt(0), workgroup barrier, one agent-scope ticket add; sc1 loads below.
-  __shared__ unsigned s_ticket;
-  __shared__ double red[4];
-  __syncthreads();
-  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (s_ticket != gridDim.x - 1) return;
-  double s16[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) s16[u] = 0.0;
-  for (int i0 = threadIdx.x; i0 < n; i0 += 4096) {
-    int ec[16];
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = i0 + 256 * u;
-      ec[u] = i < n ? elecheck[i] : 0;
-      v[u] = i < n ? __hip_atomic_load(y + (i < n ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s16[u] += (ec[u] == 1) ? v[u] : 0.0;
-  }
-  double s4[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) s4[u] = (s16[u] + s16[u + 4]) + (s16[u + 8] + s16[u + 12]);
-  double sum = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    *left_out = (red[0] + red[1]) + (red[2] + red[3]);
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next update
-  }
+  if (lane == 0) { y[row] = r; q_ele[row] = v; }
+  if (q_atoms)
+    for (int k = atoms_ptr[row] + lane; k < atoms_ptr[row + 1]; k += 64) q_atoms[atoms_of[k]] = v;
 }
 
 void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, double *y, const double *elesetq,
-                        const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of, const int *elecheck,
-                        double *q_ele, double *q_atoms, double *left_out, unsigned *ticket) {
+                        const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of, double *q_ele,
+                        double *q_atoms) {
   if (n <= 0) return;
   hipLaunchKernelGGL(gemv_finish_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, S, b, y, elesetq, eleinitq, potdiff, atoms_ptr,
-                     atoms_of, elecheck, q_ele, q_atoms, left_out, ticket);
+                     atoms_of, q_ele, q_atoms);
 }
 
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y) {

@@ -42,6 +42,7 @@
 #define CONP_GLUE_MOCK 1
 #include "fix_conp_hip.h"
 #include "kspacemodule_hip.h"
+#include "pppm_conp_hip.h"
 
 using namespace LAMMPS_NS;
 
@@ -181,6 +182,7 @@ int run_case(const char *path, bool provider, int me, int nprocs, MockCommRank *
     env.xprd = domain.xprd; env.yprd = domain.yprd; env.zprd = domain.zprd;
     env.boxlo_x = domain.boxlo[0]; env.boxlo_y = domain.boxlo[1]; env.boxlo_z = domain.boxlo[2];
     env.ntypes = ntypes; env.cutsq = cutsq_store.data(); env.cut_coul = pair.cut_coul; env.nranks = nprocs; env.rank = me;
+    env.pppm_nx = kspace.nx_pppm; env.pppm_ny = kspace.ny_pppm; env.pppm_nz = kspace.nz_pppm; env.pppm_order = kspace.order;
     conp_fix *book = nullptr;
     must(conp_fix_create(&fa, &env, &book));
     // (the bookkeeping handle of a multi-rank run would need the comm too; the provider test with ranks uses FixConpHip instead)
@@ -209,8 +211,20 @@ int run_case(const char *path, bool provider, int me, int nprocs, MockCommRank *
     fixstub.elenum = info.elenum; fixstub.elenum_all = info.elenum_all; fixstub.elytenum = info.elytenum;
     fixstub.ele2tag = ele2tag.data(); fixstub.ele2eleall = ele2eleall.data(); fixstub.eleall2tag = eleall2tag.data();
     fixstub.tag2eleall = tag2eleall.data();
-    // fix_conp.cpp:408-410: kspmod = new ...(lmp); kspmod->register_fix(this); kspmod->conp_setup(lowmemflag);
-    KSpaceModule *kspmod = new KSpaceModuleHip(&lmp);
+    // fix_conp.cpp:401-410: with the `pppm` keyword the provider IS the kspace style, found by dynamic_cast; else
+    // kspmod = new ...(lmp); then kspmod->register_fix(this); kspmod->conp_setup(lowmemflag);
+    KSpaceModule *kspmod = nullptr;
+    PPPMConpHip *pppm_style = nullptr;
+    if (fa.pppm) {
+      pppm_style = new PPPMConpHip(&lmp);                       // what `kspace_style pppm/conp/hip` creates
+      pppm_style->g_ewald = kspace.g_ewald; pppm_style->accuracy = kspace.accuracy; pppm_style->slab_volfactor = kspace.slab_volfactor;
+      pppm_style->slabflag = kspace.slabflag; pppm_style->energy = 0.0;
+      pppm_style->nx_pppm = kspace.nx_pppm; pppm_style->ny_pppm = kspace.ny_pppm; pppm_style->nz_pppm = kspace.nz_pppm;
+      pppm_style->order = kspace.order;
+      force.kspace = pppm_style;
+      kspmod = dynamic_cast<KSpaceModule *>(force.kspace);      // fix_conp.cpp:402
+      if (kspmod == nullptr) throw std::runtime_error("Fix conp couldn't detect a pppm/conp kspace style (which is required with the pppm flag)");
+    } else kspmod = new KSpaceModuleHip(&lmp);
     fixstub.kspmod = kspmod;
     kspmod->register_fix(&fixstub);
     kspmod->conp_setup(true);
@@ -224,7 +238,16 @@ int run_case(const char *path, bool provider, int me, int nprocs, MockCommRank *
       for (int j = 0; j < info.elenum_all; ++j) out.f("a %d %d %.17g\n", i, j, aaa[(size_t)i * info.elenum_all + j]);
     }
     for (int i = 0; i < info.elenum; ++i) out.f("m %d %d\n", i, ele2eleall[i]);
-    delete kspmod;                                 // fix_conp.cpp:207: the fix deletes its Ewald provider; the handle goes with it
+    if (pppm_style) {      // what ComputePotentialAtom asks of the provider (compute_potential_atom.cpp:165-175), group 1 = eleleft
+      std::vector<double> recv(nlocal, 0.0);
+      kspmod->compute_group_potential(gb, recv.data());
+      for (int i = 0; i < nlocal; ++i) if (mask[i] & gb) out.f("u %d %.17g\n", tag[i], recv[i]);
+      int i0 = 0;
+      while (i0 < nlocal && !(mask[i0] & gb)) ++i0;
+      out.f("up %d %.17g\n", tag[i0], kspmod->compute_particle_potential(i0));
+      force.kspace = &kspace;
+      delete pppm_style;                           // LAMMPS deletes its kspace style, not the fix (fix_conp.cpp:207)
+    } else delete kspmod;                          // fix_conp.cpp:207: the fix deletes its Ewald provider; the handle goes with it
     return 0;
   }
 

@@ -19,14 +19,16 @@ typedef int64_t bigint;
 
 class Error { public: [[noreturn]] void all(const char *, int, const std::string &); void warning(const char *, int, const std::string &); };
 class Memory {};
-class Atom { public: int nlocal, nghost, ntypes; bigint natoms; double **x, **f, *q; int *type, *mask; tagint *tag; int map(tagint);
+class Atom { public: int nlocal, nghost, ntypes, nmax = 0; bigint natoms; double **x, **f, *q; int *type, *mask, *molecule = nullptr; tagint *tag; int map(tagint);
              int *map_array = nullptr; int map_size = 0; };
 class KSpace { public: double g_ewald, accuracy, slab_volfactor, energy; int slabflag; int nx_pppm = 0, ny_pppm = 0, nz_pppm = 0, order = 0;
+               int compute_flag = 1, tip4pflag = 0; double qsum = 0.0;
                virtual ~KSpace() {} virtual void setup(); };
-class Pair { public: double **cutsq; double eng_coul, virial[6]; double cut_coul = 0.0; virtual ~Pair() {} virtual void *extract(const char *, int &); void ev_tally(int, int, int, int, double, double, double, double, double, double); };
-class Force { public: double qqrd2e, qqr2e, qe2f, dielectric; int newton_pair; KSpace *kspace; Pair *pair; Pair *pair_match(const std::string &, int, int nsub = 0); };
+class NeighList;
+class Pair { public: double **cutsq; double eng_coul, virial[6]; double cut_coul = 0.0; NeighList *list = nullptr; virtual ~Pair() {} virtual void *extract(const char *, int &); void ev_tally(int, int, int, int, double, double, double, double, double, double); };
+class Force { public: double qqrd2e, qqr2e, qe2f, dielectric; int newton_pair, newton = 0; KSpace *kspace; Pair *pair; Pair *pair_match(const std::string &, int, int nsub = 0); };
 class Domain { public: double xprd, yprd, zprd, zprd_half, boxlo[3]; };
-class Update { public: bigint ntimestep, laststep; char *integrate_style; };
+class Update { public: bigint ntimestep, laststep, eflag_atom = 0; char *integrate_style; };
 class Comm { public: int me, nprocs; };
 class Group { public: int *bitmask; int find(const std::string &); int ngroup = 0; std::string names[32]; };
 class Variable { public: int find(const char *); int equalstyle(int); double compute_equal(int);
@@ -49,6 +51,27 @@ class Pointers {
  protected:
   LAMMPS *lmp; MPI_Comm &world; Memory *&memory; Error *&error; Atom *&atom; Force *&force; Domain *&domain; Update *&update; Comm *&comm;
   Group *&group; Input *&input; Neighbor *&neighbor; Modify *&modify; FILE *&screen; FILE *&logfile;
+};
+
+// LAMMPS' PPPM kspace style and Compute base, as far as pppm_conp_hip.* / compute_potential_atom_hip.* touch them
+class PPPM : public KSpace, protected Pointers {
+ public:
+  explicit PPPM(LAMMPS *l) : Pointers(l) {}
+};
+class Compute : protected Pointers {
+ public:
+  Compute(LAMMPS *l, int narg, char **arg) : Pointers(l) {
+    igroup = narg > 1 ? l->group->find(arg[1]) : 0;
+    groupbit = igroup >= 0 ? l->group->bitmask[igroup] : 0;
+  }
+  virtual ~Compute() {}
+  int igroup, groupbit, peratom_flag = 0, size_peratom_cols = 0, peatomflag = 0, timeflag = 0, comm_reverse = 0;
+  bigint invoked_peratom = -1;
+  double *vector_atom = nullptr;
+  virtual void init() {}
+  virtual void setup() {}
+  virtual void compute_peratom() {}
+  virtual double memory_usage() { return 0.0; }
 };
 
 namespace FixConst { enum { POST_NEIGHBOR = 1 << 3, PRE_FORCE = 1 << 5, POST_FORCE = 1 << 7, END_OF_STEP = 1 << 10 }; }

@@ -8,9 +8,14 @@
  * port").  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
  * Every function cites the reference file:line whose arithmetic (operation order included) it
- * follows; citations are relative to /root/reference.  No reference source text is copied:
- * this file is C, uses its own data model (flat arrays, CSR neighbour lists, explicit
- * "atoms view" instead of LAMMPS classes) and restates the loops from the mathematics.
+ * follows; citations are relative to /root/reference.  This file is C with its own data model
+ * (flat arrays, CSR neighbour lists, an explicit "atoms view" instead of LAMMPS classes).  Where
+ * bit-exactness with the reference depends on the ORDER of operations -- orc_inv_project,
+ * orc_cg, the inner loop of orc_sincos_b -- the loops deliberately follow the cited lines
+ * statement by statement, down to the reference's variable names, so that a reader can check
+ * them side by side: those functions are a transliteration, not an independent derivation.
+ * That is the point of an oracle; it is also why nothing outside tests/, smoke() and the
+ * cpu_baseline leg may ever load this file.
  *
  * PARITY PIN (see DESIGN.md "Oracle"): the reference itself cannot be built in this image
  * (it needs the LAMMPS 27May2021 headers and library, which are absent, and writing stand-ins

@@ -197,11 +197,37 @@ def test_headline_b_vector_matches_oracle(oracle, headline):
     ks.close(); o.fx.close()
 
 
+def test_headline_inverse_really_inverts(headline):
+    """Ne = 4096: the matrix the GEMV streams IS the projected inverse of the Ewald matrix, not merely symmetric with zero row
+    sums.  A is rebuilt by a second handle (a_cal only, before any inverse); with P = A^-1 e e^T / (e^T A^-1 e) the projection
+    gives S A = I - P, hence  S (A v) = v  for every v with sum(v) = 0, and  S A e' = e' - A^-1 e (e^T e')/(e^T A^-1 e).
+    Checked with random probe vectors (O(n^2) each) and, through conp_invert on the same A, the plain inverse:  inv (A v) = v."""
+    s, at, alist, blist, fx = headline
+    S = fx.matrix()
+    fa = FixConp(s)
+    fa.init_lists(alist, blist)
+    fa.setup_post_neighbor(at)
+    fa.a_cal(at)
+    A = fa.matrix()
+    n = A.shape[0]
+    assert np.array_equal(A, A.T) and np.all(np.diag(A) > 0)
+    rng = np.random.default_rng(11)
+    V = rng.normal(size=(n, 6))
+    V0 = V - V.mean(axis=0)                                  # zero-sum probes
+    assert np.abs(S @ (A @ V0) - V0).max() < 1e-8 * np.abs(V0).max()
+    inv = fa.invert(A)                                       # the blocked Gauss-Jordan on the device, Ne = 4096
+    assert np.abs(inv @ (A @ V) - V).max() < 1e-8 * np.abs(V).max()
+    ainve = inv.sum(axis=1)
+    Sref_V = inv @ V - np.outer(ainve, ainve @ V) / ainve.sum()      # fix_conp.cpp:1011-1020 applied to the probes
+    assert np.abs(S @ V - Sref_V).max() < 1e-8 * np.abs(Sref_V).max()
+    fa.close()
+
+
 def test_headline_properties(headline):
     s, at, alist, blist, fx = headline
     S = fx.matrix()
     n = S.shape[0]
-    # projected inverse: symmetric, S e = 0 (electroneutrality for any b), S A S = S
+    # projected inverse: symmetric, S e = 0 (electroneutrality for any b)
     assert np.abs(S - S.T).max() / np.abs(S).max() < 1e-9
     assert np.abs(S.sum(axis=1)).max() / np.abs(S).max() < 1e-9
     # one update: charges neutral, scalar consistent, electrolyte untouched

@@ -273,3 +273,44 @@ def test_several_mpi_ranks_match_one_rank(tmp_path, name, axis, nranks):
         assert max(abs(res["q"][ts][t] - qref[t]) for t in ele_tags) < 1e-9 * scale, ts
         for r in range(nranks):
             assert res["scalar_by_rank"][r][ts] == pytest.approx(sc, rel=1e-9, abs=1e-12)
+
+
+def test_pppm_conp_hip_kspace_style_executed(tmp_path):
+    """`kspace_style pppm/conp/hip` (PPPMConpHip : PPPM, KSpaceModule): found by the dynamic_cast of fix_conp.cpp:402 when the fix
+    carries the `pppm` keyword, then conp_setup / conp_post_neighbor / a_cal / b_cal, and the mesh potentials ComputePotentialAtom
+    asks a provider for (compute_group_potential, compute_particle_potential) -- equal to the C-ABI calls through ctypes"""
+    s = systems.deck("dilute", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    mesh, order = (27, 24, 144), 5
+    case = str(tmp_path / "case.txt")
+    write_case(case, s, at, [alist, blist], fix_command_for(s, extra=["pppm"]), [(0, s.potdiff, 0, None)], mesh=(*mesh, order))
+    res, proc = run_driver(case, str(tmp_path), "provider")
+    assert res["rc"] == 0 and res["error"] is None, proc.stdout[-2000:] + proc.stderr[-2000:]
+    b_loc, e2ea, u, up = {}, {}, {}, None
+    for line in proc.stdout.splitlines():
+        t = line.split()
+        if t[0] == "b":
+            b_loc[int(t[1])] = float(t[2])
+        elif t[0] == "m":
+            e2ea[int(t[1])] = int(t[2])
+        elif t[0] == "u":
+            u[int(t[1])] = float(t[2])
+        elif t[0] == "up":
+            up = (int(t[1]), float(t[2]))
+    fx = FixConp(s, extra_args=["pppm"], pppm_mesh=mesh, pppm_order=order)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    b_all = fx.km_b_cal(at)
+    scale = np.abs(b_all).max()
+    assert len(b_loc) == fx.info().elenum
+    for i in range(len(b_loc)):
+        assert abs(b_loc[i] - b_all[e2ea[i]]) <= 1e-12 * scale          # f64 atomics in the spread: equal up to the order of additions
+    sel = (at.echeck[:at.nlocal] == 1).astype(np.int32)
+    want = fx.pppm_group_potential(at, sel)
+    tags = at.tag[:at.nlocal]
+    assert sorted(u) == sorted(int(t) for t in tags[sel != 0])
+    for i in np.nonzero(sel)[0]:
+        assert abs(u[int(tags[i])] - want[i]) <= 1e-12 * np.abs(want).max()
+    i0 = int(np.nonzero(tags == up[0])[0][0])
+    assert up[1] == pytest.approx(fx.pppm_particle_potential(at, i0), rel=1e-11)
+    fx.close()
