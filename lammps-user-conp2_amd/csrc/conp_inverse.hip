@@ -125,8 +125,9 @@ __global__ __launch_bounds__(1024) void inv_panel_lu_kernel(int m, int k0, int n
 //   after the barrier   every workgroup picks the same winner (largest |value|, lowest row index on ties = LAPACK idamax),
 //                       reads the winner's row, the owners of rows j / p exchange them in LDS, everybody eliminates
 // Slots are double-buffered by column parity (a workgroup can be at most one barrier ahead).  Only the pivots and the top
-// 64 x 64 block (L11, U11) leave the kernel -- nothing downstream reads L21.  The barrier is a monotonic agent-scope counter;
-// the spin is bounded so that every wave terminates even if a workgroup were not resident (info = -7).
+// 64 x 64 block (L11, U11) leave the kernel -- nothing downstream reads L21.  The barrier is a monotonic agent-scope counter
+// polled with sc1 loads; the exchanged slots are sc1 stores / sc1 loads, no cache-wide fences.  The spin is bounded so that
+// every wave terminates even if a workgroup were not resident (info = -7).
 constexpr int PC_MAXG = 256;
 constexpr int PC_LD = INV_NB + 1;
 
@@ -172,29 +173,42 @@ __global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int 
         if (pc_better(ov, oi, best, bi)) { best = ov; bi = oi; }
       }
       best = __shfl(best, 0, 64); bi = __shfl(bi, 0, 64);
-      if (lane == 0) { cval[par * PC_MAXG + wg] = best; cidx[par * PC_MAXG + wg] = bi; }
-      if (best >= 0.0) crow[((size_t)par * PC_MAXG + wg) * INV_NB + lane] = rows[(bi - r0) * PC_LD + lane];
+      // Hand-off without fences (an agent-scope release / acquire pair writes back and invalidates whole caches: 3.4 - 8 us per
+      // column, i.e. most of the panel's time): every published value is a write-through (sc1) store, the storing waves drain
+      // their stores (vmcnt 0) before the workgroup's ONE ticket add, and every read of a published value below is an sc1 load
+      // (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 stores, vmcnt(0), barrier, agent atomic add; sc1 loads").
+      if (lane == 0) {
+        __hip_atomic_store(cval + par * PC_MAXG + wg, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cidx + par * PC_MAXG + wg, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (best >= 0.0)
+        __hip_atomic_store(crow + ((size_t)par * PC_MAXG + wg) * INV_NB + lane, rows[(bi - r0) * PC_LD + lane], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (wave == 1 && j >= r0 && j < r0 + nr) {
-      rowj[par * INV_NB + lane] = rows[(j - r0) * PC_LD + lane];
+      __hip_atomic_store(rowj + par * INV_NB + lane, rows[(j - r0) * PC_LD + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the published slots leave this XCD's L2 before the arrival count
     __syncthreads();
     if (t == 0) {                          // grid barrier #(j+1)
-      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = (unsigned)G * (unsigned)(j + 1);
       unsigned spins = 0;
-      while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         if (++spins > (1u << 22)) { s_abort = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
     __syncthreads();
     if (s_abort) { if (t == 0) *info = -7; return; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // the same winner in every workgroup
     double v = -2.0;
     int vi = 0x7fffffff, vw = 0;
-    if (t < G) { v = cval[par * PC_MAXG + t]; vi = cidx[par * PC_MAXG + t]; vw = t; }
+    if (t < G) {
+      v = __hip_atomic_load(cval + par * PC_MAXG + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vi = __hip_atomic_load(cidx + par * PC_MAXG + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vw = t;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const double ov = __shfl_down(v, off, 64);
@@ -221,10 +235,12 @@ __global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int 
     __syncthreads();
     if (!(s_best > 0.0)) return;
     const int p = s_p;
-    if (wave == 0) s_row[lane] = crow[((size_t)par * PC_MAXG + s_win) * INV_NB + lane];
+    if (wave == 0)
+      s_row[lane] = __hip_atomic_load(crow + ((size_t)par * PC_MAXG + s_win) * INV_NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (p != j) {                          // rows j and p change places
-      if (wave == 1 && p >= r0 && p < r0 + nr) rows[(p - r0) * PC_LD + lane] = rowj[par * INV_NB + lane];
+      if (wave == 1 && p >= r0 && p < r0 + nr)
+        rows[(p - r0) * PC_LD + lane] = __hip_atomic_load(rowj + par * INV_NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (wave == 2 && j >= r0 && j < r0 + nr) rows[(j - r0) * PC_LD + lane] = s_row[lane];
     }
     __syncthreads();

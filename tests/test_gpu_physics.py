@@ -78,6 +78,7 @@ def test_electrode_potential_is_the_applied_one(system, mode, solver):
         d = -0.5 * ev * ec[ele]
     resid = phi - dv * d
     spread = resid.max() - resid.min()
-    assert spread < (1e-9 if solver == "inv" else 1e-7) * dv * ev, (spread, dv * ev)
+    # (CG: the stop criterion (r.p)/Ne < 1e-16 leaves a residual potential of order sqrt(Ne * 1e-16))
+    assert spread < (1e-9 if solver == "inv" else 1e-6) * dv * ev, (spread, dv * ev)
     assert abs(q[ele].sum()) < 1e-12                                  # and the electrodes are neutral together
     fx.close()
