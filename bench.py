@@ -230,13 +230,13 @@ def main():
             t_ms = prof["sk_gemm"][0]
             ach = flops / (t_ms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pj = os.path.join(ROOT, "profiles", "r01_bench_headline_summary.json")
+            pj = os.path.join(ROOT, "profiles", "r02_bench_headline_summary.json")
             if args.workload == "headline" and world == 1 and os.path.exists(pj):
                 pm = json.load(open(pj)).get("pmc", {}).get("sk_gemm_kernel", {})
                 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                     # rocprofv3 reports KiB; FETCH_SIZE x2: gfx950 counts 16-B-per-lane streams at half (MI355X_MICROARCH.md, HBM)
                     traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-                    traffic_src = "profiles/r01_bench_headline_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    traffic_src = "profiles/r02_bench_headline_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             roofline = dict(bound="mfma", kernel="sk_gemm_kernel (v_mfma_f64_16x16x4_f64)", achieved=ach, peak=FP64_PEAK_TFLOPS,
                             unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=t_ms,
