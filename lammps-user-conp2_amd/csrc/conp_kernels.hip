@@ -329,6 +329,125 @@ __device__ unsigned long long sk_clock_buf[1024 * 4];       // [workgroup][s_mem
 #define SK_STAMP_ADD(sum, a, b) do { } while (0)
 #endif
 
+// ================================================================================================
+// SK_INTERLEAVE build (-DSK_INTERLEAVE=1): every wave plays the same role.  Per chunk a wave multiplies panel c and, in the
+// second half of its MFMA stream, builds its share of panel c+1 one small piece at a time BETWEEN row-fragment groups of MFMAs
+// (7 pieces: two planar-vector pairs, five kz steps), so that neither SIMD partner ever leaves the matrix pipe to the other
+// for a whole build phase.  Branch-free: every thread always builds (features beyond the sphere cut land in panel rows nobody
+// reads), the chunk after the last one re-reads the last chunk's table rows and is never multiplied.
+// ================================================================================================
+#ifndef SK_INTERLEAVE
+#define SK_INTERLEAVE 0
+#endif
+#if SK_INTERLEAVE
+template <int P>
+__device__ __forceinline__ void sk_build_piece(const SkCtx &c, const SkRaw &r, double2 &Z, double *pn) {
+  if constexpr (P == 0) {
+    const double sy = c.sg0 < 0.0 ? -r.Y0.y : r.Y0.y;
+    pn[c.wa] = r.X0.x * r.Y0.x - r.X0.y * sy;
+    pn[c.wa + 64 * SK_LD] = r.X0.x * sy + r.X0.y * r.Y0.x;
+  } else if constexpr (P == 1) {
+    const double sy = c.sg1 < 0.0 ? -r.Y1.y : r.Y1.y;
+    pn[c.wa + 32 * SK_LD] = r.X1.x * r.Y1.x - r.X1.y * sy;
+    pn[c.wa + 96 * SK_LD] = r.X1.x * sy + r.X1.y * r.Y1.x;
+  } else if constexpr (P <= 6) {
+    constexpr int u = P - 2;
+    if constexpr (u == 0) Z = r.Zseed;
+    const int ml = 5 * c.gs + u;
+    const int at = (128 + 32 * (ml >> 4) + (ml & 15)) * SK_LD + (c.gj ^ (ml & 15));
+    pn[at] = Z.x;
+    pn[at + 16 * SK_LD] = Z.y;
+    if constexpr (u < 4) Z = zstep(Z, r.Zst);
+  }
+}
+
+// one row-fragment group of k-step KS: next A fragment on its way, (build piece), <= NFW MFMAs, B refills during the last group
+template <int NFW, int KS, int F>
+__device__ __forceinline__ void sk_fgroup(const SkCtx &c, const char *smem, unsigned ac, unsigned an, unsigned bn,
+                                          d4 (&acc)[4][NFW], double (&bf)[NFW], double &a0, const SkRaw &raw, double2 &Z, double *nxt) {
+  constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
+  const double a1 = F < 3 ? SK_LDS_F64(ac + (F + 1) * FA) : SK_LDS_F64(an);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (KS >= 2) sk_build_piece<(KS - 2) * 4 + F>(c, raw, Z, nxt);      // pieces 0..6 (7: nothing)
+#pragma unroll
+  for (int g = 0; g + 1 < NFW; ++g) {
+    acc[F][g] = MFMA_F64(a0, bf[g], acc[F][g]);
+    if constexpr (F == 3) { bf[g] = SK_LDS_F64(bn + g * FB); __builtin_amdgcn_sched_barrier(0); }
+  }
+  if (F < c.f0) acc[F][NFW - 1] = MFMA_F64(a0, bf[NFW - 1], acc[F][NFW - 1]);
+  if constexpr (F == 3) bf[NFW - 1] = SK_LDS_F64(bn + (NFW - 1) * FB);
+  __builtin_amdgcn_sched_barrier(0);
+  a0 = a1;
+}
+
+template <int NFW, int KS>
+__device__ __forceinline__ void sk_kstep(const SkCtx &c, const char *smem, unsigned ba, unsigned bb, d4 (&acc)[4][NFW],
+                                         double (&bf)[NFW], double &a0, const SkRaw &raw, double2 &Z, double *nxt) {
+  const unsigned q = (unsigned)(KS << 5) ^ c.pq, qn = (unsigned)(((KS + 1) & 3) << 5) ^ c.pq;
+  const unsigned ac = ba + q, an = ba + qn, bn = bb + qn;
+  sk_fgroup<NFW, KS, 0>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
+  sk_fgroup<NFW, KS, 1>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
+  sk_fgroup<NFW, KS, 2>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
+  sk_fgroup<NFW, KS, 3>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
+}
+
+template <int NFW>
+__device__ __forceinline__ void sk_chunk_interleaved(const SkCtx &c, char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1],
+                                                     const SkRaw &raw) {
+  double *nxt = reinterpret_cast<double *>(smem + (buf ^ SK_BUF1));
+  double2 Z = make_double2(0.0, 0.0);
+  if constexpr (NFW > 0) {
+    constexpr unsigned FB = 64 * SK_LD * 8;
+    const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
+    double bf[NFW], a0;
+#pragma unroll
+    for (int g = 0; g < NFW; ++g) bf[g] = SK_LDS_F64(bb + c.pq + g * FB);
+    a0 = SK_LDS_F64(ba + c.pq);
+    sk_kstep<NFW, 0>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
+    sk_kstep<NFW, 1>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
+    sk_kstep<NFW, 2>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
+    sk_kstep<NFW, 3>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
+  } else {
+    sk_build_piece<0>(c, raw, Z, nxt); sk_build_piece<1>(c, raw, Z, nxt); sk_build_piece<2>(c, raw, Z, nxt);
+    sk_build_piece<3>(c, raw, Z, nxt); sk_build_piece<4>(c, raw, Z, nxt); sk_build_piece<5>(c, raw, Z, nxt);
+    sk_build_piece<6>(c, raw, Z, nxt);
+  }
+}
+
+template <int NFW, bool late_unused>
+__device__ __forceinline__ void sk_body(const SkCtx &cin, char *smem, double *out) {
+  SkCtx c = cin;
+  c.zact = true;                       // every thread builds its five kz values (see above)
+  d4 acc[4][NFW > 0 ? NFW : 1];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < (NFW > 0 ? NFW : 1); ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
+  SkRaw raw;
+  const int clast = c.it.c1 - 1;
+  sk_load_raw(c, c.it.c0, raw);
+  sk_build_panel(c, raw, reinterpret_cast<double *>(smem));
+  sk_load_raw(c, c.it.c0 + 1 <= clast ? c.it.c0 + 1 : clast, raw);
+  __syncthreads();
+  unsigned buf = 0;
+  for (int ch = c.it.c0; ch < c.it.c1; ++ch, buf ^= SK_BUF1) {
+    sk_chunk_interleaved<NFW>(c, smem, buf, acc, raw);            // multiplies panel ch, builds panel ch + 1 out of `raw`
+    sk_load_raw(c, ch + 2 <= clast ? ch + 2 : clast, raw);        // for the build inside the NEXT iteration
+    __syncthreads();
+  }
+  {
+    unsigned lane_off = (unsigned)((64 * c.rh + c.fk) * 320 + 16 * c.cg + c.fr);
+    asm volatile("" : "+v"(lane_off));
+    double *o = out + lane_off;
+#pragma unroll
+    for (int g = 0; g < NFW; ++g)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(16 * f + 4 * r) * 320 + 64 * g] = acc[f][g][r];
+  }
+}
+#else
 // One segment = (tile, chunk range).  Between two barriers the workgroup multiplies chunk c (panel buffer c&1) and
 // builds chunk c+1 (other buffer).  The two waves of a SIMD (w and w+4) do this in OPPOSITE order -- waves 0-3
 // multiply first, waves 4-7 build first -- so one wave's operand generation overlaps its partner's MFMAs.
@@ -403,6 +522,8 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
   }
 #endif
 }
+
+#endif   // SK_INTERLEAVE
 
 // Persistent-style launch: workgroup w runs the segments seg_ptr[w] .. seg_ptr[w+1]-1 (host: equal cost per workgroup,
 // a segment boundary may fall inside a tile -- "stream-K" over the atom chunks).
