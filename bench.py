@@ -123,10 +123,24 @@ def main():
     # multi-rank: the library makes its own RCCL communicator (rank 0's unique id travels through torch.distributed) and runs
     # the collectives on its own stream, in order with its kernels.  The rehearsal on a one-GPU box cannot (RCCL refuses two
     # ranks on one device): it keeps the Python choreography over gloo.
-    if world > 1 and rehearse:
+    lib_collectives = world > 1 and not rehearse
+    if lib_collectives:
+        # should the library's own communicator not come up on some rank (RCCL missing, version clash), every rank falls back
+        # to the Python choreography over torch.distributed: the scaling run must not die of it
+        ok = 1
+        try:
+            fx.comm_init_rccl()
+        except Exception as e:          # noqa: BLE001
+            ok = 0
+            print(f"[bench] rank {rank}: conp_fix_comm_init_rccl failed ({e}); falling back to torch.distributed collectives", file=sys.stderr)
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                raise SystemExit("bench: a partner rank has no library communicator and this one has: cannot mix")
+            lib_collectives = False
+    if world > 1 and not lib_collectives:
         fx.set_stream(torch.cuda.current_stream().cuda_stream)
-    elif world > 1:
-        fx.comm_init_rccl()
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
     t_a0 = time.perf_counter()
@@ -140,7 +154,7 @@ def main():
     d_q = torch.from_numpy(at.q.copy()).cuda()
     d_b = torch.zeros(ne, dtype=torch.float64, device="cuda")
     d_sol = torch.zeros(ne, dtype=torch.float64, device="cuda")
-    if world == 1 or rehearse:
+    if not lib_collectives:
         fx.bind_device_buffers(d_b.data_ptr(), d_sol.data_ptr())
     row0, row1 = fx.row_range()
     potdiff = s.potdiff
@@ -166,7 +180,7 @@ def main():
     backend = HipBackend()
 
     def step():
-        if world == 1 or not rehearse:
+        if world == 1 or lib_collectives:
             fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), potdiff)      # N > 1: all-reduce(b) / all-gather(q) inside, on RCCL
         else:
             sharded_update(backend, ne, rank, world)
@@ -263,7 +277,7 @@ def main():
                                accuracy_relative=s.accuracy_relative, mode="ffield" if s.ff_flag == 1 else "slab",
                                solver="inv", kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
                                blist_pairs=int(info.n_blist_pairs),
-                               parallelism=f"k-shard+row-shard x{world}" + (", RCCL inside libconp_hip" if world > 1 and not rehearse else "")),
+                               parallelism=f"k-shard+row-shard x{world}" + (", RCCL inside libconp_hip" if lib_collectives else "")),
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
                    ms_per_step_host_buffers_pcie=host_ms,
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),

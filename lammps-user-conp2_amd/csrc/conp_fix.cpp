@@ -1163,6 +1163,8 @@ struct conp_fix {
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     // real-space rows: with replicated atoms this rank's row range; a sub-domain's list holds its own electrode atoms' rows only
     const int rr0 = !coulyes ? 0 : (decomposed ? 0 : row0), rr1 = !coulyes ? 0 : (decomposed ? ne : row1);
+    bool ride = false, use_fin = false;
+    BRowArgs fin{};
     if (args.pppm) {
       // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
       prof.begin("pppm_b", stream);
@@ -1173,10 +1175,21 @@ struct conp_fix {
         d_bk.zero(stream);
       prof.end(stream);
     } else {
+      // the real-space pair sums depend on x, q only: they ride along in the phase kernel's launch (spare blocks) unless the
+      // host-buffer hooks are timing the two halves of b_cal separately (Ktime / Ctime, fix_conp.cpp:553-568)
+      BRowArgs pairs = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 0,
+                                 nullptr, 0, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
+      ride = !no_fuse && !timed;
       prof.begin("elyte_phase", stream);
       launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
-                         plan.kymax, plan.nz, KPlan::ZSTRIDE, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &n_slab_part);
+                         plan.kymax, plan.nz, KPlan::ZSTRIDE, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
+                         &n_slab_part, ride ? &pairs : nullptr, d_breal.p);
       prof.end(stream);
+      // with the pair sums in hand and a small z-class table the dot kernel can finish b itself: no b_real_combine launch
+      fin = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 1, d_bk.p, slab,
+                      d_ele_z.p, d_slab_part.p, n_slab_part, 4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
+      fin.breal = d_breal.p;
+      use_fin = ride && nzc > 0 && zc_final_fits((int)own_rt_h.size(), nzc);
       prof.begin("sk_gemm", stream);
       launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                      d_Gpart.p);
@@ -1185,7 +1198,8 @@ struct conp_fix {
         // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)
         prof.begin("reduce_project", stream);
         launch_reduce_project_zclass(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, ne_pad,
-                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p);
+                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p,
+                                     use_fin ? &fin : nullptr);
         prof.end(stream);
       } else {
         prof.begin("sk_reduce", stream);
@@ -1194,18 +1208,20 @@ struct conp_fix {
         prof.begin("b_project", stream);
         if (nzc > 0)
           launch_b_project_zclass(stream, dplan, ne_pad, d_rt_mine.p, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Gw.p, d_Tzc.p, d_Rp.p,
-                                  d_zclass.p, d_Hc.p, d_bk.p);
+                                  d_zclass.p, d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);
         else
           launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
         prof.end(stream);
       }
     }
     if (timed) HIP_TRY(hipEventRecord(ev_b[1], stream));
-    prof.begin("b_real_combine", stream);
-    launch_b_real_combine(stream, ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
-                          d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
-                          4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
-    prof.end(stream);
+    if (!use_fin) {
+      prof.begin("b_real_combine", stream);
+      launch_b_real_combine(stream, ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq,
+                            d_type.p, real_params(), 1, d_bk.p, slab, d_ele_z.p, d_slab_part.p, n_slab_part,
+                            4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2, ride ? d_breal.p : nullptr);
+      prof.end(stream);
+    }
     if (timed) { HIP_TRY(hipEventRecord(ev_b[2], stream)); ev_pending = true; }
     HIP_TRY(hipGetLastError());   // a refused launch (bad grid / LDS size) must not pass silently
   }

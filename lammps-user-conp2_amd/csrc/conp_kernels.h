@@ -40,6 +40,7 @@ struct BRowArgs {
   int n_slab_part;
   double slab_pref;
   double *b_out, *slab_out;
+  const double *breal;      // NULL: the real-space pair sums are formed by whoever assembles the row; else they are read here
 };
 inline BRowArgs make_brow(int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom, const int *oth_atom,
                           const double *x, const double *q, const int *type, RealParams rp, int add_k, const double *bk, int slab,
@@ -48,7 +49,7 @@ inline BRowArgs make_brow(int ne, int ne_pad, int row0, int row1, const int *row
   BRowArgs a;
   a.ne = ne; a.ne_pad = ne_pad; a.row0 = row0; a.row1 = row1; a.row_ptr = row_ptr; a.ele_atom = ele_atom; a.oth_atom = oth_atom;
   a.x = x; a.q = q; a.type = type; a.rp = rp; a.add_k = add_k; a.bk = bk; a.slab = slab; a.ele_z = ele_z; a.slab_part = slab_part;
-  a.n_slab_part = n_slab_part; a.slab_pref = slab_pref; a.b_out = b_out; a.slab_out = slab_out;
+  a.n_slab_part = n_slab_part; a.slab_pref = slab_pref; a.b_out = b_out; a.slab_out = slab_out; a.breal = nullptr;
   return a;
 }
 
@@ -78,7 +79,10 @@ void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, 
                        double *x, double *q);
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, int nrz, double2 *Xt,
-                        double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part);
+                        double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part,
+                        const BRowArgs *rows /*NULL, or: the real-space pair sums of these rows ride along, into breal_out*/,
+                        double *breal_out);
+bool zc_final_fits(int n_own, int nzc);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
@@ -90,15 +94,17 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
 // planar-electrode fast path of the projection (<= 64 distinct electrode z values)
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part);
+                                  const int *zclass, double *Hc, double *bk_part,
+                                  const BRowArgs *fin /*non-NULL (needs fin->breal): the dot kernel finishes b itself*/);
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
                              const double *Tzc /*[C_pad][64]*/, const double *Rp, const int *zclass /*[ne_pad]*/,
-                             double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/);
+                             double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/, const BRowArgs *fin);
 // this rank's contribution to b in one launch: k-space halves + slab (rank 0) + real-space rows row0..row1
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
                            const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,
                            const double *bk, int slab, const double *ele_z, const double *slab_part, int n_slab_part,
-                           double slab_pref, double *b_out, double *slab_out);
+                           double slab_pref, double *b_out, double *slab_out,
+                           const double *breal = nullptr /*pair sums formed earlier in this update, or NULL: formed here*/);
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);
 // all rows + the charge write of plain `fix conp` in one launch (atoms_ptr / atoms_of: electrode row -> its owned and ghost atoms)
 void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, double *y, const double *elesetq,

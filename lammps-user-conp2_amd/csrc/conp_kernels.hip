@@ -27,6 +27,81 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- erfc(x)/r through the reference's 5-term polynomial (fix_conp.cpp:53-60, 1446-1454) and the pair potentials -------------
+__device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
+#pragma clang fp contract(off)
+  if (a2_r2 < 5.8 * 5.8) {
+    const double a_r = sqrt(a2_r2);
+    const double expm2 = exp(-a2_r2);
+    const double t = 1.0 / (1.0 + 0.3275911 * a_r);
+    return t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2 / a_r;
+  }
+  return 0.0;
+}
+
+// pair_potential of the reference (fix_conp.cpp:1467-1475 eta_potential_A / eta_potential, :1561-1566 ehgo_potential)
+__device__ __forceinline__ double pair_potential_dev(const RealParams &rp, double rsq, int ti, int tj, bool for_a) {
+#pragma clang fp contract(off)
+  if (rp.ehgo) {
+    const double etaij = rp.eta_ij[ti * (rp.ntypes + 1) + tj], foij = rp.fo_ij[ti * (rp.ntypes + 1) + tj];
+    const double etarij2 = etaij * etaij * rsq;
+    return foij * exp(-0.5 * etarij2) - erfcr_sqrt_dev(etarij2) * etaij;
+  }
+  if (for_a) {
+    const double etarij2 = rp.eta * rp.eta * rsq / 2;
+    return -erfcr_sqrt_dev(etarij2) * rp.eta / sqrt(2.0);
+  }
+  return -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
+}
+
+// One electrode row of b, by one wave (all 64 lanes return the same values):
+//   b[row] = (bk0 + bk1) + (bk2 + bk3)                           (k-space shard, km_ewald.cpp:789-825)
+//          - z_row * sum_j 4 pi q_j z_j / V                      (slab, km_ewald.cpp:827-847; rank 0 only)
+//          - sum_pairs q_j [erfc(g r) - erfc(eta r)] / r         (rows row0..row1 only; fix_conp.cpp:1313-1353)
+__device__ __forceinline__ double b_slab_scalar(const BRowArgs &a, int lane) {
+#pragma clang fp contract(off)
+  double sp = 0.0;
+  for (int k = lane; k < a.n_slab_part; k += 64) sp += a.slab_part[k];
+  sp = wave_sum(sp);
+  return a.slab_pref * __shfl(sp, 0, 64);
+}
+// the real-space pair sum of one row by one wave (all lanes return it)
+__device__ __forceinline__ double b_row_pairs(const BRowArgs &a, int row, int lane) {
+#pragma clang fp contract(off)
+  const int nt1 = a.rp.ntypes + 1;
+  double sum = 0.0;
+  if (row >= a.row0 && row < a.row1) {
+    for (int p = a.row_ptr[row] + lane; p < a.row_ptr[row + 1]; p += 64) {
+      const int ie = a.ele_atom[p], jo = a.oth_atom[p];
+      const double dx = a.x[3 * ie] - a.x[3 * jo], dy = a.x[3 * ie + 1] - a.x[3 * jo + 1], dz = a.x[3 * ie + 2] - a.x[3 * jo + 2];
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq < a.rp.cutsq[a.type[ie] * nt1 + a.type[jo]] && rsq < a.rp.cut_coulsq) {
+        double dudq = erfcr_sqrt_dev(a.rp.g_ewald * a.rp.g_ewald * rsq) * a.rp.g_ewald;
+        dudq += pair_potential_dev(a.rp, rsq, a.type[ie], a.type[jo], false);
+        sum -= a.q[jo] * dudq;
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  return __shfl(sum, 0, 64);
+}
+__device__ __forceinline__ void b_row(const BRowArgs &a, int row, int lane, double sc) {
+#pragma clang fp contract(off)
+  // a.breal != NULL: the pair sums were formed earlier in this update (by the spare blocks of elyte_phase_kernel)
+  const double sum = a.breal ? a.breal[row] : b_row_pairs(a, row, lane);
+  if (lane == 0) {
+    double v = 0.0;
+    if (a.add_k) {
+      const double k0 = a.bk[row], k1 = a.bk[a.ne_pad + row], k2 = a.bk[2 * (size_t)a.ne_pad + row], k3 = a.bk[3 * (size_t)a.ne_pad + row];
+      v = (k0 + k1) + (k2 + k3);
+    }
+    if (a.slab) v -= a.ele_z[row] * sc;
+    v += sum;
+    a.b_out[row] = v;
+    if (a.slab && row == 0 && a.slab_out) *a.slab_out = sc;
+  }
+}
+
 // ================================================================================================
 // 1. electrolyte phase tables  (km_ewald.cpp:685-724: libm cos/sin of unitk*x, then the angle-addition
 //    recurrence c_m = c_{m-1} c_1 - s_{m-1} s_1, s_m = s_{m-1} c_1 + c_{m-1} s_1)
@@ -35,16 +110,27 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ================================================================================================
 // One thread per (atom, axis): blockIdx.y = 0 (x), 1 (y), 2 (z) -- the three recurrences are independent, the z one is the
 // long one (nz steps), so splitting them puts 3x as many wavefronts on the chip for the same serial depth.
+// Blocks [0, 3 nb): the phase tables (axis c = block / nb).  Blocks beyond: the real-space pair sums of the electrode rows
+// (fix_conp.cpp:1313-1353), two rows per block -- they depend on x, q only, so they ride along in this launch (the chip is far
+// from full with the 3 nb phase blocks) instead of costing gather latency in a launch of their own after the structure factors.
 constexpr int EP_THREADS = 128;
-__global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nl, int nl_pad, const int *__restrict__ elyte_idx,
+__global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl, int nl_pad, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double ux, double uy, double uz, int kxmax, int kymax, int nz,
                                                           int zstride, int nrz, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
                                                           double2 *__restrict__ Zs, double *__restrict__ qc,
-                                                          double *__restrict__ slab_part) {
+                                                          double *__restrict__ slab_part, BRowArgs ra, double *__restrict__ breal_out) {
 #pragma clang fp contract(off)
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = blockIdx.y;
+  if ((int)blockIdx.x >= 3 * nb) {
+    const int row = ((int)blockIdx.x - 3 * nb) * (EP_THREADS / 64) + (threadIdx.x >> 6);
+    if (row < ra.ne) {
+      const double v = b_row_pairs(ra, row, threadIdx.x & 63);
+      if ((threadIdx.x & 63) == 0) breal_out[row] = v;
+    }
+    return;
+  }
+  const int c = (int)blockIdx.x / nb, bx = (int)blockIdx.x - c * nb;
+  const int j = bx * blockDim.x + threadIdx.x;
   double qz = 0.0;
   if (j < nl_pad) {
     double xc = 0, qq = 0;
@@ -88,7 +174,7 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nl, int nl_
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w];
-    slab_part[blockIdx.x] = tot;
+    slab_part[bx] = tot;
   }
 }
 
@@ -113,11 +199,15 @@ void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, 
 
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, int nrz, double2 *Xt,
-                        double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part) {
+                        double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part, const BRowArgs *rows,
+                        double *breal_out) {
   const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS;
   *n_slab_part = nb;
-  hipLaunchKernelGGL(elyte_phase_kernel, dim3(nb, 3), dim3(EP_THREADS), 0, s, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
-                     kymax, nz, zstride, nrz, Xt, Yt, Zs, qc, slab_part);
+  BRowArgs ra{};
+  int nrb = 0;
+  if (rows && breal_out) { ra = *rows; nrb = (ra.ne + EP_THREADS / 64 - 1) / (EP_THREADS / 64); }
+  hipLaunchKernelGGL(elyte_phase_kernel, dim3(3 * nb + nrb), dim3(EP_THREADS), 0, s, nb, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
+                     kymax, nz, zstride, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out);
 }
 
 // ================================================================================================
@@ -839,74 +929,6 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
   for (int r = 0; r < 4; ++r) out[(size_t)(16 * rf + fk + 4 * r) * 64 + 16 * wave + fr] = acc[r];
 }
 
-// ---- erfc(x)/r through the reference's 5-term polynomial (fix_conp.cpp:53-60, 1446-1454) and the pair potentials -------------
-__device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
-#pragma clang fp contract(off)
-  if (a2_r2 < 5.8 * 5.8) {
-    const double a_r = sqrt(a2_r2);
-    const double expm2 = exp(-a2_r2);
-    const double t = 1.0 / (1.0 + 0.3275911 * a_r);
-    return t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429)))) * expm2 / a_r;
-  }
-  return 0.0;
-}
-
-// pair_potential of the reference (fix_conp.cpp:1467-1475 eta_potential_A / eta_potential, :1561-1566 ehgo_potential)
-__device__ __forceinline__ double pair_potential_dev(const RealParams &rp, double rsq, int ti, int tj, bool for_a) {
-#pragma clang fp contract(off)
-  if (rp.ehgo) {
-    const double etaij = rp.eta_ij[ti * (rp.ntypes + 1) + tj], foij = rp.fo_ij[ti * (rp.ntypes + 1) + tj];
-    const double etarij2 = etaij * etaij * rsq;
-    return foij * exp(-0.5 * etarij2) - erfcr_sqrt_dev(etarij2) * etaij;
-  }
-  if (for_a) {
-    const double etarij2 = rp.eta * rp.eta * rsq / 2;
-    return -erfcr_sqrt_dev(etarij2) * rp.eta / sqrt(2.0);
-  }
-  return -erfcr_sqrt_dev(rp.eta * rp.eta * rsq) * rp.eta;
-}
-
-// One electrode row of b, by one wave (all 64 lanes return the same values):
-//   b[row] = (bk0 + bk1) + (bk2 + bk3)                           (k-space shard, km_ewald.cpp:789-825)
-//          - z_row * sum_j 4 pi q_j z_j / V                      (slab, km_ewald.cpp:827-847; rank 0 only)
-//          - sum_pairs q_j [erfc(g r) - erfc(eta r)] / r         (rows row0..row1 only; fix_conp.cpp:1313-1353)
-__device__ __forceinline__ double b_slab_scalar(const BRowArgs &a, int lane) {
-#pragma clang fp contract(off)
-  double sp = 0.0;
-  for (int k = lane; k < a.n_slab_part; k += 64) sp += a.slab_part[k];
-  sp = wave_sum(sp);
-  return a.slab_pref * __shfl(sp, 0, 64);
-}
-__device__ __forceinline__ void b_row(const BRowArgs &a, int row, int lane, double sc) {
-#pragma clang fp contract(off)
-  const int nt1 = a.rp.ntypes + 1;
-  double sum = 0.0;
-  if (row >= a.row0 && row < a.row1) {
-    for (int p = a.row_ptr[row] + lane; p < a.row_ptr[row + 1]; p += 64) {
-      const int ie = a.ele_atom[p], jo = a.oth_atom[p];
-      const double dx = a.x[3 * ie] - a.x[3 * jo], dy = a.x[3 * ie + 1] - a.x[3 * jo + 1], dz = a.x[3 * ie + 2] - a.x[3 * jo + 2];
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq < a.rp.cutsq[a.type[ie] * nt1 + a.type[jo]] && rsq < a.rp.cut_coulsq) {
-        double dudq = erfcr_sqrt_dev(a.rp.g_ewald * a.rp.g_ewald * rsq) * a.rp.g_ewald;
-        dudq += pair_potential_dev(a.rp, rsq, a.type[ie], a.type[jo], false);
-        sum -= a.q[jo] * dudq;
-      }
-    }
-  }
-  sum = wave_sum(sum);
-  if (lane == 0) {
-    double v = 0.0;
-    if (a.add_k) {
-      const double k0 = a.bk[row], k1 = a.bk[a.ne_pad + row], k2 = a.bk[2 * (size_t)a.ne_pad + row], k3 = a.bk[3 * (size_t)a.ne_pad + row];
-      v = (k0 + k1) + (k2 + k3);
-    }
-    if (a.slab) v -= a.ele_z[row] * sc;
-    v += sum;
-    a.b_out[row] = v;
-    if (a.slab && row == 0 && a.slab_out) *a.slab_out = sc;
-  }
-}
-
 // grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16.
 // The block first sums the 4 k-quarter slots of Hc for ITS rows and the nzc classes in use into LDS (one pass of coalesced
 // loads) -- reading them per thread and per row from global cost more than the 42 MB Rp stream itself (20 -> 11 us).
@@ -955,9 +977,76 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
   }
 }
 
+// ---- the same dot, finished in one launch: grid = ne_pad / 16 atom blocks; thread = (atom a of 16, row lane w of 64).  Every
+// thread walks 2 rows of each of this rank's row tiles (row = 128 tile + w, + 64), so a wave reads four 128-byte runs of Rp per
+// step; the four k-quarter slots of Hc are summed into LDS for ALL 128 rows of a tile; the 64 row lanes of an atom are added in
+// a fixed order; then slab term and real-space sum (already formed by elyte_phase's spare blocks): b is complete, no
+// b_real_combine launch.  Used when the whole Hc table of this rank fits in 64 KB of LDS (planar electrodes: 2-6 z classes).
+__global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
+                                                          const double *__restrict__ Rp, const double *__restrict__ Hc4,
+                                                          const int *__restrict__ zclass, BRowArgs ra) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) char zf_smem[];
+  double *H = reinterpret_cast<double *>(zf_smem);          // [n_own * 128][nzc]
+  __shared__ double red[64][17];
+  const int a = threadIdx.x & 15, w = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + a;
+  const int zc = zclass[i];
+  const size_t hp = (size_t)R_pad * 64;
+  // the slab scalar by the first wave, with b_real_combine's summation tree (the 16 finishing threads are lanes of that wave)
+  const double sc = (ra.slab && threadIdx.x < 64) ? b_slab_scalar(ra, threadIdx.x) : 0.0;
+  for (int e = threadIdx.x; e < n_own * 128 * nzc; e += 1024) {
+    const int rowl = e / nzc, cls = e - rowl * nzc;
+    const size_t r = (size_t)own_rt[rowl >> 7] * 128 + (rowl & 127);
+    H[e] = (Hc4[r * 64 + cls] + Hc4[hp + r * 64 + cls]) + (Hc4[2 * hp + r * 64 + cls] + Hc4[3 * hp + r * 64 + cls]);
+  }
+  __syncthreads();
+  double sum = 0.0;
+  for (int k0 = 0; k0 < n_own; k0 += 4) {        // 4 row tiles at a time: 8 Rp rows in flight per thread
+    double rp[8], hc[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = k0 + u < n_own;
+      const int kk = ok ? k0 + u : k0;
+      const int rt = own_rt[kk];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const size_t r = (size_t)rt * 128 + w + 64 * v;
+        rp[2 * u + v] = ok ? Rp[r * ne_pad + i] : 0.0;
+        hc[2 * u + v] = H[(kk * 128 + w + 64 * v) * nzc + zc];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += rp[k] * hc[k];
+  }
+  red[w][a] = sum;
+  __syncthreads();
+  if (w == 0 && i < ra.ne) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) tot += (red[k][a] + red[k + 1][a]) + (red[k + 2][a] + red[k + 3][a]);
+    double v = -tot;
+    if (ra.slab) v -= ra.ele_z[i] * sc;
+    v += ra.breal[i];
+    ra.b_out[i] = v;
+    if (ra.slab && i == 0 && ra.slab_out) *ra.slab_out = sc;
+  }
+}
+
 // (The four row-quarter partials of an atom are added, with the slab and real-space terms, by b_real_combine_kernel.  Letting the
 //  last-arriving quarter block of each atom block do that here -- sc1 hand-off, ticket -- was measured: 32 -> 47 us for the pair
 //  at the headline size, 22 -> 33 us on il_onelayer: 64 late workgroups do serially what 4096 waves of their own launch do at once.)
+// true when b_zc_final_kernel can take the place of b_zc_dot + b_real_combine
+bool zc_final_fits(int n_own, int nzc) { return n_own > 0 && (size_t)n_own * 128 * nzc * sizeof(double) <= 64 * 1024; }
+
+static void launch_b_zc_final(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
+                              const double *Hc, const int *zclass, const BRowArgs &fin) {
+  const size_t lds = (size_t)n_own * 128 * nzc * sizeof(double);
+  static DynLdsCache granted{};
+  ensure_dyn_lds(b_zc_final_kernel, lds, granted);
+  hipLaunchKernelGGL(b_zc_final_kernel, dim3(ne_pad / 16), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, fin);
+}
+
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
                             const double *Hc, const int *zclass, double *bk_part) {
   const size_t lds = (size_t)(n_own > 0 ? n_own : 1) * 32 * nzc * sizeof(double);      // the host keeps this <= 96 KB (conp_fix.cpp)
@@ -1023,7 +1112,7 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
 // sk_reduce (+ level 1 when tiles are heavily split) with the Hc product fused in, then the per-atom dot
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part) {
+                                  const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
   if (ntiles <= 0) return;
   const int nzc16 = (nzc + 15) / 16;
   int level = 0;
@@ -1034,15 +1123,17 @@ void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile
   }
   hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
                      nzc16, level);
-  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin);
+  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
-                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part) {
+                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
   const int nzc16 = (nzc + 15) / 16;
   hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
-  launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin);
+  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
 }
 
 // ================================================================================================
@@ -1063,10 +1154,11 @@ __global__ __launch_bounds__(256) void b_real_combine_kernel(BRowArgs a) {
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
                            const int *oth_atom, const double *x, const double *q, const int *type, RealParams rp, int add_k,
                            const double *bk, int slab, const double *ele_z, const double *slab_part, int n_slab_part,
-                           double slab_pref, double *b_out, double *slab_out) {
-  hipLaunchKernelGGL(b_real_combine_kernel, dim3((ne + 3) / 4), dim3(256), 0, s,
-                     make_brow(ne, ne_pad, row0, row1, row_ptr, ele_atom, oth_atom, x, q, type, rp, add_k, bk, slab, ele_z, slab_part,
-                               n_slab_part, slab_pref, b_out, slab_out));
+                           double slab_pref, double *b_out, double *slab_out, const double *breal) {
+  BRowArgs a = make_brow(ne, ne_pad, row0, row1, row_ptr, ele_atom, oth_atom, x, q, type, rp, add_k, bk, slab, ele_z, slab_part,
+                         n_slab_part, slab_pref, b_out, slab_out);
+  a.breal = breal;
+  hipLaunchKernelGGL(b_real_combine_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, a);
 }
 
 // ================================================================================================
