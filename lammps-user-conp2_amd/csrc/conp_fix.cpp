@@ -229,6 +229,10 @@ struct conp_fix {
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   int n_slab_part = 0;
   const bool no_fuse = getenv("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
+  // The host-buffer hooks report Ktime / Ctime (fix_conp.cpp:553-568).  By default they run the SAME kernels as the device hooks
+  // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
+  // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
+  const bool time_split = getenv("CONP_TIME_SPLIT") != nullptr;
   int max_nsplit = 0;              // most sk_gemm segments any tile is cut into (chooses sk_reduce's one- or two-level sum)
   DevPlan dplan{};
   Profiler prof;
@@ -617,7 +621,12 @@ struct conp_fix {
   // tile after tile, chunk after chunk, with cost (mean nba of the 4 row fragments + SK_C0) per chunk of 16 atoms (MFMA work ~ nba, operand
   // generation + barrier ~ SK_C0), and cut into num_cus equal shares.  A share is a list of segments (tile, chunk
   // range); every segment writes one partial tile, sk_reduce adds a tile's segments in order.
-  double SK_C0 = getenv("CONP_SK_C0") ? atof(getenv("CONP_SK_C0")) : 2.0;
+  // The two constants are a least-squares fit of per-segment lengths measured on the headline box (tools/sk_stamp.py ->
+  // gpurun_out/sk_segments.txt:  us = 0.475 * chunks * (mean nbf + 1.65) + 3.7 per segment): a segment's start (first panel with
+  // nothing to overlap it) and its partial-tile write cost as much as 7.7 units of chunk cost.  Round 1's model (C0 = 2, no
+  // per-segment term) left the heavy tiles' workgroups and those whose share straddles a tile boundary 3 % behind the rest.
+  double SK_C0 = getenv("CONP_SK_C0") ? atof(getenv("CONP_SK_C0")) : 1.65;
+  double SK_CSEG = getenv("CONP_SK_CSEG") ? atof(getenv("CONP_SK_CSEG")) : 7.7;
   void build_items() {
     const int nchunks = nl_pad / 16;
     const size_t nt = tiles_h.size();
@@ -628,37 +637,47 @@ struct conp_fix {
     nwg = std::min(nwg, std::max((int)(16 * nt), (int)((nt * (size_t)nchunks + 7) / 8)));
     nwg = std::max(1, nwg);
     if (getenv("CONP_SK_NWG")) nwg = std::max(1, atoi(getenv("CONP_SK_NWG")));
-    std::vector<double> start(nt + 1, 0.0);
     // MFMA work of a tile ~ mean over its 4 row fragments of their active kz blocks (per-fragment sphere culling)
     auto cost = [&](const SkTile &t) {
       double sum = 0.0;
       for (int f = 0; f < 4; ++f) sum += (double)((t.nbf >> (8 * f)) & 255u);
       return 0.25 * sum + SK_C0;
     };
-    for (size_t i = 0; i < nt; ++i) start[i + 1] = start[i] + nchunks * cost(tiles_h[i]);
-    const double W = start.back();
-    auto locate = [&](double pos, size_t &ti, int &ch) {
-      ti = 0;
-      while (ti + 1 < nt && pos >= start[ti + 1]) ++ti;
-      ch = (int)std::lround((pos - start[ti]) / cost(tiles_h[ti]));
-      ch = std::max(0, std::min(nchunks, ch));
-    };
+    // work left from (tile ti, chunk ch) to the end, without segment starts
+    std::vector<double> tail(nt + 1, 0.0);
+    for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + nchunks * cost(tiles_h[i]);
+    constexpr int MIN_SEG = 4;          // a shorter segment costs more in start-up than it carries
     items_h.clear();
     seg_ptr_h.assign(nwg + 1, 0);
     size_t ti = 0;
     int ch = 0;
     for (int w = 0; w < nwg && nt > 0; ++w) {
       seg_ptr_h[w] = (int)items_h.size();
-      size_t te = nt - 1;
-      int ce = nchunks;
-      if (w + 1 < nwg) locate(W * (w + 1) / nwg, te, ce);
-      while (ti < te) {
-        if (ch < nchunks) items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, nchunks, tiles_h[ti].nbf});
-        ++ti; ch = 0;
-      }
-      if (ti == te && ch < ce) {
-        items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, ce, tiles_h[ti].nbf});
-        ch = ce;
+      if (ti >= nt) continue;
+      const bool last = w + 1 == nwg;
+      // equal shares of what is left, counting one segment start per remaining workgroup and one per tile boundary ahead
+      const double left = tail[ti] - ch * cost(tiles_h[ti]) + SK_CSEG * ((double)(nwg - w) + (double)(nt - 1 - ti));
+      double budget = left / (nwg - w) - SK_CSEG;
+      bool first = true;
+      while (ti < nt) {
+        const double c = cost(tiles_h[ti]);
+        const int avail = nchunks - ch;
+        int take;
+        if (last) take = avail;
+        else {
+          if (!first) budget -= SK_CSEG;                     // starting another segment in this share
+          take = (int)std::lround(budget / c);
+          if (first) take = std::max(take, 1);
+          if (!first && take < MIN_SEG) break;               // not worth a new segment: the next workgroup starts this tile
+          if (avail - take < MIN_SEG) take = avail;          // do not leave a sliver of the tile behind
+          take = std::min(take, avail);
+        }
+        items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, ch + take, tiles_h[ti].nbf});
+        budget -= take * c;
+        ch += take;
+        first = false;
+        if (ch >= nchunks) { ++ti; ch = 0; }
+        if (!last && (budget < c || ch != 0)) break;         // share used up (or stopped inside a tile)
       }
     }
     for (int w = 0; w <= nwg; ++w) if (w == nwg || nt == 0) seg_ptr_h[w] = (int)items_h.size();
@@ -1176,10 +1195,10 @@ struct conp_fix {
       prof.end(stream);
     } else {
       // the real-space pair sums depend on x, q only: they ride along in the phase kernel's launch (spare blocks) unless the
-      // host-buffer hooks are timing the two halves of b_cal separately (Ktime / Ctime, fix_conp.cpp:553-568)
+      // host-buffer hooks were asked to time the two halves of b_cal separately (CONP_TIME_SPLIT; Ktime / Ctime, fix_conp.cpp:553-568)
       BRowArgs pairs = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 0,
                                  nullptr, 0, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
-      ride = !no_fuse && !timed;
+      ride = !no_fuse && !(timed && time_split);
       prof.begin("elyte_phase", stream);
       launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                          plan.kymax, plan.nz, KPlan::ZSTRIDE, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,

@@ -374,9 +374,15 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, 
     const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
     double bf[NFW], a0, a1;
     unsigned q = c.pq;                                                  // (ks ^ p) << 5 for ks = 0: the 32-byte group of k-step 0
-#pragma unroll
-    for (int g = 0; g < NFW; ++g) bf[g] = SK_LDS_F64(bb + q + g * FB);
+    // Issue order matters: LDS reads retire in order and the compiler's s_waitcnt at the top of the k-step loop must cover the
+    // loop entry AND the back edge.  A first, then the B fragments one instruction each (a paired ds_read2st64 here would merge
+    // two counter slots), exactly the order the loop body re-reads them in: the waits become lgkmcnt(NFW), (NFW-1), ... -- every
+    // fragment gets ~NFW MFMAs of cover.  (B first / A last made the loop head wait for the read issued JUST before it:
+    // one full LDS round trip per k-step with the matrix pipe idle.)
     a0 = SK_LDS_F64(ba + q);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NFW; ++g) { bf[g] = SK_LDS_F64(bb + q + g * FB); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll 1
     for (int ks = 0; ks < SK_J / 4; ++ks) {
       const unsigned qn = (unsigned)(((ks + 1) & 3) << 5) ^ c.pq;       // the group of the next k-step (wraps after the last)
@@ -407,6 +413,7 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, 
 #ifdef SK_STAMP
 __device__ unsigned long long sk_stamp_buf[1024 * 8 * 8];   // [workgroup][wave][prologue, load issue, mfma, build, barrier, epilogue, chunks, late]
 __device__ unsigned long long sk_clock_buf[1024 * 4];       // [workgroup][s_memtime start, end, s_memrealtime (100 MHz) start, end]
+__device__ unsigned long long sk_seg_buf[4096 * 4];         // [segment][workgroup << 32 | rt, nbf, chunks, s_memrealtime ticks]: cost-model fit
 #define SK_STAMP_T(t)                                                          \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
@@ -490,9 +497,10 @@ __device__ __forceinline__ void sk_chunk_interleaved(const SkCtx &c, char *smem,
     constexpr unsigned FB = 64 * SK_LD * 8;
     const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
     double bf[NFW], a0;
-#pragma unroll
-    for (int g = 0; g < NFW; ++g) bf[g] = SK_LDS_F64(bb + c.pq + g * FB);
     a0 = SK_LDS_F64(ba + c.pq);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NFW; ++g) { bf[g] = SK_LDS_F64(bb + c.pq + g * FB); __builtin_amdgcn_sched_barrier(0); }
     sk_kstep<NFW, 0>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
     sk_kstep<NFW, 1>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
     sk_kstep<NFW, 2>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
@@ -672,6 +680,9 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     c.zact = 5 * c.gs < 16 * c.it.nba;                  // this thread's 5 kz values lie in an active block
     c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * 16 + c.gj;
     double *out = part + (size_t)sg * (128 * 320);
+#ifdef SK_STAMP
+    const unsigned long long sg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (late) {
       switch (nfw) {
         case 5: sk_body<5, true>(c, smem, out); break;
@@ -691,6 +702,13 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
         default: sk_body<0, false>(c, smem, out); break;
       }
     }
+#ifdef SK_STAMP
+    if (t == 0 && sg < 4096) {
+      unsigned long long *o = sk_seg_buf + (size_t)sg * 4;
+      o[0] = ((unsigned long long)blockIdx.x << 32) | (unsigned)c.it.rt; o[1] = c.it.nbf; o[2] = (unsigned)(c.it.c1 - c.it.c0);
+      o[3] = __builtin_amdgcn_s_memrealtime() - sg_t0;
+    }
+#endif
   }
 #ifdef SK_STAMP
   if (t == 0 && blockIdx.x < 1024) {
@@ -703,6 +721,9 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
 #ifdef SK_STAMP
 extern "C" int conp_debug_sk_clock(unsigned long long *out /*[1024*4]*/) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_clock_buf), sizeof(unsigned long long) * 1024 * 4) == hipSuccess ? 0 : -1;
+}
+extern "C" int conp_debug_sk_segs(unsigned long long *out /*[4096*4]*/) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_seg_buf), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
 }
 extern "C" int conp_debug_sk_stamps(unsigned long long *out /*[1024*8*8]*/, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_stamp_buf), sizeof(unsigned long long) * 1024 * 8 * 8) != hipSuccess) return -1;
@@ -765,6 +786,15 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTil
       // 8 loads in flight; the association ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)) is fixed -> bitwise reproducible
       double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int sp = 0;
+      for (; sp + 16 <= count; sp += 16) {       // 16 partials in flight per element; additions in the order of the 8-wide loop
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += v[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += v[8 + u];
+      }
       for (; sp + 8 <= count; sp += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * step];
@@ -907,7 +937,7 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
 __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, const int *__restrict__ rt_mine, int nzc16,
                                                    const int *__restrict__ nb_act, const double *__restrict__ Gwf,
                                                    const double *__restrict__ Tzc /*[C_pad][64]*/,
-                                                   double *__restrict__ Hc4 /*[4][R_pad][64]*/, int R_pad) {
+                                                   double *__restrict__ Hc4 /*[4][64][R_pad]*/, int R_pad) {
   const int rf = blockIdx.x, rt = rf >> 3, kq = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
@@ -924,9 +954,9 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
       for (int ts = t0; ts < t1; ++ts) acc = MFMA_F64(ap[(size_t)ts * 64], bp[(size_t)ts * 256], acc);
     }
   }
-  double *out = Hc4 + (size_t)kq * R_pad * 64;
+  double *out = Hc4 + (size_t)kq * R_pad * 64 + (size_t)(16 * wave + fr) * R_pad;      // class-major: see b_zc_dot_kernel
 #pragma unroll
-  for (int r = 0; r < 4; ++r) out[(size_t)(16 * rf + fk + 4 * r) * 64 + 16 * wave + fr] = acc[r];
+  for (int r = 0; r < 4; ++r) out[16 * rf + fk + 4 * r] = acc[r];
 }
 
 // grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16.
@@ -942,10 +972,12 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
   const int i = blockIdx.x * 64 + a;
   const int zc = zclass[i];
   const size_t hp = (size_t)R_pad * 64;
-  for (int e = threadIdx.x; e < n_own * 32 * nzc; e += 1024) {
-    const int rowl = e / nzc, cls = e - rowl * nzc;
-    const size_t r = (size_t)own_rt[rowl >> 5] * 128 + blockIdx.y * 32 + (rowl & 31);
-    H[e] = (Hc4[r * 64 + cls] + Hc4[hp + r * 64 + cls]) + (Hc4[2 * hp + r * 64 + cls] + Hc4[3 * hp + r * 64 + cls]);
+  // Hc4 is class-major ([slot][class][R_pad]): the rows of one class are one contiguous run, and only the nzc classes in use are read
+  const int nrow = n_own * 32;
+  for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {
+    const int cls = e / nrow, rowl = e - cls * nrow;
+    const double *h = Hc4 + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 5] * 128 + blockIdx.y * 32 + (rowl & 31);
+    H[rowl * nzc + cls] = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);
   }
   __syncthreads();
   double sum = 0.0;
@@ -995,14 +1027,31 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   const size_t hp = (size_t)R_pad * 64;
   // the slab scalar by the first wave, with b_real_combine's summation tree (the 16 finishing threads are lanes of that wave)
   const double sc = (ra.slab && threadIdx.x < 64) ? b_slab_scalar(ra, threadIdx.x) : 0.0;
-  for (int e = threadIdx.x; e < n_own * 128 * nzc; e += 1024) {
-    const int rowl = e / nzc, cls = e - rowl * nzc;
-    const size_t r = (size_t)own_rt[rowl >> 7] * 128 + (rowl & 127);
-    H[e] = (Hc4[r * 64 + cls] + Hc4[hp + r * 64 + cls]) + (Hc4[2 * hp + r * 64 + cls] + Hc4[3 * hp + r * 64 + cls]);
+  // the first 8 row tiles' Rp values (16 per thread) are requested BEFORE the Hc table is staged: the two latencies (HBM for
+  // Rp, L2 for Hc) overlap instead of adding up -- at the headline size that is the whole Rp stream of this thread
+  double rp0[16];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const bool ok = u < n_own;
+    const int rt = own_rt[ok ? u : 0];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) rp0[2 * u + v] = ok ? Rp[((size_t)rt * 128 + w + 64 * v) * ne_pad + i] : 0.0;
+  }
+  const int nrow = n_own * 128;
+  for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {      // class-major Hc4: coalesced runs of rows, classes in use only
+    const int cls = e / nrow, rowl = e - cls * nrow;
+    const double *h = Hc4 + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 7] * 128 + (rowl & 127);
+    H[rowl * nzc + cls] = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);
   }
   __syncthreads();
   double sum = 0.0;
-  for (int k0 = 0; k0 < n_own; k0 += 4) {        // 4 row tiles at a time: 8 Rp rows in flight per thread
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {                  // same order of additions as the loop below (tiles 0..7; absent tiles add 0 * H)
+    const int kk = u < n_own ? u : 0;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) sum += rp0[2 * u + v] * H[(kk * 128 + w + 64 * v) * nzc + zc];
+  }
+  for (int k0 = 8; k0 < n_own; k0 += 4) {        // 4 row tiles at a time: 8 Rp rows in flight per thread
     double rp[8], hc[8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1062,7 +1111,7 @@ static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_p
 __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const SkTile *__restrict__ tiles, const double *__restrict__ part,
                                                            const double *__restrict__ wfull, double *__restrict__ G,
                                                            const double *__restrict__ Tzc /*[C_pad][64]*/,
-                                                           double *__restrict__ Hc4 /*[4][R_pad][64]*/, int R_pad, int nzc16,
+                                                           double *__restrict__ Hc4 /*[4][64][R_pad]*/, int R_pad, int nzc16,
                                                            int level) {
   __shared__ double tr[1280];
   const SkTile tl = tiles[blockIdx.x >> 5];
@@ -1082,6 +1131,15 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
       const double *src = part + (size_t)tl.item0 * plane + rowl * 320 + col;
       double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int sp = 0;
+      for (; sp + 16 <= count; sp += 16) {       // 16 partials in flight per element; additions in the order of the 8-wide loop
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += v[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += v[8 + u];
+      }
       for (; sp + 8 <= count; sp += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * step];
@@ -1103,10 +1161,10 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
 #pragma unroll 4
   for (int tsl = 0; tsl < 20; ++tsl)
     if (20 * q + tsl < nks) acc = MFMA_F64(tr[tsl * 64 + lane], bp[(size_t)tsl * 256], acc);
-  double *out = Hc4 + (size_t)q * R_pad * 64;
   const int rf = tl.rt * 8 + f16;
+  double *out = Hc4 + (size_t)q * R_pad * 64 + (size_t)(16 * wave + fr) * R_pad;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) out[(size_t)(16 * rf + fk + 4 * r) * 64 + 16 * wave + fr] = acc[r];
+  for (int r = 0; r < 4; ++r) out[16 * rf + fk + 4 * r] = acc[r];
 }
 
 // sk_reduce (+ level 1 when tiles are heavily split) with the Hc product fused in, then the per-atom dot
@@ -1172,19 +1230,28 @@ __device__ __forceinline__ double2 nt_load(const double2 *p) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row1, const double *__restrict__ S,
-                                                        const double *__restrict__ b, double *__restrict__ y) {
-  const int row = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= row1) return;
-  const int lane = threadIdx.x & 63;
-  const double *srow = S + (size_t)row * n;
+// this lane's share of one row's dot product S[row,:] . b -- ONE function for every GEMV kernel, so that they agree to the bit.
+// Eight 16-byte row loads in flight per lane (two groups of four, multiplied in the order a 4-wide loop would use them): with
+// 16 resident waves per CU that is 128 KB on its way per CU, what ~6 TB/s at HBM latency asks for.
+__device__ __forceinline__ double gemv_row_dot(int n, const double *__restrict__ srow, const double *__restrict__ b, int lane) {
   double s0 = 0.0, s1 = 0.0;
   if ((n & 1) == 0) {
     const double2 *s2 = reinterpret_cast<const double2 *>(srow);
     const double2 *b2 = reinterpret_cast<const double2 *>(b);
-    // 4 row loads in flight per lane; the two accumulator pairs are combined in a fixed order
-    double t0 = 0.0, t1 = 0.0;
+    double t0 = 0.0, t1 = 0.0;      // the two accumulator pairs are combined in a fixed order
     int j = lane;
+    for (; j + 448 < n / 2; j += 512) {
+      double2 a[8], c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = nt_load(s2 + j + 64 * u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = b2[j + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        s0 = fma(a[u].x, c[u].x, s0); s1 = fma(a[u].y, c[u].y, s1);
+        t0 = fma(a[u + 1].x, c[u + 1].x, t0); t1 = fma(a[u + 1].y, c[u + 1].y, t1);
+      }
+    }
     for (; j + 192 < n / 2; j += 256) {
       const double2 a0 = nt_load(s2 + j), a1 = nt_load(s2 + j + 64), a2 = nt_load(s2 + j + 128), a3 = nt_load(s2 + j + 192);
       const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
@@ -1202,7 +1269,15 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row
   } else {
     for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
   }
-  const double r = wave_sum(s0 + s1);
+  return s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row1, const double *__restrict__ S,
+                                                        const double *__restrict__ b, double *__restrict__ y) {
+  const int row = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= row1) return;
+  const int lane = threadIdx.x & 63;
+  const double r = wave_sum(gemv_row_dot(n, S + (size_t)row * n, b, lane));
   if (lane == 0) y[row] = r;
 }
 
@@ -1221,31 +1296,7 @@ __global__ __launch_bounds__(256) void gemv_finish_kernel(int n, const double *_
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  const double *srow = S + (size_t)row * n;
-  double s0 = 0.0, s1 = 0.0;
-  if ((n & 1) == 0) {
-    const double2 *s2 = reinterpret_cast<const double2 *>(srow);
-    const double2 *b2 = reinterpret_cast<const double2 *>(b);
-    double t0 = 0.0, t1 = 0.0;
-    int j = lane;
-    for (; j + 192 < n / 2; j += 256) {
-      const double2 a0 = nt_load(s2 + j), a1 = nt_load(s2 + j + 64), a2 = nt_load(s2 + j + 128), a3 = nt_load(s2 + j + 192);
-      const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
-      s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
-      t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
-      s0 = fma(a2.x, b2v.x, s0); s1 = fma(a2.y, b2v.y, s1);
-      t0 = fma(a3.x, b3.x, t0); t1 = fma(a3.y, b3.y, t1);
-    }
-    for (; j < n / 2; j += 64) {
-      const double2 a = s2[j], bb = b2[j];
-      s0 = fma(a.x, bb.x, s0);
-      s1 = fma(a.y, bb.y, s1);
-    }
-    s0 += t0; s1 += t1;
-  } else {
-    for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
-  }
-  double r = wave_sum(s0 + s1);
+  double r = wave_sum(gemv_row_dot(n, S + (size_t)row * n, b, lane));
   r = __shfl(r, 0, 64);
   double v;
   {
