@@ -289,7 +289,9 @@ int conp_fix_b_cal_device(conp_fix *fix, const double *d_x, const double *d_q);
 int conp_fix_solve_device(conp_fix *fix, double potdiff);
 int conp_fix_scatter_device(conp_fix *fix, double *d_q_atoms, double potdiff);
 int conp_fix_pre_force_device(conp_fix *fix, const double *d_x, double *d_q, double potdiff);
-/* per-kernel timing of the last N updates via HIP events on the library's stream (bench.py roofline leg) */
+/* per-kernel timing of the last N updates via HIP events on the library's stream (bench.py roofline leg).
+ * enable: 0 off, 1 a pair of events around every kernel, 2 around every 4th launch of the dominant kernel (sk_gemm) only --
+ * cheap enough to stay on inside a timed region (an event pair drains the queue around the kernel it brackets). */
 int conp_fix_profile(conp_fix *fix, int enable);
 int conp_fix_profile_read(conp_fix *fix, int *nkernels, const char **names /*[16]*/, double *avg_ms /*[16]*/, int *counts /*[16]*/);
 

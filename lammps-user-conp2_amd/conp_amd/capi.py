@@ -500,7 +500,8 @@ class FixConp:
     def pre_force_device(self, d_x: int, d_q: int, potdiff):
         self._check(self.lib.conp_fix_pre_force_device(self.h, C.c_void_p(d_x), C.c_void_p(d_q), potdiff))
 
-    def profile(self, enable: bool):
+    def profile(self, enable):
+        """0 off, 1 events around every kernel, 2 around the dominant kernel only (conp_hip.h)"""
         self._check(self.lib.conp_fix_profile(self.h, int(enable)))
 
     def profile_read(self):

@@ -34,6 +34,24 @@ def main():
         for k in ks[:20]:
             print("%-44s calls %6d  avg %10.1f us  total %10.3f ms  %5.1f%%" % (k["kernel"], k["calls"], k["avg_ns"] / 1e3,
                                                                             k["total_ns"] / 1e6, k["pct"]))
+    # per-launch durations of the update's kernels in launch order (kernel trace): the chip's clock governor needs tens of
+    # launches after the setup phase to settle, so the all-calls average above sits above the steady state -- both are printed
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        per = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        out["kernel_trace_steady"] = {}
+        print("== per-launch durations in launch order (%s): first 10 / last half" % os.path.relpath(f, root))
+        for k, v in per.items():
+            if len(v) < 20:
+                continue
+            v.sort()
+            d = [x[1] / 1e3 for x in v]
+            half = d[len(d) // 2:]
+            out["kernel_trace_steady"][k] = dict(calls=len(d), first10_avg_us=sum(d[:10]) / 10, last_half_avg_us=sum(half) / len(half),
+                                                 all_avg_us=sum(d) / len(d))
+            print("%-44s calls %6d  first 10 avg %8.1f us  last half avg %8.1f us  all %8.1f us" %
+                  (k, len(d), sum(d[:10]) / 10, sum(half) / len(half), sum(d) / len(d)))
     # PMC
     pmc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):

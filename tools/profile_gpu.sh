@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 mkdir -p $OUT
-STEPS=${STEPS:-50}
+STEPS=${STEPS:-300}
 ARGS="bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-profile ${BENCH_ARGS:-}"
 echo "== kernel trace" >&2
 # Every pass must EXIT CLEANLY.  (Round 1 masked a SIGSEGV inside exit() here; its cause was the HIP runtime's cooperative-launch
