@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="headline")
+    ap.add_argument("--solver", choices=["inv", "cg"], default="inv",
+                    help="inv: GEMV with the projected inverse (the headline); cg: the reference's conjugate-gradient solver "
+                         "(BASELINE configs[2] runs il_twolayer with it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels with HIP events")
@@ -118,7 +121,7 @@ def main():
     t_setup0 = time.perf_counter()
     s = make_workload(args.workload)
     at, alist, blist = neighbor.build_lists(s)
-    fx = FixConp(s, device=dev_index, rank=rank, nranks=world, extra_args=["pppm"] if args.pppm else [],
+    fx = FixConp(s, device=dev_index, rank=rank, nranks=world, extra_args=(["pppm"] if args.pppm else []) + (["cg"] if args.solver == "cg" else []),
                  pppm_mesh=tuple(args.pppm) if args.pppm else None)
     # multi-rank: the library makes its own RCCL communicator (rank 0's unique id travels through torch.distributed) and runs
     # the collectives on its own stream, in order with its kernels.  The rehearsal on a one-GPU box cannot (RCCL refuses two
@@ -287,7 +290,7 @@ def main():
                    config=dict(workload=s.name, Ne=int(ne), Nl=int(nl), K=int(K), kflat=int(info.kcount_flat),
                                box=[float(v) for v in s.prd], cutoff=s.cutoff, g_ewald=s.g_ewald,
                                accuracy_relative=s.accuracy_relative, mode="ffield" if s.ff_flag == 1 else "slab",
-                               solver="inv", kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
+                               solver=args.solver, kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
                                blist_pairs=int(info.n_blist_pairs),
                                parallelism=f"k-shard+row-shard x{world}" + (", RCCL inside libconp_hip" if lib_collectives else "")),
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)

@@ -664,7 +664,9 @@ struct conp_fix {
     // work left from (tile ti, chunk ch) to the end, without segment starts
     std::vector<double> tail(nt + 1, 0.0);
     for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + nchunks * cost(tiles_h[i]);
-    constexpr int MIN_SEG = 4;          // a shorter segment costs more in start-up than it carries
+    // a segment shorter than this costs more in start-up than it carries -- but only where shares are long: a small system's
+    // share IS one or two chunks (dilute: 16 chunks on 16 workgroups), and merging "slivers" there would quadruple one share
+    const int MIN_SEG = std::max(1, std::min(4, (int)((nt * (size_t)nchunks) / (size_t)nwg) / 2));
     items_h.clear();
     seg_ptr_h.assign(nwg + 1, 0);
     size_t ti = 0;
@@ -1101,25 +1103,49 @@ struct conp_fix {
   // after convergence returns at once).  The first batch is as long as the last solve needed, so a typical update costs one
   // read-back: scalars, flag, net charge and the residual history come over in ONE copy into the page-locked staging buffer.
   int cg_batch = 8;
+  const bool cg_unfused = getenv("CONP_CG_UNFUSED") != nullptr;      // comparison switch: two launches per iteration (round 1)
   void cg() {
     const int ne = idx.elenum_all;
-    const int nctl = 16 + args.maxiter + 1;                  // scal[0..8], pad, hist[0..maxiter] at offset 16
-    d_cg_res.reserve(ne); d_cg_p.reserve(ne); d_cg_ap.reserve(ne); d_cg_scal.reserve(nctl); d_cg_done.reserve(1);
+    const int nctl = 16 + args.maxiter + 1;                  // scal[0..12], pad, hist[0..maxiter] at offset 16
+    d_cg_res.reserve((size_t)2 * ne); d_cg_p.reserve((size_t)2 * ne); d_cg_ap.reserve((size_t)2 * ne);
+    d_cg_scal.reserve(nctl); d_cg_done.reserve(1);
     d_cg_done.zero(stream);
     double *hist_dev = d_cg_scal.p + 16;
-    prof.begin("cg", stream);
-    launch_cg_init(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_scal.p);
     double *ctl = pinned((size_t)ne_pad + 8 + nctl) + ne_pad + 8;
     int done = 0, iter = 1, batch = std::max(2, std::min(16, cg_batch));
-    while (iter < args.maxiter && !done) {
-      const int batch_end = std::min(args.maxiter, iter + batch);
-      for (; iter < batch_end; ++iter)
-        launch_cg_iter(stream, ne, d_A.p, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_ap.p, d_cg_scal.p, args.tolerance,
-                       d_cg_done.p, iter, hist_dev);
-      HIP_TRY(hipMemcpyAsync(ctl, d_cg_scal.p, (size_t)(16 + iter) * sizeof(double), hipMemcpyDeviceToHost, stream));
-      sync();
-      done = ctl[8] != 0.0;
-      batch = 4;
+    prof.begin("cg", stream);
+    if (cg_unfused || !cg_step_fits(ne) || args.maxiter <= 1) {
+      launch_cg_init(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_scal.p);
+      while (iter < args.maxiter && !done) {
+        const int batch_end = std::min(args.maxiter, iter + batch);
+        for (; iter < batch_end; ++iter)
+          launch_cg_iter(stream, ne, d_A.p, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_ap.p, d_cg_scal.p, args.tolerance,
+                         d_cg_done.p, iter, hist_dev);
+        HIP_TRY(hipMemcpyAsync(ctl, d_cg_scal.p, (size_t)(16 + iter) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+        done = ctl[8] != 0.0;
+        batch = 4;
+      }
+    } else {
+      // one launch per iteration (cg_step_kernel): start + matvec 1, then update(k - 1) + matvec(k) ..., and the last
+      // iteration's update alone before the read-back; same arithmetic, same bits as the two-launch form
+      auto step = [&](int it, int mode) {
+        launch_cg_step(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_ap.p, d_cg_scal.p, args.tolerance,
+                       d_cg_done.p, it, hist_dev, mode);
+      };
+      step(1, 1);                                            // iter = the iteration whose matvec is in flight
+      while (true) {
+        const int last = std::min(args.maxiter - 1, iter + batch - 1);
+        for (; iter < last; ++iter) step(iter + 1, 2);
+        step(iter, 4);
+        HIP_TRY(hipMemcpyAsync(ctl, d_cg_scal.p, (size_t)(16 + iter + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+        done = ctl[8] != 0.0;
+        if (done || iter + 1 >= args.maxiter) break;
+        ++iter;
+        step(iter, 3);
+        batch = 4;
+      }
     }
     prof.end(stream);
     cg_iterations = done ? (int)ctl[6] : 0;

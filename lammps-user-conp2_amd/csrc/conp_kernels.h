@@ -150,5 +150,9 @@ void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, doub
                     double *scal /*[8]*/);
 void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *res, double *p, double *ap, double *scal,
                     double tolerance, int *done, int iter, double *hist);
+// one launch per CG iteration (update of iteration iter - 1 repeated by every workgroup + its rows of the matvec); see the kernel
+bool cg_step_fits(int n);
+void launch_cg_step(hipStream_t s, int n, const double *A, const double *b, double *q, double *res2 /*[2][n]*/, double *p2 /*[2][n]*/,
+                    double *ap2 /*[2][n]*/, double *scal, double tolerance, int *done, int iter, double *hist, int mode);
 
 }  // namespace conp

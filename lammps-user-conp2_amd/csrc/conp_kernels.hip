@@ -1121,6 +1121,18 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
   const int stride = level == 2 ? SKR_GROUP : 1;
   const int count = level == 2 ? (tl.nsplit + SKR_GROUP - 1) / SKR_GROUP : tl.nsplit;
   const size_t step = (size_t)stride * plane;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int nks = 8 * tl.nba;
+  // the z-class operand of the product below depends on the tile only: the waves that will multiply request their 20 values
+  // now, so that the loads are in flight while the partial tiles are summed (they were five dependent-looking groups of four
+  // behind the barrier: 4 us of the 9.4 this kernel took on il_onelayer)
+  double bz[20];
+  if (wave < nzc16) {
+    const double *bp = Tzc + (size_t)(tl.ct * 320 + 80 * q + fk) * 64 + 16 * wave + fr;
+#pragma unroll
+    for (int tsl = 0; tsl < 20; ++tsl) bz[tsl] = 20 * q + tsl < nks ? bp[(size_t)tsl * 256] : 0.0;
+  }
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) {
     const int e = threadIdx.x + SKR_T * k;
@@ -1152,15 +1164,11 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
     tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sum;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave >= nzc16) return;
-  const int fr = lane & 15, fk = lane >> 4;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-  const int nks = 8 * tl.nba;
-  const double *bp = Tzc + (size_t)(tl.ct * 320 + 80 * q + fk) * 64 + 16 * wave + fr;
-#pragma unroll 4
+#pragma unroll
   for (int tsl = 0; tsl < 20; ++tsl)
-    if (20 * q + tsl < nks) acc = MFMA_F64(tr[tsl * 64 + lane], bp[(size_t)tsl * 256], acc);
+    if (20 * q + tsl < nks) acc = MFMA_F64(tr[tsl * 64 + lane], bz[tsl], acc);      // (wave-uniform condition)
   const int rf = tl.rt * 8 + f16;
   double *out = Hc4 + (size_t)q * R_pad * 64 + (size_t)(16 * wave + fr) * R_pad;
 #pragma unroll
@@ -1880,6 +1888,115 @@ void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *re
                     double tolerance, int *done, int iter, double *hist) {
   hipLaunchKernelGGL(gemv_rows_guarded_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, A, p, ap, done);
   hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, s, n, q, res, p, ap, scal, tolerance, done, iter, hist);
+}
+
+// ---- one launch per iteration.  Every workgroup first repeats the vector update of iteration iter - 1 for itself -- the same
+// code, thread -> element mapping and reduction trees as cg_update_kernel, so every workgroup holds the same bits -- with the new
+// search direction landing in LDS, then multiplies ITS 16 rows of A with it (iteration iter's matvec, gemv_rows_guarded's
+// arithmetic).  Workgroup 0 alone writes the vectors and scalars back.  State is double-buffered by iteration parity (set k & 1
+// holds p_k, A p_k and the residual entering iteration k): a fast workgroup's outputs never overwrite what a slow one still reads.
+// Redundant work per workgroup: 3 vectors of n doubles from L2 and five block reductions -- against one kernel boundary and one
+// single-workgroup kernel per iteration (il_twolayer, 6 iterations: 13 -> 7 launches per solve).
+//   mode: 1 = start (residual and direction from b, fix_conp.cpp:870-884) + matvec 1;  2 = update(iter - 1) + matvec(iter);
+//         3 = matvec(iter) only (the state was completed by a mode-4 launch);  4 = update(iter) only, one workgroup
+__global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__restrict__ A, const double *__restrict__ b,
+                                                       double *__restrict__ q, double *__restrict__ res2, double *__restrict__ p2,
+                                                       double *__restrict__ ap2, double *__restrict__ scal, double tolerance,
+                                                       int *__restrict__ done, int iter, double *__restrict__ hist, int mode) {
+  extern __shared__ __attribute__((aligned(16))) char cg_smem[];
+  double *pl = reinterpret_cast<double *>(cg_smem);          // the direction of the matvec: [n]
+  __shared__ double red[16];
+  if (*done) return;
+  const bool writer = blockIdx.x == 0;
+  const int k_upd = mode == 4 ? iter : iter - 1;             // the iteration whose update this launch applies (modes 2, 4)
+  const int so = mode == 4 ? (iter + 1) & 1 : iter & 1;      // set written: the state entering iteration k_upd + 1
+  double *res_o = res2 + (size_t)so * n, *p_o = p2 + (size_t)so * n;
+  if (mode == 1) {
+    double netr = 0, l2 = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) { const double r = b[i]; netr += r; l2 += r * r; }
+    netr = block_sum_1024(netr, red);
+    l2 = block_sum_1024(l2, red);
+    const double ave = netr / n;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const double r = b[i], pn = r - ave;
+      pl[i] = pn;
+      if (writer) { q[i] = 0.0; res_o[i] = r; p_o[i] = pn; }
+    }
+    if (writer && threadIdx.x == 0) {
+      const double lres = l2 - netr * ave;
+      scal[0] = lres; scal[1] = lres; scal[2] = netr; scal[6] = 0.0; scal[7] = 0.0; scal[8] = 0.0;
+      scal[9 + 2 * so] = lres; scal[10 + 2 * so] = lres;
+    }
+  } else if (mode == 2 || mode == 4) {
+    const int si = k_upd & 1;
+    const double *res_i = res2 + (size_t)si * n, *p_i = p2 + (size_t)si * n, *ap_i = ap2 + (size_t)si * n;
+    double ptap = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) ptap += p_i[i] * ap_i[i];
+    ptap = block_sum_1024(ptap, red);
+    // (residual norm, gamma) entering iteration k live in the parity slot scal[9 + 2 (k & 1)], scal[10 + 2 (k & 1)]: every
+    // workgroup of this launch reads slot k_upd & 1 while workgroup 0 writes the other one
+    const double lresnorm = scal[9 + 2 * si], gamma = scal[10 + 2 * si];
+    const double alpha = lresnorm / ptap;
+    double lg = 0, netr = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      if (writer) q[i] = q[i] + alpha * p_i[i];
+      const double r = res_i[i] - alpha * ap_i[i];
+      if (writer) res_o[i] = r;
+      lg += r * r; netr += r;
+    }
+    lg = block_sum_1024(lg, red);
+    netr = block_sum_1024(netr, red);
+    const double ave = netr / n;
+    lg -= netr * ave;
+    const double beta = lg / gamma;
+    double lr = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const double r = res_i[i] - alpha * ap_i[i];           // the same value as above, recomputed instead of kept
+      const double pn = beta * p_i[i] + r - ave;
+      pl[i] = pn;
+      if (writer) p_o[i] = pn;
+      lr += r * pn;
+    }
+    lr = block_sum_1024(lr, red);
+    if (writer && threadIdx.x == 0) {
+      scal[0] = lr; scal[1] = lg; scal[2] = netr; scal[3] = ptap; scal[4] = alpha; scal[5] = beta;      // what cg_update_kernel reports
+      scal[9 + 2 * so] = lr; scal[10 + 2 * so] = lg;
+      hist[k_upd] = lr;
+    }
+    if (lr / n < tolerance) {                                // uniform over the whole grid: every workgroup holds the same lr
+      if (writer) {
+        double qs = 0.0;
+        for (int i = threadIdx.x; i < n; i += 1024) qs += q[i];      // this workgroup wrote q above: visible after the block barriers
+        qs = block_sum_1024(qs, red);
+        if (threadIdx.x == 0) { *done = 1; scal[6] = (double)k_upd; scal[7] = qs; scal[8] = 1.0; }
+      }
+      return;
+    }
+  } else {
+    const double *p_i = p2 + (size_t)(iter & 1) * n;
+    for (int i = threadIdx.x; i < n; i += 1024) pl[i] = p_i[i];
+  }
+  if (mode == 4) return;
+  __syncthreads();
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const double *srow = A + (size_t)row * n;
+  double s0 = 0.0;
+  for (int j = lane; j < n; j += 64) s0 = fma(srow[j], pl[j], s0);
+  s0 = wave_sum(s0);
+  if (lane == 0) ap2[(size_t)(iter & 1) * n + row] = s0;
+}
+
+bool cg_step_fits(int n) { return n > 0 && (size_t)n * sizeof(double) <= 128 * 1024; }
+
+void launch_cg_step(hipStream_t s, int n, const double *A, const double *b, double *q, double *res2, double *p2, double *ap2,
+                    double *scal, double tolerance, int *done, int iter, double *hist, int mode) {
+  const size_t lds = (size_t)n * sizeof(double);
+  static DynLdsCache granted{};
+  ensure_dyn_lds(cg_step_kernel, lds, granted);
+  hipLaunchKernelGGL(cg_step_kernel, dim3(mode == 4 ? 1 : (n + 15) / 16), dim3(1024), lds, s, n, A, b, q, res2, p2, ap2, scal, tolerance,
+                     done, iter, hist, mode);
 }
 
 }  // namespace conp

@@ -325,6 +325,34 @@ def test_log_file_lines_inverse_solver(split, monkeypatch):
     fx.close()
 
 
+def test_cg_one_launch_per_iteration_gives_the_bits_of_the_two_launch_form(monkeypatch):
+    """cg_step_kernel (every workgroup repeats the vector update, then multiplies its rows) against the round-1 form (matvec
+    kernel + one-workgroup update kernel per iteration, CONP_CG_UNFUSED=1 read when the handle is created): same iteration
+    count, same residual history, bitwise the same charges -- also when the first batch is too short (maxiter path: 'tol' small
+    enough for several read-backs) and when convergence falls inside a batch"""
+    s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
+    for extra in (["cg"], ["cg", "tol", "1e-14", "maxiter", "60"], ["cg", "maxiter", "3"]):
+        got = []
+        for unfused in (False, True):
+            if unfused:
+                monkeypatch.setenv("CONP_CG_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("CONP_CG_UNFUSED", raising=False)
+            at, alist, blist = neighbor.build_lists(s)
+            fx = FixConp(s, extra_args=extra)
+            fx.init_lists(alist, blist)
+            fx.setup_post_neighbor(at)
+            fx.setup_pre_force(at, 0, s.potdiff)
+            for step in (1, 2, 3):
+                fx.pre_force(at, step, 0.9 * s.potdiff)
+            lines = [l for l in fx.log_drain().splitlines() if l.startswith(("Iteration", "*****"))]
+            got.append((fx.info().cg_iterations, lines, at.q.copy()))
+            fx.close()
+        assert got[0][0] == got[1][0], extra
+        assert got[0][1] == got[1][1], extra
+        assert np.array_equal(got[0][2], got[1][2]), extra
+
+
 def test_log_file_lines_cg(oracle):
     """CG residual lines (fix_conp.cpp:919-928): one per iteration, the last one with the net charge"""
     import re

@@ -4,7 +4,7 @@
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-OUT=gpurun_out/prof
+OUT=${OUT:-gpurun_out/prof}
 mkdir -p $OUT
 STEPS=${STEPS:-300}
 ARGS="bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-profile ${BENCH_ARGS:-}"
