@@ -210,6 +210,7 @@ struct conp_fix {
   int cg_iterations = 0;
   // the fix's log file (fix_conp.cpp:119): lines are buffered here and handed to the host by conp_fix_log_drain
   std::string logbuf, logdrain, mesgbuf, mesgdrain;   // mesgbuf: what the reference sends to utils::logmesg (:460, :1008)
+  bool pp_im_clean = false;      // the mesh's imaginary brick is all zero (left so by the b path's last backward pass)
   double Btime = 0., Ctime = 0., Ktime = 0.;      // accumulated like :549-552 (seconds)
   hipEvent_t ev_b[3] = {nullptr, nullptr, nullptr};
   bool ev_pending = false;
@@ -431,7 +432,7 @@ struct conp_fix {
       pppm.build(env.pppm_nx, env.pppm_ny, env.pppm_nz, env.pppm_order, env.g_ewald, env.slab_volfactor, lo, prd);
       d_pp_coeff.upload(pppm.rho_coeff, stream); d_pp_green.upload(pppm.greensfn, stream);
       d_pp_tw0.upload(pppm.twid[0], stream); d_pp_tw1.upload(pppm.twid[1], stream); d_pp_tw2.upload(pppm.twid[2], stream);
-      d_pp_re.reserve(pppm.nfft); d_pp_im.reserve(pppm.nfft);
+      d_pp_re.reserve(pppm.nfft); d_pp_im.reserve(pppm.nfft); pp_im_clean = false;
       dpppm.nx = pppm.nx; dpppm.ny = pppm.ny; dpppm.nz = pppm.nz; dpppm.order = pppm.order; dpppm.nlower = pppm.nlower;
       dpppm.nfft = pppm.nfft; dpppm.shift = pppm.shift; dpppm.shiftone = pppm.shiftone; dpppm.delvolinv = pppm.delvolinv;
       for (int c = 0; c < 3; ++c) { dpppm.delinv[c] = pppm.delinv[c]; dpppm.boxlo[c] = pppm.boxlo[c]; }
@@ -1233,7 +1234,7 @@ struct conp_fix {
       prof.begin("pppm_b", stream);
       if (env.rank == 0)
         launch_pppm_b(stream, dpppm, nl, eidx, ex, eq, ne, ne_pad, d_pp_egrid.p, d_pp_ew.p, d_pp_re.p, d_pp_im.p,
-                      d_slab_part.p, &n_slab_part, d_bk.p);
+                      d_slab_part.p, &n_slab_part, d_bk.p, &pp_im_clean);
       else
         d_bk.zero(stream);
       prof.end(stream);
@@ -2124,7 +2125,7 @@ void pppm_total_potential(conp_fix *f, const conp_atoms *at) {
   const int n = pppm_list(f, at, 2, d_idx);
   f->d_pp_scratch.reserve(2048);
   launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
-  launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p);
+  launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p); f->pp_im_clean = false;
   HIP_TRY(hipGetLastError());
   f->sync();                       // d_idx goes out of scope
 }
@@ -2233,7 +2234,7 @@ int conp_compute_potential_atom(conp_fix *f, const conp_atoms *at, const conp_ne
     d_idx.upload(all, f->stream);
     f->d_pp_scratch.reserve(2048);
     launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
-    launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p);
+    launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p); f->pp_im_clean = false;
     std::vector<int> idx;
     for (int i = 0; i < at->nlocal; ++i) if (sel[i]) idx.push_back(i);
     DevBuf<int> d_pidx;

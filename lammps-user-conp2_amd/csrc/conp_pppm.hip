@@ -5,6 +5,8 @@
 // sizes; any other length falls back to a plain O(n^2) DFT per line.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "conp_kernels.h"
 
 namespace conp {
@@ -19,9 +21,14 @@ __device__ __forceinline__ void rho1d_dev(const double *__restrict__ coeff, int 
   }
 }
 
-// elyte_particle_map + elyte_make_rho (pppm_conp.cpp:126-228): order^2 threads per charged electrolyte atom (one (z, y) stencil
-// row each, `order` atomic adds along x).  slab_part[block] = partial sums of q z for the slab term (:301-314), taken by the
-// row-0 thread of every atom.
+// elyte_particle_map + elyte_make_rho (pppm_conp.cpp:126-228): order^3 threads per charged electrolyte atom, one stencil point
+// (one atomic add) each, the x index running over adjacent lanes: a wavefront's atomic instruction then covers ~13 runs of
+// `order` consecutive doubles instead of 64 single doubles in 64 different cache lines (the first version: order^2 threads per
+// atom, `order` atomics each along x -- 13.4 us for 1280 atoms; scattered f64 atomics run ~17x below the contiguous rate,
+// MI355X_MICROARCH.md).  slab_part[block] = partial sums of q z for the slab term (:301-314), taken by the first thread of every
+// atom.  Orders above 6 (order^3 > 256) walk their stencil in several rounds of 256 threads.
+__host__ __device__ inline int spread_threads_per_atom(int order) { const int o3 = order * order * order; return o3 < 256 ? o3 : 256; }
+
 __global__ __launch_bounds__(256) void pppm_spread_kernel(PppmDev pd, int nl, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double *__restrict__ rho, double *__restrict__ slab_part,
@@ -30,9 +37,10 @@ __global__ __launch_bounds__(256) void pppm_spread_kernel(PppmDev pd, int nl, co
   __shared__ double red[4];
   if (threadIdx.x < pd.order * pd.order) coeff[threadIdx.x] = pd.rho_coeff[threadIdx.x];
   __syncthreads();
-  const int o2 = pd.order * pd.order;
-  const int apb = blockDim.x / o2;                  // atoms per pass
-  const int ja = threadIdx.x / o2, row = threadIdx.x - ja * o2;
+  const int o2 = pd.order * pd.order, o3 = o2 * pd.order;
+  const int tpa = spread_threads_per_atom(pd.order);
+  const int apb = blockDim.x / tpa;                 // atoms per pass
+  const int ja = threadIdx.x / tpa, t0 = threadIdx.x - ja * tpa;
   double qz = 0.0;
   for (int pass = 0; pass < npass; ++pass) {
     const int j = (blockIdx.x * npass + pass) * apb + ja;
@@ -47,13 +55,15 @@ __global__ __launch_bounds__(256) void pppm_spread_kernel(PppmDev pd, int nl, co
       g[c] = static_cast<int>(xs + pd.shift) - 16384;
       rho1d_dev(coeff, pd.order, g[c] + pd.shiftone - xs, w[c]);
     }
-    if (row == 0) qz += qq * x[3 * i + 2];
-    const int n = row / pd.order, m = row - n * pd.order;
-    const int mz = pwrap(n + pd.nlower + g[2], pd.nz);
-    const int my = pwrap(m + pd.nlower + g[1], pd.ny);
-    const double x0 = (pd.delvolinv * qq * w[2][n]) * w[1][m];
-    double *line = rho + ((size_t)mz * pd.ny + my) * pd.nx;
-    for (int l = 0; l < pd.order; ++l) atomicAdd(&line[pwrap(l + pd.nlower + g[0], pd.nx)], x0 * w[0][l]);
+    if (t0 == 0) qz += qq * x[3 * i + 2];
+    for (int rem = t0; rem < o3; rem += tpa) {
+      const int n = rem / o2, r2 = rem - n * o2, m = r2 / pd.order, l = r2 - m * pd.order;
+      const int mz = pwrap(n + pd.nlower + g[2], pd.nz);
+      const int my = pwrap(m + pd.nlower + g[1], pd.ny);
+      const int mx = pwrap(l + pd.nlower + g[0], pd.nx);
+      const double x0 = (pd.delvolinv * qq * w[2][n]) * w[1][m];      // the association of the row-wise version (and of :216-225)
+      atomicAdd(&rho[((size_t)mz * pd.ny + my) * pd.nx + mx], x0 * w[0][l]);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) qz += __shfl_down(qz, off, 64);
@@ -166,9 +176,11 @@ __device__ __forceinline__ void fft_stage(const double2 *__restrict__ in, double
   }
 }
 
-// flags: 1 = input is real (im not read), 2 = only the real part of the output is stored.  gmul != nullptr: the output is
+// flags: 1 = input is real (im not read), 2 = only the real part of the output is stored, 4 = ... and zeros go to `im` (which then
+// serves as the clean density brick of the next update), 8 = forward pass, influence function, backward pass in one go.
+// gmul != nullptr: the output is
 // multiplied by gscale*gmul[] (the influence function, pppm_conp.cpp:242-249) on the way out.
-__global__ __launch_bounds__(256) void pppm_fft_kernel(int nx, int ny, int nz, int axis, double sign, FftPlan fp,
+__global__ __launch_bounds__(512) void pppm_fft_kernel(int nx, int ny, int nz, int axis, double sign, FftPlan fp,
                                                        const double *__restrict__ twid, double *__restrict__ re,
                                                        double *__restrict__ im, int xs, int flags,
                                                        const double *__restrict__ gmul, double gscale) {
@@ -210,15 +222,45 @@ __global__ __launch_bounds__(256) void pppm_fft_kernel(int nx, int ny, int nz, i
     double2 *tmp = in; in = out; out = tmp;
     Ns *= R;
   }
+  if (flags & 8) {
+    // forward pass done: times the influence function, then the backward pass along the same lines before anything is stored
+    // (the 3-D backward transform is separable: it may start with this axis) -- one launch and one trip through memory fewer
+    double2 *io = const_cast<double2 *>(in);
+    for (int e = threadIdx.x; e < n * XT; e += blockDim.x) {
+      const int f = axis == 0 ? e % n : e >> xs, lx = axis == 0 ? e / n : e & (XT - 1);
+      const int line = line0 + lx;
+      if (line < nlines) {
+        const double g = gscale * gmul[base_of(line) + (size_t)f * stride];
+        double2 v = io[(f << xs) + lx];
+        v.x *= g; v.y *= g;
+        io[(f << xs) + lx] = v;
+      }
+    }
+    __syncthreads();
+    Ns = 1;
+    for (int st = 0; st < fp.nrad; ++st) {
+      const int R = fp.rad[st];
+      switch (R) {
+        case 2: fft_stage<2>(in, out, tw, n, Ns, xs, -sign); break;
+        case 3: fft_stage<3>(in, out, tw, n, Ns, xs, -sign); break;
+        case 4: fft_stage<4>(in, out, tw, n, Ns, xs, -sign); break;
+        default: fft_stage<5>(in, out, tw, n, Ns, xs, -sign); break;
+      }
+      __syncthreads();
+      double2 *tmp = in; in = out; out = tmp;
+      Ns *= R;
+    }
+  }
   for (int e = threadIdx.x; e < n * XT; e += blockDim.x) {
     const int f = axis == 0 ? e % n : e >> xs, lx = axis == 0 ? e / n : e & (XT - 1);
     const int line = line0 + lx;
     if (line < nlines) {
       const size_t a = base_of(line) + (size_t)f * stride;
       double2 v = in[(f << xs) + lx];
-      if (gmul) { const double g = gscale * gmul[a]; v.x *= g; v.y *= g; }
+      if (gmul && !(flags & 8)) { const double g = gscale * gmul[a]; v.x *= g; v.y *= g; }
       re[a] = v.x;
       if (!real_out) im[a] = v.y;
+      else if (flags & 4) im[a] = 0.0;
     }
   }
 }
@@ -227,17 +269,24 @@ __global__ __launch_bounds__(256) void pppm_fft_kernel(int nx, int ny, int nz, i
 // two launches fewer per 3-D transform -- the mesh path of a deck-sized system is bound by its launches.
 // Generic stage: element (t, line) lives at buf[t * st_t + line * st_l]; `t_fast` picks which index runs over adjacent threads
 // (the one with unit stride, so that a wavefront's LDS accesses spread over the banks).
+// quotient of two non-negative ints below 2^20 through a float reciprocal (exact there: the +0.5 keeps the product away from the
+// integer boundaries); an integer division costs ~40 instructions on this chip and a butterfly needs three
+__device__ __forceinline__ int fdiv(int a, int b, float inv_b) { (void)b; return (int)(((float)a + 0.5f) * inv_b); }
+
 template <int R>
 __device__ __forceinline__ void fft_stage_g(const double2 *__restrict__ in, double2 *__restrict__ out, const double *__restrict__ tw,
                                             int n, int Ns, int nlines, int st_t, int st_l, bool t_fast, double sign) {
   const int nb = n / R;
   const int tstep = nb / Ns;
+  const float inv_nb = 1.0f / (float)nb, inv_nl = 1.0f / (float)nlines, inv_ns = 1.0f / (float)Ns;
   double wc[R], ws[R];
 #pragma unroll
   for (int m = 1; m < R; ++m) { wc[m] = tw[2 * m * nb]; ws[m] = sign * tw[2 * m * nb + 1]; }
   for (int w = threadIdx.x; w < nb * nlines; w += blockDim.x) {
-    const int j = t_fast ? w % nb : w / nlines, lx = t_fast ? w / nb : w % nlines;
-    const int k = j % Ns;
+    int j, lx;
+    if (t_fast) { lx = fdiv(w, nb, inv_nb); j = w - lx * nb; }
+    else { j = fdiv(w, nlines, inv_nl); lx = w - j * nlines; }
+    const int k = j - Ns * fdiv(j, Ns, inv_ns);
     const double2 *src = in + lx * st_l;
     double2 *dst = out + lx * st_l;
     double2 v[R];
@@ -295,9 +344,12 @@ __device__ __forceinline__ void fft_axis_g(double2 *&in, double2 *&out, const do
 }
 
 // one workgroup per z-plane: x transforms of its ny lines, then y transforms of its nx lines.  real_in: im is not read.
-__global__ __launch_bounds__(256) void pppm_fft_xy_kernel(int nx, int ny, double sign, FftPlan fpx, FftPlan fpy,
+// real_in: 0 complex input; 1 real input in `re` (im not read); 2 real input in `im` (re not read) -- the b path spreads the charges
+// into `im`, which the previous update's last backward pass left all zero, so that no clearing launch is needed
+__global__ __launch_bounds__(512) void pppm_fft_xy_kernel(int nx, int ny, double sign, FftPlan fpx, FftPlan fpy,
                                                           const double *__restrict__ twx, const double *__restrict__ twy,
-                                                          double *__restrict__ re, double *__restrict__ im, int real_in) {
+                                                          double *__restrict__ re, double *__restrict__ im, int real_in,
+                                                          int out_flags /* 2: store the real part only, 4: ... and zeros into im */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int np = nx * ny;
   double2 *b0 = reinterpret_cast<double2 *>(smem), *b1 = b0 + np;
@@ -305,12 +357,17 @@ __global__ __launch_bounds__(256) void pppm_fft_xy_kernel(int nx, int ny, double
   for (int t = threadIdx.x; t < 2 * nx; t += blockDim.x) tx[t] = twx[t];
   for (int t = threadIdx.x; t < 2 * ny; t += blockDim.x) ty[t] = twy[t];
   const size_t base = (size_t)blockIdx.x * np;
-  for (int e = threadIdx.x; e < np; e += blockDim.x) b0[e] = make_double2(re[base + e], real_in ? 0.0 : im[base + e]);
+  for (int e = threadIdx.x; e < np; e += blockDim.x)
+    b0[e] = real_in == 2 ? make_double2(im[base + e], 0.0) : make_double2(re[base + e], real_in ? 0.0 : im[base + e]);
   __syncthreads();
   double2 *in = b0, *out = b1;
   fft_axis_g(in, out, tx, fpx, nx, ny, 1, nx, true, sign);      // x: element (t = x, line = y) at [y * nx + x]
   fft_axis_g(in, out, ty, fpy, ny, nx, nx, 1, false, sign);     // y: element (t = y, line = x)
-  for (int e = threadIdx.x; e < np; e += blockDim.x) { re[base + e] = in[e].x; im[base + e] = in[e].y; }
+  for (int e = threadIdx.x; e < np; e += blockDim.x) {
+    re[base + e] = in[e].x;
+    if (!(out_flags & 2)) im[base + e] = in[e].y;
+    else if (out_flags & 4) im[base + e] = 0.0;
+  }
 }
 
 static bool fft_factor(int n, FftPlan &fp) {
@@ -365,7 +422,23 @@ static bool mesh_smooth(const PppmDev &pd) {
 
 // forward (sign -1) or backward 3-D transform.  fused (radix path only): the forward transform takes real input and applies
 // gscale*greensfn on its last pass; the backward one stores only the real part.
-static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, double *im, bool fused, double gscale) {
+// raise a kernel's dynamic-LDS limit only when a launch needs more than it was last given (per device; see conp_kernels.hip)
+struct LdsGrant { std::atomic<size_t> granted[64]; };
+template <typename K>
+static void grant_lds(K kernel, size_t bytes, LdsGrant &g) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<size_t> &v = g.granted[dev & 63];
+  if (bytes <= v.load(std::memory_order_relaxed)) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  v.store(bytes, std::memory_order_relaxed);
+}
+
+// forward (sign -1) or backward 3-D transform.  fused (radix path only): the forward transform takes real input (from `re`, or
+// from `im` when rho_in_im) and applies gscale*greensfn on its last pass; the backward one stores only the real part (and zeros
+// into `im` when zero_im).
+static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, double *im, bool fused, double gscale,
+                 bool rho_in_im = false, bool zero_im = false) {
   const int dims[3] = {pd.nx, pd.ny, pd.nz};
   int axis0 = 0;
   {
@@ -373,10 +446,14 @@ static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, doub
     const size_t lds = (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double);
     if (fused && fft_factor(pd.nx, fpx) && fft_factor(pd.ny, fpy) && lds <= 128 * 1024) {
       // the x and y passes of every z-plane in one workgroup
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pppm_fft_xy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(256), lds, s, pd.nx, pd.ny, sign, fpx, fpy, pd.twid[0], pd.twid[1], re, im,
-                         sign < 0 ? 1 : 0);
+      static LdsGrant g{};
+      grant_lds(pppm_fft_xy_kernel, lds, g);
+      hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(512), lds, s, pd.nx, pd.ny, sign, fpx, fpy, pd.twid[0], pd.twid[1], re, im,
+                         sign < 0 ? (rho_in_im ? 2 : 1) : 0, 0);
       axis0 = 2;
+    } else if (rho_in_im) {
+      // (the caller only asks for this with a fused xy pass; keep the contract honest if a mesh ever does not qualify)
+      (void)hipMemcpyAsync(re, im, sizeof(double) * (size_t)pd.nfft, hipMemcpyDeviceToDevice, s);
     }
   }
   for (int axis = axis0; axis < 3; ++axis) {
@@ -392,9 +469,10 @@ static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, doub
       const double *gmul = nullptr;
       if (fused && sign < 0 && axis == 0) flags |= 1;
       if (fused && sign < 0 && axis == 2) gmul = pd.greensfn;
-      if (fused && sign > 0 && axis == 2) flags |= 2;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pppm_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(pppm_fft_kernel, dim3((nlines + XT - 1) / XT), dim3(256), lds, s, pd.nx, pd.ny, pd.nz, axis, sign, fp,
+      if (fused && sign > 0 && axis == 2) flags |= zero_im ? 6 : 2;
+      static LdsGrant g{};
+      grant_lds(pppm_fft_kernel, lds, g);
+      hipLaunchKernelGGL(pppm_fft_kernel, dim3((nlines + XT - 1) / XT), dim3(512), lds, s, pd.nx, pd.ny, pd.nz, axis, sign, fp,
                          pd.twid[axis], re, im, xs, flags, gmul, gscale);
       continue;
     }
@@ -402,30 +480,64 @@ static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, doub
     XT = XT < 1 ? 1 : (XT > 16 ? 16 : XT);
     const int nlines = axis == 0 ? pd.ny * pd.nz : (axis == 1 ? pd.nx * pd.nz : pd.nx * pd.ny);
     const size_t lds = ((size_t)2 * n * XT + 2 * n) * sizeof(double);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pppm_dft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsGrant g{};
+    grant_lds(pppm_dft_kernel, lds, g);
     hipLaunchKernelGGL(pppm_dft_kernel, dim3((nlines + XT - 1) / XT), dim3(256), lds, s, pd.nx, pd.ny, pd.nz, axis, sign,
                        pd.twid[axis], re, im, XT);
   }
 }
 
+// rho -> u_brick in three launches when the mesh qualifies (2,3,5-smooth, a z-plane fits in LDS): x and y forward per plane (real
+// input from `re`, or from `im` when rho_in_im), z forward * greensfn / N * z backward per bundle of lines, x and y backward per
+// plane (real part only; zeros into `im` when zero_im).  Returns false (nothing launched) when the mesh does not qualify.
+static bool poisson_three_launches(hipStream_t s, const PppmDev &pd, double *re, double *im, bool rho_in_im, bool zero_im) {
+  FftPlan fpx, fpy, fpz;
+  const size_t lds_xy = (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double);
+  if (!(fft_factor(pd.nx, fpx) && fft_factor(pd.ny, fpy) && fft_factor(pd.nz, fpz) && lds_xy <= 128 * 1024)) return false;
+  const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
+  static LdsGrant gxy{}, gz{};
+  grant_lds(pppm_fft_xy_kernel, lds_xy, gxy);
+  hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(512), lds_xy, s, pd.nx, pd.ny, -1.0, fpx, fpy, pd.twid[0], pd.twid[1], re, im,
+                     rho_in_im ? 2 : 1, 0);
+  int xs = 0;
+  while (xs < 4 && (size_t)pd.nz * 32 * (2u << xs) <= 64 * 1024) ++xs;
+  const int XT = 1 << xs, nlines = pd.nx * pd.ny;
+  const size_t lds_z = ((size_t)2 * pd.nz * XT) * sizeof(double2) + (size_t)2 * pd.nz * sizeof(double);
+  grant_lds(pppm_fft_kernel, lds_z, gz);
+  hipLaunchKernelGGL(pppm_fft_kernel, dim3((nlines + XT - 1) / XT), dim3(512), lds_z, s, pd.nx, pd.ny, pd.nz, 2, -1.0, fpz, pd.twid[2], re, im,
+                     xs, 8, pd.greensfn, gscale);
+  hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(512), lds_xy, s, pd.nx, pd.ny, +1.0, fpx, fpy, pd.twid[0], pd.twid[1], re, im, 0,
+                     zero_im ? 6 : 2);
+  return true;
+}
+
 // this rank's k-space b through the mesh: bk[0..ne) = PPPM b (slot 0), slots 1..3 zeroed
 void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_idx, const double *x, const double *q, int ne,
                    int ne_pad, const int *egrid, const double *ew, double *re, double *im, double *slab_part, int *n_slab_part,
-                   double *bk) {
+                   double *bk, bool *im_clean) {
   const bool fused = mesh_smooth(pd);
+  FftPlan fx, fy;
+  // the density brick: `im` when the last backward pass left it all zero (*im_clean) -- one launch fewer per update
+  const bool xy_fused = fused && fft_factor(pd.nx, fx) && fft_factor(pd.ny, fy) &&
+                        (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double) <= 128 * 1024;
+  const bool use_im = xy_fused && im_clean != nullptr;
   const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
-  hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, re);
+  double *rho = use_im ? im : re;
+  if (!use_im || !*im_clean) hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, rho);
   if (!fused) hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, im);
-  const int apb = 256 / (pd.order * pd.order);
+  const int apb = 256 / spread_threads_per_atom(pd.order);
   const int ngroups = (nl + apb - 1) / apb > 0 ? (nl + apb - 1) / apb : 1;
   const int npass = (ngroups + 1023) / 1024;       // at most 1024 slab partial sums (launch_b_real_combine reads them per wave)
   const int nb = (ngroups + npass - 1) / npass;
   *n_slab_part = nb;
-  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, nl, elyte_idx, x, q, re, slab_part, npass);
-  dft3(s, pd, -1.0, re, im, fused, gscale);
-  if (!fused)
-    hipLaunchKernelGGL(pppm_greens_kernel, dim3((pd.nfft + 255) / 256), dim3(256), 0, s, pd.nfft, gscale, pd.greensfn, re, im);
-  dft3(s, pd, +1.0, re, im, fused, gscale);
+  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, nl, elyte_idx, x, q, rho, slab_part, npass);
+  if (!(xy_fused && poisson_three_launches(s, pd, re, im, use_im, use_im))) {
+    dft3(s, pd, -1.0, re, im, fused, gscale, use_im, false);
+    if (!fused)
+      hipLaunchKernelGGL(pppm_greens_kernel, dim3((pd.nfft + 255) / 256), dim3(256), 0, s, pd.nfft, gscale, pd.greensfn, re, im);
+    dft3(s, pd, +1.0, re, im, fused, gscale, false, use_im);
+  }
+  if (im_clean) *im_clean = use_im;
   hipLaunchKernelGGL(pppm_gather_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, pd, ne, ne_pad, egrid, ew, re, bk);
 }
 
@@ -436,7 +548,7 @@ void launch_pppm_density(hipStream_t s, const PppmDev &pd, int n, const int *idx
                          double *slab_scratch) {
   hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, rho);
   if (n <= 0) return;
-  const int apb = 256 / (pd.order * pd.order);
+  const int apb = 256 / spread_threads_per_atom(pd.order);
   const int ngroups = (n + apb - 1) / apb;
   const int npass = (ngroups + 1023) / 1024;
   const int nb = (ngroups + npass - 1) / npass;
@@ -448,6 +560,7 @@ void launch_pppm_density(hipStream_t s, const PppmDev &pd, int n, const int *idx
 void launch_pppm_poisson(hipStream_t s, const PppmDev &pd, double *re, double *im) {
   const bool fused = mesh_smooth(pd);
   const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
+  if (fused && poisson_three_launches(s, pd, re, im, false, false)) return;
   if (!fused) hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, im);
   dft3(s, pd, -1.0, re, im, fused, gscale);
   if (!fused)
