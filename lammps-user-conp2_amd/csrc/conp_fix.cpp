@@ -210,6 +210,10 @@ struct conp_fix {
   int cg_iterations = 0;
   // the fix's log file (fix_conp.cpp:119): lines are buffered here and handed to the host by conp_fix_log_drain
   std::string logbuf, logdrain, mesgbuf, mesgdrain;   // mesgbuf: what the reference sends to utils::logmesg (:460, :1008)
+  // CONP_TIME_HOST=1: where a host-buffer update spends its host time (printed to stderr when the handle is closed)
+  const bool time_host = getenv("CONP_TIME_HOST") != nullptr;
+  double th[6] = {0, 0, 0, 0, 0, 0};    // list check, staging copies, enqueue, wait, scatter, updates
+  static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   bool pp_im_clean = false;      // the mesh's imaginary brick is all zero (left so by the b path's last backward pass)
   double Btime = 0., Ctime = 0., Ktime = 0.;      // accumulated like :549-552 (seconds)
   hipEvent_t ev_b[3] = {nullptr, nullptr, nullptr};
@@ -255,6 +259,10 @@ struct conp_fix {
   Profiler prof;
 
   ~conp_fix() {
+    if (time_host && th[5] > 0)
+      std::fprintf(stderr, "conp host-buffer update, us per call over %.0f calls: list check %.1f, staging + H2D enqueue %.1f, kernel "
+                           "enqueue %.1f, solve enqueue + wait + D2H %.1f, scatter %.1f\n", th[5], 1e6 * th[0] / th[5], 1e6 * th[1] / th[5],
+                   1e6 * th[2] / th[5], 1e6 * th[3] / th[5], 1e6 * th[4] / th[5]);
     prof.collect();
     drop_graph();
     if (nccl) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(nccl); nccl = nullptr; }
@@ -1481,15 +1489,16 @@ struct conp_fix {
       if (args.minimizer == CONP_SOLVER_INV) { solve_device(); allgather_q(); }
       scatter_device(d_q.p, potdiff);        // the device copy of q follows atom->q (post_force of the same step reuses it)
     }
+    double t0 = time_host ? now_s() : 0.0;
     double *qe = pinned((size_t)ne_pad + 8);
     HIP_TRY(hipMemcpyAsync(qe, d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
     finish_scalar(potdiff);                 // one synchronisation for the charges and the scalars
     collect_b_times();
-    const int n = at->nlocal + at->nghost;
-    for (int i = 0; i < n; ++i) {        // owned and ghost electrode atoms :1153-1158
-      if (!at->echeck[i]) continue;
-      at->q[i] = qe[idx.tag2eleall[at->tag[i]]];
-    }
+    if (time_host) { const double t1 = now_s(); th[3] += t1 - t0; t0 = t1; }
+    // owned and ghost electrode atoms :1153-1158, through the (atom, row) list of the last post_neighbor (the atom arrays keep
+    // their order between re-neighbourings; b_cal checked the count) instead of a walk over all atoms
+    for (int k = 0; k < n_ele_atoms; ++k) at->q[ele_pairs_h[2 * (size_t)k]] = qe[ele_pairs_h[2 * (size_t)k + 1]];
+    if (time_host) { th[4] += now_s() - t0; th[5] += 1.0; }
   }
 
   // fix_conp.cpp:577-580 post_force -> :1163-1201 force_cal + :1368-1444 blist_coul_cal_post_force
@@ -1533,10 +1542,14 @@ struct conp_fix {
   void b_cal(const conp_atoms *at) {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
     if (d_Rp.n == 0) km_a_read(at);      // electrode phase tables (kspmod->a_read) not built yet: b_cal before a_cal
+    double t0 = time_host ? now_s() : 0.0;
     if (elyte_list_stale(at)) { sync(); build_elyte_list(at); }       // km_ewald.cpp:686 is evaluated every step
+    if (time_host) { const double t1 = now_s(); th[0] += t1 - t0; t0 = t1; }
     upload_xq(at);
+    if (time_host) { const double t1 = now_s(); th[1] += t1 - t0; t0 = t1; }
     if (decomposed) gather_elyte(at);
     b_cal_device(d_x.p, d_q.p, true, true);
+    if (time_host) { const double t1 = now_s(); th[2] += t1 - t0; t0 = t1; }
     // (a handle that is rank r of N WITHOUT a communicator leaves this rank's shard in b: the caller sums the shards itself)
     if (nccl || rc.active()) allreduce_b();
   }

@@ -29,6 +29,9 @@ def main():
         for line in p.stdout.splitlines():
             if line.startswith(("time_pre_force_ms", "time_post_force_ms", "ERROR", "scalar")):
                 print(wl, line)
+        for line in p.stderr.splitlines():          # CONP_TIME_HOST=1: the library's own breakdown of the host-buffer update
+            if line.startswith("conp host-buffer"):
+                print(wl, line)
 
 
 if __name__ == "__main__":
