@@ -298,6 +298,9 @@ def main():
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),
                    kernels_ms={k: round(v[0], 5) for k, v in prof.items()},
                    ms_per_step_profiled_pass=dt_prof / n_prof * 1e3,
+                   order_of_passes=("setup; host-buffer hook pass; %d updates with events around every kernel (kernels_ms); "
+                                   "%d warm-up + %d timed updates (value; events around every 4th sk_gemm launch only)"
+                                   % (n_prof if not args.no_profile else 0, args.warmup, args.steps)),
                    roofline=roofline, composite_roofline=composite)
         if not args.no_cpu_baseline and world == 1:
             S = fx.matrix()
