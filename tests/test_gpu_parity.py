@@ -453,6 +453,54 @@ def test_device_update_graph_replay_matches_direct_launches():
     fx.close(); ref.close()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_geometries_match_the_oracle(oracle, seed):
+    """a sweep the decks do not cover: random box shapes, sheet counts, ion numbers (electrolyte counts that are no multiple of
+    the 16-atom chunk), Ewald parameters, boundary modes, shuffled atom order -- and in every other draw electrodes whose atoms
+    have been moved off their planes (rough electrodes: hundreds of distinct z values, the general projection kernels).  Charges,
+    b, the matrix and the structure factors against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    ne_side = int(rng.choice([4, 5, 6, 8]))                 # box edges stay above the cutoff
+    layers = int(rng.choice([1, 2]))
+    n_elyte = int(rng.choice([24, 52, 100, 212, 404]))
+    lz = float(rng.choice([44.0, 60.0, 88.0]))
+    mode = str(rng.choice(["ffield", "slab"]))
+    g_ewald = float(rng.choice([0.28, 0.35, 0.45]))
+    cutoff = float(rng.choice([6.0, 8.0]))
+    s = systems.synthetic(n_cells_x=ne_side, n_cells_y=max(1, ne_side // 2), lz=lz, n_elyte=n_elyte, layers=layers, cutoff=cutoff,
+                          accuracy_relative=float(rng.choice([1e-4, 1e-5, 1e-6])), g_ewald=g_ewald, mode=mode, seed=50 + seed,
+                          min_dist=1.5, shuffle_seed=seed if seed % 3 else None, name=f"sweep{seed}:{mode}")
+    if seed % 2:
+        ele = s.echeck != 0
+        s.x[ele, 2] += rng.normal(scale=0.15, size=int(ele.sum()))          # rough electrodes
+    at, alist, blist = neighbor.build_lists(s)
+    o = OracleRun(oracle, s, at, alist, blist)
+    o.setup()
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    q0 = at.q.copy()
+    fx.setup_pre_force(at, 0, s.potdiff)
+    o.pre_force(s.potdiff)
+    sr_o, si_o = o.fx.ks.sincos_b(at.x, q0, at.echeck, at.nlocal)
+    sr_g, si_g = fx.sfac()
+    scale = max(np.abs(sr_o).max(), np.abs(si_o).max())
+    assert max(np.abs(sr_g - sr_o).max(), np.abs(si_g - si_o).max()) / scale < 1e-11
+    b_o, q_o, sq_o = o.fx.vectors()
+    b_g, q_g, sq_g = fx.vectors()
+    assert rel_err(b_g, b_o) < 1e-10
+    assert rel_err(fx.matrix(), o.fx.matrix()) < 1e-7
+    ele = at.echeck != 0
+    assert rel_err(at.q[ele], o.q[ele]) < 1e-7
+    # a second update with moved ions
+    sol = at.echeck == 0
+    at.x[sol] += rng.normal(scale=0.03, size=(int(sol.sum()), 3))
+    fx.pre_force(at, 1, 0.7 * s.potdiff)
+    o.pre_force(0.7 * s.potdiff)
+    assert rel_err(at.q[ele], o.q[ele]) < 1e-7
+    fx.close(); o.fx.close()
+
+
 def test_ghost_image_mode_uploads_owned_atoms_only_and_gives_the_same_bits():
     """conp_env.ghost_images (what the LAMMPS glue sets): ghosts are rebuilt on the device from their owners and image shifts
     instead of being uploaded -- identical charges, also after the atoms moved and after a re-neighbour; a ghost that is NOT an
