@@ -205,7 +205,8 @@ struct conp_fix {
   std::vector<SkTile> tiles_h;   // (row tile, col tile) pairs of this rank, sorted by col tile
   std::vector<int> ele_pairs_h;    // (atom index, eleall index) of every owned or ghost electrode atom
   int n_ele_atoms = 0;
-  std::vector<int> ct_ptr_h, seg_ptr_h, rt_owner_h, own_rt_h;   // rt_owner_h: rank that owns each row tile; own_rt_h: this rank's
+  std::vector<double> tile_flo, tile_fhi;   // this rank's share of each of its tiles, as fractions of the tile's chunk axis
+  std::vector<int> ct_ptr_h, seg_ptr_h, own_rt_h;   // own_rt_h: the row tiles this rank works on (sorted)
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
   // the fix's log file (fix_conp.cpp:119): lines are buffered here and handed to the host by conp_fix_log_drain
@@ -390,39 +391,72 @@ struct conp_fix {
                     plan.kxmax, plan.kymax, d_p_ikx.p, d_p_iky.p, d_p_sgn.p, d_nb_act.p, d_wfull.p};
     d_G.reserve((size_t)plan.R_pad * plan.C_pad); d_Gw.reserve((size_t)plan.R_pad * plan.C_pad);
     d_G.zero(stream); d_Gw.zero(stream);
-    // k-shard: row tiles (rings of increasing |k_p| with decreasing kz range) are dealt to the ranks heaviest first, each to
-    // the least loaded rank so far (every rank computes the same map).  Cost of a tile = its active kz blocks per fragment.
+    // k-shard.  The structure-factor work is laid out on ONE axis -- tile after tile (col tile major), chunk after chunk, the axis
+    // build_items cuts into workgroup shares -- and rank r takes the r-th N-th of it by cost.  A tile that straddles a rank
+    // boundary is shared: each side multiplies its own chunk range, reduces and projects its partial G (the projection is linear
+    // in G), and the all-reduce of b adds the pieces.  Every rank gets the same work whatever the number of tiles (the first
+    // version dealt whole row tiles, heaviest first: 8 unequal tiles on 8 ranks left the heaviest rank 18 % above the mean, and
+    // more ranks than tiles idle).  Boundaries are fractions of a tile here; build_items turns them into chunk numbers -- both
+    // neighbours evaluate the same expression, so their ranges meet exactly.  CONP_SHARD_TILES=1: whole tiles (comparison).
     {
-      std::vector<std::pair<long, int>> order;
-      for (int rt = 0; rt < plan.n_row_tiles; ++rt) {
-        long c = 0;
-        for (int f = 0; f < 4; ++f) c += plan.nb_act16[4 * rt + f];
-        order.push_back({-(c + 8), rt});                 // + the per-chunk fixed cost (4 fragments x SK_C0)
-      }
-      std::stable_sort(order.begin(), order.end());
-      std::vector<long> load(env.nranks, 0);
-      rt_owner_h.assign(plan.n_row_tiles, 0);
-      for (auto &e : order) {
-        int best = 0;
-        for (int r = 1; r < env.nranks; ++r) if (load[r] < load[best]) best = r;
-        rt_owner_h[e.second] = best;
-        load[best] += -e.first;
+      struct GT { int rt, ct; double c; };
+      std::vector<GT> all;
+      for (int ct = 0; ct < plan.n_col_tiles; ++ct)
+        for (int rt = 0; rt < plan.n_row_tiles; ++rt) {
+          if (plan.nba(rt, ct) <= 0) continue;
+          const unsigned nbf = plan.nba16(rt, ct);
+          double sum = 0.0;
+          for (int f = 0; f < 4; ++f) sum += (double)((nbf >> (8 * f)) & 255u);
+          all.push_back(GT{rt, ct, 0.25 * sum + SK_C0});
+        }
+      std::vector<double> flo(all.size(), 0.0), fhi(all.size(), 0.0);
+      if (getenv("CONP_SHARD_TILES") && env.nranks > 1) {
+        // whole row tiles, heaviest first to the least loaded rank (every rank computes the same map)
+        std::vector<std::pair<double, int>> order;
+        std::vector<double> rtc(plan.n_row_tiles, 0.0);
+        for (const auto &g : all) rtc[g.rt] += g.c;
+        for (int rt = 0; rt < plan.n_row_tiles; ++rt) order.push_back({-rtc[rt], rt});
+        std::stable_sort(order.begin(), order.end());
+        std::vector<double> load(env.nranks, 0.0);
+        std::vector<int> owner(plan.n_row_tiles, 0);
+        for (auto &e : order) {
+          int best = 0;
+          for (int r = 1; r < env.nranks; ++r) if (load[r] < load[best]) best = r;
+          owner[e.second] = best;
+          load[best] += -e.first;
+        }
+        for (size_t t = 0; t < all.size(); ++t) if (owner[all[t].rt] == env.rank) fhi[t] = 1.0;
+      } else {
+        double W = 0.0;
+        for (const auto &g : all) W += g.c;
+        const double lo = W * (double)env.rank / (double)env.nranks, hi = W * (double)(env.rank + 1) / (double)env.nranks;
+        double S = 0.0;
+        for (size_t t = 0; t < all.size(); ++t) {
+          const double c = all[t].c;
+          flo[t] = std::min(1.0, std::max(0.0, (lo - S) / c));
+          fhi[t] = env.rank + 1 == env.nranks && t + 1 == all.size() ? 1.0 : std::min(1.0, std::max(0.0, (hi - S) / c));
+          S += c;
+        }
       }
       std::vector<int> mine(plan.n_row_tiles, 0);
+      tiles_h.clear(); tile_flo.clear(); tile_fhi.clear();
+      ct_ptr_h.assign(plan.n_col_tiles + 1, 0);
+      for (size_t t = 0; t < all.size(); ++t) {
+        if (fhi[t] > flo[t]) {
+          const int rt = all[t].rt, ct = all[t].ct;
+          tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0, plan.nba16(rt, ct)});
+          tile_flo.push_back(flo[t]); tile_fhi.push_back(fhi[t]);
+          mine[rt] = 1;
+        }
+        ct_ptr_h[all[t].ct + 1] = (int)tiles_h.size();
+      }
+      for (int ct = 0; ct < plan.n_col_tiles; ++ct) ct_ptr_h[ct + 1] = std::max(ct_ptr_h[ct + 1], ct_ptr_h[ct]);
       own_rt_h.clear();
-      for (int rt = 0; rt < plan.n_row_tiles; ++rt)
-        if (rt_owner_h[rt] == env.rank) { mine[rt] = 1; own_rt_h.push_back(rt); }
+      for (int rt = 0; rt < plan.n_row_tiles; ++rt) if (mine[rt]) own_rt_h.push_back(rt);
       d_rt_mine.upload(mine, stream);
       std::vector<int> own_up = own_rt_h;
       if (own_up.empty()) own_up.push_back(0);
       d_own_rt.upload(own_up, stream);
-    }
-    tiles_h.clear();
-    ct_ptr_h.assign(plan.n_col_tiles + 1, 0);
-    for (int ct = 0; ct < plan.n_col_tiles; ++ct) {
-      for (int rt : own_rt_h)
-        if (plan.nba(rt, ct) > 0) tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0, plan.nba16(rt, ct)});
-      ct_ptr_h[ct + 1] = (int)tiles_h.size();
     }
     d_ct_ptr.upload(ct_ptr_h, stream);
     sync();
@@ -670,27 +704,34 @@ struct conp_fix {
       for (int f = 0; f < 4; ++f) sum += (double)((t.nbf >> (8 * f)) & 255u);
       return 0.25 * sum + SK_C0;
     };
+    // this rank's chunk range of every tile (all of it on one rank; km_conp_setup); a tile may come out empty
+    std::vector<int> clo(nt, 0), chi(nt, nchunks);
+    for (size_t i = 0; i < nt; ++i) {
+      clo[i] = (int)std::lround(tile_flo[i] * nchunks);
+      chi[i] = (int)std::lround(tile_fhi[i] * nchunks);
+    }
     // work left from (tile ti, chunk ch) to the end, without segment starts
     std::vector<double> tail(nt + 1, 0.0);
-    for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + nchunks * cost(tiles_h[i]);
+    for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + (chi[i] - clo[i]) * cost(tiles_h[i]);
     // a segment shorter than this costs more in start-up than it carries -- but only where shares are long: a small system's
     // share IS one or two chunks (dilute: 16 chunks on 16 workgroups), and merging "slivers" there would quadruple one share
     const int MIN_SEG = std::max(1, std::min(4, (int)((nt * (size_t)nchunks) / (size_t)nwg) / 2));
     items_h.clear();
     seg_ptr_h.assign(nwg + 1, 0);
     size_t ti = 0;
-    int ch = 0;
+    while (ti < nt && chi[ti] <= clo[ti]) ++ti;
+    int ch = ti < nt ? clo[ti] : 0;
     for (int w = 0; w < nwg && nt > 0; ++w) {
       seg_ptr_h[w] = (int)items_h.size();
       if (ti >= nt) continue;
       const bool last = w + 1 == nwg;
       // equal shares of what is left, counting one segment start per remaining workgroup and one per tile boundary ahead
-      const double left = tail[ti] - ch * cost(tiles_h[ti]) + SK_CSEG * ((double)(nwg - w) + (double)(nt - 1 - ti));
+      const double left = tail[ti] - (ch - clo[ti]) * cost(tiles_h[ti]) + SK_CSEG * ((double)(nwg - w) + (double)(nt - 1 - ti));
       double budget = left / (nwg - w) - SK_CSEG;
       bool first = true;
       while (ti < nt) {
         const double c = cost(tiles_h[ti]);
-        const int avail = nchunks - ch;
+        const int avail = chi[ti] - ch;
         int take;
         if (last) take = avail;
         else {
@@ -705,8 +746,14 @@ struct conp_fix {
         budget -= take * c;
         ch += take;
         first = false;
-        if (ch >= nchunks) { ++ti; ch = 0; }
-        if (!last && (budget < c || ch != 0)) break;         // share used up (or stopped inside a tile)
+        bool inside = true;                                  // stopped inside a tile?
+        if (ch >= chi[ti]) {
+          ++ti;
+          while (ti < nt && chi[ti] <= clo[ti]) ++ti;
+          ch = ti < nt ? clo[ti] : 0;
+          inside = false;
+        }
+        if (!last && (budget < c || inside)) break;          // share used up (or stopped inside a tile)
       }
     }
     for (int w = 0; w <= nwg; ++w) if (w == nwg || nt == 0) seg_ptr_h[w] = (int)items_h.size();
