@@ -1165,12 +1165,13 @@ struct conp_fix {
     const int nctl = 16 + args.maxiter + 1;                  // scal[0..12], pad, hist[0..maxiter] at offset 16
     d_cg_res.reserve((size_t)2 * ne); d_cg_p.reserve((size_t)2 * ne); d_cg_ap.reserve((size_t)2 * ne);
     d_cg_scal.reserve(nctl); d_cg_done.reserve(1);
-    d_cg_done.zero(stream);
+    const bool two_launch = cg_unfused || !cg_step_fits(ne) || args.maxiter <= 1;
+    if (two_launch) d_cg_done.zero(stream);                  // (the one-launch form's start kernel clears the flag itself)
     double *hist_dev = d_cg_scal.p + 16;
     double *ctl = pinned((size_t)ne_pad + 8 + nctl) + ne_pad + 8;
     int done = 0, iter = 1, batch = std::max(2, std::min(16, cg_batch));
     prof.begin("cg", stream);
-    if (cg_unfused || !cg_step_fits(ne) || args.maxiter <= 1) {
+    if (two_launch) {
       launch_cg_init(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_scal.p);
       while (iter < args.maxiter && !done) {
         const int batch_end = std::min(args.maxiter, iter + batch);

@@ -1871,16 +1871,36 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restri
   }
 }
 
+// this lane's share of A[row,:] . p for the CG kernels: ONE accumulator in column order (what the two-launch and the one-launch
+// form must agree on to the bit); the loads of eight steps are requested together, the additions stay in order
+__device__ __forceinline__ double cg_row_dot(int n, const double *__restrict__ srow, const double *p, int lane) {
+  double s0 = 0.0;
+  int j = lane;
+  for (; j + 960 < n; j += 1024) {           // sixteen steps' loads in flight: a deck-sized row (Ne = 1664) is two round trips
+    double a[16], x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { a[u] = srow[j + 64 * u]; x[u] = p[j + 64 * u]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s0 = fma(a[u], x[u], s0);
+  }
+  for (; j + 448 < n; j += 512) {
+    double a[8], x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = srow[j + 64 * u]; x[u] = p[j + 64 * u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s0 = fma(a[u], x[u], s0);
+  }
+  for (; j < n; j += 64) s0 = fma(srow[j], p[j], s0);
+  return s0;
+}
+
 __global__ __launch_bounds__(256) void gemv_rows_guarded_kernel(int n, const double *__restrict__ S, const double *__restrict__ b,
                                                                 double *__restrict__ y, const int *__restrict__ done) {
   if (*done) return;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
-  const double *srow = S + (size_t)row * n;
-  double s0 = 0.0;
-  for (int j = lane; j < n; j += 64) s0 = fma(srow[j], b[j], s0);
-  s0 = wave_sum(s0);
+  const double s0 = wave_sum(cg_row_dot(n, S + (size_t)row * n, b, lane));
   if (lane == 0) y[row] = s0;
 }
 
@@ -1902,11 +1922,12 @@ void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *re
 __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__restrict__ A, const double *__restrict__ b,
                                                        double *__restrict__ q, double *__restrict__ res2, double *__restrict__ p2,
                                                        double *__restrict__ ap2, double *__restrict__ scal, double tolerance,
-                                                       int *__restrict__ done, int iter, double *__restrict__ hist, int mode) {
+                                                       int *__restrict__ done, int iter, double *__restrict__ hist, int mode,
+                                                       int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) char cg_smem[];
   double *pl = reinterpret_cast<double *>(cg_smem);          // the direction of the matvec: [n]
   __shared__ double red[16];
-  if (*done) return;
+  if (mode != 1 && *done) return;                            // (the start launch clears the flag of the previous solve itself)
   const bool writer = blockIdx.x == 0;
   const int k_upd = mode == 4 ? iter : iter - 1;             // the iteration whose update this launch applies (modes 2, 4)
   const int so = mode == 4 ? (iter + 1) & 1 : iter & 1;      // set written: the state entering iteration k_upd + 1
@@ -1926,23 +1947,54 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
       const double lres = l2 - netr * ave;
       scal[0] = lres; scal[1] = lres; scal[2] = netr; scal[6] = 0.0; scal[7] = 0.0; scal[8] = 0.0;
       scal[9 + 2 * so] = lres; scal[10 + 2 * so] = lres;
+      *done = 0;
     }
   } else if (mode == 2 || mode == 4) {
     const int si = k_upd & 1;
     const double *res_i = res2 + (size_t)si * n, *p_i = p2 + (size_t)si * n, *ap_i = ap2 + (size_t)si * n;
+    // up to four elements per thread (n <= 4096) stay in registers through the three passes -- one trip to L2 instead of three
+    // dependent ones; longer vectors re-read them.  Same operations in the same order either way.
+    const bool keep = n <= 4096;
+    double kp[4], kap[4], kr[4];
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + 1024 * u;
+        kp[u] = i < n ? p_i[i] : 0.0; kap[u] = i < n ? ap_i[i] : 0.0; kr[u] = i < n ? res_i[i] : 0.0;
+      }
+    }
     double ptap = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) ptap += p_i[i] * ap_i[i];
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (threadIdx.x + 1024 * u < n) ptap += kp[u] * kap[u];
+    } else {
+      for (int i = threadIdx.x; i < n; i += 1024) ptap += p_i[i] * ap_i[i];
+    }
     ptap = block_sum_1024(ptap, red);
     // (residual norm, gamma) entering iteration k live in the parity slot scal[9 + 2 (k & 1)], scal[10 + 2 (k & 1)]: every
     // workgroup of this launch reads slot k_upd & 1 while workgroup 0 writes the other one
     const double lresnorm = scal[9 + 2 * si], gamma = scal[10 + 2 * si];
     const double alpha = lresnorm / ptap;
     double lg = 0, netr = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      if (writer) q[i] = q[i] + alpha * p_i[i];
-      const double r = res_i[i] - alpha * ap_i[i];
-      if (writer) res_o[i] = r;
-      lg += r * r; netr += r;
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + 1024 * u;
+        if (i < n) {
+          if (writer) q[i] = q[i] + alpha * kp[u];
+          const double r = kr[u] - alpha * kap[u];
+          if (writer) res_o[i] = r;
+          kr[u] = r;
+          lg += r * r; netr += r;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < n; i += 1024) {
+        if (writer) q[i] = q[i] + alpha * p_i[i];
+        const double r = res_i[i] - alpha * ap_i[i];
+        if (writer) res_o[i] = r;
+        lg += r * r; netr += r;
+      }
     }
     lg = block_sum_1024(lg, red);
     netr = block_sum_1024(netr, red);
@@ -1950,12 +2002,26 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
     lg -= netr * ave;
     const double beta = lg / gamma;
     double lr = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      const double r = res_i[i] - alpha * ap_i[i];           // the same value as above, recomputed instead of kept
-      const double pn = beta * p_i[i] + r - ave;
-      pl[i] = pn;
-      if (writer) p_o[i] = pn;
-      lr += r * pn;
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + 1024 * u;
+        if (i < n) {
+          const double r = kr[u];
+          const double pn = beta * kp[u] + r - ave;
+          pl[i] = pn;
+          if (writer) p_o[i] = pn;
+          lr += r * pn;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < n; i += 1024) {
+        const double r = res_i[i] - alpha * ap_i[i];           // the same value as above, recomputed instead of kept
+        const double pn = beta * p_i[i] + r - ave;
+        pl[i] = pn;
+        if (writer) p_o[i] = pn;
+        lr += r * pn;
+      }
     }
     lr = block_sum_1024(lr, red);
     if (writer && threadIdx.x == 0) {
@@ -1978,13 +2044,12 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
   }
   if (mode == 4) return;
   __syncthreads();
-  const int row = blockIdx.x * 16 + (threadIdx.x >> 6);
-  if (row >= n) return;
+  // 16 waves: up to 16 rows per workgroup; small matrices take 8 so that more CUs pull on the matrix (Ne = 1664: 208 instead of 104)
+  const int wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * rows_per_block + wv;
+  if (wv >= rows_per_block || row >= n) return;
   const int lane = threadIdx.x & 63;
-  const double *srow = A + (size_t)row * n;
-  double s0 = 0.0;
-  for (int j = lane; j < n; j += 64) s0 = fma(srow[j], pl[j], s0);
-  s0 = wave_sum(s0);
+  const double s0 = wave_sum(cg_row_dot(n, A + (size_t)row * n, pl, lane));
   if (lane == 0) ap2[(size_t)(iter & 1) * n + row] = s0;
 }
 
@@ -1995,8 +2060,9 @@ void launch_cg_step(hipStream_t s, int n, const double *A, const double *b, doub
   const size_t lds = (size_t)n * sizeof(double);
   static DynLdsCache granted{};
   ensure_dyn_lds(cg_step_kernel, lds, granted);
-  hipLaunchKernelGGL(cg_step_kernel, dim3(mode == 4 ? 1 : (n + 15) / 16), dim3(1024), lds, s, n, A, b, q, res2, p2, ap2, scal, tolerance,
-                     done, iter, hist, mode);
+  const int rpb = n <= 4096 ? 8 : 16;
+  hipLaunchKernelGGL(cg_step_kernel, dim3(mode == 4 ? 1 : (n + rpb - 1) / rpb), dim3(1024), lds, s, n, A, b, q, res2, p2, ap2, scal, tolerance,
+                     done, iter, hist, mode, rpb);
 }
 
 }  // namespace conp
