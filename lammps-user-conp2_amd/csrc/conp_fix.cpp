@@ -86,6 +86,7 @@ struct Profiler {
     //  0.3057 -> 0.3110 ms at the headline size; every 4th launch keeps the timed region within 0.4 % of an uninstrumented run)
     if (!skipped && dominant_only && (n_dominant++ & 3) != 0) skipped = true;
     if (skipped) return;
+    if (pending.size() >= 4096) collect();        // a host that leaves profiling on for a long run must not grow this forever
     Rec r; r.name = name;
     r.a = get(); r.b = get();
     (void)hipEventRecord(r.a, s);
