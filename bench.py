@@ -271,6 +271,13 @@ def main():
                             measured="HIP events on the library's stream around every 4th sk_gemm launch of the timed region",
                             algorithmic_flops_per_launch=flops, survey_count_tflops=2 * ach,
                             note="achieved uses 4 flop per (k, atom); SURVEY 8d's reference-loop count (8 per k) would double it")
+        # the HBM-bound member of the update: the GEMV with the projected inverse streams 8 Ne^2 / N bytes once (HIP events of the
+        # per-kernel pass; rocprofv3's kernel-only duration is ~2 us shorter, profiles/r02_bench_headline_summary.txt)
+        hbm_member = None
+        if "gemv_charge" in prof and prof["gemv_charge"][0] > 0:
+            gb = 8.0 * ne * ne / world / 1e9
+            hbm_member = dict(kernel="gemv_finish_kernel", bound="hbm", achieved=gb / (prof["gemv_charge"][0] * 1e-3), peak=8000.0,
+                              unit="GB/s", frac=gb / (prof["gemv_charge"][0] * 1e-3) / 8000.0, bytes_per_launch=8.0 * ne * ne / world)
         # composite bound of one update: sum over the kernels of max(algorithmic flops / FP64 peak, algorithmic bytes /
         # HBM peak), one rank's share; achieved fraction = T_roof / measured time per update
         HBM_PEAK = 8.0e12
@@ -301,7 +308,7 @@ def main():
                    order_of_passes=("setup; host-buffer hook pass; %d updates with events around every kernel (kernels_ms); "
                                    "%d warm-up + %d timed updates (value; events around every 4th sk_gemm launch only)"
                                    % (n_prof if not args.no_profile else 0, args.warmup, args.steps)),
-                   roofline=roofline, composite_roofline=composite)
+                   roofline=roofline, roofline_hbm_member=hbm_member, composite_roofline=composite)
         if not args.no_cpu_baseline and world == 1:
             S = fx.matrix()
             base = cpu_baseline(s, at, alist, blist, S, args.cpu_threads)
