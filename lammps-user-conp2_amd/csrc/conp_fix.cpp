@@ -821,7 +821,7 @@ struct conp_fix {
         for (int t = 0; t < plan.C_pad; ++t)
           for (int c = 0; c < nzc; ++c) Tzc[(size_t)t * 64 + c] = Tz[(size_t)t * ne_pad + rep[c]];
         d_Tzc.upload(Tzc, stream); d_zclass.upload(zclass, stream);
-        d_Hc.reserve((size_t)4 * plan.R_pad * 64); d_Hc.zero(stream);
+        d_Hc.reserve((size_t)8 * plan.R_pad * 64); d_Hc.zero(stream);     // 8 slots: the reduction's column slices (b_hc: 4, the rest stay 0)
       }
     }
     sync();

@@ -753,17 +753,24 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 // are summed in two levels:  level 1 (blockIdx.y = group g) adds splits [16 g, 16 g + 16) into slot 16 g in place,
 // level 2 adds the group slots (stride 16) and writes G / Gwf.  level 0 = everything in one pass.
 constexpr int SKR_GROUP = 16;
-constexpr int SKR_T = 640, SKR_K = 1280 / SKR_T;   // threads per block, elements (of the block's 16 x 80 piece) per thread
+// a tile's 320 columns are cut into SKR_SL slices: one block per (tile, 16-row fragment, slice).  Eight slices of 40 columns
+// (round 1 and most of round 2: four of 80, two elements per thread): twice the blocks pulling on the partial tiles -- the
+// reduction is a pure stream, and 32 blocks per tile left most CUs idle for small systems and for one rank's one or two tiles
+// SL = 4 slices of 80 columns (two elements per thread) when the plan has enough tiles to fill the chip that way (headline: 8
+// tiles x 32 blocks; eight slices cost 4.7 us there: twice the Hc slots for the dot kernel to stage), 8 slices of 40 otherwise
+constexpr int SKR_T = 640;                         // threads per block
 // two levels (one more launch) once the most-split tile has more than this many partials: measured break-even on the headline
 // box -- 40 partials (one GPU) 4 us faster in one level, 57 (two ranks) equal, 113 (four ranks) 12 us faster in two
 static int skr_two_level_from() { static const int v = getenv("CONP_SKR_TWO") ? atoi(getenv("CONP_SKR_TWO")) : 4 * SKR_GROUP; return v; }
+template <int SKR_SL>
 __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
                                                         double *__restrict__ part, const double *__restrict__ wfull,
                                                         double *__restrict__ G, double *__restrict__ Gwf, int level) {
-  __shared__ double tr[1280];
-  const SkTile tl = tiles[blockIdx.x >> 5];
-  const int f16 = (blockIdx.x >> 2) & 7;       // 16-row fragment inside the 128-row tile
-  const int q = blockIdx.x & 3;                // 80-column quarter of the 320-column tile
+  constexpr int SKR_W = 320 / SKR_SL, SKR_K = 16 * SKR_W / SKR_T;      // slice width; elements per thread (2 or 1)
+  __shared__ double tr[16 * SKR_W];
+  const SkTile tl = tiles[blockIdx.x / (8 * SKR_SL)];
+  const int f16 = (blockIdx.x / SKR_SL) & 7;   // 16-row fragment inside the 128-row tile
+  const int q = blockIdx.x % SKR_SL;           // column slice of the 320-column tile
   const size_t plane = 128 * 320;
   int first = 0, count = tl.nsplit, stride = 1;
   if (level == 1) {
@@ -778,8 +785,8 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTil
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) {
     const int e = threadIdx.x + SKR_T * k;
-    const int row = e / 80, cl = e % 80;
-    const int rowl = 16 * f16 + row, col = 80 * q + cl;
+    const int row = e / SKR_W, cl = e % SKR_W;
+    const int rowl = 16 * f16 + row, col = SKR_W * q + cl;
     double sum = 0.0;
     double *src = part + (size_t)(tl.item0 + first) * plane + rowl * 320 + col;
     if (col < 32 * tl.nba) {
@@ -813,21 +820,30 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTil
   if (level == 1) return;
   __syncthreads();
   const size_t rf = (size_t)tl.rt * 8 + f16;
-  double *dst = Gwf + (rf * (C_pad / 4) + (size_t)tl.ct * 80 + 20 * q) * 64;
+  double *dst = Gwf + (rf * (C_pad / 4) + (size_t)tl.ct * 80 + (SKR_W / 4) * q) * 64;
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) dst[threadIdx.x + SKR_T * k] = tr[threadIdx.x + SKR_T * k];
 }
 
+// slices per tile: enough blocks to fill the chip
+static int skr_slices(int ntiles) { return ntiles * 32 >= 200 ? 4 : 8; }
+
+template <int SL>
+static void launch_sk_reduce_sl(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
+                                double *Gwf) {
+  if (max_nsplit > skr_two_level_from()) {
+    const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
+    hipLaunchKernelGGL(sk_reduce_kernel<SL>, dim3(ntiles * 8 * SL, ngroups), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 1);
+    hipLaunchKernelGGL(sk_reduce_kernel<SL>, dim3(ntiles * 8 * SL), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 2);
+  } else {
+    hipLaunchKernelGGL(sk_reduce_kernel<SL>, dim3(ntiles * 8 * SL), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 0);
+  }
+}
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf) {
   if (ntiles <= 0) return;
-  if (max_nsplit > skr_two_level_from()) {
-    const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 1);
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 2);
-  } else {
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Gwf, 0);
-  }
+  if (skr_slices(ntiles) == 4) launch_sk_reduce_sl<4>(s, pl, tiles, ntiles, max_nsplit, part, G, Gwf);
+  else launch_sk_reduce_sl<8>(s, pl, tiles, ntiles, max_nsplit, part, G, Gwf);
 }
 
 // structure factors in the reference's k order (parity read-back; km_ewald.cpp sfacrl_all / sfacim_all)
@@ -937,7 +953,7 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
 __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, const int *__restrict__ rt_mine, int nzc16,
                                                    const int *__restrict__ nb_act, const double *__restrict__ Gwf,
                                                    const double *__restrict__ Tzc /*[C_pad][64]*/,
-                                                   double *__restrict__ Hc4 /*[4][64][R_pad]*/, int R_pad) {
+                                                   double *__restrict__ Hc4 /*[8 slots, 4 written here][64][R_pad]*/, int R_pad) {
   const int rf = blockIdx.x, rt = rf >> 3, kq = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
@@ -964,7 +980,7 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
 // loads) -- reading them per thread and per row from global cost more than the 42 MB Rp stream itself (20 -> 11 us).
 __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
                                                         const double *__restrict__ Rp, const double *__restrict__ Hc4,
-                                                        const int *__restrict__ zclass, double *__restrict__ bk) {
+                                                        const int *__restrict__ zclass, double *__restrict__ bk, int nslot) {
   extern __shared__ __attribute__((aligned(16))) char zc_smem[];
   double *H = reinterpret_cast<double *>(zc_smem);          // [n_own * 32][nzc]
   __shared__ double red[16][64];
@@ -977,7 +993,8 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
   for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {
     const int cls = e / nrow, rowl = e - cls * nrow;
     const double *h = Hc4 + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 5] * 128 + blockIdx.y * 32 + (rowl & 31);
-    H[rowl * nzc + cls] = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);
+    const double h03 = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);       // slots = column slices of the reduction (4 or 8)
+    H[rowl * nzc + cls] = nslot == 4 ? h03 : h03 + ((h[4 * hp] + h[5 * hp]) + (h[6 * hp] + h[7 * hp]));
   }
   __syncthreads();
   double sum = 0.0;
@@ -1016,7 +1033,7 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
 // b_real_combine launch.  Used when the whole Hc table of this rank fits in 64 KB of LDS (planar electrodes: 2-6 z classes).
 __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
                                                           const double *__restrict__ Rp, const double *__restrict__ Hc4,
-                                                          const int *__restrict__ zclass, BRowArgs ra) {
+                                                          const int *__restrict__ zclass, BRowArgs ra, int nslot) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char zf_smem[];
   double *H = reinterpret_cast<double *>(zf_smem);          // [n_own * 128][nzc]
@@ -1041,7 +1058,8 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {      // class-major Hc4: coalesced runs of rows, classes in use only
     const int cls = e / nrow, rowl = e - cls * nrow;
     const double *h = Hc4 + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 7] * 128 + (rowl & 127);
-    H[rowl * nzc + cls] = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);
+    const double h03 = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);       // slots = column slices of the reduction (4 or 8)
+    H[rowl * nzc + cls] = nslot == 4 ? h03 : h03 + ((h[4 * hp] + h[5 * hp]) + (h[6 * hp] + h[7 * hp]));
   }
   __syncthreads();
   double sum = 0.0;
@@ -1089,34 +1107,36 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
 bool zc_final_fits(int n_own, int nzc) { return n_own > 0 && (size_t)n_own * 128 * nzc * sizeof(double) <= 64 * 1024; }
 
 static void launch_b_zc_final(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
-                              const double *Hc, const int *zclass, const BRowArgs &fin) {
+                              const double *Hc, const int *zclass, const BRowArgs &fin, int nslot) {
   const size_t lds = (size_t)n_own * 128 * nzc * sizeof(double);
   static DynLdsCache granted{};
   ensure_dyn_lds(b_zc_final_kernel, lds, granted);
-  hipLaunchKernelGGL(b_zc_final_kernel, dim3(ne_pad / 16), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, fin);
+  hipLaunchKernelGGL(b_zc_final_kernel, dim3(ne_pad / 16), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, fin, nslot);
 }
 
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
-                            const double *Hc, const int *zclass, double *bk_part) {
+                            const double *Hc, const int *zclass, double *bk_part, int nslot) {
   const size_t lds = (size_t)(n_own > 0 ? n_own : 1) * 32 * nzc * sizeof(double);      // the host keeps this <= 96 KB (conp_fix.cpp)
   static DynLdsCache granted{};
   ensure_dyn_lds(b_zc_dot_kernel, lds, granted);
-  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  hipLaunchKernelGGL(b_zc_dot_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, nslot);
 }
 
 // Planar electrodes with one column tile (nz <= 160): the last partial-tile sum and the Hc product in ONE kernel -- a block
 // of sk_reduce already holds its 16 x 80 piece of (w G) in LDS in MFMA-fragment order, exactly the A operand b_hc needs, so the
 // Gwf round trip and one launch go away (the decks' updates are launch-bound).  Same sums in the same order as the two
 // kernels; Hc4 slot = the block's 80-column quarter.
+template <int SKR_SL>
 __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const SkTile *__restrict__ tiles, const double *__restrict__ part,
                                                            const double *__restrict__ wfull, double *__restrict__ G,
                                                            const double *__restrict__ Tzc /*[C_pad][64]*/,
-                                                           double *__restrict__ Hc4 /*[4][64][R_pad]*/, int R_pad, int nzc16,
+                                                           double *__restrict__ Hc4 /*[SKR_SL slots][64][R_pad]*/, int R_pad, int nzc16,
                                                            int level) {
-  __shared__ double tr[1280];
-  const SkTile tl = tiles[blockIdx.x >> 5];
-  const int f16 = (blockIdx.x >> 2) & 7;
-  const int q = blockIdx.x & 3;
+  constexpr int SKR_W = 320 / SKR_SL, SKR_K = 16 * SKR_W / SKR_T;
+  __shared__ double tr[16 * SKR_W];
+  const SkTile tl = tiles[blockIdx.x / (8 * SKR_SL)];
+  const int f16 = (blockIdx.x / SKR_SL) & 7;
+  const int q = blockIdx.x % SKR_SL;
   const size_t plane = 128 * 320;
   const int stride = level == 2 ? SKR_GROUP : 1;
   const int count = level == 2 ? (tl.nsplit + SKR_GROUP - 1) / SKR_GROUP : tl.nsplit;
@@ -1124,20 +1144,21 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   const int nks = 8 * tl.nba;
-  // the z-class operand of the product below depends on the tile only: the waves that will multiply request their 20 values
-  // now, so that the loads are in flight while the partial tiles are summed (they were five dependent-looking groups of four
+  constexpr int NKS = SKR_W / 4;               // k-steps (4 columns each) of this block's slice
+  // the z-class operand of the product below depends on the tile only: the waves that will multiply request their values
+  // now, so that the loads are in flight while the partial tiles are summed (they were dependent-looking groups of four
   // behind the barrier: 4 us of the 9.4 this kernel took on il_onelayer)
-  double bz[20];
+  double bz[NKS];
   if (wave < nzc16) {
-    const double *bp = Tzc + (size_t)(tl.ct * 320 + 80 * q + fk) * 64 + 16 * wave + fr;
+    const double *bp = Tzc + (size_t)(tl.ct * 320 + SKR_W * q + fk) * 64 + 16 * wave + fr;
 #pragma unroll
-    for (int tsl = 0; tsl < 20; ++tsl) bz[tsl] = 20 * q + tsl < nks ? bp[(size_t)tsl * 256] : 0.0;
+    for (int tsl = 0; tsl < NKS; ++tsl) bz[tsl] = NKS * q + tsl < nks ? bp[(size_t)tsl * 256] : 0.0;
   }
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) {
     const int e = threadIdx.x + SKR_T * k;
-    const int row = e / 80, cl = e % 80;
-    const int rowl = 16 * f16 + row, col = 80 * q + cl;
+    const int row = e / SKR_W, cl = e % SKR_W;
+    const int rowl = 16 * f16 + row, col = SKR_W * q + cl;
     double sum = 0.0;
     if (col < 32 * tl.nba) {
       const double *src = part + (size_t)tl.item0 * plane + rowl * 320 + col;
@@ -1167,30 +1188,37 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
   if (wave >= nzc16) return;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int tsl = 0; tsl < 20; ++tsl)
-    if (20 * q + tsl < nks) acc = MFMA_F64(tr[tsl * 64 + lane], bz[tsl], acc);      // (wave-uniform condition)
+  for (int tsl = 0; tsl < NKS; ++tsl)
+    if (NKS * q + tsl < nks) acc = MFMA_F64(tr[tsl * 64 + lane], bz[tsl], acc);      // (wave-uniform condition)
   const int rf = tl.rt * 8 + f16;
-  double *out = Hc4 + (size_t)q * R_pad * 64 + (size_t)(16 * wave + fr) * R_pad;
+  double *out = Hc4 + (size_t)q * R_pad * 64 + (size_t)(16 * wave + fr) * R_pad;       // slot = this block's column slice
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[16 * rf + fk + 4 * r] = acc[r];
 }
 
 // sk_reduce (+ level 1 when tiles are heavily split) with the Hc product fused in, then the per-atom dot
+template <int SL>
+static void launch_reduce_hc_sl(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
+                                const double *Tzc, double *Hc, int nzc16) {
+  int level = 0;
+  if (max_nsplit > skr_two_level_from()) {
+    const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
+    hipLaunchKernelGGL(sk_reduce_kernel<SL>, dim3(ntiles * 8 * SL, ngroups), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, nullptr, 1);
+    level = 2;
+  }
+  hipLaunchKernelGGL(sk_reduce_hc_kernel<SL>, dim3(ntiles * 8 * SL), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
+                     nzc16, level);
+}
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
                                   const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
   if (ntiles <= 0) return;
   const int nzc16 = (nzc + 15) / 16;
-  int level = 0;
-  if (max_nsplit > skr_two_level_from()) {
-    const int ngroups = (max_nsplit + SKR_GROUP - 1) / SKR_GROUP;
-    hipLaunchKernelGGL(sk_reduce_kernel, dim3(ntiles * 32, ngroups), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, nullptr, 1);
-    level = 2;
-  }
-  hipLaunchKernelGGL(sk_reduce_hc_kernel, dim3(ntiles * 32), dim3(SKR_T), 0, s, pl.C_pad, tiles, part, pl.wfull, G, Tzc, Hc, pl.R_pad,
-                     nzc16, level);
-  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin);
-  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  const int nslot = skr_slices(ntiles);
+  if (nslot == 4) launch_reduce_hc_sl<4>(s, pl, tiles, ntiles, max_nsplit, part, G, Tzc, Hc, nzc16);
+  else launch_reduce_hc_sl<8>(s, pl, tiles, ntiles, max_nsplit, part, G, Tzc, Hc, nzc16);
+  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin, nslot);
+  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, nslot);
 }
 
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
@@ -1198,8 +1226,8 @@ void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const
   const int nzc16 = (nzc + 15) / 16;
   hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
-  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin);
-  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part);
+  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin, 4);      // b_hc writes four k-quarter slots
+  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 4);
 }
 
 // ================================================================================================
