@@ -6,7 +6,7 @@ electroneutrality projection and electrode-index bookkeeping bit-exact"):
   * structure factors, b vector: 1e-11 of the largest entry (different summation order over <= 3e4 atoms and an
     angle-addition recurrence of up to kzmax steps on both sides);
   * A matrix: 1e-11 of the largest entry;  projected inverse, elesetq, charges: 1e-8 relative to the largest entry
-    (error amplified by cond(A); LU by rocSOLVER vs the oracle's plain LU);
+    (error amplified by cond(A); the library's blocked Gauss-Jordan vs the oracle's plain LU);
   * inv_project on a GIVEN matrix: bit-exact.
 """
 import numpy as np
