@@ -705,7 +705,9 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
 #ifdef SK_STAMP
     if (t == 0 && sg < 4096) {
       unsigned long long *o = sk_seg_buf + (size_t)sg * 4;
-      o[0] = ((unsigned long long)blockIdx.x << 32) | (unsigned)c.it.rt; o[1] = c.it.nbf; o[2] = (unsigned)(c.it.c1 - c.it.c0);
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));      // which XCD this workgroup landed on
+      o[0] = ((unsigned long long)blockIdx.x << 32) | ((xcc & 15u) << 16) | (unsigned)c.it.rt; o[1] = c.it.nbf; o[2] = (unsigned)(c.it.c1 - c.it.c0);
       o[3] = __builtin_amdgcn_s_memrealtime() - sg_t0;
     }
 #endif

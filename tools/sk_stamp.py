@@ -71,9 +71,9 @@ if hasattr(lib, "conp_debug_sk_segs") and lib.conp_debug_sk_segs(sg.ctypes.data_
     out = os.path.join(ROOT, "gpurun_out", "sk_segments.txt")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
-        f.write("# wg rt nbf0 nbf1 nbf2 nbf3 chunks us\n")
+        f.write("# wg rt nbf0 nbf1 nbf2 nbf3 chunks us xcc\n")
         for r in sg:
             nbf = int(r[1])
-            f.write("%d %d %d %d %d %d %d %.2f\n" % (int(r[0]) >> 32, int(r[0]) & 0xffffffff, nbf & 255, (nbf >> 8) & 255, (nbf >> 16) & 255,
-                                                   (nbf >> 24) & 255, int(r[2]), float(r[3]) / 100.0))
+            f.write("%d %d %d %d %d %d %d %.2f %d\n" % (int(r[0]) >> 32, int(r[0]) & 0xffff, nbf & 255, (nbf >> 8) & 255, (nbf >> 16) & 255,
+                                                      (nbf >> 24) & 255, int(r[2]), float(r[3]) / 100.0, (int(r[0]) >> 16) & 15))
     print(f"  {len(sg)} segments -> {out}")
