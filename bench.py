@@ -10,7 +10,7 @@ one all-gather of q (Ne doubles) per update, made INSIDE the library on its own 
 the once-per-run A build is sharded by tiles and summed over RCCL, every rank keeps only its rows of the projected inverse
 -> "strong" scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|big|il_onelayer|il_twolayer|dilute|cond2] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|headline_slab|big|il_onelayer|il_twolayer|dilute|cond2] [--no-configs] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -34,6 +34,10 @@ def make_workload(name):
         return systems.synthetic_fast(n_cells_x=32, n_cells_y=16, lz=600.0, n_elyte=32768, cutoff=16.0,
                                       accuracy_relative=1e-7, g_ewald=0.21218, mode="ffield", seed=12345,
                                       name="synthetic graphene/IL 4096 electrode + 32768 electrolyte, ffield")
+    if name == "headline_slab":      # the same box in the reference's DEFAULT geometry: boundary p p f + kspace_modify slab 3.0
+        return systems.synthetic_fast(n_cells_x=32, n_cells_y=16, lz=600.0, n_elyte=32768, cutoff=16.0,
+                                      accuracy_relative=1e-7, g_ewald=0.21218, mode="slab", seed=12345,
+                                      name="synthetic graphene/IL 4096 electrode + 32768 electrolyte, slab 3.0")
     if name == "big":
         return systems.synthetic_fast(n_cells_x=64, n_cells_y=32, lz=1200.0, n_elyte=262144, cutoff=12.0,
                                       accuracy_relative=1e-6, g_ewald=0.2554, mode="ffield", seed=12345,
@@ -80,6 +84,98 @@ def cpu_baseline(s, at, alist, blist, S_matrix, threads):
                        f"real-space b {t3 - t2:.3f}, GEMV {t4 - t3:.3f}); oracle/conp_oracle.c -O3 -mavx2 -mfma")
 
 
+def sk_gemm_flops(info, world=1):
+    """algorithmic work of the structure-factor contraction per launch (DESIGN.md "roofline"): one complex MAC per (half-space
+    k, atom) with the +-kz pair sharing its products = 4 flop per k per atom (SURVEY 8d counts the reference loop's 8)"""
+    return 4.0 * info.n_elyte_charged * info.kcount / world
+
+
+def composite_roofline(info, ms_per_step, world=1, pppm=False):
+    """T_roof = sum over the kernels of max(algorithmic flops / FP64 peak, algorithmic bytes / HBM peak)"""
+    ne = info.elenum_all
+    t_roof = {
+        "structure_factors_mfma": 0.0 if pppm else sk_gemm_flops(info, world) / (FP64_PEAK_TFLOPS * 1e12),
+        "b_projection_hbm": 0.0 if pppm else 8.0 * 2.0 * info.kcount_flat * ne / world / (HBM_PEAK_GBS * 1e9),
+        "b_real_space_hbm": info.n_blist_pairs * (8 + 32) / world / (HBM_PEAK_GBS * 1e9),
+        "gemv_hbm": 8.0 * ne * ne / world / (HBM_PEAK_GBS * 1e9),
+    }
+    t_roof_ms = 1e3 * sum(t_roof.values())
+    return dict(t_roof_ms=t_roof_ms, frac=t_roof_ms / ms_per_step, parts_ms={k: 1e3 * v for k, v in t_roof.items()},
+                note="sum of per-kernel max(algorithmic flops / 78.6 TF, algorithmic bytes / 8 TB/s); collectives excluded"
+                     + ("; PPPM mesh passes not counted (mesh-dependent, SURVEY 8d)" if pppm else ""))
+
+
+def measure_config(label, workload, solver="inv", pppm=None, steps=200, warmup=20, dev_index=0):
+    """one BASELINE config on one GPU, device-resident like the headline: setup, a per-kernel pass (HIP events around every
+    kernel), warm-up, K timed updates.  Returns the entry of the JSON line's `configs` block."""
+    import torch
+    from conp_amd import FixConp, neighbor
+    t0 = time.perf_counter()
+    s = make_workload(workload)
+    at, alist, blist = neighbor.build_lists(s)
+    extra = (["pppm"] if pppm else []) + (["cg"] if solver == "cg" else [])
+    fx = FixConp(s, device=dev_index, extra_args=extra, pppm_mesh=tuple(pppm) if pppm else None)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.linalg_setup(at)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    info = fx.info()
+    d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda()
+    d_q = torch.from_numpy(at.q.copy()).cuda()
+
+    def run(n):
+        for _ in range(n):
+            fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)
+
+    fx.profile(1)
+    run(max(50, steps // 2))
+    torch.cuda.synchronize()
+    prof = fx.profile_read()
+    fx.profile(0)
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    info = fx.info()                      # (cg_iterations of the last solve)
+    kernels = {k: round(v[0], 5) for k, v in prof.items() if k not in ("a_kspace", "a_real", "inverse")}
+    dom = max(kernels, key=kernels.get) if kernels else None
+    dominant = None
+    if dom is not None:
+        t_ms = kernels[dom]
+        ne = info.elenum_all
+        if dom == "sk_gemm":
+            ach = sk_gemm_flops(info) / (t_ms * 1e-3) / 1e12
+            dominant = dict(kernel="sk_gemm_kernel", ms=t_ms, bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=ach / FP64_PEAK_TFLOPS)
+        elif dom in ("gemv_charge", "gemv", "cg"):
+            # inverse: the matrix once; CG: the matrix once per iteration (fix_conp.cpp:864-930)
+            passes = max(1, int(info.cg_iterations)) if dom == "cg" else 1
+            gbs = 8.0 * ne * ne * passes / 1e9 / (t_ms * 1e-3)
+            dominant = dict(kernel=dom, ms=t_ms, bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                            matrix_passes=passes)
+        else:
+            dominant = dict(kernel=dom, ms=t_ms, bound="launch latency / small transforms", frac=None)
+    out = dict(workload=s.name, Ne=int(info.elenum_all), Nl=int(info.n_elyte_charged), K=int(info.kcount),
+               mode="ffield" if s.ff_flag == 1 else "slab", solver=solver,
+               kspace=("pppm %dx%dx%d order 5" % tuple(pppm)) if pppm else "ewald",
+               ms_per_update=ms, updates_per_s=1e3 / ms, steps=steps, warmup=warmup, kernels_ms=kernels, dominant_kernel=dominant,
+               composite_roofline=composite_roofline(info, ms, pppm=bool(pppm)), setup_s=t_setup)
+    fx.close()
+    return label, out
+
+
+# every BASELINE.json config that fits one GPU, measured AFTER the headline's timed region (so `value` is untouched)
+AUX_CONFIGS = [
+    ("configs[1] il_onelayer inv", dict(workload="il_onelayer", solver="inv")),
+    ("configs[2] il_twolayer cg+etypes", dict(workload="il_twolayer", solver="cg")),
+    ("configs[3] il_onelayer pppm 40x45x180", dict(workload="il_onelayer", solver="inv", pppm=(40, 45, 180))),
+    ("headline slab 3.0 (reference default geometry)", dict(workload="headline_slab", solver="inv", steps=100, warmup=10)),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +188,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels with HIP events")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (the other BASELINE configs, measured after the headline's timed region)")
     ap.add_argument("--pppm", type=int, nargs=3, metavar=("NX", "NY", "NZ"), default=None,
                     help="k-space b through the PPPM mesh (`pppm` keyword, BASELINE configs[3]) with this mesh, order 5")
     args = ap.parse_args()
@@ -127,21 +225,16 @@ def main():
     # the collectives on its own stream, in order with its kernels.  The rehearsal on a one-GPU box cannot (RCCL refuses two
     # ranks on one device): it keeps the Python choreography over gloo.
     lib_collectives = world > 1 and not rehearse
+    collectives = "none (one rank)" if world == 1 else "gloo rehearsal on one GPU (torch.distributed choreography)"
     if lib_collectives:
-        # should the library's own communicator not come up on some rank (RCCL missing, version clash), every rank falls back
-        # to the Python choreography over torch.distributed: the scaling run must not die of it
-        ok = 1
-        try:
-            fx.comm_init_rccl()
-        except Exception as e:          # noqa: BLE001
-            ok = 0
-            print(f"[bench] rank {rank}: conp_fix_comm_init_rccl failed ({e}); falling back to torch.distributed collectives", file=sys.stderr)
-        flag = torch.tensor([ok], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if ok:
-                raise SystemExit("bench: a partner rank has no library communicator and this one has: cannot mix")
-            lib_collectives = False
+        # Every rank gets the library's communicator or none does: FixConp.comm_init_rccl agrees on RCCL's availability BEFORE the
+        # collective ncclCommInitRank and again after it (all ranks take the same branch, no rank exits alone).  Without it the
+        # run falls back to the Python choreography over torch.distributed -- and SAYS so in the JSON line ("collectives").
+        lib_collectives = fx.comm_init_rccl()
+        collectives = "rccl-in-library" if lib_collectives else "torch-fallback"
+        if not lib_collectives:
+            print(f"[bench] rank {rank}: no RCCL communicator inside the library on some rank; ALL ranks fall back to "
+                  "torch.distributed collectives", file=sys.stderr)
     if world > 1 and not lib_collectives:
         fx.set_stream(torch.cuda.current_stream().cuda_stream)
     fx.init_lists(alist, blist)
@@ -251,8 +344,7 @@ def main():
         # dominant kernel: the structure-factor contraction.  Algorithmic work per launch (DESIGN.md "roofline"):
         # one complex MAC per (half-space k, atom) with the +-kz pair sharing its products = 4 real FMA per (kxy,kz)
         # pair = 4 flop per k per atom.  (SURVEY 8d counts the reference loop's 16 flop per pair = 8 per k.)
-        shard = 1.0 / world
-        flops = 4.0 * nl * K * shard
+        flops = sk_gemm_flops(info, world)
         roofline = None
         if "sk_gemm" in timed_prof:
             t_ms = timed_prof["sk_gemm"][0]
@@ -278,19 +370,7 @@ def main():
             gb = 8.0 * ne * ne / world / 1e9
             hbm_member = dict(kernel="gemv_finish_kernel", bound="hbm", achieved=gb / (prof["gemv_charge"][0] * 1e-3), peak=8000.0,
                               unit="GB/s", frac=gb / (prof["gemv_charge"][0] * 1e-3) / 8000.0, bytes_per_launch=8.0 * ne * ne / world)
-        # composite bound of one update: sum over the kernels of max(algorithmic flops / FP64 peak, algorithmic bytes /
-        # HBM peak), one rank's share; achieved fraction = T_roof / measured time per update
-        HBM_PEAK = 8.0e12
-        n_planar_rows = 2.0 * info.kcount_flat                 # ~ rows of the electrode planar table
-        t_roof = {
-            "structure_factors_mfma": flops / (FP64_PEAK_TFLOPS * 1e12),
-            "b_projection_hbm": 8.0 * n_planar_rows * ne * shard / HBM_PEAK,            # the electrode planar table, streamed once
-            "b_real_space_hbm": info.n_blist_pairs * (8 + 32) / world / HBM_PEAK,       # 2 indices + gathered x, q per pair
-            "gemv_hbm": 8.0 * ne * ne / world / HBM_PEAK,
-        }
-        t_roof_ms = 1e3 * sum(t_roof.values())
-        composite = dict(t_roof_ms=t_roof_ms, frac=t_roof_ms / ms_per_step, parts_ms={k: 1e3 * v for k, v in t_roof.items()},
-                         note="sum of per-kernel max(algorithmic flops / 78.6 TF, algorithmic bytes / 8 TB/s); collectives excluded")
+        composite = composite_roofline(info, ms_per_step, world, pppm=bool(args.pppm))
         out = dict(metric="charge-solve updates/sec + ns/day, 4096-atom electrode / 32k electrolyte", value=value,
                    unit="updates/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
@@ -300,6 +380,7 @@ def main():
                                solver=args.solver, kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
                                blist_pairs=int(info.n_blist_pairs),
                                parallelism=f"k-shard+row-shard x{world}" + (", RCCL inside libconp_hip" if lib_collectives else "")),
+                   collectives=collectives,
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
                    ms_per_step_host_buffers_pcie=host_ms,
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),
@@ -320,8 +401,21 @@ def main():
                 mt = cpu_baseline(s, at, alist, blist, S, 16)
                 out["cpu_baseline_16_threads"] = mt
                 out["speedup_vs_cpu_baseline_16_threads"] = value / mt["value"]
+        fx.close()
+        fx = None
+        # ---- the other BASELINE configs on this GPU (after `value` was measured; each in a handle of its own)
+        if world == 1 and args.workload == "headline" and not args.no_configs:
+            cfgs = {}
+            for label, kw in AUX_CONFIGS:
+                try:
+                    k, v = measure_config(label, dev_index=dev_index, **kw)
+                    cfgs[k] = v
+                except Exception as e:      # noqa: BLE001 -- one config failing must not lose the headline line
+                    cfgs[label] = dict(error=str(e))
+            out["configs"] = cfgs
         print(json.dumps(out))
-    fx.close()
+    if fx is not None:
+        fx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -184,6 +184,12 @@ int conp_fix_set_comm(conp_fix *fix, const conp_comm *comm);
 #define CONP_RCCL_ID_BYTES 128
 int conp_rccl_unique_id(void *id_out /*[CONP_RCCL_ID_BYTES]*/);
 int conp_fix_comm_init_rccl(conp_fix *fix, const void *id /*[CONP_RCCL_ID_BYTES]*/);
+/* conp_rccl_available: 0 when librccl loads with every entry point the library calls -- local and cheap; ranks agree on it (MIN over
+ * ranks) BEFORE the collective conp_fix_comm_init_rccl, so that a rank without RCCL cannot strand its partners inside
+ * ncclCommInitRank.  conp_fix_comm_destroy_rccl: all ranks together give the communicator back (an initialisation that failed
+ * somewhere: the host then makes the two exchanges itself). */
+int conp_rccl_available(void);
+int conp_fix_comm_destroy_rccl(conp_fix *fix);
 
 /* ---- KSpaceModule provider surface (kspacemodule.h:30-40), Ewald provider (km_ewald.cpp) ---- */
 int conp_km_conp_setup(conp_fix *fix, double qsqsum, int64_t natoms);     /* km_ewald.cpp:63-132 (qsqsum: Allreduce'd sum q^2 :72-78) */

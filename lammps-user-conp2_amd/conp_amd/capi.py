@@ -92,7 +92,7 @@ SYMBOLS = [
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
     "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
-    "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl",
+    "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl", "conp_rccl_available", "conp_fix_comm_destroy_rccl",
     "conp_pppm_make_rho", "conp_pppm_compute_group_potential", "conp_pppm_compute_particle_potential",
     "conp_compute_potential_atom",
 ]
@@ -465,16 +465,37 @@ class FixConp:
         self._check(self.lib.conp_fix_set_comm(self.h, C.byref(self._comm)))
 
     def comm_init_rccl(self, group=None):
-        """one RCCL communicator inside the library (one rank per GPU): rank 0 makes the id, torch.distributed carries its 128 bytes"""
+        """One RCCL communicator inside the library (one rank per GPU): rank 0 makes the id, torch.distributed carries its 128 bytes.
+        Returns True when EVERY rank has its communicator, False when every rank is without one (all ranks take the same branch):
+          1. each rank probes librccl locally (conp_rccl_available) and the ranks agree (MIN) before anything collective is
+             entered -- a rank that cannot load RCCL never leaves its partners inside ncclCommInitRank;
+          2. rank 0's id (or the news that it could not make one) is broadcast;
+          3. after ncclCommInitRank the ranks agree again; on any failure every rank destroys its communicator."""
         import torch
         import torch.distributed as dist
+
+        def all_ok(ok):
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            flag = torch.tensor([1 if ok else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+
+        if not all_ok(self.lib.conp_rccl_available() == 0):
+            return False
         buf = (C.c_char * 128)()
+        obj = [None]
         if dist.get_rank(group) == 0:
-            self._check(self.lib.conp_rccl_unique_id(buf))
-        obj = [bytes(buf.raw)]
+            if self.lib.conp_rccl_unique_id(buf) == 0:
+                obj = [bytes(buf.raw)]
         dist.broadcast_object_list(obj, src=0, group=group)
+        if obj[0] is None:
+            return False
         idb = (C.c_char * 128).from_buffer_copy(obj[0])
-        self._check(self.lib.conp_fix_comm_init_rccl(self.h, idb))
+        rc = self.lib.conp_fix_comm_init_rccl(self.h, idb)
+        if all_ok(rc == 0):
+            return True
+        self.lib.conp_fix_comm_destroy_rccl(self.h)
+        return False
 
     # -- device-resident path --------------------------------------------------------------------
     def set_stream(self, stream_ptr: int):

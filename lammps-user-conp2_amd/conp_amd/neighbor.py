@@ -146,7 +146,10 @@ def build_lists(sys_, order_seed: int | None = 1, special_frac: float = 0.0):
 def build_lists_decomposed(sys_, nranks: int, axis: int = 0, order_seed: int | None = 1):
     """LAMMPS' spatial decomposition into `nranks` slabs along `axis`: per rank (atoms, alist, blist).  A rank owns the atoms of
     its slab; its ghosts are every image -- periodic copies AND the unshifted atoms of other ranks -- within cutoff + skin of the
-    slab.  Half lists, newton off: an owned-ghost pair is in the list of each owner."""
+    slab.  Half lists.  newton off: an owned-ghost pair is in the list of each owner.  newton on
+    (sys_.newton): it is in the list of exactly ONE of its two owners -- the coordinate tie-break of _half_pairs is the same
+    comparison on both ranks (a ghost is its owner shifted by a lattice vector), so the ranks agree on who keeps the pair; what
+    that rank adds to the other rank's electrode atom is the reference's newtonbuf + MPI_Allreduce route (fix_conp.cpp:1345-1361)."""
     cutneigh = sys_.cutoff + sys_.skin
     prd = sys_.prd
     shifts = []

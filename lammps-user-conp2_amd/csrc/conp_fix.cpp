@@ -210,6 +210,7 @@ struct conp_fix {
   std::vector<int> ct_ptr_h, seg_ptr_h, own_rt_h;   // own_rt_h: the row tiles this rank works on (sorted)
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
+  int inverse_retries = 0;       // times the last inverse fell back from the multi-workgroup panel (barrier time-out, info = -7)
   // the fix's log file (fix_conp.cpp:119): lines are buffered here and handed to the host by conp_fix_log_drain
   std::string logbuf, logdrain, mesgbuf, mesgdrain;   // mesgbuf: what the reference sends to utils::logmesg (:460, :1008)
   // CONP_TIME_HOST=1: where a host-buffer update spends its host time (printed to stderr when the handle is closed)
@@ -241,21 +242,22 @@ struct conp_fix {
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p, d_Srows, d_xg, d_qg, d_pp_ele, d_pp_scratch,
       d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
-  DevBuf<double2> d_Xt, d_Yt, d_Zt;
+  DevBuf<double2> d_Xt, d_Yt, d_Zt, d_Xe, d_Ye;      // d_Xe / d_Ye: electrode atoms' axis phases [k][ne_pad] (once per run)
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of;
   bool left_stale = false;          // the fused GEMV + charge write leaves the fix scalar's group-1 sum to refresh_scalar()
   double left_potdiff = 0.0;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
+  bool b_bound = false, q_bound = false;         // conp_fix_bind_device_buffers gave us the host's vectors
   int n_slab_part = 0;
-  const bool no_fuse = getenv("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
+  const bool no_fuse = exp_switch("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
   // The host-buffer hooks report Ktime / Ctime (fix_conp.cpp:553-568).  By default they run the SAME kernels as the device hooks
   // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
   // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
-  const bool time_split = getenv("CONP_TIME_SPLIT") != nullptr;
+  const bool time_split = exp_switch("CONP_TIME_SPLIT") != nullptr;
   int max_nsplit = 0;              // most sk_gemm segments any tile is cut into (chooses sk_reduce's one- or two-level sum)
   DevPlan dplan{};
   Profiler prof;
@@ -405,13 +407,18 @@ struct conp_fix {
       for (int ct = 0; ct < plan.n_col_tiles; ++ct)
         for (int rt = 0; rt < plan.n_row_tiles; ++rt) {
           if (plan.nba(rt, ct) <= 0) continue;
-          const unsigned nbf = plan.nba16(rt, ct);
+          const unsigned nbf = plan.nfa16(rt, ct);
           double sum = 0.0;
           for (int f = 0; f < 4; ++f) sum += (double)((nbf >> (8 * f)) & 255u);
-          all.push_back(GT{rt, ct, 0.25 * sum + SK_C0});
+          all.push_back(GT{rt, ct, 0.125 * sum + SK_C0});     // nbf counts 8-kz column fragments: two per kz block
         }
       std::vector<double> flo(all.size(), 0.0), fhi(all.size(), 0.0);
-      if (getenv("CONP_SHARD_TILES") && env.nranks > 1) {
+#ifdef CONP_DIAG
+      const bool whole_tiles = getenv("CONP_SHARD_TILES") && env.nranks > 1;     // diagnostic library only
+#else
+      const bool whole_tiles = false;
+#endif
+      if (whole_tiles) {
         // whole row tiles, heaviest first to the least loaded rank (every rank computes the same map)
         std::vector<std::pair<double, int>> order;
         std::vector<double> rtc(plan.n_row_tiles, 0.0);
@@ -445,7 +452,7 @@ struct conp_fix {
       for (size_t t = 0; t < all.size(); ++t) {
         if (fhi[t] > flo[t]) {
           const int rt = all[t].rt, ct = all[t].ct;
-          tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0, plan.nba16(rt, ct)});
+          tiles_h.push_back(SkTile{rt, ct, plan.nba(rt, ct), 0, 0, plan.nfa16(rt, ct)});
           tile_flo.push_back(flo[t]); tile_fhi.push_back(fhi[t]);
           mine[rt] = 1;
         }
@@ -458,6 +465,19 @@ struct conp_fix {
       std::vector<int> own_up = own_rt_h;
       if (own_up.empty()) own_up.push_back(0);
       d_own_rt.upload(own_up, stream);
+      // planar vectors of this rank's row tiles, packed for the planar fast path of the projection (b_zc_final_kernel):
+      // |kx| in bits 0-11, |ky| in bits 12-23, bit 24 = negative ky; padding vectors: the all-zero X row kxmax + 1
+      {
+        std::vector<int> pack((size_t)own_up.size() * 64);
+        for (size_t u = 0; u < own_up.size(); ++u)
+          for (int w = 0; w < 64; ++w) {
+            const int p = own_up[u] * 64 + w;
+            const int ikx = p < plan.np ? plan.p_ikx[p] : plan.kxmax + 1, iky = p < plan.np ? plan.p_iky[p] : 0;
+            const int neg = p < plan.np && plan.p_sgn[p] < 0 ? 1 : 0;
+            pack[u * 64 + w] = ikx | (iky << 12) | (neg << 24);
+          }
+        d_own_pv.upload(pack, stream);
+      }
     }
     d_ct_ptr.upload(ct_ptr_h, stream);
     sync();
@@ -521,7 +541,7 @@ struct conp_fix {
   int64_t n_b_pairs = 0;
   void build_b_rows_device(const conp_atoms *at) {
     const int ne = idx.elenum_all;
-    static const bool on_host = getenv("CONP_ROWS_HOST") != nullptr;
+    static const bool on_host = exp_switch("CONP_ROWS_HOST") != nullptr;
     if (on_host) {
       build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
       d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
@@ -565,8 +585,11 @@ struct conp_fix {
       d_ainve.reserve(ne_pad);
       d_bk.zero(stream); d_breal.zero(stream); d_b_own.zero(stream); d_eleallq_own.zero(stream); d_qele.zero(stream);
       d_elesetq.zero(stream); d_eleinitq.zero(stream);
-      if (!d_b) d_b = d_b_own.p;
-      if (!d_eleallq) d_eleallq = d_eleallq_own.p;
+      // own vectors may just have been re-allocated (more electrode atoms than at the last re-neighbouring): a pointer kept from
+      // before would dangle.  Only vectors the host bound itself (conp_fix_bind_device_buffers) are left alone.
+      if (!b_bound) d_b = d_b_own.p;
+      if (!q_bound) d_eleallq = d_eleallq_own.p;
+      drop_graph();
       row0 = std::min(ne, env.rank * rows_per);
       row1 = std::min(ne, row0 + rows_per);
     }
@@ -628,7 +651,8 @@ struct conp_fix {
     d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
-    d_Gpart.reserve((size_t)items_h.size() * 128 * 320);
+    // partial tiles: fragments beyond a tile's sphere cut are never written -- all zero from the start, finite ever after
+    if ((size_t)items_h.size() * 128 * 320 > d_Gpart.n) { d_Gpart.reserve((size_t)items_h.size() * 128 * 320); d_Gpart.zero(stream); }
   }
   bool elyte_list_stale(const conp_atoms *at) {
     size_t k = 0;
@@ -687,8 +711,8 @@ struct conp_fix {
   // per-segment term) left the heavy tiles' workgroups and those whose share straddles a tile boundary 3 % behind the rest.
   // (Tried on top: a linear ramp of the shares so that early finishers' partial-tile stores overlap the others' last chunks --
   //  no effect at +-8 / 16 / 24 units, 244.1 - 244.5 us.  What is left is a +-2 % spread between XCDs.)
-  double SK_C0 = getenv("CONP_SK_C0") ? atof(getenv("CONP_SK_C0")) : 1.65;
-  double SK_CSEG = getenv("CONP_SK_CSEG") ? atof(getenv("CONP_SK_CSEG")) : 7.7;
+  double SK_C0 = exp_switch("CONP_SK_C0") ? atof(exp_switch("CONP_SK_C0")) : 1.65;
+  double SK_CSEG = exp_switch("CONP_SK_CSEG") ? atof(exp_switch("CONP_SK_CSEG")) : 7.7;
   void build_items() {
     const int nchunks = nl_pad / 16;
     const size_t nt = tiles_h.size();
@@ -698,12 +722,12 @@ struct conp_fix {
     int nwg = std::max(1, num_cus);
     nwg = std::min(nwg, std::max((int)(16 * nt), (int)((nt * (size_t)nchunks + 7) / 8)));
     nwg = std::max(1, nwg);
-    if (getenv("CONP_SK_NWG")) nwg = std::max(1, atoi(getenv("CONP_SK_NWG")));
+    if (exp_switch("CONP_SK_NWG")) nwg = std::max(1, atoi(exp_switch("CONP_SK_NWG")));
     // MFMA work of a tile ~ mean over its 4 row fragments of their active kz blocks (per-fragment sphere culling)
     auto cost = [&](const SkTile &t) {
       double sum = 0.0;
       for (int f = 0; f < 4; ++f) sum += (double)((t.nbf >> (8 * f)) & 255u);
-      return 0.25 * sum + SK_C0;
+      return 0.125 * sum + SK_C0;                 // in kz blocks of 16 (the unit the constants were fitted in): two column fragments each
     };
     // this rank's chunk range of every tile (all of it on one rank; km_conp_setup); a tile may come out empty
     std::vector<int> clo(nt, 0), chi(nt, nchunks);
@@ -791,6 +815,21 @@ struct conp_fix {
     electrode_plan_tables(kt, plan, ne, ne_pad, csk_h, snk_h, Rp, Tz);
     for (int i = 0; i < ne; ++i) z[i] = xele_h[3 * (size_t)i + 2];
     d_Rp.upload(Rp, stream); d_Tz.upload(Tz, stream); d_ele_z.upload(z, stream);
+    // axis phases of the electrode atoms, k-major: the planar fast path of the projection rebuilds Rp's rows from them per
+    // update instead of streaming the table (row 0 = (1, 0); rows of padding atoms stay zero).  (Function scope: the uploads
+    // are asynchronous, the vectors must live until the sync() at the end.)
+    std::vector<double2> xe, ye;
+    {
+      const int kflat = kt.kcount_flat, d0 = kt.kcount_dims[0], d1 = kt.kcount_dims[1];
+      xe.assign((size_t)(d0 + 2) * ne_pad, make_double2(0.0, 0.0));     // row kxmax + 1: all zero -- padding planar vectors point there
+      ye.assign((size_t)(d1 + 1) * ne_pad, make_double2(0.0, 0.0));
+      for (int i = 0; i < ne; ++i) {
+        xe[i] = make_double2(1.0, 0.0); ye[i] = make_double2(1.0, 0.0);
+        for (int k = 1; k <= d0; ++k) xe[(size_t)k * ne_pad + i] = make_double2(csk_h[(size_t)i * kflat + k - 1], snk_h[(size_t)i * kflat + k - 1]);
+        for (int k = 1; k <= d1; ++k) ye[(size_t)k * ne_pad + i] = make_double2(csk_h[(size_t)i * kflat + d0 + k - 1], snk_h[(size_t)i * kflat + d0 + k - 1]);
+      }
+      d_Xe.upload(xe, stream); d_Ye.upload(ye, stream);
+    }
     if (args.pppm) {   // aaa_map_rho (pppm_conp.cpp:318-344): stencil weights and lower-left mesh index of every electrode atom
       std::vector<int> eg((size_t)ne * 3);
       std::vector<double> ew((size_t)ne * 24, 0.0);
@@ -812,7 +851,7 @@ struct conp_fix {
         if (it == cls.end()) { it = cls.emplace(z[i], (int)cls.size()).first; rep.push_back(i); }
         zclass[i] = it->second;
       }
-      const bool off = getenv("CONP_NO_ZCLASS") != nullptr;
+      const bool off = exp_switch("CONP_NO_ZCLASS") != nullptr;
       nzc = (!off && cls.size() <= 64 && 4 * cls.size() <= (size_t)ne) ? (int)cls.size() : 0;   // worthwhile only if it compresses
       // b_zc_dot keeps Hc for 32 rows of every row tile and every class in LDS
       if ((size_t)plan.n_row_tiles * 32 * (size_t)nzc * sizeof(double) > 96 * 1024) nzc = 0;
@@ -1124,7 +1163,13 @@ struct conp_fix {
     d_ipiv.reserve(n + 1); d_info.reserve(2);
     // the in-place elimination destroys A: keep a copy while the multi-workgroup panel (grid barriers) is in use, so that a
     // barrier time-out (info = -7: some workgroup was not resident) can be answered by the one-workgroup panel
-    static const bool single = getenv("CONP_PANEL_SINGLE") != nullptr;
+    // comparison / test switches, read per call and only here: CONP_PANEL_SINGLE = the one-workgroup panel, CONP_PANEL_MAXG = cap
+    // on the panel's workgroups, CONP_PANEL_SPIN = polls of its grid barrier before it gives up (0 forces the time-out: the
+    // restore-and-retry below runs, tests/test_gpu_parity.py)
+    const bool single = exp_switch("CONP_PANEL_SINGLE") != nullptr;
+    const int max_wg = exp_switch("CONP_PANEL_MAXG") ? atoi(exp_switch("CONP_PANEL_MAXG")) : 0;
+    const unsigned spin_limit = exp_switch("CONP_PANEL_SPIN") ? (unsigned)strtoul(exp_switch("CONP_PANEL_SPIN"), nullptr, 10) : (1u << 22);
+    inverse_retries = 0;
     if (!single) {
       d_inv_backup.reserve((size_t)n * n);
       HIP_TRY(hipMemcpyAsync(d_inv_backup.p, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -1132,12 +1177,14 @@ struct conp_fix {
     int info = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
       prof.begin("inverse", stream);
-      const bool multi = launch_inverse(stream, n, A, d_inv_work.p, d_ipiv.p, d_info.p, num_cus, attempt == 0 && !single);
+      const bool multi = launch_inverse(stream, n, A, d_inv_work.p, d_ipiv.p, d_info.p, num_cus, attempt == 0 && !single, max_wg, spin_limit);
       prof.end(stream);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(&info, d_info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync();
       if (!(multi && info == -7)) break;
+      ++inverse_retries;
+      mesgf("conp/hip: the inverse's multi-workgroup panel timed out at its grid barrier; repeating with the one-workgroup panel\n");
       HIP_TRY(hipMemcpyAsync(A, d_inv_backup.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     }
     d_inv_backup.release();
@@ -1160,7 +1207,7 @@ struct conp_fix {
   // after convergence returns at once).  The first batch is as long as the last solve needed, so a typical update costs one
   // read-back: scalars, flag, net charge and the residual history come over in ONE copy into the page-locked staging buffer.
   int cg_batch = 8;
-  const bool cg_unfused = getenv("CONP_CG_UNFUSED") != nullptr;      // comparison switch: two launches per iteration (round 1)
+  const bool cg_unfused = exp_switch("CONP_CG_UNFUSED") != nullptr;      // comparison switch: two launches per iteration (round 1)
   void cg() {
     const int ne = idx.elenum_all;
     const int nctl = 16 + args.maxiter + 1;                  // scal[0..12], pad, hist[0..maxiter] at offset 16
@@ -1319,8 +1366,8 @@ struct conp_fix {
         // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)
         prof.begin("reduce_project", stream);
         launch_reduce_project_zclass(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, ne_pad,
-                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_zclass.p, d_Hc.p, d_bk.p,
-                                     use_fin ? &fin : nullptr);
+                                     (int)own_rt_h.size(), d_own_rt.p, nzc, d_Tzc.p, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p,
+                                     d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);
         prof.end(stream);
       } else {
         prof.begin("sk_reduce", stream);
@@ -1329,7 +1376,7 @@ struct conp_fix {
         prof.begin("b_project", stream);
         if (nzc > 0)
           launch_b_project_zclass(stream, dplan, ne_pad, d_rt_mine.p, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Gw.p, d_Tzc.p, d_Rp.p,
-                                  d_zclass.p, d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);
+                                  d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);
         else
           launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
         prof.end(stream);
@@ -1441,8 +1488,10 @@ struct conp_fix {
       sync();
       rc.sum(h, ne);
       HIP_TRY(hipMemcpyAsync(d_b, h, ne * sizeof(double), hipMemcpyHostToDevice, stream));
+#ifdef CONP_DIAG
     } else if (getenv("CONP_RANK_EMULATION")) {
-      // tools/rank_emulation.py: one rank's compute time measured on a box that has no partner ranks
+      // diagnostic library only (tools/rank_emulation.py): one rank's compute time measured on a box that has no partner ranks
+#endif
     } else throw ConpError(CONP_ERR_STATE, "an update on several ranks needs conp_fix_comm_init_rccl or conp_fix_set_comm (or do the "
                                            "two collectives yourself between conp_fix_b_cal_device / _solve_device / _scatter_device)");
     prof.end(stream);
@@ -1469,7 +1518,7 @@ struct conp_fix {
 
   // plain `fix conp` on one rank with the inverse solver: GEMV and charge write in one launch (gemv_finish_kernel)
   bool can_fuse_solve() const {
-    static const bool off = getenv("CONP_NO_FUSE") != nullptr;
+    static const bool off = exp_switch("CONP_NO_FUSE") != nullptr;
     return !off && args.minimizer == CONP_SOLVER_INV && !args.conq && !args.cond && env.nranks == 1 && !nccl && !s_sharded &&
            runstage >= 3;
   }
@@ -1616,7 +1665,7 @@ struct conp_fix {
   double *g_dq = nullptr;
   double g_pot = 0.0;
   int g_warm = 0, g_pot_changes = 0;
-  bool graph_off = getenv("CONP_GRAPH") == nullptr || atoi(getenv("CONP_GRAPH")) == 0;
+  bool graph_off = exp_switch("CONP_GRAPH") == nullptr || atoi(exp_switch("CONP_GRAPH")) == 0;
   // called at the top of every C-ABI entry that may touch the device: the handle's device becomes the thread's current one
   // (a host that drives several GPUs from one thread may have switched), and a captured update graph is dropped
   void drop_graph() {
@@ -2371,6 +2420,25 @@ int conp_fix_comm_init_rccl(conp_fix *f, const void *id_in) {
   g_rccl.ok(g_rccl.CommInitRank(&f->nccl, f->env.nranks, id, f->env.rank), "ncclCommInitRank");
   // results of the in-library collectives land in the library's own vectors
   f->d_b = f->d_b_own.p; f->d_eleallq = f->d_eleallq_own.p;
+  f->b_bound = f->q_bound = false;
+  CONP_GUARD_END
+}
+
+// 0 when librccl can be loaded and has every entry point the library calls.  Cheap and local (no communication): hosts call it on
+// every rank and AGREE on the answer (MPI_Allreduce MIN, torch.distributed ...) BEFORE the collective conp_fix_comm_init_rccl,
+// so that a rank without RCCL cannot leave its partners waiting inside ncclCommInitRank.
+int conp_rccl_available(void) {
+  try { g_rccl.load(); } catch (...) { return CONP_ERR_NO_DEVICE; }
+  return CONP_OK;
+}
+
+// Gives the communicator back (all ranks, together: after an initialisation that failed on some rank, the host falls back to
+// doing the exchanges itself).  The library's vectors stay its own.
+int conp_fix_comm_destroy_rccl(conp_fix *f) {
+  CONP_GUARD_BEGIN
+  if (!f) throw ConpError(CONP_ERR_ARG, "null argument");
+  f->drop_graph();
+  if (f->nccl) { f->sync(); (void)g_rccl.CommDestroy(f->nccl); f->nccl = nullptr; }
   CONP_GUARD_END
 }
 
@@ -2390,8 +2458,8 @@ int conp_fix_bind_device_buffers(conp_fix *f, double *d_b, double *d_q) {
   if (f->nccl && d_q) throw ConpError(CONP_ERR_STATE, "with an RCCL communicator the library gathers q into its own buffer "
                                                       "(nranks * ceil(Ne / nranks) entries); read it with conp_fix_get_vectors");
   const size_t nb = f->idx.elenum_all * sizeof(double);
-  if (d_b) { if (f->d_b && nb) HIP_TRY(hipMemcpy(d_b, f->d_b, nb, hipMemcpyDeviceToDevice)); f->d_b = d_b; }
-  if (d_q) { if (f->d_eleallq && nb) HIP_TRY(hipMemcpy(d_q, f->d_eleallq, nb, hipMemcpyDeviceToDevice)); f->d_eleallq = d_q; }
+  if (d_b) { if (f->d_b && nb) HIP_TRY(hipMemcpy(d_b, f->d_b, nb, hipMemcpyDeviceToDevice)); f->d_b = d_b; f->b_bound = true; }
+  if (d_q) { if (f->d_eleallq && nb) HIP_TRY(hipMemcpy(d_q, f->d_eleallq, nb, hipMemcpyDeviceToDevice)); f->d_eleallq = d_q; f->q_bound = true; }
   CONP_GUARD_END
 }
 

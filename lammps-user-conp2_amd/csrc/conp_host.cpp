@@ -176,7 +176,7 @@ void KPlan::build(const KTables &kt) {
   for (int k = 0; k < kt.kcount; ++k) w[(size_t)k_p[k] * nz + k_m[k]] += 2.0 * kt.ug[k];
   wfull.assign((size_t)R_pad * C_pad, 0.0);
   nb_act.assign(n_row_tiles, 0);
-  nb_act16.assign((size_t)n_row_tiles * 4, 0);
+  nf_act16.assign((size_t)n_row_tiles * 4, 0);
   for (int p = 0; p < np; ++p)
     for (int m = 0; m < nz; ++m) {
       const double ww = w[(size_t)p * nz + m];
@@ -186,7 +186,7 @@ void KPlan::build(const KTables &kt) {
       wfull[(size_t)row_b(p) * C_pad + col_c(m)] = ww;
       wfull[(size_t)row_b(p) * C_pad + col_s(m)] = ww;
       nb_act[p / PT] = std::max(nb_act[p / PT], (m >> 4) + 1);
-      nb_act16[p / 16] = std::max(nb_act16[p / 16], (m >> 4) + 1);
+      nf_act16[p / 16] = std::max(nf_act16[p / 16], (m >> 3) + 1);
     }
   sf_row_a.assign(kt.kcount, 0); sf_col_c.assign(kt.kcount, 0);
   for (int k = 0; k < kt.kcount; ++k) { sf_row_a[k] = row_a(k_p[k]); sf_col_c[k] = col_c(k_m[k]); }

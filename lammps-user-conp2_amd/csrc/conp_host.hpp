@@ -52,21 +52,23 @@ struct KPlan {
   int nblk = 0;                           // ceil(nz / 16)
   int n_row_tiles = 0, n_col_tiles = 0, R_pad = 0, C_pad = 0;
   std::vector<int> nb_act;                // per row tile: number of leading 16-kz blocks that hold a listed k (sphere cut)
-  std::vector<int> nb_act16;              // the same per 16 planar vectors (one MFMA row fragment): [n_row_tiles * 4]
+  std::vector<int> nf_act16;              // per 16 planar vectors (one MFMA row fragment): leading 8-kz COLUMN FRAGMENTS with a listed k: [n_row_tiles * 4]
   std::vector<double> w;                  // [np][nz] weights
   std::vector<double> wfull;              // [R_pad][C_pad] weights expanded to G's layout (0 in padding)
-  std::vector<int> sf_row_a, sf_col_c;    // per reference k: G row of (p,'a') and col of (m,'c') (b row = +PT, s col = +16)
+  std::vector<int> sf_row_a, sf_col_c;    // per reference k: G row of (p,'a') and col of (m,'c') (b row = +PT, s col = +8)
 
-  // G column layout: kz block b = m >> 4 occupies 32 columns: 16 'c' (cos) then 16 's' (sin)
+  // G column layout: one 16-column MFMA fragment per 8 kz values: 8 'c' (cos) columns then 8 's' (sin) columns, so that the sphere
+  // cut is applied in steps of 8 kz per row fragment.  Two fragments = the 32 columns of one 16-kz block: everything that works
+  // per block (nb_act, the reductions, the projections, the SYRK's chunks) sees the same column set as with 16 + 16.
   int row_a(int p) const { return (p / PT) * (2 * PT) + (p % PT); }
   int row_b(int p) const { return row_a(p) + PT; }
-  int col_c(int m) const { return 32 * (m >> 4) + (m & 15); }
-  int col_s(int m) const { return col_c(m) + 16; }
+  int col_c(int m) const { return 16 * (m >> 3) + (m & 7); }
+  int col_s(int m) const { return col_c(m) + 8; }
   int nba(int rt, int ct) const { return std::max(0, std::min(CT_BLK, nb_act[rt] - CT_BLK * ct)); }
-  // active kz blocks of row fragment f (planar vectors 16 f .. 16 f + 15 of row tile rt) inside col tile ct, packed 4 x 8 bit
-  unsigned nba16(int rt, int ct) const {
+  // active column fragments of row fragment f (planar vectors 16 f .. 16 f + 15 of row tile rt) inside col tile ct, packed 4 x 8 bit
+  unsigned nfa16(int rt, int ct) const {
     unsigned v = 0;
-    for (int f = 0; f < 4; ++f) v |= (unsigned)std::max(0, std::min(CT_BLK, nb_act16[4 * rt + f] - CT_BLK * ct)) << (8 * f);
+    for (int f = 0; f < 4; ++f) v |= (unsigned)std::max(0, std::min(2 * CT_BLK, nf_act16[4 * rt + f] - 2 * CT_BLK * ct)) << (8 * f);
     return v;
   }
 

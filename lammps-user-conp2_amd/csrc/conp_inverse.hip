@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int 
                                                              double *__restrict__ P, int *__restrict__ piv, int *__restrict__ info,
                                                              double *__restrict__ cval, int *__restrict__ cidx,
                                                              double *__restrict__ crow, double *__restrict__ rowj,
-                                                             unsigned *__restrict__ counter) {
+                                                             unsigned *__restrict__ counter, unsigned spin_limit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *rows = reinterpret_cast<double *>(smem);          // [rpw][PC_LD]
   double *s_row = rows + (size_t)rpw * PC_LD;               // [64]
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void inv_panel_coop_kernel(int n, int k0, int 
       const unsigned target = (unsigned)G * (unsigned)(j + 1);
       unsigned spins = 0;
       while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > (1u << 22)) { s_abort = 1; break; }
+        if (++spins > spin_limit) { s_abort = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -471,7 +471,7 @@ size_t inverse_workspace_doubles(int n) {
 // Should a workgroup ever not become resident, the bounded spin ends every wave and sets info = -7; the caller then restores
 // the matrix and repeats with multi_wg = false.
 bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/, int num_cus,
-                    bool multi_wg) {
+                    bool multi_wg, int max_wg, unsigned spin_limit) {
   const int ld = (n + 127) / 128 * 128;
   double *P = work;
   double *Wb = P + (size_t)n * INV_NB;
@@ -490,9 +490,9 @@ bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
   const size_t lds_prep = 2 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double), lds_fix = 3 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fix);
-  // test / fallback switches, read per call: CONP_PANEL_SINGLE = one-workgroup panel, CONP_PANEL_MAXG = cap on workgroups
-  bool multi = multi_wg && getenv("CONP_PANEL_SINGLE") == nullptr;
-  const int maxg_env = getenv("CONP_PANEL_MAXG") ? atoi(getenv("CONP_PANEL_MAXG")) : PC_MAXG;
+  // (the caller reads the comparison switches -- one place: conp_fix.cpp invert_device)
+  const bool multi = multi_wg;
+  const int maxg_env = max_wg > 0 ? max_wg : PC_MAXG;
   bool used_multi = false;
   for (int k0 = 0; k0 < n; k0 += INV_NB) {
     const int nbw = (n - k0 < INV_NB) ? n - k0 : INV_NB;
@@ -505,10 +505,19 @@ bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
       rpw = rpw < 64 ? 64 : (rpw + 15) / 16 * 16;
       const int G = (m + rpw - 1) / rpw;
       const size_t lds = ((size_t)rpw * PC_LD + INV_NB + 4) * sizeof(double) + 8 * sizeof(int);
-      if (lds <= 150 * 1024 && G <= ncu) {
+      bool fits = lds <= 150 * 1024 && G <= ncu;
+      if (fits) {
+        // the grid barrier needs every workgroup resident: ask the runtime how many of THIS footprint (registers, LDS) a CU
+        // takes instead of assuming one (it is one with > 80 KB of LDS; small panels pack several per CU, which is fine too)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_panel_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(inv_panel_coop_kernel), 256, lds) != hipSuccess ||
+            (long long)per_cu * ncu < G)
+          fits = false;
+      }
+      if (fits) {
         hipLaunchKernelGGL(inv_panel_coop_kernel, dim3(G), dim3(256), lds, s, n, k0, nbw, rpw, (const double *)M, P, piv_all + k0, info,
-                           cval, cidx, crow, rowj, counters + k0 / INV_NB);
+                           cval, cidx, crow, rowj, counters + k0 / INV_NB, spin_limit);
         panel_done = true;
         used_multi = true;
       }

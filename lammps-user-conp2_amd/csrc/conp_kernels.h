@@ -5,6 +5,13 @@
 
 namespace conp {
 
+// Comparison switches (environment): each selects an alternative code path whose results stay inside the tolerances stated in
+// DESIGN.md (two-launch CG, host row regrouping, graph replay, one-workgroup inverse panel ...).  They exist for the A/B tests
+// and tools; the first read of a switch that is set says so on stderr, once, so that a stray variable in a job script cannot go
+// unnoticed.  Switches that would change the PHYSICS of a run (sk_gemm ablation, rank emulation, whole-tile sharding) are not
+// here at all: they are compiled into the diagnostic library only (-DCONP_DIAG, `make diag`).
+const char *exp_switch(const char *name);
+
 struct DevPlan {              // device copy of KPlan geometry
   int np, nz, n_row_tiles, n_col_tiles, R_pad, C_pad, kxmax, kymax;
   const int *p_ikx, *p_iky, *p_sgn;   // [n_row_tiles*64] padded (padding: 0,0,0 -> sgn 0 marks "no vector")
@@ -13,7 +20,7 @@ struct DevPlan {              // device copy of KPlan geometry
 };
 
 struct SkItem { int rt, ct, nba, c0, c1; unsigned nbf; };   // one sk_gemm segment: tile + chunk range [c0, c1) of 16 atoms;
-                                                          // nbf = active kz blocks per 16-row fragment, 4 x 8 bit
+                                                          // nbf = active 8-kz column fragments per 16-row fragment, 4 x 8 bit
 struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
@@ -94,10 +101,12 @@ void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *c
 // planar-electrode fast path of the projection (<= 64 distinct electrode z values)
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part,
+                                  const double2 *Xe /*[kxmax+2][ne_pad] electrode axis phases, last row zero*/, const double2 *Ye /*[kymax+1][ne_pad]*/,
+                                  const int *own_pv /*[n_own][64] packed planar vectors of the own row tiles*/, const int *zclass, double *Hc, double *bk_part,
                                   const BRowArgs *fin /*non-NULL (needs fin->breal): the dot kernel finishes b itself*/);
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
-                             const double *Tzc /*[C_pad][64]*/, const double *Rp, const int *zclass /*[ne_pad]*/,
+                             const double *Tzc /*[C_pad][64]*/, const double *Rp, const double2 *Xe, const double2 *Ye,
+                             const int *own_pv, const int *zclass /*[ne_pad]*/,
                              double *Hc /*[4][R_pad][64]*/, double *bk_part /*[4][ne_pad]*/, const BRowArgs *fin);
 // this rank's contribution to b in one launch: k-space halves + slab (rank 0) + real-space rows row0..row1
 void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1, const int *row_ptr, const int *ele_atom,
@@ -144,7 +153,7 @@ size_t inverse_workspace_doubles(int n);
 // returns true when the multi-workgroup panel was used (then info == -7 means "a grid barrier timed out": restore M, repeat
 // with multi_wg = false)
 bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/, int num_cus,
-                    bool multi_wg);
+                    bool multi_wg, int max_wg /*0: no cap*/, unsigned spin_limit /*polls of the panel's grid barrier before info = -7*/);
 // CG (fix_conp.cpp:864-930): state vectors on device; returns via *d_done
 void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, double *q, double *res, double *p,
                     double *scal /*[8]*/);

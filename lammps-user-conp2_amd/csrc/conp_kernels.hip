@@ -12,12 +12,26 @@
 #include "conp_kernels.h"
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 namespace conp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+const char *exp_switch(const char *name) {
+  const char *v = getenv(name);
+  if (v) {
+    static std::atomic<unsigned long long> said{0};
+    unsigned h = 0;
+    for (const char *c = name; *c; ++c) h = h * 31u + (unsigned char)*c;
+    const unsigned long long bit = 1ull << (h & 63u);
+    if (!(said.fetch_or(bit) & bit))
+      fprintf(stderr, "libconp_hip: comparison switch %s=%s is set -- a non-default code path is in use\n", name, v);
+  }
+  return v;
+}
 
 __device__ double block_sum_1024(double v, double *red);
 
@@ -157,12 +171,28 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
     t[(size_t)off * 16] = make_double2(sc, 0.0);
     double cm = c1, sm = s1;
     if (nrow > 1 && stride == 1) t[(size_t)(off + 1) * 16] = make_double2(sc * c1, sc * s1);
-    int next = stride > 2 ? stride : 2;   // first stored m >= 2 that is a multiple of stride
-    for (int m = 2; m < nrow; ++m) {
-      const double cn = cm * c1 - sm * s1;
-      const double sn = sm * c1 + cm * s1;
-      cm = cn; sm = sn;
-      if (m == next) { t[(size_t)(off + m / stride) * 16] = make_double2(sc * cm, sc * sm); next += stride; }
+    if (stride == 1) {
+      for (int m = 2; m < nrow; ++m) {
+        const double cn = cm * c1 - sm * s1;
+        const double sn = sm * c1 + cm * s1;
+        cm = cn; sm = sn;
+        t[(size_t)(off + m) * 16] = make_double2(sc * cm, sc * sm);
+      }
+    } else {
+      // seeds only (z axis): `stride` unit steps reach the first seed and give the seed-to-seed rotation, then one step per
+      // stored row -- nrow / stride dependent steps instead of nrow (the z chain is the launch's longest: ~150 steps)
+      for (int m = 2; m <= stride; ++m) {
+        const double cn = cm * c1 - sm * s1;
+        const double sn = sm * c1 + cm * s1;
+        cm = cn; sm = sn;
+      }
+      const double cs = cm, ss = sm;
+      for (int m = stride; m < nrow; m += stride) {
+        t[(size_t)(off + m / stride) * 16] = make_double2(sc * cm, sc * sm);
+        const double cn = cm * cs - sm * ss;
+        const double sn = sm * cs + cm * ss;
+        cm = cn; sm = sn;
+      }
     }
   }
   if (c != 2) return;
@@ -266,6 +296,14 @@ __device__ __forceinline__ double2 zstep(double2 z, double2 st) {
   return r;
 }
 
+// Partial tiles (sk_gemm -> sk_reduce) are stored MFMA-fragment-major: the 16 x 16 fragment (row fragment f16 of 8, column
+// fragment fi of 20) is one run of 256 doubles, inside it register pair (r, r + 2) of lane (fk, fr) is one 16-byte unit:
+//   element (row = 16 f16 + 4 r + fk, col = 16 fi + fr)  at  (f16 * 20 + fi) * 256 + (r & 1) * 128 + (16 fk + fr) * 2 + (r >> 1)
+__device__ __forceinline__ unsigned sk_part_off(int rowl, int col) {
+  const int r = (rowl >> 2) & 3;
+  return (unsigned)((((rowl >> 4) * 20 + (col >> 4)) << 8) + ((r & 1) << 7) + ((((rowl & 3) << 4) + (col & 15)) << 1) + (r >> 1));
+}
+
 struct SkRaw {        // raw inputs of one thread for one chunk
   double2 X0, Y0, X1, Y1, Zseed, Zst;
 };
@@ -317,12 +355,12 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int ml = 5 * c.gs + u;                        // kz index inside the col tile
-      const int feat = 128 + 32 * (ml >> 4) + (ml & 15);
-      const int at = feat * SK_LD + (c.gj ^ (ml & 15));   // (feat and feat + 16 have the same low bits)
+      // column fragment ml >> 3 = 8 cos features then 8 sin features (KPlan::col_c / col_s): feature low bits ml & 7 and 8 + (ml & 7)
+      const int feat = 128 + 16 * (ml >> 3) + (ml & 7);
       // (kz beyond nz - 1: the seed rows there are never written (zero) or the recurrence just runs on -- finite values in G
       //  columns that carry zero weight and no listed k; not worth two selects per value)
-      pn[at] = Z.x;
-      pn[at + 16 * SK_LD] = Z.y;
+      pn[feat * SK_LD + (c.gj ^ (ml & 7))] = Z.x;
+      pn[(feat + 8) * SK_LD + (c.gj ^ (8 + (ml & 7)))] = Z.y;
       Z = zstep(Z, r.Zst);
     }
   }
@@ -340,33 +378,6 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
 // kz cut never grows with f; a fragment whose cut is shorter still than NFW - 1 multiplies a few zero-weight columns: G entries
 // no listed k reads).  One wave-uniform branch per row fragment instead of one per MFMA.
 #define SK_LDS_F64(byte_addr) (*reinterpret_cast<const double *>(smem + (byte_addr)))
-#ifndef SK_MFMA_PREFETCH
-#define SK_MFMA_PREFETCH 1
-#endif
-#if !SK_MFMA_PREFETCH
-// comparison build (-DSK_MFMA_PREFETCH=0): all fragment reads of a k-step at its top, column-major MFMAs -- the first version's order
-template <int NFW>
-__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
-  if constexpr (NFW > 0) {
-    constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
-    const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
-#pragma unroll 1
-    for (int ks = 0; ks < SK_J / 4; ++ks) {
-      const unsigned q = (unsigned)(ks << 5) ^ c.pq;
-      double af[4], bf[NFW];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) af[f] = SK_LDS_F64(ba + q + f * FA);
-#pragma unroll
-      for (int g = 0; g < NFW; ++g) bf[g] = SK_LDS_F64(bb + q + g * FB);
-#pragma unroll
-      for (int g = 0; g < NFW; ++g)
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-          if (g + 1 < NFW || f < c.f0) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
-    }
-  }
-}
-#else
 template <int NFW>
 __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
   if constexpr (NFW > 0) {
@@ -405,6 +416,63 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, 
     }
   }
 }
+
+// Straight-line form of the same phase: all four k-steps unrolled, the sphere cut F0 a template parameter -- no loop, no branch,
+// no scalar bookkeeping between MFMAs.  The (k-step, lane)-dependent 32-byte group of the swizzle costs one address register per
+// k-step and operand side (8 in all, XORed with the buffer bit once per chunk); fragment / column-group offsets are immediates.
+template <int NFW, int F0>
+__device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
+  if constexpr (NFW > 0) {
+    constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
+    unsigned aa[4], ab[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned q = (unsigned)(ks << 5) ^ c.pq;
+      aa[ks] = (c.base_a ^ buf) + q;
+      ab[ks] = (c.base_b ^ buf) + q;
+    }
+    double bf[NFW], a0, a1;
+    a0 = SK_LDS_F64(aa[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NFW; ++g) { bf[g] = SK_LDS_F64(ab[0] + g * FB); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kn = (ks + 1) & 3;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        // the last row fragment of the last k-step has nothing left to fetch
+        if (!(ks == 3 && f == 3)) a1 = f < 3 ? SK_LDS_F64(aa[ks] + (f + 1) * FA) : SK_LDS_F64(aa[kn]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g + 1 < NFW; ++g) {
+          acc[f][g] = MFMA_F64(a0, bf[g], acc[f][g]);
+          if (f == 3 && ks < 3) { bf[g] = SK_LDS_F64(ab[kn] + g * FB); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if (f < F0) acc[f][NFW - 1] = MFMA_F64(a0, bf[NFW - 1], acc[f][NFW - 1]);
+        if (f == 3 && ks < 3) bf[NFW - 1] = SK_LDS_F64(ab[kn] + (NFW - 1) * FB);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = a1;
+      }
+    }
+  }
+}
+
+// The product multiplies with the straight-line form; -DSK_MFMA_LOOP=1 (`make loopform`) builds the round-2 loop form for A/B runs.
+#ifndef SK_MFMA_LOOP
+#define SK_MFMA_LOOP 0
+#endif
+#if SK_MFMA_LOOP
+#define SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc) sk_mfma_chunk<NFW>(c, smem, buf, acc)
+#else
+#define SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc) sk_mfma_chunk_u<NFW, F0>(c, smem, buf, acc)
+#endif
+// Ablation switches (phases of the kernel turned off, TIMING ONLY, results are garbage) exist in the diagnostic build
+// -DSK_ABLATE only (`make ablate`, tools/sk_ablate.sh); in the product build the tests below fold to constants.
+#ifdef SK_ABLATE
+#define SK_DBG(c, bit) ((c).dbg & (bit))
+#else
+#define SK_DBG(c, bit) 0
 #endif
 
 // ---- diagnostic build only (-DSK_STAMP, `make stamp`, tools/sk_stamp.py): s_memtime stamps around the phases of a chunk,
@@ -426,130 +494,10 @@ __device__ unsigned long long sk_seg_buf[4096 * 4];         // [segment][workgro
 #define SK_STAMP_ADD(sum, a, b) do { } while (0)
 #endif
 
-// ================================================================================================
-// SK_INTERLEAVE build (-DSK_INTERLEAVE=1): every wave plays the same role.  Per chunk a wave multiplies panel c and, in the
-// second half of its MFMA stream, builds its share of panel c+1 one small piece at a time BETWEEN row-fragment groups of MFMAs
-// (7 pieces: two planar-vector pairs, five kz steps), so that neither SIMD partner ever leaves the matrix pipe to the other
-// for a whole build phase.  Branch-free: every thread always builds (features beyond the sphere cut land in panel rows nobody
-// reads), the chunk after the last one re-reads the last chunk's table rows and is never multiplied.
-// ================================================================================================
-#ifndef SK_INTERLEAVE
-#define SK_INTERLEAVE 0
-#endif
-#if SK_INTERLEAVE
-template <int P>
-__device__ __forceinline__ void sk_build_piece(const SkCtx &c, const SkRaw &r, double2 &Z, double *pn) {
-  if constexpr (P == 0) {
-    const double sy = c.sg0 < 0.0 ? -r.Y0.y : r.Y0.y;
-    pn[c.wa] = r.X0.x * r.Y0.x - r.X0.y * sy;
-    pn[c.wa + 64 * SK_LD] = r.X0.x * sy + r.X0.y * r.Y0.x;
-  } else if constexpr (P == 1) {
-    const double sy = c.sg1 < 0.0 ? -r.Y1.y : r.Y1.y;
-    pn[c.wa + 32 * SK_LD] = r.X1.x * r.Y1.x - r.X1.y * sy;
-    pn[c.wa + 96 * SK_LD] = r.X1.x * sy + r.X1.y * r.Y1.x;
-  } else if constexpr (P <= 6) {
-    constexpr int u = P - 2;
-    if constexpr (u == 0) Z = r.Zseed;
-    const int ml = 5 * c.gs + u;
-    const int at = (128 + 32 * (ml >> 4) + (ml & 15)) * SK_LD + (c.gj ^ (ml & 15));
-    pn[at] = Z.x;
-    pn[at + 16 * SK_LD] = Z.y;
-    if constexpr (u < 4) Z = zstep(Z, r.Zst);
-  }
-}
-
-// one row-fragment group of k-step KS: next A fragment on its way, (build piece), <= NFW MFMAs, B refills during the last group
-template <int NFW, int KS, int F>
-__device__ __forceinline__ void sk_fgroup(const SkCtx &c, const char *smem, unsigned ac, unsigned an, unsigned bn,
-                                          d4 (&acc)[4][NFW], double (&bf)[NFW], double &a0, const SkRaw &raw, double2 &Z, double *nxt) {
-  constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
-  const double a1 = F < 3 ? SK_LDS_F64(ac + (F + 1) * FA) : SK_LDS_F64(an);
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (KS >= 2) sk_build_piece<(KS - 2) * 4 + F>(c, raw, Z, nxt);      // pieces 0..6 (7: nothing)
-#pragma unroll
-  for (int g = 0; g + 1 < NFW; ++g) {
-    acc[F][g] = MFMA_F64(a0, bf[g], acc[F][g]);
-    if constexpr (F == 3) { bf[g] = SK_LDS_F64(bn + g * FB); __builtin_amdgcn_sched_barrier(0); }
-  }
-  if (F < c.f0) acc[F][NFW - 1] = MFMA_F64(a0, bf[NFW - 1], acc[F][NFW - 1]);
-  if constexpr (F == 3) bf[NFW - 1] = SK_LDS_F64(bn + (NFW - 1) * FB);
-  __builtin_amdgcn_sched_barrier(0);
-  a0 = a1;
-}
-
-template <int NFW, int KS>
-__device__ __forceinline__ void sk_kstep(const SkCtx &c, const char *smem, unsigned ba, unsigned bb, d4 (&acc)[4][NFW],
-                                         double (&bf)[NFW], double &a0, const SkRaw &raw, double2 &Z, double *nxt) {
-  const unsigned q = (unsigned)(KS << 5) ^ c.pq, qn = (unsigned)(((KS + 1) & 3) << 5) ^ c.pq;
-  const unsigned ac = ba + q, an = ba + qn, bn = bb + qn;
-  sk_fgroup<NFW, KS, 0>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
-  sk_fgroup<NFW, KS, 1>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
-  sk_fgroup<NFW, KS, 2>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
-  sk_fgroup<NFW, KS, 3>(c, smem, ac, an, bn, acc, bf, a0, raw, Z, nxt);
-}
-
-template <int NFW>
-__device__ __forceinline__ void sk_chunk_interleaved(const SkCtx &c, char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1],
-                                                     const SkRaw &raw) {
-  double *nxt = reinterpret_cast<double *>(smem + (buf ^ SK_BUF1));
-  double2 Z = make_double2(0.0, 0.0);
-  if constexpr (NFW > 0) {
-    constexpr unsigned FB = 64 * SK_LD * 8;
-    const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
-    double bf[NFW], a0;
-    a0 = SK_LDS_F64(ba + c.pq);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < NFW; ++g) { bf[g] = SK_LDS_F64(bb + c.pq + g * FB); __builtin_amdgcn_sched_barrier(0); }
-    sk_kstep<NFW, 0>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
-    sk_kstep<NFW, 1>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
-    sk_kstep<NFW, 2>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
-    sk_kstep<NFW, 3>(c, smem, ba, bb, acc, bf, a0, raw, Z, nxt);
-  } else {
-    sk_build_piece<0>(c, raw, Z, nxt); sk_build_piece<1>(c, raw, Z, nxt); sk_build_piece<2>(c, raw, Z, nxt);
-    sk_build_piece<3>(c, raw, Z, nxt); sk_build_piece<4>(c, raw, Z, nxt); sk_build_piece<5>(c, raw, Z, nxt);
-    sk_build_piece<6>(c, raw, Z, nxt);
-  }
-}
-
-template <int NFW, bool late_unused>
-__device__ __forceinline__ void sk_body(const SkCtx &cin, char *smem, double *out) {
-  SkCtx c = cin;
-  c.zact = true;                       // every thread builds its five kz values (see above)
-  d4 acc[4][NFW > 0 ? NFW : 1];
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int g = 0; g < (NFW > 0 ? NFW : 1); ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
-  SkRaw raw;
-  const int clast = c.it.c1 - 1;
-  sk_load_raw(c, c.it.c0, raw);
-  sk_build_panel(c, raw, reinterpret_cast<double *>(smem));
-  sk_load_raw(c, c.it.c0 + 1 <= clast ? c.it.c0 + 1 : clast, raw);
-  __syncthreads();
-  unsigned buf = 0;
-  for (int ch = c.it.c0; ch < c.it.c1; ++ch, buf ^= SK_BUF1) {
-    sk_chunk_interleaved<NFW>(c, smem, buf, acc, raw);            // multiplies panel ch, builds panel ch + 1 out of `raw`
-    sk_load_raw(c, ch + 2 <= clast ? ch + 2 : clast, raw);        // for the build inside the NEXT iteration
-    __syncthreads();
-  }
-  {
-    unsigned lane_off = (unsigned)((64 * c.rh + c.fk) * 320 + 16 * c.cg + c.fr);
-    asm volatile("" : "+v"(lane_off));
-    double *o = out + lane_off;
-#pragma unroll
-    for (int g = 0; g < NFW; ++g)
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[(16 * f + 4 * r) * 320 + 64 * g] = acc[f][g][r];
-  }
-}
-#else
 // One segment = (tile, chunk range).  Between two barriers the workgroup multiplies chunk c (panel buffer c&1) and
 // builds chunk c+1 (other buffer).  The two waves of a SIMD (w and w+4) do this in OPPOSITE order -- waves 0-3
 // multiply first, waves 4-7 build first -- so one wave's operand generation overlaps its partner's MFMAs.
-template <int NFW, bool late>
+template <int NFW, bool late, int F0>
 __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out) {
   d4 acc[4][NFW > 0 ? NFW : 1];
 #pragma unroll
@@ -572,21 +520,21 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
     const bool more = ch + 1 < c.it.c1;
     if (!late) {
       SK_STAMP_T(st_a);
-      if (more && !(c.dbg & 4)) sk_load_raw(c, ch + 1, raw);
+      if (more && !(SK_DBG(c, 4))) sk_load_raw(c, ch + 1, raw);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_load, st_a, st_b);
-      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, smem, buf, acc);
+      if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_mfma, st_b, st_a);
-      if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
+      if (more && !(SK_DBG(c, 1))) sk_build_panel(c, raw, nxt);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
     } else {
 #if SK_LATE_MODE == 1
       // full stagger: build first, multiply second
       SK_STAMP_T(st_a);
-      if (more && !(c.dbg & 1)) sk_build_panel(c, raw, nxt);
+      if (more && !(SK_DBG(c, 1))) sk_build_panel(c, raw, nxt);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
-      if (ch + 2 < c.it.c1 && !(c.dbg & 4)) sk_load_raw(c, ch + 2, raw);
+      if (ch + 2 < c.it.c1 && !(SK_DBG(c, 4))) sk_load_raw(c, ch + 2, raw);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_load, st_b, st_a);
-      if (!(c.dbg & 2)) sk_mfma_chunk<NFW>(c, smem, buf, acc);
+      if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_mfma, st_a, st_b);
 #else
 #error "only the full stagger (SK_LATE_MODE 1) is kept: half stagger measured 264 vs 260 us (DESIGN.md)"
@@ -595,21 +543,24 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
     __syncthreads();
     SK_STAMP_T(st_a); SK_STAMP_ADD(s_bar, st_b, st_a);
   }
-  // ---- partial tile out: part[segment][128][320] (only the active fragments)
-  if (c.dbg & 16) return;
+  // ---- partial tile out (only the active fragments), fragment-major: sk_part_off().  Two 16-byte stores per fragment, each
+  //      wave-instruction one contiguous KB (the row-major layout took four 8-byte stores per fragment, each four 128-byte pieces:
+  //      the store tail of a segment is issue-bound)
+  if (SK_DBG(c, 16)) return;
   SK_STAMP_T(st_a);
   {
-    // one lane-dependent offset, made opaque per segment: left to itself the compiler hoists all 80 store addresses out of the
-    // segment loop and spills them (600 bytes of scratch, reloaded at every tile write)
-    unsigned lane_off = (unsigned)((64 * c.rh + c.fk) * 320 + 16 * c.cg + c.fr);
+    // one lane-dependent offset, made opaque per segment: left to itself the compiler hoists all store addresses out of the
+    // segment loop and spills them
+    unsigned lane_off = (unsigned)(((4 * c.rh * 20 + c.cg) << 8) + 2 * (16 * c.fk + c.fr));
     asm volatile("" : "+v"(lane_off));
-    double *o = out + lane_off;
+    double2 *o = reinterpret_cast<double2 *>(out + lane_off);
 #pragma unroll
     for (int g = 0; g < NFW; ++g)
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[(16 * f + 4 * r) * 320 + 64 * g] = acc[f][g][r];
+      for (int f = 0; f < 4; ++f) {
+        o[((f * 20 + 4 * g) << 7)] = make_double2(acc[f][g][0], acc[f][g][2]);
+        o[((f * 20 + 4 * g) << 7) + 64] = make_double2(acc[f][g][1], acc[f][g][3]);
+      }
   }
 #ifdef SK_STAMP
   SK_STAMP_T(st_b); SK_STAMP_ADD(s_epi, st_a, st_b);
@@ -621,7 +572,6 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
 #endif
 }
 
-#endif   // SK_INTERLEAVE
 
 // Persistent-style launch: workgroup w runs the segments seg_ptr[w] .. seg_ptr[w+1]-1 (host: equal cost per workgroup,
 // a segment boundary may fall inside a tile -- "stream-K" over the atom chunks).
@@ -645,21 +595,25 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   c.pq = (unsigned)(c.fr >> 2) << 5;
   c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
   c.nrx16 = (unsigned)(pl.kxmax + 2) * 16; c.nry16 = (unsigned)(pl.kymax + 1) * 16; c.nrz16 = (unsigned)(1 + pl.n_col_tiles * 32) * 16;
-  const bool late = wave >= 4 && !(dbg & 8);
+  const bool late = wave >= 4 && !(SK_DBG(c, 8));
 #ifdef SK_STAMP
   unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const int s0 = seg_ptr[blockIdx.x], s1 = seg_ptr[blockIdx.x + 1];
   for (int sg = s0; sg < s1; ++sg) {
     c.it = items[sg];
-    const int nfrag = 2 * c.it.nba;                     // active column fragments of this tile
+    // per row fragment f (16 planar vectors) only the leading nff_f column fragments (8 kz each) are inside the cut-off sphere;
+    // the tile's count is the largest of them (<= 2 nba; an odd count leaves the last fragment of the last kz block unwritten:
+    // the partial buffer is zeroed when allocated, those columns carry no listed k and zero weight)
+    int nfrag = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { const int nff = (int)((c.it.nbf >> (8 * f)) & 255u); nfrag = nff > nfrag ? nff : nfrag; }
     const int nfw = (nfrag - c.cg + 3) >> 2;            // fragments of this wave: fi = 4 g + cg < nfrag   (wave-uniform)
-    // per row fragment f (16 planar vectors) only the leading nbf_f <= nba kz blocks are inside the cut-off sphere
     // f0 = the first row fragment whose cut leaves out this wave's last column fragment (4: none)
     int f0 = 4;
 #pragma unroll
     for (int f = 3; f >= 0; --f) {
-      const int nff = 2 * (int)((c.it.nbf >> (8 * f)) & 255u);
+      const int nff = (int)((c.it.nbf >> (8 * f)) & 255u);
       const int n = (nff - c.cg + 3) >> 2;
       if (n < nfw) f0 = f;
     }
@@ -669,7 +623,7 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     //  cut behind it would be wrong; fall back to no culling then)
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      const int nff = 2 * (int)((c.it.nbf >> (8 * f)) & 255u);
+      const int nff = (int)((c.it.nbf >> (8 * f)) & 255u);
       if (f >= f0 && ((nff - c.cg + 3) >> 2) >= nfw) f0 = 4;
     }
     c.f0 = __builtin_amdgcn_readfirstlane(f0);
@@ -677,31 +631,33 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     c.xoff0 = (unsigned)pl.p_ikx[p0] * 16 + c.gj; c.yoff0 = (unsigned)pl.p_iky[p0] * 16 + c.gj;
     c.xoff1 = (unsigned)pl.p_ikx[p1] * 16 + c.gj; c.yoff1 = (unsigned)pl.p_iky[p1] * 16 + c.gj;
     c.sg0 = (double)pl.p_sgn[p0]; c.sg1 = (double)pl.p_sgn[p1];       // 0 marks a padding row
-    c.zact = 5 * c.gs < 16 * c.it.nba;                  // this thread's 5 kz values lie in an active block
+    c.zact = 5 * c.gs < 8 * nfrag;                      // this thread's 5 kz values reach into an active column fragment
     c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * 16 + c.gj;
     double *out = part + (size_t)sg * (128 * 320);
 #ifdef SK_STAMP
     const unsigned long long sg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (late) {
-      switch (nfw) {
-        case 5: sk_body<5, true>(c, smem, out); break;
-        case 4: sk_body<4, true>(c, smem, out); break;
-        case 3: sk_body<3, true>(c, smem, out); break;
-        case 2: sk_body<2, true>(c, smem, out); break;
-        case 1: sk_body<1, true>(c, smem, out); break;
-        default: sk_body<0, true>(c, smem, out); break;
-      }
-    } else {
-      switch (nfw) {
-        case 5: sk_body<5, false>(c, smem, out); break;
-        case 4: sk_body<4, false>(c, smem, out); break;
-        case 3: sk_body<3, false>(c, smem, out); break;
-        case 2: sk_body<2, false>(c, smem, out); break;
-        case 1: sk_body<1, false>(c, smem, out); break;
-        default: sk_body<0, false>(c, smem, out); break;
-      }
-    }
+    // one body per (column fragments of this wave, stagger role, sphere cut): the MFMA phase is straight-line code.  f0 = 4 (no
+    // culling) is always correct -- culled fragments only hold G entries that no listed k reads -- and serves as the default.
+#define SK_BODY_F0(N, L)                                       \
+  switch (c.f0) {                                              \
+    case 1: sk_body<N, L, 1>(c, smem, out); break;             \
+    case 2: sk_body<N, L, 2>(c, smem, out); break;             \
+    case 3: sk_body<N, L, 3>(c, smem, out); break;             \
+    default: sk_body<N, L, 4>(c, smem, out); break;            \
+  }
+#define SK_BODY_NFW(L)                                         \
+  switch (nfw) {                                               \
+    case 5: SK_BODY_F0(5, L) break;                            \
+    case 4: SK_BODY_F0(4, L) break;                            \
+    case 3: SK_BODY_F0(3, L) break;                            \
+    case 2: SK_BODY_F0(2, L) break;                            \
+    case 1: SK_BODY_F0(1, L) break;                            \
+    default: sk_body<0, L, 4>(c, smem, out); break;            \
+  }
+    if (late) { SK_BODY_NFW(true) } else { SK_BODY_NFW(false) }
+#undef SK_BODY_NFW
+#undef SK_BODY_F0
 #ifdef SK_STAMP
     if (t == 0 && sg < 4096) {
       unsigned long long *o = sk_seg_buf + (size_t)sg * 4;
@@ -743,7 +699,11 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
   const size_t lds = SK_LDS_BYTES;
   static DynLdsCache granted{};
   ensure_dyn_lds(sk_gemm_kernel, lds, granted);
-  static const int dbg = getenv("CONP_SK_DBG") ? atoi(getenv("CONP_SK_DBG")) : 0;   // ablation switches for experiments
+#ifdef SK_ABLATE
+  static const int dbg = getenv("CONP_SK_DBG") ? atoi(getenv("CONP_SK_DBG")) : 0;   // diagnostic build only
+#else
+  const int dbg = 0;
+#endif
   hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, nl_pad, Xt, Yt, Zs, qc, part, dbg);
 }
 
@@ -754,6 +714,55 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 // A thread walks its splits serially (8 loads in flight), so heavily split tiles (multi-GPU shards: one tile cut 256 ways)
 // are summed in two levels:  level 1 (blockIdx.y = group g) adds splits [16 g, 16 g + 16) into slot 16 g in place,
 // level 2 adds the group slots (stride 16) and writes G / Gwf.  level 0 = everything in one pass.
+// Sum of one element's partials over `count` splits `step` doubles apart.  8 (16) loads in flight; the association
+// ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)) is fixed -> bitwise reproducible.  part_sum2: the same for both halves of a 16-byte unit
+// (rows r and r + 2 of a fragment: the two elements a thread of the 80-column slices owns), each with exactly that order.
+__device__ __forceinline__ double part_sum1(const double *__restrict__ src, size_t step, int count) {
+  double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int sp = 0;
+  for (; sp + 16 <= count; sp += 16) {       // 16 partials in flight per element; additions in the order of the 8-wide loop
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * step];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += v[u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += v[8 + u];
+  }
+  for (; sp + 8 <= count; sp += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * step];
+  }
+  for (int u = 0; sp < count; ++sp, ++u) s8[u] += src[(size_t)sp * step];
+  return ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+}
+__device__ __forceinline__ double2 part_sum2(const double *__restrict__ src, size_t step, int count) {
+  double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int sp = 0;
+  for (; sp + 16 <= count; sp += 16) {
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)(sp + u) * step);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a8[u] += v[u].x; b8[u] += v[u].y; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a8[u] += v[8 + u].x; b8[u] += v[8 + u].y; }
+  }
+  for (; sp + 8 <= count; sp += 8) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)(sp + u) * step);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a8[u] += v[u].x; b8[u] += v[u].y; }
+  }
+  for (int u = 0; sp < count; ++sp, ++u) {
+    const double2 v = *reinterpret_cast<const double2 *>(src + (size_t)sp * step);
+    a8[u] += v.x; b8[u] += v.y;
+  }
+  return make_double2(((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7])),
+                      ((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7])));
+}
+
 constexpr int SKR_GROUP = 16;
 // a tile's 320 columns are cut into SKR_SL slices: one block per (tile, 16-row fragment, slice).  Eight slices of 40 columns
 // (round 1 and most of round 2: four of 80, two elements per thread): twice the blocks pulling on the partial tiles -- the
@@ -763,7 +772,7 @@ constexpr int SKR_GROUP = 16;
 constexpr int SKR_T = 640;                         // threads per block
 // two levels (one more launch) once the most-split tile has more than this many partials: measured break-even on the headline
 // box -- 40 partials (one GPU) 4 us faster in one level, 57 (two ranks) equal, 113 (four ranks) 12 us faster in two
-static int skr_two_level_from() { static const int v = getenv("CONP_SKR_TWO") ? atoi(getenv("CONP_SKR_TWO")) : 4 * SKR_GROUP; return v; }
+static int skr_two_level_from() { static const int v = exp_switch("CONP_SKR_TWO") ? atoi(exp_switch("CONP_SKR_TWO")) : 4 * SKR_GROUP; return v; }
 template <int SKR_SL>
 __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
                                                         double *__restrict__ part, const double *__restrict__ wfull,
@@ -784,42 +793,30 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTil
     count = (tl.nsplit + SKR_GROUP - 1) / SKR_GROUP;
   }
   const size_t step = (size_t)stride * plane;
+  // this thread's element(s): (row0, cl) and, in the 80-column slices, (row0 + 8, cl) -- the other half of the same 16-byte unit
+  const int row0 = threadIdx.x / SKR_W, cl = threadIdx.x % SKR_W;
+  const int col = SKR_W * q + cl;
+  static_assert(SKR_K == 1 || SKR_T / SKR_W == 8, "the two elements of a thread are 8 rows apart");
+  double sums[SKR_K];
 #pragma unroll
-  for (int k = 0; k < SKR_K; ++k) {
-    const int e = threadIdx.x + SKR_T * k;
-    const int row = e / SKR_W, cl = e % SKR_W;
-    const int rowl = 16 * f16 + row, col = SKR_W * q + cl;
-    double sum = 0.0;
-    double *src = part + (size_t)(tl.item0 + first) * plane + rowl * 320 + col;
-    if (col < 32 * tl.nba) {
-      // 8 loads in flight; the association ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)) is fixed -> bitwise reproducible
-      double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int sp = 0;
-      for (; sp + 16 <= count; sp += 16) {       // 16 partials in flight per element; additions in the order of the 8-wide loop
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * step];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += v[u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += v[8 + u];
-      }
-      for (; sp + 8 <= count; sp += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * step];
-      }
-      for (int u = 0; sp < count; ++sp, ++u) s8[u] += src[(size_t)sp * step];
-      sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  for (int k = 0; k < SKR_K; ++k) sums[k] = 0.0;
+  double *src = part + (size_t)(tl.item0 + first) * plane + sk_part_off(16 * f16 + row0, col);
+  if (col < 32 * tl.nba) {
+    if constexpr (SKR_K == 2) { const double2 v = part_sum2(src, step, count); sums[0] = v.x; sums[1] = v.y; }
+    else sums[0] = part_sum1(src, step, count);
+    if (level == 1) {                            // this thread is the only reader and writer of the unit
+      if constexpr (SKR_K == 2) *reinterpret_cast<double2 *>(src) = make_double2(sums[0], sums[1]);
+      else src[0] = sums[0];
     }
-    if (level == 1) {
-      if (col < 32 * tl.nba) src[0] = sum;       // this thread is the only reader and writer of the element
-      continue;
-    }
-    const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
-    G[grow * C_pad + gcol] = sum;
-    tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sum;
   }
   if (level == 1) return;
+#pragma unroll
+  for (int k = 0; k < SKR_K; ++k) {
+    const int row = row0 + 8 * k, rowl = 16 * f16 + row;
+    const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
+    G[grow * C_pad + gcol] = sums[k];
+    tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sums[k];
+  }
   __syncthreads();
   const size_t rf = (size_t)tl.rt * 8 + f16;
   double *dst = Gwf + (rf * (C_pad / 4) + (size_t)tl.ct * 80 + (SKR_W / 4) * q) * 64;
@@ -855,7 +852,7 @@ __global__ void sfac_gather_kernel(int kcount, int C_pad, int PT, const int *__r
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= kcount) return;
   const size_t ra = (size_t)row_a[k] * C_pad, rb = (size_t)(row_a[k] + PT) * C_pad;
-  const int cc = col_c[k], cs = col_c[k] + 16;
+  const int cc = col_c[k], cs = col_c[k] + 8;
   const double CC = G[ra + cc], CS = G[ra + cs], SC = G[rb + cc], SS = G[rb + cs];
   const double sg = (double)k_sign[k];
   // (p,+m): Sr = CC - SS, Si = CS + SC ; (p,-m): Sr = CC + SS, Si = SC - CS   (km_ewald.cpp:768-773)
@@ -1028,13 +1025,17 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
   }
 }
 
-// ---- the same dot, finished in one launch: grid = ne_pad / 16 atom blocks; thread = (atom a of 16, row lane w of 64).  Every
-// thread walks 2 rows of each of this rank's row tiles (row = 128 tile + w, + 64), so a wave reads four 128-byte runs of Rp per
-// step; the four k-quarter slots of Hc are summed into LDS for ALL 128 rows of a tile; the 64 row lanes of an atom are added in
-// a fixed order; then slab term and real-space sum (already formed by elyte_phase's spare blocks): b is complete, no
-// b_real_combine launch.  Used when the whole Hc table of this rank fits in 64 KB of LDS (planar electrodes: 2-6 z classes).
+// ---- the same dot, finished in one launch: grid = ne_pad / 16 atom blocks; thread = (atom a of 16, planar vector w of 64).
+// Every thread takes planar vector 64 tile + w of each of this rank's row tiles, i.e. G rows w ('a') and 64 + w ('b').  Their
+// electrode phases are NOT streamed from the [R_pad][Ne] table (34 MB at the headline size, once per update) but rebuilt from
+// the electrode atoms' axis tables Xe[kx][i], Ye[ky][i] (3 MB, L2-resident) with the products the host used to fill that table
+// (electrode_trig, km_ewald.cpp:464-477; no FMA contraction: the same bits).  The four k-quarter slots of Hc are summed into
+// LDS for ALL 128 rows of a tile; the 64 row lanes of an atom are added in a fixed order; then slab term and real-space sum
+// (already formed by elyte_phase's spare blocks): b is complete, no b_real_combine launch.  Used when the whole Hc table of
+// this rank fits in 64 KB of LDS (planar electrodes: 2-6 z classes).
 __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
-                                                          const double *__restrict__ Rp, const double *__restrict__ Hc4,
+                                                          const double2 *__restrict__ Xe, const double2 *__restrict__ Ye,
+                                                          const int *__restrict__ own_pv, const double *__restrict__ Hc4,
                                                           const int *__restrict__ zclass, BRowArgs ra, int nslot) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char zf_smem[];
@@ -1046,15 +1047,17 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   const size_t hp = (size_t)R_pad * 64;
   // the slab scalar by the first wave, with b_real_combine's summation tree (the 16 finishing threads are lanes of that wave)
   const double sc = (ra.slab && threadIdx.x < 64) ? b_slab_scalar(ra, threadIdx.x) : 0.0;
-  // the first 8 row tiles' Rp values (16 per thread) are requested BEFORE the Hc table is staged: the two latencies (HBM for
-  // Rp, L2 for Hc) overlap instead of adding up -- at the headline size that is the whole Rp stream of this thread
-  double rp0[16];
+  // the first 8 row tiles' phases are requested BEFORE the Hc table is staged: the two latencies overlap instead of adding up --
+  // at the headline size that is everything this thread reads
+  double2 xe0[8], ye0[8];
+  int sg0[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const bool ok = u < n_own;
-    const int rt = own_rt[ok ? u : 0];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) rp0[2 * u + v] = ok ? Rp[((size_t)rt * 128 + w + 64 * v) * ne_pad + i] : 0.0;
+    const bool ok = u < n_own;                   // an absent tile gets a zero X phase: it adds 0 * H
+    const int pk = own_pv[(ok ? u : 0) * 64 + w];      // |kx| | |ky| << 12 | (ky < 0) << 24
+    sg0[u] = (pk >> 24) & 1;
+    xe0[u] = ok ? Xe[(size_t)(pk & 4095) * ne_pad + i] : make_double2(0.0, 0.0);
+    ye0[u] = Ye[(size_t)((pk >> 12) & 4095) * ne_pad + i];
   }
   const int nrow = n_own * 128;
   for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {      // class-major Hc4: coalesced runs of rows, classes in use only
@@ -1065,28 +1068,40 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   }
   __syncthreads();
   double sum = 0.0;
+  // (cos, sin)(kx x +- ky y) of a planar vector for atom i: neg flips the sign of sin(ky y); padding vectors read the all-zero
+  // row kxmax + 1 of Xe (like the electrolyte's X table) and come out as zero
+  auto phase = [](double2 X, double2 Y, int neg, double &pa, double &pb) {
+    const double sy = neg ? -Y.y : Y.y;
+    pa = X.x * Y.x - X.y * sy;
+    pb = X.x * sy + X.y * Y.x;
+  };
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {                  // same order of additions as the loop below (tiles 0..7; absent tiles add 0 * H)
+  for (int u = 0; u < 8; ++u) {                  // tiles 0..7 (absent tiles add 0 * H)
     const int kk = u < n_own ? u : 0;
-#pragma unroll
-    for (int v = 0; v < 2; ++v) sum += rp0[2 * u + v] * H[(kk * 128 + w + 64 * v) * nzc + zc];
+    double pa, pb;
+    phase(xe0[u], ye0[u], sg0[u], pa, pb);
+    sum += pa * H[(kk * 128 + w) * nzc + zc];
+    sum += pb * H[(kk * 128 + w + 64) * nzc + zc];
   }
-  for (int k0 = 8; k0 < n_own; k0 += 4) {        // 4 row tiles at a time: 8 Rp rows in flight per thread
-    double rp[8], hc[8];
+  for (int k0 = 8; k0 < n_own; k0 += 4) {        // 4 row tiles at a time
+    double2 xe[4], ye[4];
+    int sg[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const bool ok = k0 + u < n_own;
-      const int kk = ok ? k0 + u : k0;
-      const int rt = own_rt[kk];
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const size_t r = (size_t)rt * 128 + w + 64 * v;
-        rp[2 * u + v] = ok ? Rp[r * ne_pad + i] : 0.0;
-        hc[2 * u + v] = H[(kk * 128 + w + 64 * v) * nzc + zc];
-      }
+      const int pk = own_pv[(ok ? k0 + u : k0) * 64 + w];
+      sg[u] = (pk >> 24) & 1;
+      xe[u] = ok ? Xe[(size_t)(pk & 4095) * ne_pad + i] : make_double2(0.0, 0.0);
+      ye[u] = Ye[(size_t)((pk >> 12) & 4095) * ne_pad + i];
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sum += rp[k] * hc[k];
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k0 + u < n_own ? k0 + u : k0;
+      double pa, pb;
+      phase(xe[u], ye[u], sg[u], pa, pb);
+      sum += pa * H[(kk * 128 + w) * nzc + zc];
+      sum += pb * H[(kk * 128 + w + 64) * nzc + zc];
+    }
   }
   red[w][a] = sum;
   __syncthreads();
@@ -1108,12 +1123,13 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
 // true when b_zc_final_kernel can take the place of b_zc_dot + b_real_combine
 bool zc_final_fits(int n_own, int nzc) { return n_own > 0 && (size_t)n_own * 128 * nzc * sizeof(double) <= 64 * 1024; }
 
-static void launch_b_zc_final(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
-                              const double *Hc, const int *zclass, const BRowArgs &fin, int nslot) {
+static void launch_b_zc_final(hipStream_t s, const DevPlan &pl, int n_own, const int *own_rt, int ne_pad, int nzc, const double2 *Xe,
+                              const double2 *Ye, const int *own_pv, const double *Hc, const int *zclass, const BRowArgs &fin, int nslot) {
   const size_t lds = (size_t)n_own * 128 * nzc * sizeof(double);
   static DynLdsCache granted{};
   ensure_dyn_lds(b_zc_final_kernel, lds, granted);
-  hipLaunchKernelGGL(b_zc_final_kernel, dim3(ne_pad / 16), dim3(1024), lds, s, n_own, own_rt, R_pad, ne_pad, nzc, Rp, Hc, zclass, fin, nslot);
+  hipLaunchKernelGGL(b_zc_final_kernel, dim3(ne_pad / 16), dim3(1024), lds, s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Xe, Ye, own_pv, Hc,
+                     zclass, fin, nslot);
 }
 
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
@@ -1156,35 +1172,22 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
 #pragma unroll
     for (int tsl = 0; tsl < NKS; ++tsl) bz[tsl] = NKS * q + tsl < nks ? bp[(size_t)tsl * 256] : 0.0;
   }
+  const int row0 = threadIdx.x / SKR_W, cl = threadIdx.x % SKR_W;      // element(s) of this thread: see sk_reduce_kernel
+  const int col = SKR_W * q + cl;
+  double sums[SKR_K];
+#pragma unroll
+  for (int k = 0; k < SKR_K; ++k) sums[k] = 0.0;
+  if (col < 32 * tl.nba) {
+    const double *src = part + (size_t)tl.item0 * plane + sk_part_off(16 * f16 + row0, col);
+    if constexpr (SKR_K == 2) { const double2 v = part_sum2(src, step, count); sums[0] = v.x; sums[1] = v.y; }
+    else sums[0] = part_sum1(src, step, count);
+  }
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) {
-    const int e = threadIdx.x + SKR_T * k;
-    const int row = e / SKR_W, cl = e % SKR_W;
-    const int rowl = 16 * f16 + row, col = SKR_W * q + cl;
-    double sum = 0.0;
-    if (col < 32 * tl.nba) {
-      const double *src = part + (size_t)tl.item0 * plane + rowl * 320 + col;
-      double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int sp = 0;
-      for (; sp + 16 <= count; sp += 16) {       // 16 partials in flight per element; additions in the order of the 8-wide loop
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * step];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += v[u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += v[8 + u];
-      }
-      for (; sp + 8 <= count; sp += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(sp + u) * step];
-      }
-      for (int u = 0; sp < count; ++sp, ++u) s8[u] += src[(size_t)sp * step];
-      sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-    }
+    const int row = row0 + 8 * k, rowl = 16 * f16 + row;
     const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
-    G[grow * C_pad + gcol] = sum;
-    tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sum;
+    G[grow * C_pad + gcol] = sums[k];
+    tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sums[k];
   }
   __syncthreads();
   if (wave >= nzc16) return;
@@ -1213,22 +1216,24 @@ static void launch_reduce_hc_sl(hipStream_t s, const DevPlan &pl, const SkTile *
 }
 void launch_reduce_project_zclass(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part,
                                   double *G, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Tzc, const double *Rp,
-                                  const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
+                                  const double2 *Xe, const double2 *Ye, const int *own_pv, const int *zclass, double *Hc,
+                                  double *bk_part, const BRowArgs *fin) {
   if (ntiles <= 0) return;
   const int nzc16 = (nzc + 15) / 16;
   const int nslot = skr_slices(ntiles);
   if (nslot == 4) launch_reduce_hc_sl<4>(s, pl, tiles, ntiles, max_nsplit, part, G, Tzc, Hc, nzc16);
   else launch_reduce_hc_sl<8>(s, pl, tiles, ntiles, max_nsplit, part, G, Tzc, Hc, nzc16);
-  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin, nslot);
+  if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, nslot);
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, nslot);
 }
 
 void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const int *rt_mine, int n_own, const int *own_rt, int nzc, const double *Gwf,
-                             const double *Tzc, const double *Rp, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
+                             const double *Tzc, const double *Rp, const double2 *Xe, const double2 *Ye, const int *own_pv, const int *zclass,
+                             double *Hc, double *bk_part, const BRowArgs *fin) {
   const int nzc16 = (nzc + 15) / 16;
   hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
-  if (fin) launch_b_zc_final(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, *fin, 4);      // b_hc writes four k-quarter slots
+  if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 4);      // b_hc writes four k-quarter slots
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 4);
 }
 
@@ -1260,8 +1265,20 @@ void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1
 // ================================================================================================
 // 5. dense solve pieces.  GEMV: one wave per row, 16-byte loads (fix_conp.cpp:1135-1139 ddot_ per row)
 // ================================================================================================
-// the matrix is streamed once per update and is far larger than L2: non-temporal loads keep it from evicting the phase tables
+// Cache policy of the matrix stream.  The matrix is read once per update, every update.  A small matrix (the decks: 5 - 22 MB)
+// stays in L2 / the Infinity Cache between updates with plain loads.  A large one is streamed with non-temporal loads so that it
+// does not evict the phase tables and partial tiles the next update reads.  Measured at the headline size (134 MB of matrix beside
+// ~110 MB of other per-update traffic, nominally inside the 256 MiB Infinity Cache): plain loads made the GEMV 1.5 us faster and
+// the phase and reduction kernels 3.5 us slower -- the matrix does not stay resident beside that much written data.
+constexpr size_t GEMV_RESIDENT_BYTES = (size_t)64 << 20;
+static bool gemv_nt(size_t matrix_bytes) {
+  static const char *e = exp_switch("CONP_GEMV_NT");      // comparison switch: 0 / 1 forces the policy
+  if (e) return atoi(e) != 0;
+  return matrix_bytes > GEMV_RESIDENT_BYTES;
+}
+template <bool NT>
 __device__ __forceinline__ double2 nt_load(const double2 *p) {
+  if constexpr (!NT) return *p;
   double2 v;
   v.x = __builtin_nontemporal_load(&p->x);
   v.y = __builtin_nontemporal_load(&p->y);
@@ -1271,6 +1288,7 @@ __device__ __forceinline__ double2 nt_load(const double2 *p) {
 // this lane's share of one row's dot product S[row,:] . b -- ONE function for every GEMV kernel, so that they agree to the bit.
 // Eight 16-byte row loads in flight per lane (two groups of four, multiplied in the order a 4-wide loop would use them): with
 // 16 resident waves per CU that is 128 KB on its way per CU, what ~6 TB/s at HBM latency asks for.
+template <bool NT>
 __device__ __forceinline__ double gemv_row_dot(int n, const double *__restrict__ srow, const double *__restrict__ b, int lane) {
   double s0 = 0.0, s1 = 0.0;
   if ((n & 1) == 0) {
@@ -1281,7 +1299,7 @@ __device__ __forceinline__ double gemv_row_dot(int n, const double *__restrict__
     for (; j + 448 < n / 2; j += 512) {
       double2 a[8], c[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = nt_load(s2 + j + 64 * u);
+      for (int u = 0; u < 8; ++u) a[u] = nt_load<NT>(s2 + j + 64 * u);
 #pragma unroll
       for (int u = 0; u < 8; ++u) c[u] = b2[j + 64 * u];
 #pragma unroll
@@ -1291,7 +1309,7 @@ __device__ __forceinline__ double gemv_row_dot(int n, const double *__restrict__
       }
     }
     for (; j + 192 < n / 2; j += 256) {
-      const double2 a0 = nt_load(s2 + j), a1 = nt_load(s2 + j + 64), a2 = nt_load(s2 + j + 128), a3 = nt_load(s2 + j + 192);
+      const double2 a0 = nt_load<NT>(s2 + j), a1 = nt_load<NT>(s2 + j + 64), a2 = nt_load<NT>(s2 + j + 128), a3 = nt_load<NT>(s2 + j + 192);
       const double2 b0 = b2[j], b1 = b2[j + 64], b2v = b2[j + 128], b3 = b2[j + 192];
       s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
       t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
@@ -1310,12 +1328,13 @@ __device__ __forceinline__ double gemv_row_dot(int n, const double *__restrict__
   return s0 + s1;
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row1, const double *__restrict__ S,
                                                         const double *__restrict__ b, double *__restrict__ y) {
   const int row = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= row1) return;
   const int lane = threadIdx.x & 63;
-  const double r = wave_sum(gemv_row_dot(n, S + (size_t)row * n, b, lane));
+  const double r = wave_sum(gemv_row_dot<NT>(n, S + (size_t)row * n, b, lane));
   if (lane == 0) y[row] = r;
 }
 
@@ -1326,6 +1345,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int n, int row0, int row
 // update.  The fix scalar's group-1 sum of y (:1150, :1159) is formed when somebody asks for it (left_sum_kernel): a first
 // version made the last block to finish compute it in this launch -- 1024 ticket adds on one address plus the fences cost
 // more than the launch they saved (gemv 23 + finish 7 us -> 38 us fused).
+template <bool NT>
 __global__ __launch_bounds__(256) void gemv_finish_kernel(int n, const double *__restrict__ S, const double *__restrict__ b,
                                                           double *__restrict__ y, const double *__restrict__ elesetq,
                                                           const double *__restrict__ eleinitq, double potdiff,
@@ -1334,7 +1354,7 @@ __global__ __launch_bounds__(256) void gemv_finish_kernel(int n, const double *_
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  double r = wave_sum(gemv_row_dot(n, S + (size_t)row * n, b, lane));
+  double r = wave_sum(gemv_row_dot<NT>(n, S + (size_t)row * n, b, lane));
   r = __shfl(r, 0, 64);
   double v;
   {
@@ -1351,13 +1371,20 @@ void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, 
                         const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of, double *q_ele,
                         double *q_atoms) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(gemv_finish_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, S, b, y, elesetq, eleinitq, potdiff, atoms_ptr,
-                     atoms_of, q_ele, q_atoms);
+  if (gemv_nt((size_t)n * n * sizeof(double)))
+    hipLaunchKernelGGL(gemv_finish_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, s, n, S, b, y, elesetq, eleinitq, potdiff, atoms_ptr,
+                       atoms_of, q_ele, q_atoms);
+  else
+    hipLaunchKernelGGL(gemv_finish_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, s, n, S, b, y, elesetq, eleinitq, potdiff, atoms_ptr,
+                       atoms_of, q_ele, q_atoms);
 }
 
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y) {
   if (row1 <= row0) return;
-  hipLaunchKernelGGL(gemv_rows_kernel, dim3((row1 - row0 + 3) / 4), dim3(256), 0, s, n, row0, row1, S, b, y);
+  if (gemv_nt((size_t)(row1 - row0) * n * sizeof(double)))
+    hipLaunchKernelGGL(gemv_rows_kernel<true>, dim3((row1 - row0 + 3) / 4), dim3(256), 0, s, n, row0, row1, S, b, y);
+  else
+    hipLaunchKernelGGL(gemv_rows_kernel<false>, dim3((row1 - row0 + 3) / 4), dim3(256), 0, s, n, row0, row1, S, b, y);
 }
 
 // fix_conp.cpp:1149-1159 in one launch:

@@ -194,6 +194,16 @@ def test_inverse_matches_numpy():
         results.append(inv)
     assert np.abs(results[0] - results[1]).max() <= 1e-12 * np.abs(ref).max()
     assert np.abs(results[0] - results[2]).max() <= 1e-12 * np.abs(ref).max()
+    # the panel's grid barrier gives up (forced: zero polls allowed): info = -7, the matrix is restored from its copy and the
+    # one-workgroup panel repeats the inverse -- the bits of the CONP_PANEL_SINGLE run, and the fall-back says so
+    fx.mesg_drain()
+    os.environ["CONP_PANEL_SPIN"] = "0"
+    try:
+        inv = fx.invert(a)
+    finally:
+        del os.environ["CONP_PANEL_SPIN"]
+    assert "timed out at its grid barrier" in fx.mesg_drain()
+    assert np.array_equal(inv, results[2])
     m = rng.normal(size=(300, 300)); spd = m @ m.T / 300 + np.eye(300)
     inv = fx.invert(spd)
     assert np.abs(inv - np.linalg.inv(spd)).max() / np.abs(inv).max() < 1e-12

@@ -16,9 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _make(name):
-    return {"small_slab": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab"),
-            "dilute_ffield": lambda: systems.deck("dilute", "ffield", etypes=True),
-            "dilute_slab_generic": lambda: systems.deck("dilute", "slab", etypes=False)}[name]()
+    import dataclasses
+    newton = name.endswith("_newton")          # `newton on`: owned-ghost pairs are listed ONCE, by one of the two ranks
+    s = {"small_slab": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab"),
+         "dilute_ffield": lambda: systems.deck("dilute", "ffield", etypes=True),
+         "dilute_slab_generic": lambda: systems.deck("dilute", "slab", etypes=False)}[name.replace("_newton", "")]()
+    return dataclasses.replace(s, newton=True) if newton else s
 
 
 def _decomposed_worker(rank, world, port, name, axis, solver, out):
@@ -49,8 +52,12 @@ def _decomposed_worker(rank, world, port, name, axis, solver, out):
     dist.destroy_process_group()
 
 
+# the *_newton cases: contributions to an electrode atom that is a GHOST on the rank that lists the pair -- the reference's
+# newtonbuf + MPI_Allreduce route (fix_conp.cpp:1311, 1345-1361); here they travel in the all-reduce of b / of the A build
 @pytest.mark.parametrize("name,axis,world,solver", [("small_slab", 0, 2, "inv"), ("dilute_ffield", 2, 2, "inv"),
-                                                    ("dilute_slab_generic", 1, 3, "inv"), ("small_slab", 1, 2, "cg")])
+                                                    ("dilute_slab_generic", 1, 3, "inv"), ("small_slab", 1, 2, "cg"),
+                                                    ("small_slab_newton", 0, 2, "inv"), ("dilute_ffield_newton", 2, 2, "inv"),
+                                                    ("dilute_slab_generic_newton", 1, 3, "inv")])
 def test_decomposed_ranks_match_one_rank(name, axis, world, solver):
     import torch.multiprocessing as mp
     s = _make(name)
@@ -105,7 +112,7 @@ def _rccl_worker(rank, world, port, out):
     s = systems.deck("il_onelayer", "ffield")
     at, alist, blist = neighbor.build_lists(s)
     fx = FixConp(s, device=0, rank=rank, nranks=world)
-    fx.comm_init_rccl()                                        # ncclGetUniqueId on rank 0, 128 bytes broadcast, ncclCommInitRank
+    assert fx.comm_init_rccl()                                 # availability agreed, ncclGetUniqueId on rank 0, 128 bytes broadcast, ncclCommInitRank
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
     fx.linalg_setup(at)                                        # tiles dealt to the ranks, all-reduce(A) on RCCL

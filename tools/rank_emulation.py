@@ -2,7 +2,10 @@
 """Per-rank compute time of the sharded update WITHOUT the collectives: one process builds the handle of rank r of N
 (conp_env.rank / nranks) on the single GPU and times b_cal_device + solve_device + scatter_device.  Used to see how the
 k-shard / row-shard scales before an N-GPU node is available; the two 32-KB RCCL collectives come on top.
-usage: python tools/rank_emulation.py [--workload NAME] [N ...]"""
+Runs against the PRODUCT library: the three device entry points below contain no collective (the host would make them between
+the calls), so no emulation switch is involved.
+usage: python tools/rank_emulation.py [--workload NAME] [--json PATH] [N ...]
+       --json: append {workload: {N: {rank: {ms_per_update, kernels_ms}}, ...}} to PATH (profiles/r03_rank_emulation.json)"""
 import os
 import sys
 import time
@@ -20,8 +23,15 @@ def main():
     from conp_amd import FixConp, neighbor
     argv = sys.argv[1:]
     wl = "headline"
-    if argv and argv[0] == "--workload":
-        wl, argv = argv[1], argv[2:]
+    jpath = None
+    while argv and argv[0].startswith("--"):
+        if argv[0] == "--workload":
+            wl, argv = argv[1], argv[2:]
+        elif argv[0] == "--json":
+            jpath, argv = argv[1], argv[2:]
+        else:
+            raise SystemExit(__doc__)
+    record = {}
     s = bench.make_workload(wl)
     at, alist, blist = neighbor.build_lists(s)
     d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda()
@@ -58,9 +68,21 @@ def main():
             prof = {k: round(v[0], 4) for k, v in fx.profile_read().items()}
             fx.profile(False)
             print(f"N={n} rank={rank}: {ms:.4f} ms/update (compute only)  {prof}", flush=True)
+            record.setdefault(str(n), {})[str(rank)] = dict(ms_per_update=ms, kernels_ms=prof)
             worst = ms if worst is None else max(worst, ms)
             fx.close()
         print(f"N={n}: slowest sampled rank {worst:.4f} ms", flush=True)
+        record[str(n)]["slowest_sampled_rank_ms"] = worst
+    if jpath:
+        import json
+        doc = {}
+        if os.path.exists(jpath):
+            doc = json.load(open(jpath))
+        doc["_about"] = ("per-rank COMPUTE time of the k-shard / row-shard update, one process per emulated rank on ONE MI355X "
+                         "(tools/rank_emulation.py); the two Ne-double collectives (all-reduce b, all-gather q) are not in these "
+                         "numbers; NOT a hardware scaling curve")
+        doc[s.name] = record
+        json.dump(doc, open(jpath, "w"), indent=1)
 
 
 if __name__ == "__main__":
