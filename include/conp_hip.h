@@ -232,6 +232,9 @@ typedef struct {
   int n_zclasses;          /* distinct electrode z values when the planar fast path of the projection is active, else 0 */
   double unitk[3], volume, gsqmx, ug_tot, totsetq, scalar_output, totinve, slabcorr;
   int64_t n_blist_pairs, n_alist_pairs, n_elyte_charged;
+  int inverse_path;        /* how the last inverse (fix_conp.cpp:947-949) was formed: 0 none yet, 1 positive-definite elimination (no
+                              pivot search), 2 partial pivoting */
+  int inverse_retries;     /* 1: the multi-workgroup pivot panel timed out at its grid barrier and the one-workgroup panel redid it */
 } conp_info;
 int conp_fix_info(const conp_fix *fix, conp_info *out);
 /* integer tables; pass NULL for those not wanted.  Sizes: kcount / kcount_expand */

@@ -210,6 +210,7 @@ struct conp_fix {
   std::vector<int> ct_ptr_h, seg_ptr_h, own_rt_h;   // own_rt_h: the row tiles this rank works on (sorted)
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
+  int inverse_path = 0;          // conp_info.inverse_path: 1 positive-definite elimination, 2 partial pivoting
   int inverse_retries = 0;       // times the last inverse fell back from the multi-workgroup panel (barrier time-out, info = -7)
   // the fix's log file (fix_conp.cpp:119): lines are buffered here and handed to the host by conp_fix_log_drain
   std::string logbuf, logdrain, mesgbuf, mesgdrain;   // mesgbuf: what the reference sends to utils::logmesg (:460, :1008)
@@ -240,7 +241,7 @@ struct conp_fix {
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p, d_Srows, d_xg, d_qg, d_pp_ele, d_pp_scratch,
-      d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
+      d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_Wz, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt, d_Xe, d_Ye;      // d_Xe / d_Ye: electrode atoms' axis phases [k][ne_pad] (once per run)
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
@@ -271,6 +272,7 @@ struct conp_fix {
     drop_graph();
     if (nccl) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(nccl); nccl = nullptr; }
     if (h_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_pin); }
+    if (h_np) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_np); }
     for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -539,21 +541,25 @@ struct conp_fix {
   // real-space rows of b (blist_coul_cal membership, fix_conp.cpp:1326-1350) from the list that is already on the device;
   // CONP_ROWS_HOST=1 keeps the host counting sort (same output) for comparison
   int64_t n_b_pairs = 0;
+  unsigned *h_np = nullptr;            // page-locked word the regrouping's pair count lands in
+  bool np_pending = false;
   void build_b_rows_device(const conp_atoms *at) {
     const int ne = idx.elenum_all;
-    static const bool on_host = exp_switch("CONP_ROWS_HOST") != nullptr;
+    const bool on_host = exp_switch("CONP_ROWS_HOST") != nullptr;      // read per call: the A/B test flips it between two handles
+    np_pending = false;
     if (on_host) {
       build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
       d_b_rowptr.upload(brows.row_ptr, stream); d_b_ele.upload(brows.ele_atom, stream); d_b_oth.upload(brows.oth_atom, stream);
       n_b_pairs = brows.npairs();
       return;
     }
-    const size_t sb = b_rows_scratch_bytes(bl_inum, bl_nneigh);
+    const size_t sb = b_rows_scratch_bytes(ne, bl_nneigh);
     d_rows_scratch.reserve(sb);
     d_b_rowptr.reserve((size_t)ne + 1); d_b_ele.reserve(std::max<size_t>(bl_nneigh, 1)); d_b_oth.reserve(std::max<size_t>(bl_nneigh, 1));
-    n_b_pairs = launch_build_b_rows(stream, bl_inum, bl_nneigh, d_bl_ilist.p, d_bl_numneigh.p, d_bl_first.p, d_bl_neigh.p,
-                                    d_atom2eleall.p, at->nlocal, env.newton_pair != 0, ne, d_rows_scratch.p, sb, d_b_rowptr.p,
-                                    d_b_ele.p, d_b_oth.p);
+    if (!h_np) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_np), 64, hipHostMallocDefault));
+    launch_build_b_rows(stream, bl_inum, bl_nneigh, d_bl_ilist.p, d_bl_numneigh.p, d_bl_first.p, d_bl_neigh.p, d_atom2eleall.p,
+                        at->nlocal, env.newton_pair != 0, ne, d_rows_scratch.p, sb, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, h_np);
+    np_pending = true;                 // the count is read after post_neighbor's closing sync()
     HIP_TRY(hipGetLastError());
   }
 
@@ -620,6 +626,7 @@ struct conp_fix {
     mark("b rows (device)");
     nlocal_cur = at->nlocal;
     sync();
+    if (np_pending) { n_b_pairs = *h_np; np_pending = false; }
     mark("sync");
   }
 
@@ -951,6 +958,17 @@ struct conp_fix {
   void km_a_cal_device() {
     const int ne = idx.elenum_all;
     const int trank = setup_sharded() ? env.rank : 0, tranks = setup_sharded() ? env.nranks : 1;
+    // planar electrodes (z classes, as in the projection's fast path): contraction over the planar rows only -- ~100x fewer flops.
+    // CONP_A_GENERAL: comparison switch, always the (planar, kz) contraction.
+    if (nzc > 0 && nzc <= 8 && exp_switch("CONP_A_GENERAL") == nullptr) {
+      d_A.reserve((size_t)ne * ne);
+      d_A.zero(stream);
+      d_Wz.reserve((size_t)plan.R_pad * nzc * nzc);
+      prof.begin("a_kspace", stream);
+      launch_a_kspace_zclass(stream, dplan, ne, ne_pad, nzc, d_Rp.p, d_Tzc.p, d_zclass.p, d_Wz.p, d_A.p, trank, tranks);
+      prof.end(stream);
+      return;
+    }
     // kz chunks (16-kz blocks) dealt to nsplit groups of about equal work: heaviest first to the lightest group; a chunk costs
     // as many row tiles as reach it
     int nchunk = 0;
@@ -1170,11 +1188,31 @@ struct conp_fix {
     const int max_wg = exp_switch("CONP_PANEL_MAXG") ? atoi(exp_switch("CONP_PANEL_MAXG")) : 0;
     const unsigned spin_limit = exp_switch("CONP_PANEL_SPIN") ? (unsigned)strtoul(exp_switch("CONP_PANEL_SPIN"), nullptr, 10) : (1u << 22);
     inverse_retries = 0;
-    if (!single) {
-      d_inv_backup.reserve((size_t)n * n);
-      HIP_TRY(hipMemcpyAsync(d_inv_backup.p, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    }
+    inverse_path = 2;
+    // CONP_INV_GENERAL: comparison switch, always the pivoted elimination
+    const bool try_spd = exp_switch("CONP_INV_GENERAL") == nullptr;
+    d_inv_backup.reserve((size_t)n * n);
+    HIP_TRY(hipMemcpyAsync(d_inv_backup.p, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     int info = 0;
+    if (try_spd) {
+      // an exactly symmetric matrix (the fix's own A always is, fix_conp.cpp:826-831) is first taken for positive definite: block
+      // Gauss-Jordan on its own diagonal, no pivot search.  A non-positive pivot says it was not (info = -8): restore, pivot.
+      int sym = 0;
+      launch_symmetry_check(stream, n, A, d_info.p);
+      HIP_TRY(hipMemcpyAsync(&sym, d_info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      sync();
+      if (sym) {
+        prof.begin("inverse", stream);
+        launch_inverse_spd(stream, n, A, d_inv_work.p, d_info.p);
+        prof.end(stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&info, d_info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        sync();
+        if (info == 0) { inverse_path = 1; d_inv_backup.release(); return; }
+        HIP_TRY(hipMemcpyAsync(A, d_inv_backup.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        info = 0;
+      }
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
       prof.begin("inverse", stream);
       const bool multi = launch_inverse(stream, n, A, d_inv_work.p, d_ipiv.p, d_info.p, num_cus, attempt == 0 && !single, max_wg, spin_limit);
@@ -2013,7 +2051,10 @@ int conp_fix_info(const conp_fix *f, conp_info *o) {
   for (int i = 0; i < 3; ++i) o->unitk[i] = f->kt.unitk[i];
   o->volume = f->kt.volume; o->gsqmx = f->kt.gsqmx; o->ug_tot = f->kt.ug_tot; o->totsetq = f->totsetq;
   o->scalar_output = f->scalar_output; o->totinve = f->totinve; o->slabcorr = f->slabcorr;
-  o->n_blist_pairs = f->n_b_pairs; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
+  int64_t nbp = f->n_b_pairs;
+  if (f->np_pending) { HIP_TRY(hipStreamSynchronize(f->stream)); nbp = *f->h_np; }     // (the count of a regrouping still in flight)
+  o->n_blist_pairs = nbp;
+  o->inverse_path = f->inverse_path; o->inverse_retries = f->inverse_retries; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
   CONP_GUARD_END
 }
 

@@ -13,6 +13,13 @@
 //   5. M -= Cct^T * Wb        (MFMA, all rows/cols; the zeroed blocks keep rows K / cols K untouched)
 //   6. M[i,K] = -C[i,:] * Dinv (i not in K);  M[K,j] = Wb[:,j] (j not in K);  M[K,K] = Dinv
 // After the last step the row swaps are undone as column swaps in reverse order: inv(A) = inv(P A) P.
+//
+// Symmetric positive definite matrices (the electrode matrix IS one: the Hessian of the Gaussian-charge Ewald energy, exactly
+// symmetric after a_symmetrise -- the reference's own CG solver relies on that) take the same block steps WITHOUT steps 1 and 2:
+// every diagonal block of a Schur complement of an SPD matrix is SPD, so the 64 x 64 block is inverted in place with its own
+// diagonal as pivots (inv_block_spd_kernel) and no row ever moves -- no pivot search over the panel, no grid barrier, no swaps.
+// A pivot that is not positive (the matrix was not SPD after all) sets info = -8: the caller restores the matrix and runs the
+// pivoted elimination above.  launch_inverse_spd is tried first whenever the matrix is exactly symmetric.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -325,6 +332,55 @@ __global__ __launch_bounds__(256) void inv_block_kernel(int nbw, const double *_
   }
 }
 
+
+// ---- SPD path, step 3': Dinv = (M[K,K])^-1 by in-place Gauss-Jordan on the diagonal block, pivots = its own diagonal ------
+// One workgroup, the block in LDS.  A pivot <= 0 or not finite: info = -8 (not positive definite -> pivoted path).
+__global__ __launch_bounds__(256) void inv_block_spd_kernel(int n, int k0, int nbw, const double *__restrict__ M,
+                                                            double *__restrict__ Dinv, int *__restrict__ info) {
+  if (*info != 0) return;
+  __shared__ double B[INV_NB][INV_NB + 1];
+  __shared__ double s_col[INV_NB];
+  __shared__ int s_bad;
+  const int t = threadIdx.x;
+  if (t == 0) s_bad = 0;
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    B[r][c] = (r < nbw && c < nbw) ? M[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);     // padding block = identity
+  }
+  __syncthreads();
+  for (int j = 0; j < nbw; ++j) {
+    const double p = B[j][j];
+    if (t == 0 && (!(p > 0.0) || !(p <= 1.7976931348623157e308))) s_bad = 1;
+    if (t < INV_NB) s_col[t] = B[t][j];               // column j before it is overwritten
+    __syncthreads();
+    if (s_bad) { if (t == 0) *info = -8; return; }
+    const double pinv = 1.0 / p;
+    // row j: B[j][c] *= pinv (c != j), B[j][j] = pinv;  rows r != j: B[r][c] -= B[r][j] * (B[j][c] * pinv), B[r][j] = -B[r][j] * pinv
+    for (int e = t; e < INV_NB * INV_NB; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      if (r == j) continue;
+      const double f = s_col[r];
+      if (c == j) B[r][c] = -f * pinv;
+      else B[r][c] -= f * (B[j][c] * pinv);
+    }
+    __syncthreads();
+    if (t < INV_NB) B[j][t] = (t == j) ? pinv : B[j][t] * pinv;
+    __syncthreads();
+  }
+  for (int e = t; e < INV_NB * INV_NB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Dinv[e] = (r < nbw && c < nbw) ? B[r][c] : 0.0;
+  }
+}
+
+// 1 in *flag when M is exactly symmetric (flag preset to 1; any asymmetric pair clears it)
+__global__ void inv_symmetry_kernel(int n, const double *__restrict__ M, int *__restrict__ flag) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n * n) return;
+  const int r = (int)(e / n), c = (int)(e % n);
+  if (c > r && M[e] != M[(size_t)c * n + r]) *flag = 0;
+}
+
 // ---- 4. Wb[k][j] = sum_l Dinv[k][l] M[k0+l][j] (0 for j in K);  Cct[k][i] = M[i][k0+k] (0 for i in K) --------------
 // One workgroup per 64 columns j; thread (jl, kg) forms 16 of the 64 k outputs of its column from an LDS copy of the
 // 64 x 64 slab of M; the transposed copy Cct goes through LDS so that reads (along k) and writes (along i) both coalesce.
@@ -535,6 +591,35 @@ bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
   }
   hipLaunchKernelGGL(inv_col_swaps_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, piv_all, M, info);
   return used_multi;
+}
+
+// exact symmetry test: *flag_dev (device int) = 1 / 0
+void launch_symmetry_check(hipStream_t s, int n, const double *M, int *flag_dev) {
+  const int one = 1;
+  (void)hipMemcpyAsync(flag_dev, &one, sizeof(int), hipMemcpyHostToDevice, s);
+  const size_t tot = (size_t)n * n;
+  hipLaunchKernelGGL(inv_symmetry_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, M, flag_dev);
+}
+
+// The SPD elimination (header comment): per 64-column block step the diagonal block's inverse, then steps 4-6 of the pivoted
+// path unchanged.  info = -8 when a pivot was not positive; the matrix content is then meaningless (the caller keeps a copy).
+void launch_inverse_spd(hipStream_t s, int n, double *M, double *work, int *info /*[1]*/) {
+  const int ld = (n + 127) / 128 * 128;
+  double *P = work;
+  double *Wb = P + (size_t)n * INV_NB;
+  double *Cct = Wb + (size_t)INV_NB * ld;
+  double *Dinv = Cct + (size_t)INV_NB * ld;
+  (void)hipMemsetAsync(info, 0, sizeof(int), s);
+  const size_t lds_prep = 2 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double), lds_fix = 3 * (size_t)INV_NB * (INV_NB + 1) * sizeof(double);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(inv_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fix);
+  for (int k0 = 0; k0 < n; k0 += INV_NB) {
+    const int nbw = (n - k0 < INV_NB) ? n - k0 : INV_NB;
+    hipLaunchKernelGGL(inv_block_spd_kernel, dim3(1), dim3(256), 0, s, n, k0, nbw, (const double *)M, Dinv, info);
+    hipLaunchKernelGGL(inv_prep_kernel, dim3(ld / INV_NB), dim3(256), lds_prep, s, n, ld, k0, nbw, M, Dinv, Wb, Cct, info);
+    hipLaunchKernelGGL(inv_update_kernel, dim3(ld / 128, ld / 128), dim3(256), 0, s, n, ld, Cct, Wb, M, info);
+    hipLaunchKernelGGL(inv_fixup_kernel, dim3((n + INV_NB - 1) / INV_NB), dim3(256), lds_fix, s, n, ld, k0, nbw, Dinv, Wb, Cct, M, info);
+  }
 }
 
 }  // namespace conp

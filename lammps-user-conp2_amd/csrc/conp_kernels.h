@@ -125,10 +125,11 @@ void launch_charge_finish(hipStream_t s, int ne, int nall, const int *atom2eleal
 void launch_cond_potdiff(hipStream_t s, int ne, const double *setzvec, const double *eleallq, const double *slab_part,
                          int n_slab_part, double lz, double rightcharge, double vmult, double *out);
 void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out);
-size_t b_rows_scratch_bytes(int inum, size_t nneigh);
-int64_t launch_build_b_rows(hipStream_t s, int inum, size_t nneigh, const int *ilist, const int *numneigh, const int *first,
-                            const int *neigh, const int *arow, int nlocal, int newton, int ne, void *scratch, size_t scratch_bytes,
-                            int *row_ptr, int *ele, int *oth);
+size_t b_rows_scratch_bytes(int ne, size_t nneigh);
+void launch_build_b_rows(hipStream_t s, int inum, size_t nneigh, const int *ilist, const int *numneigh, const int *first,
+                         const int *neigh, const int *arow, int nlocal, int newton, int ne, void *scratch, size_t scratch_bytes,
+                         int *row_ptr, int *ele, int *oth, unsigned *np_pinned /*page-locked host word: the number of pairs, valid
+                         after the stream has been synchronised*/);
 void launch_post_force(hipStream_t s, int inum, const int *ilist, const int *numneigh, const int *first, const int *neigh, int nlocal,
                        int nall, int newton, const double *x,
                        const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
@@ -137,6 +138,9 @@ void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v
 
 // ---- once-per-run matrix work ------------------------------------------------------------------
 int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk, int nranks);
+// planar electrodes: the same matrix through the z-class factorisation (contraction over the planar rows only)
+void launch_a_kspace_zclass(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, int nzc, const double *Rp, const double *Tzc,
+                            const int *zclass, double *Wz /*[R_pad * nzc * nzc] scratch*/, double *A, int rank, int nranks);
 // rank r of nranks computes the lower-triangle tiles r, r + nranks, ... into its zero-initialised A
 void launch_a_kspace(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, const double *Rp, const double *Tz, double *A, int nsplit,
                      const int *chunk_group, int rank, int nranks);
@@ -152,6 +156,9 @@ void launch_inv_project_apply(hipStream_t s, int n, double *A, const double *ain
 size_t inverse_workspace_doubles(int n);
 // returns true when the multi-workgroup panel was used (then info == -7 means "a grid barrier timed out": restore M, repeat
 // with multi_wg = false)
+// symmetric positive definite matrices: no pivot search, no grid barrier (conp_inverse.hip); info = -8: not positive definite
+void launch_symmetry_check(hipStream_t s, int n, const double *M, int *flag_dev);
+void launch_inverse_spd(hipStream_t s, int n, double *M, double *work, int *info /*[1]*/);
 bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all /*[n]*/, int *info /*[1]*/, int num_cus,
                     bool multi_wg, int max_wg /*0: no cap*/, unsigned spin_limit /*polls of the panel's grid barrier before info = -7*/);
 // CG (fix_conp.cpp:864-930): state vectors on device; returns via *d_done

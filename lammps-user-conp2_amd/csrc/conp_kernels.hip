@@ -41,6 +41,23 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// cache-policy experiments (comparison builds only; the product leaves both at 0): non-temporal partial-tile stores / loads,
+// non-temporal phase-table stores
+#ifndef SK_PART_NT
+#define SK_PART_NT 0
+#endif
+#ifndef EP_TABLE_NT
+#define EP_TABLE_NT 0
+#endif
+__device__ __forceinline__ void st_d2(double2 *p, double2 v, bool nt) {
+  if (nt) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); }
+  else *p = v;
+}
+__device__ __forceinline__ double2 ld_d2(const double2 *p, bool nt) {
+  if (nt) { double2 v; v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y); return v; }
+  return *p;
+}
+
 // ---- erfc(x)/r through the reference's 5-term polynomial (fix_conp.cpp:53-60, 1446-1454) and the pair potentials -------------
 __device__ __forceinline__ double erfcr_sqrt_dev(double a2_r2) {
 #pragma clang fp contract(off)
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
         const double cn = cm * c1 - sm * s1;
         const double sn = sm * c1 + cm * s1;
         cm = cn; sm = sn;
-        t[(size_t)(off + m) * 16] = make_double2(sc * cm, sc * sm);
+        st_d2(t + (size_t)(off + m) * 16, make_double2(sc * cm, sc * sm), EP_TABLE_NT);
       }
     } else {
       // seeds only (z axis): `stride` unit steps reach the first seed and give the seed-to-seed rotation, then one step per
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
       }
       const double cs = cm, ss = sm;
       for (int m = stride; m < nrow; m += stride) {
-        t[(size_t)(off + m / stride) * 16] = make_double2(sc * cm, sc * sm);
+        st_d2(t + (size_t)(off + m / stride) * 16, make_double2(sc * cm, sc * sm), EP_TABLE_NT);
         const double cn = cm * cs - sm * ss;
         const double sn = sm * cs + cm * ss;
         cm = cn; sm = sn;
@@ -558,8 +575,8 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
     for (int g = 0; g < NFW; ++g)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        o[((f * 20 + 4 * g) << 7)] = make_double2(acc[f][g][0], acc[f][g][2]);
-        o[((f * 20 + 4 * g) << 7) + 64] = make_double2(acc[f][g][1], acc[f][g][3]);
+        st_d2(o + ((f * 20 + 4 * g) << 7), make_double2(acc[f][g][0], acc[f][g][2]), SK_PART_NT);
+        st_d2(o + ((f * 20 + 4 * g) << 7) + 64, make_double2(acc[f][g][1], acc[f][g][3]), SK_PART_NT);
       }
   }
 #ifdef SK_STAMP
@@ -742,7 +759,7 @@ __device__ __forceinline__ double2 part_sum2(const double *__restrict__ src, siz
   for (; sp + 16 <= count; sp += 16) {
     double2 v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)(sp + u) * step);
+    for (int u = 0; u < 16; ++u) v[u] = ld_d2(reinterpret_cast<const double2 *>(src + (size_t)(sp + u) * step), SK_PART_NT);
 #pragma unroll
     for (int u = 0; u < 8; ++u) { a8[u] += v[u].x; b8[u] += v[u].y; }
 #pragma unroll
@@ -751,12 +768,12 @@ __device__ __forceinline__ double2 part_sum2(const double *__restrict__ src, siz
   for (; sp + 8 <= count; sp += 8) {
     double2 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(src + (size_t)(sp + u) * step);
+    for (int u = 0; u < 8; ++u) v[u] = ld_d2(reinterpret_cast<const double2 *>(src + (size_t)(sp + u) * step), SK_PART_NT);
 #pragma unroll
     for (int u = 0; u < 8; ++u) { a8[u] += v[u].x; b8[u] += v[u].y; }
   }
   for (int u = 0; sp < count; ++sp, ++u) {
-    const double2 v = *reinterpret_cast<const double2 *>(src + (size_t)sp * step);
+    const double2 v = ld_d2(reinterpret_cast<const double2 *>(src + (size_t)sp * step), SK_PART_NT);
     a8[u] += v.x; b8[u] += v.y;
   }
   return make_double2(((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7])),
@@ -1698,6 +1715,88 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
         const int j = bj * 128 + wj * 64 + 16 * g + fr;
         if (i < ne && j < i) A[(size_t)i * ne + j] = acc[f][g][r];
       }
+}
+
+// ---- planar electrodes (few distinct electrode z values, the z classes of the projection's fast path): the k-space part of A
+// factorises the same way b does.  Tz[t][i] depends on the atom's class only, so
+//     A_ij = sum_r Rp[r][i] Rp[r][j] W_r[c(i)][c(j)],      W_r[c][c'] = sum_t w(r,t) Tzc[t][c] Tzc[t][c']       (R_pad x nzc^2, tiny)
+// -- a contraction over the 2 n_p planar rows instead of over all (planar, kz) pairs: at the headline size 3.4e10 instead of
+// 3.9e12 flop.  As a GEMM: k index = (r, c'), A operand Rp[r][i] W_r[c(i)][c'], B operand Rp[r][j] [c(j) == c'].
+// Same tile / rank conventions and the same output (strict lower triangle) as a_kspace_lds_kernel.
+__global__ __launch_bounds__(256) void a_wz_kernel(int R_pad, int C_pad, int nzc, const double *__restrict__ wfull,
+                                                   const double *__restrict__ Tzc /*[C_pad][64]*/, double *__restrict__ Wz /*[R_pad][nzc][nzc]*/) {
+  // one wavefront per (row r, class pair): fixed-order sum over the columns
+  const int lane = threadIdx.x & 63;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= R_pad * nzc * nzc) return;
+  const int r = u / (nzc * nzc), cc = u - r * nzc * nzc, c = cc / nzc, cp = cc - c * nzc;
+  double s = 0.0;
+  for (int t = lane; t < C_pad; t += 64) {
+    const double w = wfull[(size_t)r * C_pad + t];
+    if (w != 0.0) s += w * Tzc[(size_t)t * 64 + c] * Tzc[(size_t)t * 64 + cp];
+  }
+  s = wave_sum(s);
+  if (lane == 0) Wz[u] = s;
+}
+
+__global__ __launch_bounds__(256, 2) void a_kspace_zc_kernel(int R_pad, int ne, int ne_pad, int nzc, const double *__restrict__ Wz,
+                                                             const double *__restrict__ Rp, const int *__restrict__ zclass,
+                                                             double *__restrict__ A, int tile_first, int tile_stride) {
+  int tidx = blockIdx.x * tile_stride + tile_first, bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= tidx) ++bi;
+  const int bj = tidx - bi * (bi + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  if (bi == bj && wj > wi) return;               // wave tile strictly above the diagonal
+  const int ibase = bi * 128 + wi * 64 + fr, jbase = bj * 128 + wj * 64 + fr;
+  int ci[4], cj[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) { ci[f] = zclass[ibase + 16 * f]; cj[f] = zclass[jbase + 16 * f]; }
+  d4 acc[4][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int nk = R_pad * nzc;                    // k = r * nzc + c'   (R_pad is a multiple of 128: nk of 4)
+#pragma unroll 2
+  for (int k0 = 0; k0 < nk; k0 += 4) {
+    const int k = k0 + fk, r = k / nzc, cp = k - r * nzc;
+    const double *rp = Rp + (size_t)r * ne_pad;
+    const double *wz = Wz + (size_t)r * nzc * nzc + cp;
+    double af[4], bf[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      af[f] = rp[ibase + 16 * f] * wz[ci[f] * nzc];
+      bf[f] = cj[f] == cp ? rp[jbase + 16 * f] : 0.0;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[f][g] = MFMA_F64(af[f], bf[g], acc[f][g]);
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = bi * 128 + wi * 64 + 16 * f + fk + 4 * r;
+        const int j = bj * 128 + wj * 64 + 16 * g + fr;
+        if (i < ne && j < i) A[(size_t)i * ne + j] = acc[f][g][r];
+      }
+}
+
+void launch_a_kspace_zclass(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, int nzc, const double *Rp, const double *Tzc,
+                            const int *zclass, double *Wz /*[R_pad * nzc * nzc] scratch*/, double *A, int rank, int nranks) {
+  const int nb = ne_pad / 128;
+  const int ntiles_all = nb * (nb + 1) / 2;
+  const int ntiles = ntiles_all > rank ? (ntiles_all - rank + nranks - 1) / nranks : 0;
+  const int nu = pl.R_pad * nzc * nzc;
+  hipLaunchKernelGGL(a_wz_kernel, dim3((nu + 3) / 4), dim3(256), 0, s, pl.R_pad, pl.C_pad, nzc, pl.wfull, Tzc, Wz);
+  if (ntiles > 0)
+    hipLaunchKernelGGL(a_kspace_zc_kernel, dim3(ntiles), dim3(256), 0, s, pl.R_pad, ne, ne_pad, nzc, (const double *)Wz, Rp, zclass, A, rank,
+                       nranks);
 }
 
 // A (strict lower triangle) = fixed-order sum of the split copies: ((A0 + A1) + (A2 + A3)), copies 1.. in `parts`

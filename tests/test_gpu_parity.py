@@ -118,6 +118,28 @@ def test_full_chain_matches_oracle(oracle, case):
     o.fx.close()
 
 
+@pytest.mark.parametrize("deck,mode", [("il_twolayer", "ffield"), ("il_onelayer", "slab"), ("dilute", "ffield")])
+def test_planar_a_matrix_factorisation_equals_the_general_contraction(deck, mode, monkeypatch):
+    """planar electrodes: the k-space part of A is contracted over the planar rows only (z classes, like the projection's fast
+    path) instead of over every (planar, kz) pair -- the same matrix to rounding (CONP_A_GENERAL forces the general kernel)"""
+    s = systems.deck(deck, mode, etypes=(deck != "dilute"))
+    at, alist, blist = neighbor.build_lists(s)
+    mats = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("CONP_A_GENERAL", "1")
+        fx = FixConp(s)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.a_cal(at)
+        assert fx.info().n_zclasses in (2, 4)
+        mats.append(fx.matrix())
+        fx.close()
+    a_zc, a_gen = mats
+    assert np.array_equal(a_zc, a_zc.T)
+    assert np.abs(a_zc - a_gen).max() <= 1e-12 * np.abs(a_gen).max()
+
+
 def test_dilute_step0_charge_matches_persist_log():
     """the reference's own known answer (tests/dilute/persist.log:143) straight from the GPU path"""
     import json, os
@@ -207,6 +229,28 @@ def test_inverse_matches_numpy():
     m = rng.normal(size=(300, 300)); spd = m @ m.T / 300 + np.eye(300)
     inv = fx.invert(spd)
     assert np.abs(inv - np.linalg.inv(spd)).max() / np.abs(inv).max() < 1e-12
+    # An exactly symmetric, positive definite matrix (the electrode matrix is one) is eliminated on its own diagonal blocks --
+    # no pivot search, no grid barrier; the same inverse as the pivoted elimination (CONP_INV_GENERAL) to rounding.  A symmetric
+    # matrix that is NOT positive definite is noticed (a pivot <= 0), restored and pivoted; a general matrix never tries.
+    assert fx.info().inverse_path == 1
+    m = rng.normal(size=(1500, 1500)); spd = m @ m.T / 1500 + 0.5 * np.eye(1500)
+    inv_spd = fx.invert(spd)
+    assert fx.info().inverse_path == 1
+    os.environ["CONP_INV_GENERAL"] = "1"
+    try:
+        inv_gen = fx.invert(spd)
+    finally:
+        del os.environ["CONP_INV_GENERAL"]
+    assert fx.info().inverse_path == 2
+    ref = np.linalg.inv(spd)
+    assert np.abs(inv_spd - ref).max() / np.abs(ref).max() < 1e-12 and np.abs(inv_gen - ref).max() / np.abs(ref).max() < 1e-12
+    assert np.abs(inv_spd @ spd - np.eye(1500)).max() < 1e-10
+    indef = spd.copy(); indef[700:, 700:] *= -1.0; indef = (indef + indef.T) / 2        # symmetric, indefinite, well conditioned
+    inv = fx.invert(indef)
+    assert fx.info().inverse_path == 2
+    assert np.abs(inv @ indef - np.eye(1500)).max() < 1e-9
+    fx.invert(a)                                                                         # the general matrix from above
+    assert fx.info().inverse_path == 2
     sing = rng.normal(size=(80, 80)); sing[17] = 0.0
     with pytest.raises(ConpError) as e:
         fx.invert(sing)
