@@ -241,7 +241,7 @@ struct conp_fix {
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p, d_Srows, d_xg, d_qg, d_pp_ele, d_pp_scratch,
-      d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_Wz, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
+      d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_Wz, d_Spk, d_yp, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt, d_Xe, d_Ye;      // d_Xe / d_Ye: electrode atoms' axis phases [k][ne_pad] (once per run)
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
@@ -610,15 +610,17 @@ struct conp_fix {
     // electrode rows of the real-space b are regrouped from it on the device (conp_rows.hip: count, scan, emit, stable sort)
     {
       size_t nneigh = 0;
+      int iown = 0;                       // list owners are owned atoms: the per-atom tables are needed up to the largest owner only
       for (int ii = 0; ii < blist.inum; ++ii) {
         const int i = blist.ilist[ii];
         nneigh = std::max(nneigh, (size_t)blist.first[i] + (size_t)blist.numneigh[i]);
+        iown = std::max(iown, i + 1);
       }
       bl_inum = blist.inum;
       bl_nneigh = nneigh;
       d_bl_ilist.upload(blist.ilist, (size_t)blist.inum, stream);
-      d_bl_numneigh.upload(blist.numneigh, (size_t)nall, stream);
-      d_bl_first.upload(blist.first, (size_t)nall, stream);
+      d_bl_numneigh.upload(blist.numneigh, (size_t)std::max(iown, 1), stream);
+      d_bl_first.upload(blist.first, (size_t)std::max(iown, 1), stream);
       d_bl_neigh.upload(blist.neigh, std::max<size_t>(nneigh, 1), stream);
     }
     mark("list upload");
@@ -713,13 +715,16 @@ struct conp_fix {
   // generation + barrier ~ SK_C0), and cut into num_cus equal shares.  A share is a list of segments (tile, chunk
   // range); every segment writes one partial tile, sk_reduce adds a tile's segments in order.
   // The two constants are a least-squares fit of per-segment lengths measured on the headline box (tools/sk_stamp.py ->
-  // gpurun_out/sk_segments.txt:  us = 0.475 * chunks * (mean nbf + 1.65) + 3.7 per segment): a segment's start (first panel with
-  // nothing to overlap it) and its partial-tile write cost as much as 7.7 units of chunk cost.  Round 1's model (C0 = 2, no
+  // tools/sk_fit.py; round 3's kernel:  us = 0.483 * chunks * (mean kz blocks + 1.37) + 2.8 per segment): a segment's start (first
+  // panel with nothing to overlap it) and its partial-tile write cost as much as 5.74 units of chunk cost.  The fit leaves 1 % rms
+  // per segment; what remains between workgroups (max / median 1.05 on the box measured) is the speed of the XCD a workgroup
+  // lands on (+-3 %, different XCDs on different boxes) -- nothing a static plan can see, and an adaptive one would give up the
+  // run-to-run reproducibility of the bits.  Round 1's model (C0 = 2, no
   // per-segment term) left the heavy tiles' workgroups and those whose share straddles a tile boundary 3 % behind the rest.
   // (Tried on top: a linear ramp of the shares so that early finishers' partial-tile stores overlap the others' last chunks --
   //  no effect at +-8 / 16 / 24 units, 244.1 - 244.5 us.  What is left is a +-2 % spread between XCDs.)
-  double SK_C0 = exp_switch("CONP_SK_C0") ? atof(exp_switch("CONP_SK_C0")) : 1.65;
-  double SK_CSEG = exp_switch("CONP_SK_CSEG") ? atof(exp_switch("CONP_SK_CSEG")) : 7.7;
+  double SK_C0 = exp_switch("CONP_SK_C0") ? atof(exp_switch("CONP_SK_C0")) : 1.37;
+  double SK_CSEG = exp_switch("CONP_SK_CSEG") ? atof(exp_switch("CONP_SK_CSEG")) : 5.74;
   void build_items() {
     const int nchunks = nl_pad / 16;
     const size_t nt = tiles_h.size();
@@ -1013,6 +1018,7 @@ struct conp_fix {
       std::fprintf(stderr, "    a_cal %-20s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tm).count());
       tm = t;
     };
+    ++s_generation;
     km_a_read(at);
     mk("electrode tables");
     km_a_cal_device();
@@ -1078,6 +1084,7 @@ struct conp_fix {
     catch (const std::exception &e) { throw ConpError(CONP_ERR_IO, e.what()); }
     upload_atoms_static(at);                                   // atom2eleall follows the new numbering
     build_b_rows_device(at);                                   // rows follow the new numbering (the list is on the device)
+    ++s_generation;
     HIP_TRY(hipMemcpyAsync(d_A.p, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     km_a_read(at);                                             // kspmod->a_read(): electrode phase tables (:772)
     sync();
@@ -1151,6 +1158,7 @@ struct conp_fix {
 
   // fix_conp.cpp:982-1067 inv_project on device, bit-exact operation order
   void inv_project_device(int n, double *A, const std::vector<double> *eleallz, double zhalf) {
+    ++s_generation;                          // (every writer of the device matrix says so: the packed copy follows)
     d_ainve.reserve(n);
     launch_inv_project(stream, n, A, 0, nullptr, d_ainve.p, d_scalars.p + 4, 0);
     HIP_TRY(hipMemcpyAsync(&totinve, d_scalars.p + 4, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1177,6 +1185,7 @@ struct conp_fix {
 
   // LU-quality inverse in place of dgetrf_/dgetri_ (fix_conp.cpp:947-949): blocked Gauss-Jordan, partial pivoting
   void invert_device(int n, double *A) {
+    ++s_generation;
     d_inv_work.reserve(inverse_workspace_doubles(n));
     d_ipiv.reserve(n + 1); d_info.reserve(2);
     // the in-place elimination destroys A: keep a copy while the multi-workgroup panel (grid barriers) is in use, so that a
@@ -1560,8 +1569,31 @@ struct conp_fix {
     return !off && args.minimizer == CONP_SOLVER_INV && !args.conq && !args.cond && env.nranks == 1 && !nccl && !s_sharded &&
            runstage >= 3;
   }
+  // The projected inverse as a symmetric matrix (conp_kernels.hip "GEMV ... as a SYMMETRIC matrix"): from 2048 electrode atoms up
+  // the fused solve reads packed lower-triangle tiles, half the bytes of the row-by-row product.  Packed once per matrix
+  // (spk_of: the matrix generation it was made from).  CONP_GEMV_FULL: comparison switch, always the row-by-row product.
+  long s_generation = 0, spk_of = -1;
+  bool use_sym_gemv() const {
+    static const bool off = exp_switch("CONP_GEMV_FULL") != nullptr;
+    return !off && idx.elenum_all >= 2048;
+  }
   void solve_scatter_fused(double *d_q_atoms, double potdiff) {
     const int ne = idx.elenum_all;
+    if (use_sym_gemv()) {
+      if (spk_of != s_generation) {
+        d_Spk.reserve(sym_packed_doubles(ne_pad));
+        d_yp.reserve((size_t)(ne_pad / 128) * ne_pad);
+        launch_sym_pack(stream, ne, ne_pad, d_A.p, d_Spk.p);
+        spk_of = s_generation;
+      }
+      prof.begin("gemv_charge", stream);
+      launch_sym_gemv_finish(stream, ne, ne_pad, d_Spk.p, d_b, d_yp.p, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr,
+                             potdiff, d_ele_csr_ptr.p, d_ele_csr_of.p, d_qele.p, d_q_atoms);
+      prof.end(stream);
+      left_stale = true; left_potdiff = potdiff;
+      HIP_TRY(hipGetLastError());
+      return;
+    }
     prof.begin("gemv_charge", stream);
     launch_gemv_finish(stream, ne, d_A.p, d_b, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr, potdiff, d_ele_csr_ptr.p,
                        d_ele_csr_of.p, d_qele.p, d_q_atoms);
@@ -2097,6 +2129,7 @@ int conp_fix_set_matrix(conp_fix *f, const double *aaa, int runstage) {
   if (f->s_sharded) { f->d_Srows.release(); f->s_sharded = false; }
   const size_t ne = f->idx.elenum_all;
   f->d_A.reserve(ne * ne);
+  ++f->s_generation;
   HIP_TRY(hipMemcpyAsync(f->d_A.p, aaa, ne * ne * sizeof(double), hipMemcpyHostToDevice, f->stream));
   f->sync();
   f->runstage = runstage;

@@ -43,7 +43,7 @@ struct KPlan {
   static constexpr int PT = 64;       // planar vectors per row tile (128 G rows: 64 'a' rows then 64 'b' rows)
   static constexpr int CT_BLK = 10;   // 16-kz blocks per column tile (160 kz values = 320 G columns)
   static constexpr int CT_COLS = 32 * CT_BLK;
-  static constexpr int ZSTRIDE = 5;   // the phase kernel stores a z-phase seed every 5th kz
+  static constexpr int ZSTRIDE = 5;   // seeds per column tile = 160 / ZSTRIDE = 32: kz = s of the tile, extended by 32-kz rotations (conp_kernels.hip)
   int kxmax = 0, kymax = 0, nz = 0;   // nz = kzmax + 1 (m = 0 .. kzmax)
   int np = 0;                         // planar vectors incl. the origin; sorted by |k_p|^2 (origin first)
   std::vector<int> p_ikx, p_iky, p_sgn;   // per p: |kx|, |ky|, sign of ky (+1/-1); origin = (0,0,+1)

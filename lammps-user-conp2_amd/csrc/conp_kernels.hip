@@ -175,41 +175,52 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
     // everything a workgroup loads for a chunk sits in a few contiguous KB instead of one 256-byte piece per 512-KB row
     const int NR = c == 0 ? kxmax + 2 : (c == 1 ? kymax + 1 : nrz);
     double2 *t = (c == 0 ? Xt : (c == 1 ? Yt : Zs)) + ((size_t)(j >> 4) * NR) * 16 + (j & 15);
-    // X and Y: every row.  Z: row 0 of Zs is the unit step (cos, sin)(uz z); row 1 + s is the seed for m = s*zstride --
-    // sk_gemm regenerates the m's in between with the same recurrence, so the values equal the full table's.
-    const int stride = (c == 2) ? zstride : 1;
-    const int off = (c == 2) ? 1 : 0;
+    // X and Y: every row.  Z: sk_gemm's thread (gs = 8 q + r, atom) generates the five kz values 40 q + r + 8 u (u < 5) of a
+    // column tile (160 kz) from ONE seed by repeated rotation with the 8-kz step: row 0 of Zs is that step, (cos, sin)(8 uz z);
+    // row 1 + 32 ct + gs is the seed, the phase at m = 160 ct + 40 q + r.  Same recurrence as the reference's, re-associated.
     // the x table carries the charge (q cos, q sin): one multiply here instead of two per planar vector in sk_gemm
     const double sc = (c == 0) ? qq : 1.0;
     double c1, s1;
     sincos(ang, &s1, &c1);
-    if (c == 0) t[(size_t)(kxmax + 1) * 16] = make_double2(0.0, 0.0);   // row for padding planar vectors (no contribution)
-    if (c == 2) { t[0] = make_double2(c1, s1); qc[j] = qq; qz = qq * xc; }
-    t[(size_t)off * 16] = make_double2(sc, 0.0);
-    double cm = c1, sm = s1;
-    if (nrow > 1 && stride == 1) t[(size_t)(off + 1) * 16] = make_double2(sc * c1, sc * s1);
-    if (stride == 1) {
+    auto rot = [](double &cr, double &sr, double cw, double sw) {       // (cr, sr) *= (cw, sw), the reference's angle addition
+      const double cn = cr * cw - sr * sw;
+      const double sn = sr * cw + cr * sw;
+      cr = cn; sr = sn;
+    };
+    if (c != 2) {
+      if (c == 0) t[(size_t)(kxmax + 1) * 16] = make_double2(0.0, 0.0);   // row for padding planar vectors (no contribution)
+      t[0] = make_double2(sc, 0.0);
+      double cm = c1, sm = s1;
+      if (nrow > 1) t[16] = make_double2(sc * c1, sc * s1);
       for (int m = 2; m < nrow; ++m) {
-        const double cn = cm * c1 - sm * s1;
-        const double sn = sm * c1 + cm * s1;
-        cm = cn; sm = sn;
-        st_d2(t + (size_t)(off + m) * 16, make_double2(sc * cm, sc * sm), EP_TABLE_NT);
+        rot(cm, sm, c1, s1);
+        st_d2(t + (size_t)m * 16, make_double2(sc * cm, sc * sm), EP_TABLE_NT);
       }
     } else {
-      // seeds only (z axis): `stride` unit steps reach the first seed and give the seed-to-seed rotation, then one step per
-      // stored row -- nrow / stride dependent steps instead of nrow (the z chain is the launch's longest: ~150 steps)
-      for (int m = 2; m <= stride; ++m) {
-        const double cn = cm * c1 - sm * s1;
-        const double sn = sm * c1 + cm * s1;
-        cm = cn; sm = sn;
-      }
-      const double cs = cm, ss = sm;
-      for (int m = stride; m < nrow; m += stride) {
-        st_d2(t + (size_t)(off + m / stride) * 16, make_double2(sc * cm, sc * sm), EP_TABLE_NT);
-        const double cn = cm * cs - sm * ss;
-        const double sn = sm * cs + cm * ss;
-        cm = cn; sm = sn;
-      }
+      qc[j] = qq; qz = qq * xc;
+      const int nct = (nrz - 1) / 32;                 // column tiles
+      // eight seeds in flight (r = 0 .. 7), advanced together by 40 kz per step: the dependent chain is 7 unit steps, 3 steps to
+      // the 40-kz rotation and 4 steps per column tile (a walk in unit steps would be 160 per tile: the launch's longest chain)
+      double sc8[8], ss8[8];
+      sc8[0] = 1.0; ss8[0] = 0.0;
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { sc8[r] = sc8[r - 1]; ss8[r] = ss8[r - 1]; rot(sc8[r], ss8[r], c1, s1); }
+      double c8 = sc8[7], s8 = ss8[7];
+      rot(c8, s8, c1, s1);                            // the 8-kz rotation
+      t[0] = make_double2(c8, s8);
+      double c40 = c8, s40 = s8;
+      rot(c40, s40, c8, s8);                          // 16
+      rot(c40, s40, c40, s40);                        // 32
+      rot(c40, s40, c8, s8);                          // 40
+      for (int ct = 0; ct < nct; ++ct)
+#pragma unroll
+        for (int q40 = 0; q40 < 4; ++q40) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            st_d2(t + (size_t)(1 + 32 * ct + 8 * q40 + r) * 16, make_double2(sc8[r], ss8[r]), EP_TABLE_NT);
+            rot(sc8[r], ss8[r], c40, s40);
+          }
+        }
     }
   }
   if (c != 2) return;
@@ -314,25 +325,28 @@ __device__ __forceinline__ double2 zstep(double2 z, double2 st) {
 }
 
 // Partial tiles (sk_gemm -> sk_reduce) are stored MFMA-fragment-major: the 16 x 16 fragment (row fragment f16 of 8, column
-// fragment fi of 20) is one run of 256 doubles, inside it register pair (r, r + 2) of lane (fk, fr) is one 16-byte unit:
-//   element (row = 16 f16 + 4 r + fk, col = 16 fi + fr)  at  (f16 * 20 + fi) * 256 + (r & 1) * 128 + (16 fk + fr) * 2 + (r >> 1)
+// fragment fi of 20) is one run of 256 doubles, inside it the accumulator register pair (r, r + 1), r even, of lane (fk, fr) is one
+// 16-byte unit (two ADJACENT registers: the store needs no register shuffling):
+//   element (row = 16 f16 + 4 r + fk, col = 16 fi + fr)  at  (f16 * 20 + fi) * 256 + (r >> 1) * 128 + (16 fk + fr) * 2 + (r & 1)
 __device__ __forceinline__ unsigned sk_part_off(int rowl, int col) {
   const int r = (rowl >> 2) & 3;
-  return (unsigned)((((rowl >> 4) * 20 + (col >> 4)) << 8) + ((r & 1) << 7) + ((((rowl & 3) << 4) + (col & 15)) << 1) + (r >> 1));
+  return (unsigned)((((rowl >> 4) * 20 + (col >> 4)) << 8) + ((r >> 1) << 7) + ((((rowl & 3) << 4) + (col & 15)) << 1) + (r & 1));
 }
 
 struct SkRaw {        // raw inputs of one thread for one chunk
-  double2 X0, Y0, X1, Y1, Zseed, Zst;
+  double2 X0, Y0, X1, Y1, Zseed, Zst;     // Zseed: phase at the thread's first kz of the column tile, Zst: the 8-kz rotation
 };
 
 struct SkCtx {        // per-thread constants of one work item
   SkItem it;
   int nl_pad, nz;
   int gj, gs;                       // generation role: atom gj of the chunk, sub-index gs 0..31
-  unsigned xoff0, yoff0, xoff1, yoff1, zoff;   // row * 16 + gj inside a chunk block of the phase tables
+  unsigned xy0, xy1, zoff;          // (row * 16 + gj) inside a chunk block of the phase tables: X in the low, Y in the high half-word
   unsigned nrx16, nry16, nrz16;                // rows per chunk block * 16 (X, Y, Z tables)
-  double sg0, sg1;
-  bool zact;
+  bool neg0, neg1;                  // ky < 0: flips the sign of sin(ky y)
+  bool zact;                        // this thread's kz values reach into an active column fragment
+  unsigned za;                      // doubles offset of (cos feature of the thread's first kz, atom gj) in a panel (swizzled)
+  int dsin;                         // from a cos feature to its sin feature
   int fr, fk, rh, cg;
   unsigned wa;                      // generation: doubles offset of (feature gs, atom gj) in a panel (swizzled)
   // MFMA fragments: this lane's element of A / B fragment 0 at k-step ks sits at byte  base + ((ks ^ p) << 5),  p = fr >> 2
@@ -347,8 +361,8 @@ struct SkCtx {        // per-thread constants of one work item
 __device__ __forceinline__ void sk_load_raw(const SkCtx &c, int ch, SkRaw &r) {
   // blocked tables: element (row, atom) of chunk ch at (ch * NR + row) * 16 + (atom & 15); the row offsets already hold row * 16 + gj
   const unsigned bx = (unsigned)ch * c.nrx16, by = (unsigned)ch * c.nry16, bz = (unsigned)ch * c.nrz16;
-  r.X0 = c.Xt[bx + c.xoff0]; r.Y0 = c.Yt[by + c.yoff0];
-  r.X1 = c.Xt[bx + c.xoff1]; r.Y1 = c.Yt[by + c.yoff1];
+  r.X0 = c.Xt[bx + (c.xy0 & 0xffffu)]; r.Y0 = c.Yt[by + (c.xy0 >> 16)];
+  r.X1 = c.Xt[bx + (c.xy1 & 0xffffu)]; r.Y1 = c.Yt[by + (c.xy1 >> 16)];
   if (c.zact) { r.Zst = c.Zs[bz + c.gj]; r.Zseed = c.Zs[bz + c.zoff]; }
 }
 
@@ -358,27 +372,35 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
   // sg is +1 or -1 (0 only on padding rows, whose X row is all zero anyway): a sign flip, not an FP64 multiply
   // features gs, 32 + gs, 64 + gs, 96 + gs share their low four bits: one swizzled column for all four
   {
-    const double sy = c.sg0 < 0.0 ? -r.Y0.y : r.Y0.y;
+    const double sy = c.neg0 ? -r.Y0.y : r.Y0.y;
     pn[c.wa] = r.X0.x * r.Y0.x - r.X0.y * sy;
     pn[c.wa + 64 * SK_LD] = r.X0.x * sy + r.X0.y * r.Y0.x;
   }
   {
-    const double sy = c.sg1 < 0.0 ? -r.Y1.y : r.Y1.y;
+    const double sy = c.neg1 ? -r.Y1.y : r.Y1.y;
     pn[c.wa + 32 * SK_LD] = r.X1.x * r.Y1.x - r.X1.y * sy;
     pn[c.wa + 96 * SK_LD] = r.X1.x * sy + r.X1.y * r.Y1.x;
   }
   if (c.zact) {
+    // thread (gs = 8 q + r, gj) owns the kz values 40 q + r + 8 u (u < 5) of the column tile: column fragments 5 q + u, position r.
+    // Column fragment kz >> 3 = 8 cos features then 8 sin features (KPlan::col_c / col_s): the thread's cos features are 16 rows
+    // apart with the SAME swizzle column (gj ^ r) -- one address register and immediate offsets; the sin feature sits 8 rows below
+    // its cos feature, its swizzle key has bit 3 set: column (gj ^ r) ^ 8, i.e. 8 doubles to the right or to the left depending
+    // on bit 3 of gj alone.  Threads whose first kz lies beyond the tile's sphere cut skip the lot (zact) -- with 40 kz per 8
+    // sub-indices those are whole wavefronts, the high ones: the late waves (4-7) of a tile that is cut short have little to
+    // build before they multiply.  (kz beyond nz - 1: the recurrence just runs on -- finite values in G columns that carry zero
+    // weight and no listed k.)
+    // What this replaced, measured: ten separately computed offsets (the first form of the 8-kz layout) cost either ten
+    // registers -- spills in the NFW = 5 bodies -- or per-chunk integer arithmetic on the build's critical path (3 % at the
+    // headline size, 7 % at 16384 / 262144); kz values strided by 32 (every thread busy on every tile) lost the short build of
+    // the late waves: 12 % at the headline size.
     double2 Z = r.Zseed;
+    double *pz = pn + c.za;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
-      const int ml = 5 * c.gs + u;                        // kz index inside the col tile
-      // column fragment ml >> 3 = 8 cos features then 8 sin features (KPlan::col_c / col_s): feature low bits ml & 7 and 8 + (ml & 7)
-      const int feat = 128 + 16 * (ml >> 3) + (ml & 7);
-      // (kz beyond nz - 1: the seed rows there are never written (zero) or the recurrence just runs on -- finite values in G
-      //  columns that carry zero weight and no listed k; not worth two selects per value)
-      pn[feat * SK_LD + (c.gj ^ (ml & 7))] = Z.x;
-      pn[(feat + 8) * SK_LD + (c.gj ^ (8 + (ml & 7)))] = Z.y;
-      Z = zstep(Z, r.Zst);
+      pz[u * 16 * SK_LD] = Z.x;
+      pz[u * 16 * SK_LD + c.dsin] = Z.y;
+      if (u < 4) Z = zstep(Z, r.Zst);
     }
   }
 }
@@ -575,8 +597,8 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
     for (int g = 0; g < NFW; ++g)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        st_d2(o + ((f * 20 + 4 * g) << 7), make_double2(acc[f][g][0], acc[f][g][2]), SK_PART_NT);
-        st_d2(o + ((f * 20 + 4 * g) << 7) + 64, make_double2(acc[f][g][1], acc[f][g][3]), SK_PART_NT);
+        st_d2(o + ((f * 20 + 4 * g) << 7), make_double2(acc[f][g][0], acc[f][g][1]), SK_PART_NT);
+        st_d2(o + ((f * 20 + 4 * g) << 7) + 64, make_double2(acc[f][g][2], acc[f][g][3]), SK_PART_NT);
       }
   }
 #ifdef SK_STAMP
@@ -607,6 +629,8 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   c.gj = t & 15; c.gs = t >> 4;
   c.fr = lane & 15; c.fk = lane >> 4;
   c.wa = (unsigned)(c.gs * SK_LD + (c.gj ^ (c.gs & 15)));
+  c.za = (unsigned)((128 + 16 * 5 * (c.gs >> 3) + (c.gs & 7)) * SK_LD + (c.gj ^ (c.gs & 7)));
+  c.dsin = 8 * SK_LD + ((c.gj & 8) ? -8 : 8);
   c.base_a = ((unsigned)(64 * c.rh + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
   c.base_b = ((unsigned)(128 + 16 * c.cg + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
   c.pq = (unsigned)(c.fr >> 2) << 5;
@@ -645,10 +669,11 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     }
     c.f0 = __builtin_amdgcn_readfirstlane(f0);
     const int p0 = c.it.rt * 64 + c.gs, p1 = p0 + 32;
-    c.xoff0 = (unsigned)pl.p_ikx[p0] * 16 + c.gj; c.yoff0 = (unsigned)pl.p_iky[p0] * 16 + c.gj;
-    c.xoff1 = (unsigned)pl.p_ikx[p1] * 16 + c.gj; c.yoff1 = (unsigned)pl.p_iky[p1] * 16 + c.gj;
-    c.sg0 = (double)pl.p_sgn[p0]; c.sg1 = (double)pl.p_sgn[p1];       // 0 marks a padding row
-    c.zact = 5 * c.gs < 8 * nfrag;                      // this thread's 5 kz values reach into an active column fragment
+    // (a table has at most kmax + 2 < 4096 rows of 16: the offsets fit in 16 bits)
+    c.xy0 = ((unsigned)pl.p_ikx[p0] * 16 + c.gj) | (((unsigned)pl.p_iky[p0] * 16 + c.gj) << 16);
+    c.xy1 = ((unsigned)pl.p_ikx[p1] * 16 + c.gj) | (((unsigned)pl.p_iky[p1] * 16 + c.gj) << 16);
+    c.neg0 = pl.p_sgn[p0] < 0; c.neg1 = pl.p_sgn[p1] < 0;             // (padding vectors read the all-zero X row)
+    c.zact = 40 * (c.gs >> 3) + (c.gs & 7) < 8 * nfrag;     // the thread's first kz lies in an active column fragment
     c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * 16 + c.gj;
     double *out = part + (size_t)sg * (128 * 320);
 #ifdef SK_STAMP
@@ -780,6 +805,9 @@ __device__ __forceinline__ double2 part_sum2(const double *__restrict__ src, siz
                       ((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7])));
 }
 
+// first row of a reducing thread: with one element per thread the 16 rows in order; with two (a 16-byte unit = rows 4 r + fk and
+// 4 (r + 1) + fk, r even) the unit index u = 0..7 -> rows {0..3, 8..11}, the partner 4 rows below
+template <int K> __device__ __forceinline__ int skr_row0(int u) { return K == 1 ? u : (u & 3) + 8 * (u >> 2); }
 constexpr int SKR_GROUP = 16;
 // a tile's 320 columns are cut into SKR_SL slices: one block per (tile, 16-row fragment, slice).  Eight slices of 40 columns
 // (round 1 and most of round 2: four of 80, two elements per thread): twice the blocks pulling on the partial tiles -- the
@@ -810,10 +838,11 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTil
     count = (tl.nsplit + SKR_GROUP - 1) / SKR_GROUP;
   }
   const size_t step = (size_t)stride * plane;
-  // this thread's element(s): (row0, cl) and, in the 80-column slices, (row0 + 8, cl) -- the other half of the same 16-byte unit
-  const int row0 = threadIdx.x / SKR_W, cl = threadIdx.x % SKR_W;
+  // this thread's element(s): (row0, cl) and, in the 80-column slices, (row0 + 4, cl) -- the other half of the same 16-byte unit
+  const int cl = threadIdx.x % SKR_W;
+  const int row0 = skr_row0<SKR_K>(threadIdx.x / SKR_W);
   const int col = SKR_W * q + cl;
-  static_assert(SKR_K == 1 || SKR_T / SKR_W == 8, "the two elements of a thread are 8 rows apart");
+  static_assert(SKR_K == 1 || SKR_T / SKR_W == 8, "the 80-column slices: 8 row pairs per block");
   double sums[SKR_K];
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) sums[k] = 0.0;
@@ -829,7 +858,7 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTil
   if (level == 1) return;
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) {
-    const int row = row0 + 8 * k, rowl = 16 * f16 + row;
+    const int row = row0 + 4 * k, rowl = 16 * f16 + row;
     const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
     G[grow * C_pad + gcol] = sums[k];
     tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sums[k];
@@ -1189,7 +1218,8 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
 #pragma unroll
     for (int tsl = 0; tsl < NKS; ++tsl) bz[tsl] = NKS * q + tsl < nks ? bp[(size_t)tsl * 256] : 0.0;
   }
-  const int row0 = threadIdx.x / SKR_W, cl = threadIdx.x % SKR_W;      // element(s) of this thread: see sk_reduce_kernel
+  const int cl = threadIdx.x % SKR_W;                                   // element(s) of this thread: see sk_reduce_kernel
+  const int row0 = skr_row0<SKR_K>(threadIdx.x / SKR_W);
   const int col = SKR_W * q + cl;
   double sums[SKR_K];
 #pragma unroll
@@ -1201,7 +1231,7 @@ __global__ __launch_bounds__(SKR_T) void sk_reduce_hc_kernel(int C_pad, const Sk
   }
 #pragma unroll
   for (int k = 0; k < SKR_K; ++k) {
-    const int row = row0 + 8 * k, rowl = 16 * f16 + row;
+    const int row = row0 + 4 * k, rowl = 16 * f16 + row;
     const size_t grow = (size_t)tl.rt * 128 + rowl, gcol = (size_t)tl.ct * 320 + col;
     G[grow * C_pad + gcol] = sums[k];
     tr[(cl >> 2) * 64 + (cl & 3) * 16 + row] = wfull[grow * C_pad + gcol] * sums[k];
@@ -1394,6 +1424,120 @@ void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, 
   else
     hipLaunchKernelGGL(gemv_finish_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, s, n, S, b, y, elesetq, eleinitq, potdiff, atoms_ptr,
                        atoms_of, q_ele, q_atoms);
+}
+
+
+// ---- GEMV with the projected inverse as a SYMMETRIC matrix: half the bytes ---------------------------------------------------
+// S = A^-1 - (A^-1 e)(A^-1 e)^T / (e^T A^-1 e) is symmetric (A is; fix_conp.cpp:826-831, :982-1067); as computed it is symmetric up
+// to rounding (~1e-16 relative).  The product below uses its LOWER triangle for both halves -- the matrix (S_lower + S_lower^T -
+// diag), equal to S within that rounding -- packed once per run as 128 x 128 tiles (tile (bi, bj <= bi) at bi (bi + 1) / 2 + bj,
+// row-major inside; the diagonal tiles hold both mirrored halves): 4 Ne^2 bytes per update instead of 8 Ne^2.
+// One workgroup per tile: the tile passes through LDS in two halves of 64 rows; 128 threads form the direct products
+// (rows of block bi against b[block bj]), 128 the transposed ones (columns -> rows of block bj against b[block bi]).  Every
+// (row block, source tile) pair owns one slot of yp[nb][ne_pad]: nothing is added across workgroups, the finishing kernel sums
+// a row's nb slots in a fixed order -> bitwise reproducible.
+constexpr int SG_T = 128;                 // tile edge
+constexpr int SG_LD = SG_T + 1;           // LDS row stride (odd: conflict-free row- and column-wise)
+__global__ __launch_bounds__(256) void sym_pack_kernel(int ne, const double *__restrict__ S, double *__restrict__ Spk) {
+  int t = blockIdx.x, bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  double *out = Spk + (size_t)t * SG_T * SG_T;
+  for (int e = threadIdx.x; e < SG_T * SG_T; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    int i = bi * SG_T + r, j = bj * SG_T + c;
+    if (j > i) { const int k = i; i = j; j = k; }            // diagonal tile, upper half: the mirrored lower element
+    out[e] = (i < ne && j < ne) ? S[(size_t)i * ne + j] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void sym_gemv_kernel(int ne_pad, const double *__restrict__ Spk, const double *__restrict__ b,
+                                                          double *__restrict__ yp /*[nb][ne_pad]*/) {
+  __shared__ double L[64 * SG_LD];
+  __shared__ double bi_s[SG_T], bj_s[SG_T];
+  int t = blockIdx.x, bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  const int tid = threadIdx.x;
+  const double2 *tile = reinterpret_cast<const double2 *>(Spk + (size_t)t * SG_T * SG_T);
+  // both halves' loads are issued up front (16 x 16 bytes per thread per half: the whole tile is in flight)
+  double2 v0[16], v1[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) v0[u] = tile[tid + 256 * u];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) v1[u] = tile[4096 + tid + 256 * u];
+  if (tid < SG_T) bi_s[tid] = b[bi * SG_T + tid]; else bj_s[tid - SG_T] = b[bj * SG_T + tid - SG_T];
+  double acc_t = 0.0;                              // transposed: thread tid < 128 owns column tid
+  const bool direct = tid >= SG_T;
+  const int u_ = tid - SG_T, dr = u_ >> 1, dh = u_ & 1;     // direct: row dr of the half, columns with ((c >> 4) & 1) == dh
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e2 = tid + 256 * u;                // double2 index inside the half: row = e2 >> 6, column pair = e2 & 63
+      const int r = e2 >> 6, c = (e2 & 63) * 2;
+      const double2 v = half == 0 ? v0[u] : v1[u];
+      L[r * SG_LD + c] = v.x; L[r * SG_LD + c + 1] = v.y;
+    }
+    __syncthreads();
+    if (!direct) {
+      if (bi != bj) {
+        const double *bb = bi_s + 64 * half;
+#pragma unroll 16
+        for (int r = 0; r < 64; ++r) acc_t = fma(L[r * SG_LD + tid], bb[r], acc_t);
+      }
+    } else {
+      double a = 0.0;
+      const double *row = L + dr * SG_LD;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) { const int c = 32 * m + 16 * dh + n; a = fma(row[c], bj_s[c], a); }
+      a += __shfl_xor(a, 1, 64);                   // the two column halves of the row (adjacent lanes), fixed order
+      if (dh == 0) yp[(size_t)bj * ne_pad + bi * SG_T + 64 * half + dr] = a;
+    }
+  }
+  if (!direct && bi != bj) yp[(size_t)bi * ne_pad + bj * SG_T + tid] = acc_t;
+}
+
+// y[row] = sum of the row's nb slots (fixed order), then the charge write of gemv_finish_kernel's tail
+__global__ __launch_bounds__(256) void sym_finish_kernel(int n, int ne_pad, int nb, const double *__restrict__ yp, double *__restrict__ y,
+                                                         const double *__restrict__ elesetq, const double *__restrict__ eleinitq,
+                                                         double potdiff, const int *__restrict__ atoms_ptr,
+                                                         const int *__restrict__ atoms_of, double *__restrict__ q_ele,
+                                                         double *__restrict__ q_atoms) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < nb; k += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] += k + u < nb ? yp[(size_t)(k + u) * ne_pad + row] : 0.0;
+  }
+  const double r = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  double v;
+  {
+#pragma clang fp contract(off)
+    v = r + potdiff * elesetq[row];
+    if (eleinitq) v += eleinitq[row];
+  }
+  y[row] = r; q_ele[row] = v;
+  if (q_atoms)
+    for (int k = atoms_ptr[row]; k < atoms_ptr[row + 1]; ++k) q_atoms[atoms_of[k]] = v;
+}
+
+size_t sym_packed_doubles(int ne_pad) { const size_t nb = ne_pad / SG_T; return nb * (nb + 1) / 2 * SG_T * SG_T; }
+void launch_sym_pack(hipStream_t s, int ne, int ne_pad, const double *S, double *Spk) {
+  const int nb = ne_pad / SG_T;
+  hipLaunchKernelGGL(sym_pack_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, ne, S, Spk);
+}
+void launch_sym_gemv_finish(hipStream_t s, int n, int ne_pad, const double *Spk, const double *b, double *yp, double *y,
+                            const double *elesetq, const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of,
+                            double *q_ele, double *q_atoms) {
+  const int nb = ne_pad / SG_T;
+  hipLaunchKernelGGL(sym_gemv_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, ne_pad, Spk, b, yp);
+  hipLaunchKernelGGL(sym_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, ne_pad, nb, (const double *)yp, y, elesetq, eleinitq,
+                     potdiff, atoms_ptr, atoms_of, q_ele, q_atoms);
 }
 
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y) {

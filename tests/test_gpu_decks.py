@@ -197,6 +197,29 @@ def test_headline_b_vector_matches_oracle(oracle, headline):
     ks.close(); o.fx.close()
 
 
+def test_headline_charges_are_the_product_of_the_projected_inverse_with_b(headline):
+    """Ne = 4096: the fused solve multiplies with the projected inverse taken as a SYMMETRIC matrix (packed lower-triangle tiles,
+    half the bytes).  q_ele must equal S b + dV S d computed on the host from the full matrix the library hands out -- to the
+    asymmetry of the computed S (~1e-16 relative) times the condition of the sum -- and so must the row-by-row product
+    (CONP_GEMV_FULL is read when the first update of the process runs, so the comparison is against numpy, not a second handle)."""
+    import torch
+    s, at, alist, blist, fx = headline
+    S = fx.matrix()
+    assert np.abs(S - S.T).max() <= 1e-12 * np.abs(S).max()
+    d_x = torch.from_numpy(np.ascontiguousarray(at.x)).cuda(); d_q = torch.from_numpy(at.q.copy()).cuda()
+    fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)
+    torch.cuda.synchronize()
+    b, y, setq = fx.vectors()
+    want = S @ b
+    assert np.abs(y - want).max() <= 1e-11 * np.abs(want).max()
+    q = d_q.cpu().numpy()
+    m = fx.maps()
+    loc = {int(t): i for i, t in enumerate(at.tag[:at.nlocal])}
+    qe = np.array([q[loc[int(t)]] for t in m["eleall2tag"]])
+    assert np.abs(qe - (want + s.potdiff * setq)).max() <= 1e-11 * np.abs(qe).max()
+    assert abs(qe.sum()) < 1e-9
+
+
 def test_headline_inverse_really_inverts(headline):
     """Ne = 4096: the matrix the GEMV streams IS the projected inverse of the Ewald matrix, not merely symmetric with zero row
     sums.  A is rebuilt by a second handle (a_cal only, before any inverse); with P = A^-1 e e^T / (e^T A^-1 e) the projection

@@ -132,7 +132,7 @@ def test_planar_a_matrix_factorisation_equals_the_general_contraction(deck, mode
         fx.init_lists(alist, blist)
         fx.setup_post_neighbor(at)
         fx.a_cal(at)
-        assert fx.info().n_zclasses in (2, 4)
+        assert fx.info().n_zclasses in (2, 4, 6)             # dilute: three-layer electrodes
         mats.append(fx.matrix())
         fx.close()
     a_zc, a_gen = mats

@@ -109,3 +109,32 @@ def test_pair_rows_match_the_reference_membership_rule(newton, etypes):
     # post-force pair set: no newton / ghost filter (fix_conp.cpp:1411)
     gp = capi.host_pair_rows(2, blist, at, newton)
     assert gp["npairs"] >= got["npairs"]
+
+
+def test_sk_gemm_kernel_does_not_spill():
+    """the dominant kernel sits at the 256-register budget of two waves per SIMD; a change that tips the NFW = 5 bodies over it
+    makes the allocator spill inside the chunk loop (round 3: -15 % at the 16384 / 262144 size, invisible in the parity tests).
+    Cross-compile the kernels for gfx950 (no GPU needed) and read the compiler's resource remarks."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "lammps-user-conp2_amd", "csrc", "conp_kernels.hip")
+    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", src, "-o", os.devnull,
+                        "-I" + os.path.join(root, "include"), "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", p.stderr)
+    sk = [b for b in blocks if b.startswith("_ZN4conp14sk_gemm_kernel")]
+    assert len(sk) == 1
+    scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", sk[0]).group(1))
+    vspill = int(re.search(r"VGPRs Spill: (\d+)", sk[0]).group(1))
+    sspill = int(re.search(r"SGPRs Spill: (\d+)", sk[0]).group(1))
+    vgprs = int(re.search(r" VGPRs: (\d+)", sk[0]).group(1))
+    assert (scratch, vspill, sspill) == (0, 0, 0), (scratch, vspill, sspill)
+    assert vgprs <= 256

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Least-squares fit of the stream-K cost model of sk_gemm (conp_fix.cpp build_items) to per-segment lengths measured by the stamp
+build (tools/sk_stamp.py -> gpurun_out/sk_segments.txt):   us = a * chunks * (mean kz blocks + C0) + a * CSEG  per segment,
+kz blocks = active 8-kz column fragments / 2.  Prints a, C0, CSEG (the constants SK_C0 / SK_CSEG) and the residual spread per XCD."""
+import sys
+
+import numpy as np
+
+path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/sk_segments.txt"
+d = np.loadtxt(path)
+wg, rt, chunks, us, xcc = d[:, 0], d[:, 1], d[:, 6], d[:, 7], d[:, 8]
+nb = d[:, 2:6].mean(axis=1) / 2.0
+# us = a*chunks*nb + (a*C0)*chunks + (a*CSEG)
+X = np.stack([chunks * nb, chunks, np.ones_like(chunks)], 1)
+coef, *_ = np.linalg.lstsq(X, us, rcond=None)
+a, ac0, acseg = coef
+res = us - X @ coef
+print(f"segments {len(us)}: a = {a:.4f} us per chunk per kz block, C0 = {ac0 / a:.3f}, CSEG = {acseg / a:.2f} (in chunk-block units); "
+      f"rms residual {res.std():.2f} us of mean {us.mean():.1f} us")
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print(f"  XCD {x}: {m.sum():3d} segments, mean residual {res[m].mean():+.2f} us ({100 * res[m].mean() / us[m].mean():+.2f} %)")
+# per-workgroup totals: the slowest workgroup sets the kernel's length
+tot = {}
+for w, u in zip(wg, us):
+    tot[w] = tot.get(w, 0.0) + u
+t = np.array(list(tot.values()))
+print(f"  per-workgroup totals: min {t.min():.1f}  median {np.median(t):.1f}  max {t.max():.1f} us  (max / median = {t.max() / np.median(t):.3f})")
