@@ -245,7 +245,7 @@ struct conp_fix {
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt, d_Xe, d_Ye;      // d_Xe / d_Ye: electrode atoms' axis phases [k][ne_pad] (once per run)
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of, d_ele_csr_row;
   bool left_stale = false;          // the fused GEMV + charge write leaves the fix scalar's group-1 sum to refresh_scalar()
   double left_potdiff = 0.0;
   DevBuf<unsigned char> d_mask;
@@ -531,7 +531,9 @@ struct conp_fix {
       for (int r = 0; r < ne; ++r) ptr[r + 1] += ptr[r];
       std::vector<int> fill(ptr.begin(), ptr.end() - 1);
       for (int k = 0; k < n_ele_atoms; ++k) of[fill[ele_pairs_h[2 * (size_t)k + 1]]++] = ele_pairs_h[2 * (size_t)k];
-      d_ele_csr_ptr.upload(ptr, stream); d_ele_csr_of.upload(of, stream);
+      std::vector<int> rowof(of.size(), 0);
+      for (int r = 0; r < ne; ++r) for (int k = ptr[r]; k < ptr[r + 1]; ++k) rowof[k] = r;
+      d_ele_csr_ptr.upload(ptr, stream); d_ele_csr_of.upload(of, stream); d_ele_csr_row.upload(rowof, stream);
     }
     if (ele_pairs_h.empty()) { ele_pairs_h.push_back(0); ele_pairs_h.push_back(0); }
     d_ele_pairs.upload(ele_pairs_h, stream);
@@ -1588,7 +1590,7 @@ struct conp_fix {
       }
       prof.begin("gemv_charge", stream);
       launch_sym_gemv_finish(stream, ne, ne_pad, d_Spk.p, d_b, d_yp.p, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr,
-                             potdiff, d_ele_csr_ptr.p, d_ele_csr_of.p, d_qele.p, d_q_atoms);
+                             potdiff, d_ele_csr_ptr.p, d_ele_csr_of.p, d_ele_csr_row.p, d_qele.p, d_q_atoms);
       prof.end(stream);
       left_stale = true; left_potdiff = potdiff;
       HIP_TRY(hipGetLastError());

@@ -119,7 +119,7 @@ size_t sym_packed_doubles(int ne_pad);
 void launch_sym_pack(hipStream_t s, int ne, int ne_pad, const double *S, double *Spk);
 void launch_sym_gemv_finish(hipStream_t s, int n, int ne_pad, const double *Spk, const double *b, double *yp /*[ne_pad / 128][ne_pad]*/,
                             double *y, const double *elesetq, const double *eleinitq, double potdiff, const int *atoms_ptr,
-                            const int *atoms_of, double *q_ele, double *q_atoms);
+                            const int *atoms_of, const int *atoms_row /*row of every CSR entry*/, double *q_ele, double *q_atoms);
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y);
 // all rows + the charge write of plain `fix conp` in one launch (atoms_ptr / atoms_of: electrode row -> its owned and ghost atoms)
 void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, double *y, const double *elesetq,

@@ -1451,41 +1451,43 @@ __global__ __launch_bounds__(256) void sym_pack_kernel(int ne, const double *__r
   }
 }
 
-__global__ __launch_bounds__(256, 2) void sym_gemv_kernel(int ne_pad, const double *__restrict__ Spk, const double *__restrict__ b,
+__global__ __launch_bounds__(256, 3) void sym_gemv_kernel(int ne_pad, const double *__restrict__ Spk, const double *__restrict__ b,
                                                           double *__restrict__ yp /*[nb][ne_pad]*/) {
-  __shared__ double L[64 * SG_LD];
+  // the tile passes through LDS in four quarters of 32 rows (33 KB: three workgroups per CU -- all 528 tiles of the headline
+  // size are resident at once; with 64-row halves two fitted per CU and sixteen tiles ran in a second round: 16.8 us)
+  __shared__ double L[32 * SG_LD];
   __shared__ double bi_s[SG_T], bj_s[SG_T];
   int t = blockIdx.x, bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
   const int bj = t - bi * (bi + 1) / 2;
   const int tid = threadIdx.x;
   const double2 *tile = reinterpret_cast<const double2 *>(Spk + (size_t)t * SG_T * SG_T);
-  // both halves' loads are issued up front (16 x 16 bytes per thread per half: the whole tile is in flight)
-  double2 v0[16], v1[16];
+  // the whole tile is requested up front: 4 quarters x 8 x 16 bytes per thread
+  double2 v[4][8];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) v0[u] = tile[tid + 256 * u];
+  for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
-  for (int u = 0; u < 16; ++u) v1[u] = tile[4096 + tid + 256 * u];
+    for (int u = 0; u < 8; ++u) v[qd][u] = tile[2048 * qd + tid + 256 * u];
   if (tid < SG_T) bi_s[tid] = b[bi * SG_T + tid]; else bj_s[tid - SG_T] = b[bj * SG_T + tid - SG_T];
   double acc_t = 0.0;                              // transposed: thread tid < 128 owns column tid
   const bool direct = tid >= SG_T;
-  const int u_ = tid - SG_T, dr = u_ >> 1, dh = u_ & 1;     // direct: row dr of the half, columns with ((c >> 4) & 1) == dh
+  // direct: row dr of the quarter, columns 32 m + 8 dh + n (m < 4, n < 8): conflict-free row-wise reads with the odd stride
+  const int u_ = tid - SG_T, dr = u_ >> 2, dh = u_ & 3;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int qd = 0; qd < 4; ++qd) {
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e2 = tid + 256 * u;                // double2 index inside the half: row = e2 >> 6, column pair = e2 & 63
+    for (int u = 0; u < 8; ++u) {
+      const int e2 = tid + 256 * u;                // double2 index inside the quarter: row = e2 >> 6, column pair = e2 & 63
       const int r = e2 >> 6, c = (e2 & 63) * 2;
-      const double2 v = half == 0 ? v0[u] : v1[u];
-      L[r * SG_LD + c] = v.x; L[r * SG_LD + c + 1] = v.y;
+      L[r * SG_LD + c] = v[qd][u].x; L[r * SG_LD + c + 1] = v[qd][u].y;
     }
     __syncthreads();
     if (!direct) {
       if (bi != bj) {
-        const double *bb = bi_s + 64 * half;
+        const double *bb = bi_s + 32 * qd;
 #pragma unroll 16
-        for (int r = 0; r < 64; ++r) acc_t = fma(L[r * SG_LD + tid], bb[r], acc_t);
+        for (int r = 0; r < 32; ++r) acc_t = fma(L[r * SG_LD + tid], bb[r], acc_t);
       }
     } else {
       double a = 0.0;
@@ -1493,37 +1495,50 @@ __global__ __launch_bounds__(256, 2) void sym_gemv_kernel(int ne_pad, const doub
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 16; ++n) { const int c = 32 * m + 16 * dh + n; a = fma(row[c], bj_s[c], a); }
-      a += __shfl_xor(a, 1, 64);                   // the two column halves of the row (adjacent lanes), fixed order
-      if (dh == 0) yp[(size_t)bj * ne_pad + bi * SG_T + 64 * half + dr] = a;
+        for (int n = 0; n < 8; ++n) { const int c = 32 * m + 8 * dh + n; a = fma(row[c], bj_s[c], a); }
+      a += __shfl_xor(a, 1, 64);                   // the four column groups of the row (adjacent lanes), fixed order
+      a += __shfl_xor(a, 2, 64);
+      if (dh == 0) yp[(size_t)bj * ne_pad + bi * SG_T + 32 * qd + dr] = a;
     }
   }
   if (!direct && bi != bj) yp[(size_t)bi * ne_pad + bj * SG_T + tid] = acc_t;
 }
 
-// y[row] = sum of the row's nb slots (fixed order), then the charge write of gemv_finish_kernel's tail
-__global__ __launch_bounds__(256) void sym_finish_kernel(int n, int ne_pad, int nb, const double *__restrict__ yp, double *__restrict__ y,
+// y[row] = sum of the row's nb slots (fixed order), q = y + dV setq (+ qinit); then the charge write of gemv_finish_kernel's tail:
+// the block's rows own a contiguous run of the CSR atom list, walked by all threads (row of an entry: atoms_row)
+constexpr int SF_T = 64;                  // rows per finishing block: 64 blocks at Ne = 4096
+__global__ __launch_bounds__(SF_T) void sym_finish_kernel(int n, int ne_pad, int nb, const double *__restrict__ yp, double *__restrict__ y,
                                                          const double *__restrict__ elesetq, const double *__restrict__ eleinitq,
                                                          double potdiff, const int *__restrict__ atoms_ptr,
-                                                         const int *__restrict__ atoms_of, double *__restrict__ q_ele,
-                                                         double *__restrict__ q_atoms) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= n) return;
-  double s4[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int k = 0; k < nb; k += 4) {
+                                                         const int *__restrict__ atoms_of, const int *__restrict__ atoms_row,
+                                                         double *__restrict__ q_ele, double *__restrict__ q_atoms) {
+  __shared__ double vq[SF_T];
+  const int row0 = blockIdx.x * SF_T, row = row0 + threadIdx.x;
+  if (row < n) {
+    // 32 slots in flight per round (the loads are the kernel: one dependent round trip per four slots took 7 us); additions in
+    // the order of a 4-wide loop -> the same bits whatever nb
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < nb; k0 += 32) {
+      double w[32];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s4[u] += k + u < nb ? yp[(size_t)(k + u) * ne_pad + row] : 0.0;
-  }
-  const double r = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  double v;
-  {
+      for (int u = 0; u < 32; ++u) w[u] = k0 + u < nb ? yp[(size_t)(k0 + u) * ne_pad + row] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) s4[u & 3] += w[u];
+    }
+    const double r = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    double v;
+    {
 #pragma clang fp contract(off)
-    v = r + potdiff * elesetq[row];
-    if (eleinitq) v += eleinitq[row];
+      v = r + potdiff * elesetq[row];
+      if (eleinitq) v += eleinitq[row];
+    }
+    y[row] = r; q_ele[row] = v;
+    vq[threadIdx.x] = v;
   }
-  y[row] = r; q_ele[row] = v;
-  if (q_atoms)
-    for (int k = atoms_ptr[row]; k < atoms_ptr[row + 1]; ++k) q_atoms[atoms_of[k]] = v;
+  __syncthreads();
+  if (!q_atoms) return;
+  const int rend = row0 + SF_T < n ? row0 + SF_T : n;
+  for (int k = atoms_ptr[row0] + threadIdx.x; k < atoms_ptr[rend]; k += SF_T) q_atoms[atoms_of[k]] = vq[atoms_row[k] - row0];
 }
 
 size_t sym_packed_doubles(int ne_pad) { const size_t nb = ne_pad / SG_T; return nb * (nb + 1) / 2 * SG_T * SG_T; }
@@ -1533,11 +1548,11 @@ void launch_sym_pack(hipStream_t s, int ne, int ne_pad, const double *S, double 
 }
 void launch_sym_gemv_finish(hipStream_t s, int n, int ne_pad, const double *Spk, const double *b, double *yp, double *y,
                             const double *elesetq, const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of,
-                            double *q_ele, double *q_atoms) {
+                            const int *atoms_row, double *q_ele, double *q_atoms) {
   const int nb = ne_pad / SG_T;
   hipLaunchKernelGGL(sym_gemv_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, ne_pad, Spk, b, yp);
-  hipLaunchKernelGGL(sym_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, ne_pad, nb, (const double *)yp, y, elesetq, eleinitq,
-                     potdiff, atoms_ptr, atoms_of, q_ele, q_atoms);
+  hipLaunchKernelGGL(sym_finish_kernel, dim3((n + SF_T - 1) / SF_T), dim3(SF_T), 0, s, n, ne_pad, nb, (const double *)yp, y, elesetq, eleinitq,
+                     potdiff, atoms_ptr, atoms_of, atoms_row, q_ele, q_atoms);
 }
 
 void launch_gemv_rows(hipStream_t s, int n, int row0, int row1, const double *S, const double *b, double *y) {
