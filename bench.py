@@ -287,7 +287,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- auxiliary passes FIRST (not `value`): they also let the chip's clock governor settle -- a rocprofv3 trace of this command
-    #      shows sk_gemm going from 274 to 242 us over the first ~65 launches after the setup phase (profiles/r02_*), so a
+    #      shows sk_gemm going from 274 to 242 us over the first ~65 launches after the setup phase (profiles/r02_*, r03_*), so a
     #      short timed loop started cold would measure the ramp, not the update.
     # (a) the host-buffer hook (what FixConpHip::pre_force calls): H2D of x, q and D2H of the charges every update.
     #     PCIe-inclusive, reported beside `value`, never as `value`.
@@ -350,13 +350,13 @@ def main():
             t_ms = timed_prof["sk_gemm"][0]
             ach = flops / (t_ms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pj = os.path.join(ROOT, "profiles", "r02_bench_headline_summary.json")
+            pj = os.path.join(ROOT, "profiles", "r03_bench_headline_summary.json")
             if args.workload == "headline" and world == 1 and os.path.exists(pj):
                 pm = json.load(open(pj)).get("pmc", {}).get("sk_gemm_kernel", {})
                 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                     # rocprofv3 reports KiB; FETCH_SIZE x2: gfx950 counts 16-B-per-lane streams at half (MI355X_MICROARCH.md, HBM)
                     traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-                    traffic_src = "profiles/r02_bench_headline_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    traffic_src = "profiles/r03_bench_headline_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             roofline = dict(bound="mfma", kernel="sk_gemm_kernel (v_mfma_f64_16x16x4_f64)", achieved=ach, peak=FP64_PEAK_TFLOPS,
                             unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=t_ms, launches_averaged=timed_prof["sk_gemm"][1],
@@ -364,12 +364,23 @@ def main():
                             algorithmic_flops_per_launch=flops, survey_count_tflops=2 * ach,
                             note="achieved uses 4 flop per (k, atom); SURVEY 8d's reference-loop count (8 per k) would double it")
         # the HBM-bound member of the update: the GEMV with the projected inverse streams 8 Ne^2 / N bytes once (HIP events of the
-        # per-kernel pass; rocprofv3's kernel-only duration is ~2 us shorter, profiles/r02_bench_headline_summary.txt)
+        # per-kernel pass; rocprofv3's kernel-only duration is ~2 us shorter, profiles/r03_bench_headline_summary.txt)
         hbm_member = None
         if "gemv_charge" in prof and prof["gemv_charge"][0] > 0:
-            gb = 8.0 * ne * ne / world / 1e9
-            hbm_member = dict(kernel="gemv_finish_kernel", bound="hbm", achieved=gb / (prof["gemv_charge"][0] * 1e-3), peak=8000.0,
-                              unit="GB/s", frac=gb / (prof["gemv_charge"][0] * 1e-3) / 8000.0, bytes_per_launch=8.0 * ne * ne / world)
+            t_s = prof["gemv_charge"][0] * 1e-3
+            gb = 8.0 * ne * ne / world / 1e9                      # SURVEY 8d's algorithmic count: the matrix once
+            sym = world == 1 and ne >= 2048 and args.solver == "inv" and not os.environ.get("CONP_GEMV_FULL")
+            # from 2048 electrode atoms up the fused solve takes the projected inverse as a symmetric matrix: packed lower-triangle
+            # tiles of 128 x 128, half the bytes actually read; both counts are given
+            nb = (ne + 127) // 128
+            gb_exec = (nb * (nb + 1) // 2) * 128 * 128 * 8.0 / 1e9 if sym else gb
+            hbm_member = dict(kernel="sym_gemv_kernel + sym_finish_kernel" if sym else "gemv_finish_kernel", bound="hbm",
+                              achieved=gb / t_s, peak=HBM_PEAK_GBS, unit="GB/s", frac=gb / t_s / HBM_PEAK_GBS,
+                              bytes_per_launch=8.0 * ne * ne / world,
+                              executed_bytes_per_launch=gb_exec * 1e9, executed_gbs=gb_exec / t_s,
+                              frac_executed=gb_exec / t_s / HBM_PEAK_GBS,
+                              note="achieved / frac: SURVEY 8d's algorithmic bytes (8 Ne^2) over the HIP-event time of the launch(es); "
+                                   "executed_*: the bytes this formulation reads (symmetric storage: 4 Ne^2)")
         composite = composite_roofline(info, ms_per_step, world, pppm=bool(args.pppm))
         out = dict(metric="charge-solve updates/sec + ns/day, 4096-atom electrode / 32k electrolyte", value=value,
                    unit="updates/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,

@@ -207,7 +207,7 @@ struct conp_fix {
   std::vector<int> ele_pairs_h;    // (atom index, eleall index) of every owned or ghost electrode atom
   int n_ele_atoms = 0;
   std::vector<double> tile_flo, tile_fhi;   // this rank's share of each of its tiles, as fractions of the tile's chunk axis
-  std::vector<int> ct_ptr_h, seg_ptr_h, own_rt_h;   // own_rt_h: the row tiles this rank works on (sorted)
+  std::vector<int> ct_ptr_h, seg_ptr_h, seg_idx_h, own_rt_h;   // own_rt_h: the row tiles this rank works on (sorted)
   double evscale = 0, totsetq = 0, scalar_output = 0, totinve = 0, slabcorr = 0;
   int cg_iterations = 0;
   int inverse_path = 0;          // conp_info.inverse_path: 1 positive-definite elimination, 2 partial pivoting
@@ -245,7 +245,7 @@ struct conp_fix {
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt, d_Xe, d_Ye;      // d_Xe / d_Ye: electrode atoms' axis phases [k][ne_pad] (once per run)
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of, d_ele_csr_row;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_seg_idx, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of, d_ele_csr_row;
   bool left_stale = false;          // the fused GEMV + charge write leaves the fix scalar's group-1 sum to refresh_scalar()
   double left_potdiff = 0.0;
   DevBuf<unsigned char> d_mask;
@@ -743,59 +743,96 @@ struct conp_fix {
       for (int f = 0; f < 4; ++f) sum += (double)((t.nbf >> (8 * f)) & 255u);
       return 0.125 * sum + SK_C0;                 // in kz blocks of 16 (the unit the constants were fitted in): two column fragments each
     };
+    struct Seg { int tile, c0, c1, wg; };
+    std::vector<Seg> segs;
+    // cuts the chunk ranges [clo, chi) of the tiles, laid end to end, into `nshare` shares of equal cost; share s goes to
+    // workgroup wg0 + s * wgstride
+    auto cut = [&](const std::vector<int> &clo, const std::vector<int> &chi, int nshare, int wg0, int wgstride) {
+      // work left from (tile ti, chunk ch) to the end, without segment starts
+      std::vector<double> tail(nt + 1, 0.0);
+      for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + std::max(0, chi[i] - clo[i]) * cost(tiles_h[i]);
+      size_t total = 0;
+      for (size_t i = 0; i < nt; ++i) total += (size_t)std::max(0, chi[i] - clo[i]);
+      // a segment shorter than this costs more in start-up than it carries -- but only where shares are long: a small system's
+      // share IS one or two chunks (dilute: 16 chunks on 16 workgroups), and merging "slivers" there would quadruple one share
+      const int MIN_SEG = std::max(1, std::min(4, (int)(total / (size_t)nshare) / 2));
+      size_t ti = 0;
+      while (ti < nt && chi[ti] <= clo[ti]) ++ti;
+      int ch = ti < nt ? clo[ti] : 0;
+      for (int w = 0; w < nshare && nt > 0; ++w) {
+        if (ti >= nt) continue;
+        const bool last = w + 1 == nshare;
+        // equal shares of what is left, counting one segment start per remaining workgroup and one per tile boundary ahead
+        const double left = tail[ti] - (ch - clo[ti]) * cost(tiles_h[ti]) + SK_CSEG * ((double)(nshare - w) + (double)(nt - 1 - ti));
+        double budget = left / (nshare - w) - SK_CSEG;
+        bool first = true;
+        while (ti < nt) {
+          const double c = cost(tiles_h[ti]);
+          const int avail = chi[ti] - ch;
+          int take;
+          if (last) take = avail;
+          else {
+            if (!first) budget -= SK_CSEG;                     // starting another segment in this share
+            take = (int)std::lround(budget / c);
+            if (first) take = std::max(take, 1);
+            if (!first && take < MIN_SEG) break;               // not worth a new segment: the next workgroup starts this tile
+            if (avail - take < MIN_SEG) take = avail;          // do not leave a sliver of the tile behind
+            take = std::min(take, avail);
+          }
+          segs.push_back(Seg{(int)ti, ch, ch + take, wg0 + w * wgstride});
+          budget -= take * c;
+          ch += take;
+          first = false;
+          bool inside = true;                                  // stopped inside a tile?
+          if (ch >= chi[ti]) {
+            ++ti;
+            while (ti < nt && chi[ti] <= clo[ti]) ++ti;
+            ch = ti < nt ? clo[ti] : 0;
+            inside = false;
+          }
+          if (!last && (budget < c || inside)) break;          // share used up (or stopped inside a tile)
+        }
+      }
+    };
     // this rank's chunk range of every tile (all of it on one rank; km_conp_setup); a tile may come out empty
     std::vector<int> clo(nt, 0), chi(nt, nchunks);
+    bool whole = true;
     for (size_t i = 0; i < nt; ++i) {
       clo[i] = (int)std::lround(tile_flo[i] * nchunks);
       chi[i] = (int)std::lround(tile_fhi[i] * nchunks);
+      whole = whole && clo[i] == 0 && chi[i] == nchunks;
     }
-    // work left from (tile ti, chunk ch) to the end, without segment starts
-    std::vector<double> tail(nt + 1, 0.0);
-    for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + (chi[i] - clo[i]) * cost(tiles_h[i]);
-    // a segment shorter than this costs more in start-up than it carries -- but only where shares are long: a small system's
-    // share IS one or two chunks (dilute: 16 chunks on 16 workgroups), and merging "slivers" there would quadruple one share
-    const int MIN_SEG = std::max(1, std::min(4, (int)((nt * (size_t)nchunks) / (size_t)nwg) / 2));
-    items_h.clear();
-    seg_ptr_h.assign(nwg + 1, 0);
-    size_t ti = 0;
-    while (ti < nt && chi[ti] <= clo[ti]) ++ti;
-    int ch = ti < nt ? clo[ti] : 0;
-    for (int w = 0; w < nwg && nt > 0; ++w) {
-      seg_ptr_h[w] = (int)items_h.size();
-      if (ti >= nt) continue;
-      const bool last = w + 1 == nwg;
-      // equal shares of what is left, counting one segment start per remaining workgroup and one per tile boundary ahead
-      const double left = tail[ti] - (ch - clo[ti]) * cost(tiles_h[ti]) + SK_CSEG * ((double)(nwg - w) + (double)(nt - 1 - ti));
-      double budget = left / (nwg - w) - SK_CSEG;
-      bool first = true;
-      while (ti < nt) {
-        const double c = cost(tiles_h[ti]);
-        const int avail = chi[ti] - ch;
-        int take;
-        if (last) take = avail;
-        else {
-          if (!first) budget -= SK_CSEG;                     // starting another segment in this share
-          take = (int)std::lround(budget / c);
-          if (first) take = std::max(take, 1);
-          if (!first && take < MIN_SEG) break;               // not worth a new segment: the next workgroup starts this tile
-          if (avail - take < MIN_SEG) take = avail;          // do not leave a sliver of the tile behind
-          take = std::min(take, avail);
-        }
-        items_h.push_back(SkItem{tiles_h[ti].rt, tiles_h[ti].ct, tiles_h[ti].nba, ch, ch + take, tiles_h[ti].nbf});
-        budget -= take * c;
-        ch += take;
-        first = false;
-        bool inside = true;                                  // stopped inside a tile?
-        if (ch >= chi[ti]) {
-          ++ti;
-          while (ti < nt && chi[ti] <= clo[ti]) ++ti;
-          ch = ti < nt ? clo[ti] : 0;
-          inside = false;
-        }
-        if (!last && (budget < c || inside)) break;          // share used up (or stopped inside a tile)
+    // XCD-aware shares (the full chip on whole tiles): workgroups are dealt to the eight XCDs round-robin (w mod 8), each XCD has
+    // its own L2 and the phase tables are blocked by atom chunk.  XCD x takes the x-th eighth of the atoms of EVERY tile, cut into
+    // nwg / 8 shares for its workgroups w = x, x + 8, ...: equal work per XCD by construction, and an XCD pulls only its eighth of
+    // the tables through the fabric (round 2: one axis over all tiles -- every XCD read ~70 % of the tables: 5.6 table volumes per
+    // launch at the memory side, profiles/r03).  The block -> XCD map is not an architectural promise; nothing but the traffic
+    // depends on it.
+    const bool xcd_aware = whole && nwg >= 64 && nwg % 8 == 0 && nchunks >= 64 && exp_switch("CONP_SK_FLAT") == nullptr;
+    if (xcd_aware) {
+      std::vector<int> lo(nt), hi(nt);
+      for (int x = 0; x < 8; ++x) {
+        for (size_t i = 0; i < nt; ++i) { lo[i] = (int)((long)nchunks * x / 8); hi[i] = (int)((long)nchunks * (x + 1) / 8); }
+        cut(lo, hi, nwg / 8, x, 8);
       }
+    } else cut(clo, chi, nwg, 0, 1);
+    // segments tile-major (a tile's partial tiles are contiguous: the reducing kernels walk item0 .. item0 + nsplit - 1), and every
+    // workgroup's list of segment indices
+    std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.tile != b.tile ? a.tile < b.tile : a.c0 < b.c0; });
+    items_h.clear();
+    std::vector<std::vector<int>> per_wg(nwg);
+    for (const Seg &g : segs) {
+      per_wg[g.wg].push_back((int)items_h.size());
+      items_h.push_back(SkItem{tiles_h[g.tile].rt, tiles_h[g.tile].ct, tiles_h[g.tile].nba, g.c0, g.c1, tiles_h[g.tile].nbf});
     }
-    for (int w = 0; w <= nwg; ++w) if (w == nwg || nt == 0) seg_ptr_h[w] = (int)items_h.size();
+    seg_ptr_h.assign(nwg + 1, 0);
+    seg_idx_h.clear();
+    for (int w = 0; w < nwg; ++w) {
+      seg_ptr_h[w] = (int)seg_idx_h.size();
+      seg_idx_h.insert(seg_idx_h.end(), per_wg[w].begin(), per_wg[w].end());
+    }
+    seg_ptr_h[nwg] = (int)seg_idx_h.size();
+    if (seg_idx_h.empty()) seg_idx_h.push_back(0);
     // tiles -> their segments (contiguous in items_h)
     size_t it = 0;
     max_nsplit = 0;
@@ -806,6 +843,7 @@ struct conp_fix {
     }
     d_items.upload(items_h, stream);
     d_seg_ptr.upload(seg_ptr_h, stream);
+    d_seg_idx.upload(seg_idx_h, stream);
     d_tiles.upload(tiles_h, stream);
   }
 
@@ -1408,7 +1446,7 @@ struct conp_fix {
       fin.breal = d_breal.p;
       use_fin = ride && nzc > 0 && zc_final_fits((int)own_rt_h.size(), nzc);
       prof.begin("sk_gemm", stream);
-      launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
+      launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, d_seg_idx.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                      d_Gpart.p);
       prof.end(stream);
       if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {

@@ -334,42 +334,66 @@ __global__ __launch_bounds__(256) void inv_block_kernel(int nbw, const double *_
 
 
 // ---- SPD path, step 3': Dinv = (M[K,K])^-1 by in-place Gauss-Jordan on the diagonal block, pivots = its own diagonal ------
-// One workgroup, the block in LDS.  A pivot <= 0 or not finite: info = -8 (not positive definite -> pivoted path).
+// One workgroup; the block lives in REGISTERS: thread (r = t >> 2, cg = t & 3) holds B[r][16 cg .. 16 cg + 15].  Per column j the
+// owners publish row j and column j through LDS (double-buffered by the parity of j: one barrier per column), then every thread
+// updates its 16 values:   row j: B[j][c] = B[j][c] / p (c != j), 1 / p (c = j);   rows r != j: B[r][c] -= B[r][j] B[j][c] / p
+// (c != j), B[r][j] = -B[r][j] / p.  A pivot <= 0 or not finite: info = -8 (not positive definite -> pivoted path).
+// (A first version kept the block in LDS: 64 LDS accesses per thread and three barriers per column, 160 us per block, half of the
+//  whole inverse.)
 __global__ __launch_bounds__(256) void inv_block_spd_kernel(int n, int k0, int nbw, const double *__restrict__ M,
                                                             double *__restrict__ Dinv, int *__restrict__ info) {
   if (*info != 0) return;
-  __shared__ double B[INV_NB][INV_NB + 1];
-  __shared__ double s_col[INV_NB];
-  __shared__ int s_bad;
-  const int t = threadIdx.x;
-  if (t == 0) s_bad = 0;
-  for (int e = t; e < INV_NB * INV_NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    B[r][c] = (r < nbw && c < nbw) ? M[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);     // padding block = identity
+  __shared__ double s_row[2][INV_NB], s_col[2][INV_NB];
+  const int t = threadIdx.x, r = t >> 2, cg = t & 3;
+  double bv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = 16 * cg + k;
+    bv[k] = (r < nbw && c < nbw) ? M[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);     // padding block = identity
   }
+  // publish row 0 / column 0
+  if (r == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_row[0][16 * cg + k] = bv[k];
+  }
+  if (cg == 0) s_col[0][r] = bv[0];
   __syncthreads();
+  bool bad = false;
   for (int j = 0; j < nbw; ++j) {
-    const double p = B[j][j];
-    if (t == 0 && (!(p > 0.0) || !(p <= 1.7976931348623157e308))) s_bad = 1;
-    if (t < INV_NB) s_col[t] = B[t][j];               // column j before it is overwritten
-    __syncthreads();
-    if (s_bad) { if (t == 0) *info = -8; return; }
+    const int par = j & 1;
+    const double p = s_row[par][j];
+    if (!(p > 0.0) || !(p <= 1.7976931348623157e308)) { bad = true; break; }      // (the same value in every thread: uniform)
     const double pinv = 1.0 / p;
-    // row j: B[j][c] *= pinv (c != j), B[j][j] = pinv;  rows r != j: B[r][c] -= B[r][j] * (B[j][c] * pinv), B[r][j] = -B[r][j] * pinv
-    for (int e = t; e < INV_NB * INV_NB; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      if (r == j) continue;
-      const double f = s_col[r];
-      if (c == j) B[r][c] = -f * pinv;
-      else B[r][c] -= f * (B[j][c] * pinv);
+    const double f = s_col[par][r];
+    const bool prow = r == j;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = 16 * cg + k;
+      const double rj = s_row[par][c];
+      if (prow) bv[k] = (c == j) ? pinv : bv[k] * pinv;
+      else bv[k] = (c == j) ? -f * pinv : bv[k] - f * (rj * pinv);
+    }
+    // publish row j + 1 / column j + 1 of the updated block into the other buffer
+    const int jn = j + 1;
+    if (jn < nbw) {
+      if (r == jn) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_row[par ^ 1][16 * cg + k] = bv[k];
+      }
+      if (cg == (jn >> 4)) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k == (jn & 15)) v = bv[k];
+        s_col[par ^ 1][r] = v;
+      }
     }
     __syncthreads();
-    if (t < INV_NB) B[j][t] = (t == j) ? pinv : B[j][t] * pinv;
-    __syncthreads();
   }
-  for (int e = t; e < INV_NB * INV_NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Dinv[e] = (r < nbw && c < nbw) ? B[r][c] : 0.0;
+  if (bad) { if (t == 0) *info = -8; return; }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = 16 * cg + k;
+    Dinv[r * INV_NB + c] = (r < nbw && c < nbw) ? bv[k] : 0.0;
   }
 }
 

@@ -90,7 +90,7 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         const BRowArgs *rows /*NULL, or: the real-space pair sums of these rows ride along, into breal_out*/,
                         double *breal_out);
 bool zc_final_fits(int n_own, int nzc);
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, const int *seg_idx, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);

@@ -612,10 +612,10 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
 }
 
 
-// Persistent-style launch: workgroup w runs the segments seg_ptr[w] .. seg_ptr[w+1]-1 (host: equal cost per workgroup,
+// Persistent-style launch: workgroup w runs the segments seg_idx[seg_ptr[w] .. seg_ptr[w+1]-1] (host: equal cost per workgroup,
 // a segment boundary may fall inside a tile -- "stream-K" over the atom chunks).
 __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkItem *__restrict__ items,
-                                                         const int *__restrict__ seg_ptr, int nl_pad,
+                                                         const int *__restrict__ seg_ptr, const int *__restrict__ seg_idx, int nl_pad,
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
                                                          double *__restrict__ part, int dbg) {
@@ -641,7 +641,8 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const int s0 = seg_ptr[blockIdx.x], s1 = seg_ptr[blockIdx.x + 1];
-  for (int sg = s0; sg < s1; ++sg) {
+  for (int sgi = s0; sgi < s1; ++sgi) {
+    const int sg = seg_idx[sgi];
     c.it = items[sg];
     // per row fragment f (16 planar vectors) only the leading nff_f column fragments (8 kz each) are inside the cut-off sphere;
     // the tile's count is the largest of them (<= 2 nba; an odd count leaves the last fragment of the last kz block unwritten:
@@ -735,7 +736,7 @@ extern "C" int conp_debug_sk_stamps(unsigned long long *out /*[1024*8*8]*/, int 
 }
 #endif
 
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, int nwg, int nl_pad,
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, const int *seg_idx, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
   if (nwg <= 0) return;
   const size_t lds = SK_LDS_BYTES;
@@ -746,7 +747,7 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 #else
   const int dbg = 0;
 #endif
-  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, nl_pad, Xt, Yt, Zs, qc, part, dbg);
+  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, seg_idx, nl_pad, Xt, Yt, Zs, qc, part, dbg);
 }
 
 // G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:

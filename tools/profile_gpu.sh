@@ -21,5 +21,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARG
 echo "== pmc WRITE pass" >&2
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
 find $OUT -name "*.csv" | head -40 >&2
-python3 tools/collect_profiles.py $OUT > $OUT/summary.txt 2>&1
+python3 tools/collect_profiles.py $OUT $OUT/summary.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# keep what is judged (summary, kernel statistics) and drop the per-dispatch CSVs: gpurun merges at most 64 MiB back
+find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
+find $OUT -name "*counter_collection.csv" -size +2M -delete 2>/dev/null
+du -sh $OUT >&2
