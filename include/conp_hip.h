@@ -77,7 +77,8 @@ typedef struct {
   const double *cutsq;                            /* coulpair->cutsq flattened [(ntypes+1)*(ntypes+1)] (fix_conp.cpp:1235) */
   double cut_coul;                                /* *coulpair->extract("cut_coul") (fix_conp.cpp:1237) */
   int one_electrode;                              /* groupbit == jgroupbit (fix_conp.cpp:295) */
-  int device;                                     /* HIP device ordinal of this rank; -1: rank modulo the visible devices */
+  int device;                                     /* HIP device ordinal of this rank; -1: rank modulo the visible devices;
+                                                     -(2 + l): node-local rank l modulo the visible devices (MPI hosts) */
   int rank, nranks;                               /* shard id for the multi-GPU path (section "sharding") */
   /* `pppm` keyword (fix_conp.cpp:162, 401-404): mesh and stencil order of the pppm/conp kspace style, i.e. LAMMPS PPPM's
    * nx_pppm, ny_pppm, nz_pppm, order (pppm_conp.cpp:242, 206); ignored without the keyword */

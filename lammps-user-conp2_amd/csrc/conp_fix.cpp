@@ -295,7 +295,10 @@ struct conp_fix {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw ConpError(CONP_ERR_NO_DEVICE, "no HIP device visible: libconp_hip has no CPU fallback");
-    if (env.device < 0) env.device = env.rank % ndev;      // "this rank's GPU": ranks of a node spread over its devices
+    // "this rank's GPU": -1 = global rank modulo the visible devices; -(2 + l) = NODE-LOCAL rank l modulo the visible devices (what
+    // an MPI host passes: with several nodes the global rank says nothing about which of THIS node's GPUs is free)
+    if (env.device <= -2) env.device = (-env.device - 2) % ndev;
+    else if (env.device < 0) env.device = env.rank % ndev;
     if (env.device >= ndev) throw ConpError(CONP_ERR_NO_DEVICE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(env.device));
     hipDeviceProp_t prop;

@@ -27,28 +27,15 @@
 #include "variable.h"
 #endif
 
+#include "conp_mpi_comm.h"
+
 using namespace LAMMPS_NS;
 using namespace FixConst;
 
 // ---- conp_comm on MPI: the collectives FixConp makes on `world` (fix_conp.cpp:415, 492, 523, 535, 643, 822, 1356;
 // km_ewald.cpp:77, 784), handed to the library as callbacks.  ctx = &world.
-static int cb_allreduce_sum(void *ctx, double *buf, int64_t n) {
-  return MPI_Allreduce(MPI_IN_PLACE, buf, (int)n, MPI_DOUBLE, MPI_SUM, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
-}
-static int cb_allreduce_max_int(void *ctx, int *buf, int n) {
-  return MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_INT, MPI_MAX, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
-}
-static int cb_allgather_int(void *ctx, int value, int *out) {
-  return MPI_Allgather(&value, 1, MPI_INT, out, 1, MPI_INT, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
-}
-static int cb_allgatherv(void *ctx, const void *send, int64_t nbytes, void *recv, const int64_t *counts, const int64_t *displs) {
-  MPI_Comm w = *static_cast<MPI_Comm *>(ctx);
-  int n = 1;
-  MPI_Comm_size(w, &n);
-  std::vector<int> c(n), d(n);
-  for (int r = 0; r < n; ++r) { c[r] = (int)counts[r]; d[r] = (int)displs[r]; }
-  return MPI_Allgatherv(send, (int)nbytes, MPI_BYTE, recv, c.data(), d.data(), MPI_BYTE, w) != MPI_SUCCESS;
-}
+// (conp_mpi_comm.h: shared with KSpaceModuleHip, counts checked against MPI's int range)
+using conp_glue::cb_allreduce_sum; using conp_glue::cb_allreduce_max_int; using conp_glue::cb_allgather_int; using conp_glue::cb_allgatherv;
 
 void FixConpHip::fail_if(int status) {
   if (status != CONP_OK) error->all(FLERR, conp_last_error());
@@ -114,7 +101,8 @@ void FixConpHip::init() {
     env.one_electrode = (groupbit == jgroupbit);                           // :295
     // several MPI ranks (spatial decomposition): every rank drives its own handle on its own atoms and lists; device -1 lets the
     // library take GPU (rank mod visible devices), so that ranks of a node spread over its GPUs or share one
-    env.device = comm->nprocs > 1 ? -1 : 0; env.rank = comm->me; env.nranks = comm->nprocs;
+    env.device = comm->nprocs > 1 ? -(2 + conp_glue::node_local_rank(world)) : 0;     // ranks of a NODE spread over its GPUs
+    env.rank = comm->me; env.nranks = comm->nprocs;
     // ghosts that are periodic images of owned atoms are rebuilt on the device; a rank whose ghosts belong to other ranks fails
     // the library's check at post_neighbor and uploads them as they are
     env.ghost_images = 1;

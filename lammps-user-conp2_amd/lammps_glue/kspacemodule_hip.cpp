@@ -16,25 +16,16 @@
 #include "kspace.h"
 #endif
 
+#include "conp_mpi_comm.h"
+
 using namespace LAMMPS_NS;
 
-/* the same MPI-backed callbacks as fix_conp_hip.cpp (ctx = &world) */
-static int km_allreduce_sum(void *ctx, double *buf, int64_t n) {
-  return MPI_Allreduce(MPI_IN_PLACE, buf, (int)n, MPI_DOUBLE, MPI_SUM, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
-}
-static int km_allreduce_max_int(void *ctx, int *buf, int n) {
-  return MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_INT, MPI_MAX, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
-}
-static int km_allgather_int(void *ctx, int value, int *out) {
-  return MPI_Allgather(&value, 1, MPI_INT, out, 1, MPI_INT, *static_cast<MPI_Comm *>(ctx)) != MPI_SUCCESS;
-}
+/* the same MPI-backed callbacks as fix_conp_hip.cpp (ctx = &world): conp_mpi_comm.h */
+static int km_allreduce_sum(void *ctx, double *buf, int64_t n) { return conp_glue::cb_allreduce_sum(ctx, buf, n); }
+static int km_allreduce_max_int(void *ctx, int *buf, int n) { return conp_glue::cb_allreduce_max_int(ctx, buf, n); }
+static int km_allgather_int(void *ctx, int value, int *out) { return conp_glue::cb_allgather_int(ctx, value, out); }
 static int km_allgatherv(void *ctx, const void *send, int64_t nbytes, void *recv, const int64_t *counts, const int64_t *displs) {
-  MPI_Comm w = *static_cast<MPI_Comm *>(ctx);
-  int n = 1;
-  MPI_Comm_size(w, &n);
-  std::vector<int> c(n), d(n);
-  for (int r = 0; r < n; ++r) { c[r] = (int)counts[r]; d[r] = (int)displs[r]; }
-  return MPI_Allgatherv(send, (int)nbytes, MPI_BYTE, recv, c.data(), d.data(), MPI_BYTE, w) != MPI_SUCCESS;
+  return conp_glue::cb_allgatherv(ctx, send, nbytes, recv, counts, displs);
 }
 
 KSpaceModuleHip::KSpaceModuleHip(LAMMPS *lmp) : KSpaceModule(), Pointers(lmp), h(nullptr), first(true) {}
@@ -79,7 +70,8 @@ void KSpaceModuleHip::conp_setup(bool lowmem) {
     env.ntypes = atom->ntypes;
     cutsq0.assign((size_t)(atom->ntypes + 1) * (atom->ntypes + 1), 0.0);   /* the provider computes no real-space pairs */
     env.cutsq = cutsq0.data();
-    env.device = comm->nprocs > 1 ? -1 : 0; env.rank = comm->me; env.nranks = comm->nprocs;
+    env.device = comm->nprocs > 1 ? -(2 + conp_glue::node_local_rank(world)) : 0;     // ranks of a NODE spread over its GPUs
+    env.rank = comm->me; env.nranks = comm->nprocs;
     fail_if(conp_fix_create(&fa, &env, &h));
     if (comm->nprocs > 1) {
       conp_comm cc;
