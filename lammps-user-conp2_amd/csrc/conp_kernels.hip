@@ -270,17 +270,19 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
 
 // ================================================================================================
 // 2. structure-factor contraction on the FP64 matrix cores.
-//    Work item = (row tile rt: 64 planar vectors = 128 G rows, col tile ct: up to 10 kz blocks = 320 G cols,
-//    atom split).  Only the leading `nba` kz blocks of a row tile hold listed k vectors (sphere cut-off), so only
-//    2*nba column fragments are computed; they are dealt round-robin to the 4 column groups of the workgroup.
-//    Workgroup = 512 threads = 8 waves = 2 row halves x 4 column groups; wave tile = 4 x (<=5) fragments.
+//    Work item = (row tile rt: 64 planar vectors = 128 G rows, col tile ct: up to 20 column fragments = 160 kz = 320 G cols,
+//    atom split).  A column fragment = 8 kz: 8 cos + 8 sin columns.  Only the leading column fragments of a row fragment hold
+//    listed k vectors (sphere cut-off) and only those are computed; they are dealt round-robin to the 4 column groups of the
+//    workgroup.  Workgroup = 512 threads = 8 waves = 2 row halves x 4 column groups; wave tile = 4 x (<=5) fragments.
 //    Atoms are walked in chunks of J = 16 through a double-buffered LDS operand panel, panel[feature][atom]:
 //      features   0..127 : a_pj / b_pj  = q_j (cos,sin)(theta_pj)  from the X / Y phase tables (one complex product)
-//      features 128..447 : c_mj / s_mj  regenerated from a z-phase seed (every 5th kz) with the reference's
-//                          angle-addition recurrence (km_ewald.cpp:709-719)
-//    Row stride J+2 doubles makes every MFMA-fragment ds_read_b64 conflict-free (16 rows x 2 atoms per 32 lanes).
-//    Software pipeline per chunk: issue global loads for chunk c+1 -> MFMA on chunk c -> build panel c+1 -> barrier.
-//    Partial tiles go to part[item][128][320]; sk_reduce sums a tile's splits in a fixed order (deterministic).
+//      features 128..447 : c_mj / s_mj  regenerated from a z-phase seed (one per thread: kz = 40 q + r, then steps of 8) with the
+//                          reference's angle-addition recurrence (km_ewald.cpp:709-719)
+//    Rows are NOT padded: the atom column is XOR-swizzled with the low four bits of the feature index (SK_LD below), which makes
+//    every MFMA-fragment ds_read_b64 and every 16-lane ds_write_b64 conflict-free.
+//    Software pipeline per chunk: issue global loads for chunk c+1 -> MFMA on chunk c -> build panel c+1 -> barrier (waves 4-7:
+//    build first, multiply second).  Partial tiles go to part[segment] in fragment-major order (sk_part_off); sk_reduce sums a
+//    tile's segments in a fixed order (deterministic).
 // ================================================================================================
 #ifndef SK_LATE_MODE
 #define SK_LATE_MODE 1
@@ -1452,10 +1454,10 @@ __global__ __launch_bounds__(256) void sym_pack_kernel(int ne, const double *__r
   }
 }
 
-__global__ __launch_bounds__(256, 3) void sym_gemv_kernel(int ne_pad, const double *__restrict__ Spk, const double *__restrict__ b,
+__global__ __launch_bounds__(256, 4) void sym_gemv_kernel(int ne_pad, const double *__restrict__ Spk, const double *__restrict__ b,
                                                           double *__restrict__ yp /*[nb][ne_pad]*/) {
-  // the tile passes through LDS in four quarters of 32 rows (33 KB: three workgroups per CU -- all 528 tiles of the headline
-  // size are resident at once; with 64-row halves two fitted per CU and sixteen tiles ran in a second round: 16.8 us)
+  // the tile passes through LDS in four quarters of 32 rows (33 KB, 64 data registers: four workgroups per CU -- all 528 tiles of
+  // the headline size are resident at once; with 64-row halves two fitted per CU and sixteen tiles ran in a second round)
   __shared__ double L[32 * SG_LD];
   __shared__ double bi_s[SG_T], bj_s[SG_T];
   int t = blockIdx.x, bi = 0;
@@ -1463,10 +1465,12 @@ __global__ __launch_bounds__(256, 3) void sym_gemv_kernel(int ne_pad, const doub
   const int bj = t - bi * (bi + 1) / 2;
   const int tid = threadIdx.x;
   const double2 *tile = reinterpret_cast<const double2 *>(Spk + (size_t)t * SG_T * SG_T);
-  // the whole tile is requested up front: 4 quarters x 8 x 16 bytes per thread
-  double2 v[4][8];
+  // two quarters are requested up front (8 x 16 bytes per thread each), quarter qd + 2 when quarter qd goes into LDS: the second
+  // half of the tile arrives while the first is being multiplied (everything up front made the launch one burst of 67 MB
+  // followed by an LDS tail)
+  double2 v[2][8];                                 // quarter qd lives in v[qd & 1]
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd)
+  for (int qd = 0; qd < 2; ++qd)
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[qd][u] = tile[2048 * qd + tid + 256 * u];
   if (tid < SG_T) bi_s[tid] = b[bi * SG_T + tid]; else bj_s[tid - SG_T] = b[bj * SG_T + tid - SG_T];
@@ -1481,7 +1485,11 @@ __global__ __launch_bounds__(256, 3) void sym_gemv_kernel(int ne_pad, const doub
     for (int u = 0; u < 8; ++u) {
       const int e2 = tid + 256 * u;                // double2 index inside the quarter: row = e2 >> 6, column pair = e2 & 63
       const int r = e2 >> 6, c = (e2 & 63) * 2;
-      L[r * SG_LD + c] = v[qd][u].x; L[r * SG_LD + c + 1] = v[qd][u].y;
+      L[r * SG_LD + c] = v[qd & 1][u].x; L[r * SG_LD + c + 1] = v[qd & 1][u].y;
+    }
+    if (qd + 2 < 4) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[qd & 1][u] = tile[2048 * (qd + 2) + tid + 256 * u];
     }
     __syncthreads();
     if (!direct) {
