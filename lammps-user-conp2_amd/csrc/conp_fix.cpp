@@ -394,7 +394,7 @@ struct conp_fix {
     d_wfull.upload(plan.wfull, stream);
     d_sf_row_a.upload(plan.sf_row_a, stream); d_sf_col_c.upload(plan.sf_col_c, stream);
     d_k_sign.upload(plan.k_sign, stream); d_k_p.upload(plan.k_p, stream); d_k_m.upload(plan.k_m, stream);
-    d_nb_act.upload(plan.nb_act, stream);
+    d_nb_act.upload(plan.nba_rc, stream);
     dplan = DevPlan{plan.np, plan.nz, plan.n_row_tiles, plan.n_col_tiles, plan.R_pad, plan.C_pad,
                     plan.kxmax, plan.kymax, d_p_ikx.p, d_p_iky.p, d_p_sgn.p, d_nb_act.p, d_wfull.p};
     d_G.reserve((size_t)plan.R_pad * plan.C_pad); d_Gw.reserve((size_t)plan.R_pad * plan.C_pad);
@@ -1019,17 +1019,17 @@ struct conp_fix {
     }
     // kz chunks (16-kz blocks) dealt to nsplit groups of about equal work: heaviest first to the lightest group; a chunk costs
     // as many row tiles as reach it
-    int nchunk = 0;
-    for (int v : plan.nb_act) nchunk = std::max(nchunk, v);
-    const int nsplit = a_kspace_nsplit(ne_pad, num_cus, nchunk, tranks);
-    std::vector<int> group(std::max(nchunk, 1), 0);
+    const int nchunk = plan.n_col_tiles * KPlan::CT_BLK;
+    std::vector<int> group(nchunk, -1);
+    int nsplit = 1;
     {
       std::vector<std::pair<int, int>> cost;
       for (int c = 0; c < nchunk; ++c) {
         int n = 0;
-        for (int v : plan.nb_act) n += v > c;
-        cost.push_back({-n, c});
+        for (int rt = 0; rt < plan.n_row_tiles; ++rt) n += plan.nba(rt, c / KPlan::CT_BLK) > c % KPlan::CT_BLK;
+        if (n) cost.push_back({-n, c});
       }
+      nsplit = a_kspace_nsplit(ne_pad, num_cus, (int)cost.size(), tranks);
       std::stable_sort(cost.begin(), cost.end());
       std::vector<int> load(nsplit, 0);
       for (auto &e : cost) {
@@ -1440,7 +1440,7 @@ struct conp_fix {
       ride = !no_fuse && !(timed && time_split);
       prof.begin("elyte_phase", stream);
       launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
-                         plan.kymax, plan.nz, KPlan::ZSTRIDE, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
+                         plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
                          &n_slab_part, ride ? &pairs : nullptr, d_breal.p);
       prof.end(stream);
       // with the pair sums in hand and a small z-class table the dot kernel can finish b itself: no b_real_combine launch

@@ -168,6 +168,7 @@ void KPlan::build(const KTables &kt) {
   }
   nblk = (nz + 15) / 16;
   n_col_tiles = (nblk + CT_BLK - 1) / CT_BLK;
+  kzt = ((nz + n_col_tiles - 1) / n_col_tiles + 7) / 8 * 8;      // <= 160 because n_col_tiles = ceil(nz / 160)
   n_row_tiles = (np + PT - 1) / PT;
   R_pad = n_row_tiles * 2 * PT;
   C_pad = n_col_tiles * CT_COLS;
@@ -175,8 +176,8 @@ void KPlan::build(const KTables &kt) {
   w.assign((size_t)np * nz, 0.0);
   for (int k = 0; k < kt.kcount; ++k) w[(size_t)k_p[k] * nz + k_m[k]] += 2.0 * kt.ug[k];
   wfull.assign((size_t)R_pad * C_pad, 0.0);
-  nb_act.assign(n_row_tiles, 0);
-  nf_act16.assign((size_t)n_row_tiles * 4, 0);
+  nba_rc.assign((size_t)n_col_tiles * n_row_tiles, 0);
+  nfa_fc.assign((size_t)n_col_tiles * n_row_tiles * 4, 0);
   for (int p = 0; p < np; ++p)
     for (int m = 0; m < nz; ++m) {
       const double ww = w[(size_t)p * nz + m];
@@ -185,8 +186,10 @@ void KPlan::build(const KTables &kt) {
       wfull[(size_t)row_a(p) * C_pad + col_s(m)] = ww;
       wfull[(size_t)row_b(p) * C_pad + col_c(m)] = ww;
       wfull[(size_t)row_b(p) * C_pad + col_s(m)] = ww;
-      nb_act[p / PT] = std::max(nb_act[p / PT], (m >> 4) + 1);
-      nf_act16[p / 16] = std::max(nf_act16[p / 16], (m >> 3) + 1);
+      const int ct = m / kzt, ml = m - ct * kzt;
+      int &nb = nba_rc[(size_t)ct * n_row_tiles + p / PT], &nf = nfa_fc[(size_t)ct * n_row_tiles * 4 + p / 16];
+      nb = std::max(nb, (ml >> 4) + 1);
+      nf = std::max(nf, (ml >> 3) + 1);
     }
   sf_row_a.assign(kt.kcount, 0); sf_col_c.assign(kt.kcount, 0);
   for (int k = 0; k < kt.kcount; ++k) { sf_row_a[k] = row_a(k_p[k]); sf_col_c[k] = col_c(k_m[k]); }

@@ -41,18 +41,21 @@ struct KTables {
 // ------------------------------------------------------------------------------------------------
 struct KPlan {
   static constexpr int PT = 64;       // planar vectors per row tile (128 G rows: 64 'a' rows then 64 'b' rows)
-  static constexpr int CT_BLK = 10;   // 16-kz blocks per column tile (160 kz values = 320 G columns)
+  static constexpr int CT_BLK = 10;   // 16-kz blocks of column SPACE per column tile (320 G columns); a tile USES the first kzt / 16 of them
   static constexpr int CT_COLS = 32 * CT_BLK;
-  static constexpr int ZSTRIDE = 5;   // seeds per column tile = 160 / ZSTRIDE = 32: kz = s of the tile, extended by 32-kz rotations (conp_kernels.hip)
+
   int kxmax = 0, kymax = 0, nz = 0;   // nz = kzmax + 1 (m = 0 .. kzmax)
   int np = 0;                         // planar vectors incl. the origin; sorted by |k_p|^2 (origin first)
   std::vector<int> p_ikx, p_iky, p_sgn;   // per p: |kx|, |ky|, sign of ky (+1/-1); origin = (0,0,+1)
   std::vector<int> flat2p;                // reference flat index (x axis, y axis, (k,+-l,0)) -> p ; z-axis entries -> -1
   std::vector<int> k_p, k_m, k_sign;      // per reference k index
   int nblk = 0;                           // ceil(nz / 16)
+  int kzt = 16 * CT_BLK;                  // kz values per column tile: nz spread evenly over the tiles (a multiple of 8, <= 160), so that
+                                          // no tile is a runt (slab geometry, nz = 378: 3 x 128 instead of 160 + 160 + 58)
   int n_row_tiles = 0, n_col_tiles = 0, R_pad = 0, C_pad = 0;
-  std::vector<int> nb_act;                // per row tile: number of leading 16-kz blocks that hold a listed k (sphere cut)
-  std::vector<int> nf_act16;              // per 16 planar vectors (one MFMA row fragment): leading 8-kz COLUMN FRAGMENTS with a listed k: [n_row_tiles * 4]
+  std::vector<int> nba_rc;                // [n_col_tiles][n_row_tiles]: leading 16-kz blocks OF THE COLUMN TILE that hold a listed k (sphere cut)
+  std::vector<int> nfa_fc;                // [n_col_tiles][n_row_tiles * 4]: the same per 16 planar vectors (one MFMA row fragment), in
+                                          // 8-kz COLUMN FRAGMENTS of the tile
   std::vector<double> w;                  // [np][nz] weights
   std::vector<double> wfull;              // [R_pad][C_pad] weights expanded to G's layout (0 in padding)
   std::vector<int> sf_row_a, sf_col_c;    // per reference k: G row of (p,'a') and col of (m,'c') (b row = +PT, s col = +8)
@@ -62,13 +65,13 @@ struct KPlan {
   // per block (nb_act, the reductions, the projections, the SYRK's chunks) sees the same column set as with 16 + 16.
   int row_a(int p) const { return (p / PT) * (2 * PT) + (p % PT); }
   int row_b(int p) const { return row_a(p) + PT; }
-  int col_c(int m) const { return 16 * (m >> 3) + (m & 7); }
+  int col_c(int m) const { const int ct = m / kzt, ml = m - ct * kzt; return CT_COLS * ct + 16 * (ml >> 3) + (ml & 7); }
   int col_s(int m) const { return col_c(m) + 8; }
-  int nba(int rt, int ct) const { return std::max(0, std::min(CT_BLK, nb_act[rt] - CT_BLK * ct)); }
+  int nba(int rt, int ct) const { return nba_rc[(size_t)ct * n_row_tiles + rt]; }
   // active column fragments of row fragment f (planar vectors 16 f .. 16 f + 15 of row tile rt) inside col tile ct, packed 4 x 8 bit
   unsigned nfa16(int rt, int ct) const {
     unsigned v = 0;
-    for (int f = 0; f < 4; ++f) v |= (unsigned)std::max(0, std::min(2 * CT_BLK, nf_act16[4 * rt + f] - 2 * CT_BLK * ct)) << (8 * f);
+    for (int f = 0; f < 4; ++f) v |= (unsigned)nfa_fc[((size_t)ct * n_row_tiles + rt) * 4 + f] << (8 * f);
     return v;
   }
 

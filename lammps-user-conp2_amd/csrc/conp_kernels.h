@@ -15,7 +15,7 @@ const char *exp_switch(const char *name);
 struct DevPlan {              // device copy of KPlan geometry
   int np, nz, n_row_tiles, n_col_tiles, R_pad, C_pad, kxmax, kymax;
   const int *p_ikx, *p_iky, *p_sgn;   // [n_row_tiles*64] padded (padding: 0,0,0 -> sgn 0 marks "no vector")
-  const int *nb_act;                  // [n_row_tiles] active kz blocks per row tile
+  const int *nb_act;                  // [n_col_tiles][n_row_tiles] active 16-kz blocks of the column tile per row tile (KPlan::nba_rc)
   const double *wfull;                // [R_pad][C_pad]
 };
 
@@ -85,7 +85,7 @@ void launch_potential_pair(hipStream_t s, int inum, const int *ilist, const int 
 void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, const int *img, double px, double py, double pz,
                        double *x, double *q);
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
-                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, int nrz, double2 *Xt,
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int kzt, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part,
                         const BRowArgs *rows /*NULL, or: the real-space pair sums of these rows ride along, into breal_out*/,
                         double *breal_out);

@@ -148,7 +148,7 @@ constexpr int EP_THREADS = 128;
 __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl, int nl_pad, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double ux, double uy, double uz, int kxmax, int kymax, int nz,
-                                                          int zstride, int nrz, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
+                                                          int kzt, int nrz, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
                                                           double2 *__restrict__ Zs, double *__restrict__ qc,
                                                           double *__restrict__ slab_part, BRowArgs ra, double *__restrict__ breal_out) {
 #pragma clang fp contract(off)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
     double2 *t = (c == 0 ? Xt : (c == 1 ? Yt : Zs)) + ((size_t)(j >> 4) * NR) * 16 + (j & 15);
     // X and Y: every row.  Z: sk_gemm's thread (gs = 8 q + r, atom) generates the five kz values 40 q + r + 8 u (u < 5) of a
     // column tile (160 kz) from ONE seed by repeated rotation with the 8-kz step: row 0 of Zs is that step, (cos, sin)(8 uz z);
-    // row 1 + 32 ct + gs is the seed, the phase at m = 160 ct + 40 q + r.  Same recurrence as the reference's, re-associated.
+    // row 1 + 32 ct + gs is the seed, the phase at m = kzt ct + 40 q + r (kzt = kz values per column tile, KPlan::kzt).  Same recurrence as the reference's, re-associated.
     // the x table carries the charge (q cos, q sin): one multiply here instead of two per planar vector in sk_gemm
     const double sc = (c == 0) ? qq : 1.0;
     double c1, s1;
@@ -199,28 +199,43 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
     } else {
       qc[j] = qq; qz = qq * xc;
       const int nct = (nrz - 1) / 32;                 // column tiles
-      // eight seeds in flight (r = 0 .. 7), advanced together by 40 kz per step: the dependent chain is 7 unit steps, 3 steps to
-      // the 40-kz rotation and 4 steps per column tile (a walk in unit steps would be 160 per tile: the launch's longest chain)
-      double sc8[8], ss8[8];
-      sc8[0] = 1.0; ss8[0] = 0.0;
+      // eight seeds in flight (r = 0 .. 7), advanced together by 40 kz per step inside a column tile, and their copies at the
+      // tile's start by the tile's kz count kzt per tile: the dependent chain is 7 unit steps, a handful to the 40-kz and kzt
+      // rotations, then one step per column tile + 3 inside it (a walk in unit steps would be 160 per tile: the launch's longest)
+      double bc8[8], bs8[8];
+      bc8[0] = 1.0; bs8[0] = 0.0;
 #pragma unroll
-      for (int r = 1; r < 8; ++r) { sc8[r] = sc8[r - 1]; ss8[r] = ss8[r - 1]; rot(sc8[r], ss8[r], c1, s1); }
-      double c8 = sc8[7], s8 = ss8[7];
+      for (int r = 1; r < 8; ++r) { bc8[r] = bc8[r - 1]; bs8[r] = bs8[r - 1]; rot(bc8[r], bs8[r], c1, s1); }
+      double c8 = bc8[7], s8 = bs8[7];
       rot(c8, s8, c1, s1);                            // the 8-kz rotation
       t[0] = make_double2(c8, s8);
       double c40 = c8, s40 = s8;
       rot(c40, s40, c8, s8);                          // 16
       rot(c40, s40, c40, s40);                        // 32
       rot(c40, s40, c8, s8);                          // 40
-      for (int ct = 0; ct < nct; ++ct)
+      double ct_c = 1.0, ct_s = 0.0;                  // the kzt-kz rotation: (8-kz rotation)^(kzt / 8), square and multiply
+      {
+        double pc = c8, ps = s8;
+        for (int e = kzt >> 3; e; e >>= 1) {
+          if (e & 1) rot(ct_c, ct_s, pc, ps);
+          rot(pc, ps, pc, ps);
+        }
+      }
+      for (int ct = 0; ct < nct; ++ct) {
+        double sc8[8], ss8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { sc8[r] = bc8[r]; ss8[r] = bs8[r]; }
 #pragma unroll
         for (int q40 = 0; q40 < 4; ++q40) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             st_d2(t + (size_t)(1 + 32 * ct + 8 * q40 + r) * 16, make_double2(sc8[r], ss8[r]), EP_TABLE_NT);
-            rot(sc8[r], ss8[r], c40, s40);
+            if (q40 < 3) rot(sc8[r], ss8[r], c40, s40);
           }
         }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rot(bc8[r], bs8[r], ct_c, ct_s);
+      }
     }
   }
   if (c != 2) return;
@@ -256,7 +271,7 @@ void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, 
 }
 
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
-                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int zstride, int nrz, double2 *Xt,
+                        double ux, double uy, double uz, int kxmax, int kymax, int nz, int kzt, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part, const BRowArgs *rows,
                         double *breal_out) {
   const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS;
@@ -265,7 +280,7 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
   int nrb = 0;
   if (rows && breal_out) { ra = *rows; nrb = (ra.ne + EP_THREADS / 64 - 1) / (EP_THREADS / 64); }
   hipLaunchKernelGGL(elyte_phase_kernel, dim3(3 * nb + nrb), dim3(EP_THREADS), 0, s, nb, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
-                     kymax, nz, zstride, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out);
+                     kymax, nz, kzt, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out);
 }
 
 // ================================================================================================
@@ -1009,8 +1024,7 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
   if (rt_mine[rt]) {
     for (int ct = 0; ct < n_col_tiles; ++ct) {
-      int nba = nb_act[rt] - 10 * ct;
-      nba = nba < 0 ? 0 : (nba > 10 ? 10 : nba);
+      const int nba = nb_act[ct * (R_pad >> 7) + rt];
       const int nks = 8 * nba, t0 = nks * kq / 4, t1 = nks * (kq + 1) / 4;
       const double *ap = Gwf + ((size_t)rf * (C_pad / 4) + (size_t)ct * 80) * 64 + lane;
       const double *bp = Tzc + (size_t)(ct * 320 + fk) * 64 + 16 * wave + fr;
@@ -1833,8 +1847,7 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
   for (int f = 0; f < 4; ++f)
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
-  int nchunk = 0;
-  for (int rt = 0; rt < n_row_tiles; ++rt) nchunk = nb_act[rt] > nchunk ? nb_act[rt] : nchunk;
+  const int nchunk = C_pad / AK_TC;        // 10 per column tile; a chunk nobody reaches belongs to no group (chunk_group = -1)
   const double *li = L + fk * AK_LD + wi * 64 + fr, *lj = L + fk * AK_LD + 128 + wj * 64 + fr;
   for (int c = 0; c < nchunk; ++c) {
     if (chunk_group[c] != split) continue;
@@ -1846,8 +1859,10 @@ __global__ __launch_bounds__(256, 2) void a_kspace_lds_kernel(int R_pad, int C_p
     }
     __syncthreads();
     if (idle) continue;
+    const int *nbc = nb_act + (c / 10) * n_row_tiles;
+    const int cl = c % 10;
     for (int r = 0; r < R_pad; ++r) {
-      if (nb_act[r >> 7] <= c) { r |= 127; continue; }      // this row tile's sphere cut ends before kz block c
+      if (nbc[r >> 7] <= cl) { r |= 127; continue; }        // this row tile's sphere cut ends before kz block cl of the column tile
       double ri[4], rj[4], ww[8];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
