@@ -241,24 +241,29 @@ struct conp_fix {
   bool own_stream = false;
   DevBuf<double> d_x, d_q, d_qc, d_slab_part, d_Gpart, d_G, d_Gw, d_wfull, d_Rp, d_Tz, d_ele_z, d_bk, d_breal, d_b_own,
       d_eleallq_own, d_qele, d_elesetq, d_eleinitq, d_A, d_cutsq, d_scalars, d_ainve, d_sfr, d_sfi, d_cg_res, d_cg_p, d_Srows, d_xg, d_qg, d_pp_ele, d_pp_scratch,
-      d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_Hc, d_Wz, d_Spk, d_yp, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
+      d_cg_ap, d_cg_scal, d_inv_work, d_inv_backup, d_Tzc, d_TzcT, d_Hpart, d_Hc, d_Wz, d_Spk, d_yp, d_f, d_pfacc, d_pp_coeff, d_pp_green, d_pp_tw0, d_pp_tw1,
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt, d_Xe, d_Ye;      // d_Xe / d_Ye: electrode atoms' axis phases [k][ne_pad] (once per run)
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_seg_idx, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of, d_ele_csr_row;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_seg_idx, d_hslot_ptr, d_hslot_idx, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of, d_ele_csr_row;
   bool left_stale = false;          // the fused GEMV + charge write leaves the fix scalar's group-1 sum to refresh_scalar()
   double left_potdiff = 0.0;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
+  DevBuf<SkProj> d_skproj;
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   bool b_bound = false, q_bound = false;         // conp_fix_bind_device_buffers gave us the host's vectors
   int n_slab_part = 0;
   const bool no_fuse = exp_switch("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
+  const bool sk_partials = exp_switch("CONP_SK_PARTIALS") != nullptr;   // comparison switch: partial tiles + reducing launch, no projection in sk_gemm
+  const char *hc_presum_env = exp_switch("CONP_HC_PRESUM");      // comparison switch: 1 / 0 = always / never add the pieces in a launch of their own
   // The host-buffer hooks report Ktime / Ctime (fix_conp.cpp:553-568).  By default they run the SAME kernels as the device hooks
   // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
   // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
   const bool time_split = exp_switch("CONP_TIME_SPLIT") != nullptr;
+  int hslots = 0;                  // entries of the owned row tiles' segment lists (d_hslot_idx)
+  bool g_current = true;           // d_G holds the last update's structure factors (false after a projecting update: conp_fix_get_sfac re-forms it)
   int max_nsplit = 0;              // most sk_gemm segments any tile is cut into (chooses sk_reduce's one- or two-level sum)
   DevPlan dplan{};
   Profiler prof;
@@ -666,7 +671,28 @@ struct conp_fix {
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
     // partial tiles: fragments beyond a tile's sphere cut are never written -- all zero from the start, finite ever after
-    if ((size_t)items_h.size() * 128 * 320 > d_Gpart.n) { d_Gpart.reserve((size_t)items_h.size() * 128 * 320); d_Gpart.zero(stream); }
+    reserve_partials();
+  }
+  // After an update whose sk_gemm projected its tiles (planar electrodes) G was never formed: the phase tables of that update are
+  // still on the device, so the contraction is run again in the partial-tile mode and reduced (structure factors are a diagnostic
+  // getter: conp_fix_get_sfac, KSpaceModule::sfac in the reference's energy output).
+  void refresh_structure_factors() {
+    if (g_current) return;
+    reserve_partials(true);
+    launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, d_seg_idx.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
+                   d_Gpart.p);
+    launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, d_Gw.p);
+    g_current = true;
+  }
+  // sk_gemm's output per segment: the projected piece (planar electrodes) or the partial tile.  The partial tiles of a projecting
+  // handle are allocated when somebody asks for the structure factors (conp_fix_get_sfac).
+  bool sk_projects() const {
+    return nzc > 0 && nzc <= sk_hc_max_classes() && !args.pppm && !sk_partials && !no_fuse;
+  }
+  void reserve_partials(bool tiles_too = false) {
+    if (sk_projects()) d_Hpart.reserve(std::max<size_t>(1, items_h.size()) * sk_hc_stride());
+    if (!sk_projects() || tiles_too)
+      if ((size_t)items_h.size() * 128 * 320 > d_Gpart.n) { d_Gpart.reserve((size_t)items_h.size() * 128 * 320); d_Gpart.zero(stream); }
   }
   bool elyte_list_stale(const conp_atoms *at) {
     size_t k = 0;
@@ -848,6 +874,17 @@ struct conp_fix {
     d_seg_ptr.upload(seg_ptr_h, stream);
     d_seg_idx.upload(seg_idx_h, stream);
     d_tiles.upload(tiles_h, stream);
+    // per owned row tile: the segments that worked on it, over all its column tiles (sk_gemm's projected pieces are added in
+    // this order: launch_project_zclass_pieces)
+    std::vector<int> hptr(own_rt_h.size() + 1, 0), hidx;
+    for (size_t k = 0; k < own_rt_h.size(); ++k) {
+      for (const auto &tl : tiles_h)
+        if (tl.rt == own_rt_h[k]) for (int i = 0; i < tl.nsplit; ++i) hidx.push_back(tl.item0 + i);
+      hptr[k + 1] = (int)hidx.size();
+    }
+    hslots = (int)hidx.size();
+    if (hidx.empty()) hidx.push_back(0);
+    d_hslot_ptr.upload(hptr, stream); d_hslot_idx.upload(hidx, stream);
   }
 
   void gather_xele(const conp_atoms *at) {
@@ -915,6 +952,12 @@ struct conp_fix {
         for (int t = 0; t < plan.C_pad; ++t)
           for (int c = 0; c < nzc; ++c) Tzc[(size_t)t * 64 + c] = Tz[(size_t)t * ne_pad + rep[c]];
         d_Tzc.upload(Tzc, stream); d_zclass.upload(zclass, stream);
+        // class-major copy for sk_gemm's projecting epilogue (16 adjacent columns of one class per load)
+        std::vector<double> TzcT((size_t)std::max(nzc, 1) * plan.C_pad, 0.0);
+        for (int t = 0; t < plan.C_pad; ++t)
+          for (int c = 0; c < nzc; ++c) TzcT[(size_t)c * plan.C_pad + t] = Tzc[(size_t)t * 64 + c];
+        d_TzcT.upload(TzcT, stream);
+        d_skproj.upload(std::vector<SkProj>{SkProj{d_wfull.p, d_TzcT.p, nzc, plan.C_pad}}, stream);
         d_Hc.reserve((size_t)8 * plan.R_pad * 64); d_Hc.zero(stream);     // 8 slots: the reduction's column slices (b_hc: 4, the rest stay 0)
       }
     }
@@ -1448,11 +1491,22 @@ struct conp_fix {
                       d_ele_z.p, d_slab_part.p, n_slab_part, 4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
       fin.breal = d_breal.p;
       use_fin = ride && nzc > 0 && zc_final_fits((int)own_rt_h.size(), nzc);
+      const bool proj = sk_projects();
+      reserve_partials();
       prof.begin("sk_gemm", stream);
       launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, d_seg_idx.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
-                     d_Gpart.p);
+                     proj ? d_Hpart.p : d_Gpart.p, proj ? d_skproj.p : nullptr);
       prof.end(stream);
-      if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
+      g_current = !proj;
+      if (proj) {
+        // planar electrodes: the segments left their projected pieces (128 x nzc each); the dot kernel adds them per row tile
+        // (a launch of its own first when there are many: every block of the dot kernel would re-add them all)
+        const bool presum = hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 16 * (int)own_rt_h.size();
+        prof.begin("reduce_project", stream);
+        launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Hpart.p, d_hslot_ptr.p, d_hslot_idx.p,
+                                     presum, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);
+        prof.end(stream);
+      } else if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
         // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)
         prof.begin("reduce_project", stream);
         launch_reduce_project_zclass(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, ne_pad,
@@ -2193,6 +2247,7 @@ int conp_fix_get_vectors(conp_fix *f, double *bbb_all, double *eleallq, double *
 int conp_fix_get_sfac(conp_fix *f, double *sr, double *si) {
   CONP_GUARD_BEGIN
   f->drop_graph();
+  f->refresh_structure_factors();
   const int K = f->kt.kcount;
   f->d_sfr.reserve(K); f->d_sfi.reserve(K);
   launch_sfac_gather(f->stream, K, f->plan.C_pad, KPlan::PT, f->d_sf_row_a.p, f->d_sf_col_c.p, f->d_k_sign.p, f->d_G.p,

@@ -21,6 +21,8 @@ struct DevPlan {              // device copy of KPlan geometry
 
 struct SkItem { int rt, ct, nba, c0, c1; unsigned nbf; };   // one sk_gemm segment: tile + chunk range [c0, c1) of 16 atoms;
                                                           // nbf = active 8-kz column fragments per 16-row fragment, 4 x 8 bit
+// parameter block of sk_gemm's projecting epilogue (device memory): weights [R_pad][C_pad], z-class phases class-major [nzc][C_pad]
+struct SkProj { const double *wfull, *tzt; int nzc, cpad; };
 struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
@@ -91,7 +93,12 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         double *breal_out);
 bool zc_final_fits(int n_own, int nzc);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, const int *seg_idx, int nwg, int nl_pad,
-                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part);
+                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj = nullptr);
+int sk_hc_stride();           // doubles per segment of sk_gemm's projected output
+int sk_hc_max_classes();      // most z classes the projecting mode takes
+void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
+                                  const int *slot_ptr, const int *slot_idx, bool presum, const double *Rp, const double2 *Xe,
+                                  const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);
 void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,

@@ -372,6 +372,7 @@ struct SkCtx {        // per-thread constants of one work item
   int f0;                           // row fragments f >= f0 skip the wave's last column fragment (sphere culling), wave-uniform
   const double2 *Xt, *Yt, *Zs;
   const double *qc;
+  const SkProj *proj;               // projected output (planar electrodes, sk_project_out) when not null
   int dbg;
 };
 
@@ -550,6 +551,116 @@ __device__ unsigned long long sk_seg_buf[4096 * 4];         // [segment][workgro
 #define SK_STAMP_ADD(sum, a, b) do { } while (0)
 #endif
 
+// Planar electrodes: every electrode atom's z phase is one of a few columns ("z classes", b_hc_kernel), and all the update needs
+// from G is  Hc[r][zc] = sum_t w[r][t] G[r][t] Tzc[t][zc]  -- linear in G, so a segment projects ITS partial tile before it leaves
+// the registers and writes 128 x nzc doubles instead of 128 x 320: the 59 MB of partial tiles per update (headline size), the
+// launch that summed and projected them (15 us) and their write-back go away; the segments' Hc pieces (8 KB each) are added in a
+// fixed order by whoever consumes them (hc_sum_kernel / b_zc_final_kernel).
+//   lane (fk, fr) of wave (rh, cg) holds G[16 (4 rh + f) + fk + 4 r][16 (4 g + cg) + fr]: it forms, per class, the sum over ITS
+//   columns (g) of w G Tzc for its 16 rows; the 16 lanes fr of a row are added by DPP shifts inside the register file (lane 15
+//   ends up with the total), the four column groups cg through 4 KB of LDS per class.  Two barriers per segment -- a first version
+//   went through LDS per row fragment (eight barriers, a dozen serialised LDS / memory waits per fragment): 8 us per segment.
+constexpr int SK_HC = 8;          // class stride of a segment's Hc piece: [SK_HC][128] doubles
+constexpr int SK_HC_MAX = 8;
+// v + (v of the lane CTRL's shift away in the 16-lane row, 0 beyond the row's edge)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return v + __hiloint2double(hi, lo);
+}
+template <int NFW>
+__device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&acc)[4][NFW > 0 ? NFW : 1], double *__restrict__ hout) {
+  double *L = reinterpret_cast<double *>(smem);
+  // everything this needs is derived HERE, behind opaque copies of the thread index and the parameter block's address: left to
+  // itself the compiler forms the lane's offsets and loads the parameters at the top of the kernel and carries them through the
+  // chunk loop -- 32 more SGPRs and spills in a kernel that has no register to spare
+  unsigned t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const SkProj *pp = c.proj;
+  asm volatile("" : "+s"(pp));
+  // (constant address space spelled out: scalar loads, wave-uniform values)
+  const __attribute__((address_space(4))) SkProj *cp = (const __attribute__((address_space(4))) SkProj *)pp;
+  const int nzc = cp->nzc;
+  const unsigned cpad = (unsigned)cp->cpad;
+  const double *wfull = cp->wfull, *tzt = cp->tzt;
+  const unsigned fr = t & 15, fk = (t >> 4) & 3, rh = (t >> 6) & 1, cg = t >> 7;
+  const unsigned colb = (unsigned)c.it.ct * 320 + 16 * cg + fr;                                  // + 64 g
+  // (global address space spelled out: the pointers come out of memory behind an asm barrier, the compiler would use FLAT loads,
+  //  which count on the LDS counter too -- every wait for an LDS read then waits for the weights in flight)
+  typedef __attribute__((address_space(1))) const double *gcd_t;
+  gcd_t wp = (gcd_t)(wfull + ((unsigned)c.it.rt * 128 + 64 * rh + fk) * cpad + colb);             // + (16 f + 4 r) * cpad
+  gcd_t tzg = (gcd_t)tzt;
+  // the weights of row fragment f + 1 are requested as soon as those of f have been used; the tile's z-class phases go through LDS
+  double wv[NFW > 0 ? NFW : 1][4];
+  if constexpr (NFW > 0) {
+#pragma unroll
+    for (int g = 0; g < NFW; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wv[g][r] = wp[(unsigned)(4 * r) * cpad + 64 * g];
+  }
+  double *Tl = L;                                                                                 // [nzc][320]
+  double *Lp = L + SK_HC_MAX * 320;                                                               // [nzc][128 rows][4 cg]
+  for (unsigned e = t; e < (unsigned)nzc * 320; e += 512) {
+    const unsigned zc = e / 320, cc = e - zc * 320;
+    Tl[e] = tzg[zc * cpad + (unsigned)c.it.ct * 320 + cc];
+  }
+  const double *tl = Tl + 16 * cg + fr;                                                           // + zc * 320 + 64 g
+  double *lp = Lp + (64 * rh + fk) * 4 + cg;                                                      // + (zc * 128 + 16 f + 4 r) * 4
+  __syncthreads();
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    // (w G) in place: the accumulators are done with
+    if constexpr (NFW > 0) {
+#pragma unroll
+      for (int g = 0; g < NFW; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[f][g][r] *= wv[g][r];
+    }
+    for (int zc = 0; zc < nzc; ++zc) {
+      double s[4] = {0.0, 0.0, 0.0, 0.0};
+      if constexpr (NFW > 0) {
+#pragma unroll
+        for (int g = 0; g < NFW; ++g) {
+          const double tv = tl[zc * 320 + 64 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[r] += acc[f][g][r] * tv;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[r] = dpp_add<0x111>(s[r]);      // row_shr:1
+          s[r] = dpp_add<0x112>(s[r]);      // row_shr:2
+          s[r] = dpp_add<0x114>(s[r]);      // row_shr:4
+          s[r] = dpp_add<0x118>(s[r]);      // row_shr:8 -> lane 15 of the row: all 16
+        }
+      }
+      if (fr == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lp[(zc * 128 + 16 * f + 4 * r) * 4] = s[r];
+      }
+    }
+    if constexpr (NFW > 0) {
+      if (f < 3) {
+        // not earlier: the registers are the ones this row fragment's accumulators free.  (Requesting them right after the
+        // multiplies above, to have the class loop in between, makes the allocator spill hundreds of registers; pulling the
+        // wave's weights into L2 with throw-away loads during the segment's last chunk changed nothing: A/B 240.8 vs 240.6 us.)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < NFW; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wv[g][r] = wp[(unsigned)(16 * (f + 1) + 4 * r) * cpad + 64 * g];
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned o = t; o < (unsigned)nzc * 128; o += 512) {
+    const double2 *src = reinterpret_cast<const double2 *>(Lp + 4 * o);
+    const double2 v0 = src[0], v1 = src[1];
+    hout[o] = (v0.x + v0.y) + (v1.x + v1.y);
+  }
+  __syncthreads();          // (the next segment's prologue writes panels into this memory)
+}
+
 // One segment = (tile, chunk range).  Between two barriers the workgroup multiplies chunk c (panel buffer c&1) and
 // builds chunk c+1 (other buffer).  The two waves of a SIMD (w and w+4) do this in OPPOSITE order -- waves 0-3
 // multiply first, waves 4-7 build first -- so one wave's operand generation overlaps its partner's MFMAs.
@@ -604,7 +715,9 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
   //      the store tail of a segment is issue-bound)
   if (SK_DBG(c, 16)) return;
   SK_STAMP_T(st_a);
-  {
+  if (c.proj) {
+    sk_project_out<NFW>(c, smem, acc, out);
+  } else {
     // one lane-dependent offset, made opaque per segment: left to itself the compiler hoists all store addresses out of the
     // segment loop and spills them
     unsigned lane_off = (unsigned)(((4 * c.rh * 20 + c.cg) << 8) + 2 * (16 * c.fk + c.fr));
@@ -635,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
                                                          const int *__restrict__ seg_ptr, const int *__restrict__ seg_idx, int nl_pad,
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
-                                                         double *__restrict__ part, int dbg) {
+                                                         double *__restrict__ part, const SkProj *__restrict__ proj, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // panel buffer 0 at byte 0, buffer 1 at byte SK_BUF1
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -643,15 +756,8 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   c.dbg = dbg;
   c.nl_pad = nl_pad; c.nz = pl.nz;
   c.rh = wave & 1; c.cg = wave >> 1;
-  c.gj = t & 15; c.gs = t >> 4;
-  c.fr = lane & 15; c.fk = lane >> 4;
-  c.wa = (unsigned)(c.gs * SK_LD + (c.gj ^ (c.gs & 15)));
-  c.za = (unsigned)((128 + 16 * 5 * (c.gs >> 3) + (c.gs & 7)) * SK_LD + (c.gj ^ (c.gs & 7)));
-  c.dsin = 8 * SK_LD + ((c.gj & 8) ? -8 : 8);
-  c.base_a = ((unsigned)(64 * c.rh + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
-  c.base_b = ((unsigned)(128 + 16 * c.cg + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
-  c.pq = (unsigned)(c.fr >> 2) << 5;
   c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
+  c.proj = proj;
   c.nrx16 = (unsigned)(pl.kxmax + 2) * 16; c.nry16 = (unsigned)(pl.kymax + 1) * 16; c.nrz16 = (unsigned)(1 + pl.n_col_tiles * 32) * 16;
   const bool late = wave >= 4 && !(SK_DBG(c, 8));
 #ifdef SK_STAMP
@@ -661,6 +767,20 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
   for (int sgi = s0; sgi < s1; ++sgi) {
     const int sg = seg_idx[sgi];
     c.it = items[sg];
+    // the lane's constants are formed per segment from an opaque copy of the thread index: formed once at the top of the kernel
+    // they would be live across the epilogue, which has no register to spare for them (they were spilled around it)
+    {
+      unsigned tt = threadIdx.x;
+      asm volatile("" : "+v"(tt));
+      c.gj = tt & 15; c.gs = tt >> 4;
+      c.fr = tt & 15; c.fk = (tt >> 4) & 3;
+      c.wa = (unsigned)(c.gs * SK_LD + (c.gj ^ (c.gs & 15)));
+      c.za = (unsigned)((128 + 16 * 5 * (c.gs >> 3) + (c.gs & 7)) * SK_LD + (c.gj ^ (c.gs & 7)));
+      c.dsin = 8 * SK_LD + ((c.gj & 8) ? -8 : 8);
+      c.base_a = ((unsigned)(64 * c.rh + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
+      c.base_b = ((unsigned)(128 + 16 * c.cg + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
+      c.pq = (unsigned)(c.fr >> 2) << 5;
+    }
     // per row fragment f (16 planar vectors) only the leading nff_f column fragments (8 kz each) are inside the cut-off sphere;
     // the tile's count is the largest of them (<= 2 nba; an odd count leaves the last fragment of the last kz block unwritten:
     // the partial buffer is zeroed when allocated, those columns carry no listed k and zero weight)
@@ -693,7 +813,8 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     c.neg0 = pl.p_sgn[p0] < 0; c.neg1 = pl.p_sgn[p1] < 0;             // (padding vectors read the all-zero X row)
     c.zact = 40 * (c.gs >> 3) + (c.gs & 7) < 8 * nfrag;     // the thread's first kz lies in an active column fragment
     c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * 16 + c.gj;
-    double *out = part + (size_t)sg * (128 * 320);
+    // projecting: `part` takes the segment's piece [SK_HC][128] instead of its partial tile
+    double *out = part + (size_t)sg * (proj ? SK_HC * 128 : 128 * 320);
 #ifdef SK_STAMP
     const unsigned long long sg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -753,8 +874,13 @@ extern "C" int conp_debug_sk_stamps(unsigned long long *out /*[1024*8*8]*/, int 
 }
 #endif
 
+int sk_hc_stride() { return SK_HC * 128; }
+int sk_hc_max_classes() { return SK_HC_MAX; }
+
+// proj == nullptr: partial tiles [segment][128 x 320] into `part`; otherwise (planar electrodes, at most sk_hc_max_classes() z
+// classes; proj = device copy of the parameter block) the segments' projected pieces [segment][sk_hc_stride()]
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, const int *seg_idx, int nwg, int nl_pad,
-                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part) {
+                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj) {
   if (nwg <= 0) return;
   const size_t lds = SK_LDS_BYTES;
   static DynLdsCache granted{};
@@ -764,7 +890,7 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 #else
   const int dbg = 0;
 #endif
-  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, seg_idx, nl_pad, Xt, Yt, Zs, qc, part, dbg);
+  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, seg_idx, nl_pad, Xt, Yt, Zs, qc, part, proj, dbg);
 }
 
 // G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:
@@ -1037,6 +1163,36 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
   for (int r = 0; r < 4; ++r) out[16 * rf + fk + 4 * r] = acc[r];
 }
 
+// sum of one Hc element over the segments slot_idx[s0 .. s1) that worked on its row tile (sk_project_out's pieces, `stride` doubles
+// apart), eight loads in flight, fixed association: bitwise reproducible
+__device__ __forceinline__ double hc_slot_sum(const double *__restrict__ h, const int *__restrict__ slot_idx, int s0, int s1, size_t stride) {
+  double acc = 0.0;
+  int s = s0;
+  for (; s + 8 <= s1; s += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = h[(size_t)slot_idx[s + u] * stride];
+    acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  double v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = s + u < s1 ? h[(size_t)slot_idx[s + u] * stride] : 0.0;
+  return acc + (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+}
+
+// the segments' Hc pieces of every owned row tile added into slot 0 of Hc4 (class-major, [64][R_pad]) for the consumers that read
+// that table (b_zc_dot_kernel: row quarters of ALL tiles per block); one block per owned row tile
+__global__ __launch_bounds__(256) void hc_sum_kernel(const int *__restrict__ own_rt, int R_pad, int nzc, const double *__restrict__ Hp,
+                                                     const int *__restrict__ slot_ptr, const int *__restrict__ slot_idx,
+                                                     double *__restrict__ Hc4) {
+  const int k = blockIdx.x, rt = own_rt[k];
+  const int s0 = slot_ptr[k], s1 = slot_ptr[k + 1];
+  for (int e = threadIdx.x; e < 128 * nzc; e += 256) {
+    const int cls = e >> 7, row = e & 127;
+    Hc4[(size_t)cls * R_pad + (size_t)rt * 128 + row] = hc_slot_sum(Hp + cls * 128 + row, slot_idx, s0, s1, (size_t)SK_HC * 128);
+  }
+}
+
 // grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16.
 // The block first sums the 4 k-quarter slots of Hc for ITS rows and the nzc classes in use into LDS (one pass of coalesced
 // loads) -- reading them per thread and per row from global cost more than the 42 MB Rp stream itself (20 -> 11 us).
@@ -1099,7 +1255,8 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
 __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad, int nzc,
                                                           const double2 *__restrict__ Xe, const double2 *__restrict__ Ye,
                                                           const int *__restrict__ own_pv, const double *__restrict__ Hc4,
-                                                          const int *__restrict__ zclass, BRowArgs ra, int nslot) {
+                                                          const int *__restrict__ zclass, BRowArgs ra, int nslot,
+                                                          const int *__restrict__ slot_ptr, const int *__restrict__ slot_idx) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char zf_smem[];
   double *H = reinterpret_cast<double *>(zf_smem);          // [n_own * 128][nzc]
@@ -1123,6 +1280,13 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
     ye0[u] = Ye[(size_t)((pk >> 12) & 4095) * ne_pad + i];
   }
   const int nrow = n_own * 128;
+  if (slot_ptr) {
+    // Hc4 = the segments' projected pieces (sk_project_out): the pieces of a row tile are added here, in list order
+    for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {
+      const int cls = e / nrow, rowl = e - cls * nrow, k = rowl >> 7;
+      H[rowl * nzc + cls] = hc_slot_sum(Hc4 + cls * 128 + (rowl & 127), slot_idx, slot_ptr[k], slot_ptr[k + 1], (size_t)SK_HC * 128);
+    }
+  } else
   for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {      // class-major Hc4: coalesced runs of rows, classes in use only
     const int cls = e / nrow, rowl = e - cls * nrow;
     const double *h = Hc4 + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 7] * 128 + (rowl & 127);
@@ -1187,12 +1351,13 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
 bool zc_final_fits(int n_own, int nzc) { return n_own > 0 && (size_t)n_own * 128 * nzc * sizeof(double) <= 64 * 1024; }
 
 static void launch_b_zc_final(hipStream_t s, const DevPlan &pl, int n_own, const int *own_rt, int ne_pad, int nzc, const double2 *Xe,
-                              const double2 *Ye, const int *own_pv, const double *Hc, const int *zclass, const BRowArgs &fin, int nslot) {
+                              const double2 *Ye, const int *own_pv, const double *Hc, const int *zclass, const BRowArgs &fin, int nslot,
+                              const int *slot_ptr = nullptr, const int *slot_idx = nullptr) {
   const size_t lds = (size_t)n_own * 128 * nzc * sizeof(double);
   static DynLdsCache granted{};
   ensure_dyn_lds(b_zc_final_kernel, lds, granted);
   hipLaunchKernelGGL(b_zc_final_kernel, dim3(ne_pad / 16), dim3(1024), lds, s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Xe, Ye, own_pv, Hc,
-                     zclass, fin, nslot);
+                     zclass, fin, nslot, slot_ptr, slot_idx);
 }
 
 static void launch_b_zc_dot(hipStream_t s, int n_own, const int *own_rt, int R_pad, int ne_pad, int nzc, const double *Rp,
@@ -1298,6 +1463,19 @@ void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const
   hipLaunchKernelGGL(b_hc_kernel, dim3(pl.R_pad / 16, 4), dim3(256), 0, s, pl.C_pad, pl.n_col_tiles, rt_mine, nzc16,
                      pl.nb_act, Gwf, Tzc, Hc, pl.R_pad);
   if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 4);      // b_hc writes four k-quarter slots
+  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 4);
+}
+
+// planar electrodes, sk_gemm in projecting mode: Hp = the segments' pieces; slot lists per owned row tile.  fin: the dot kernel
+// adds the pieces itself (presum: hc_sum first -- many pieces per tile, every block of the dot kernel would re-add them all);
+// otherwise hc_sum -> slot 0 of Hc (the other slots stay zero) -> b_zc_dot.
+void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
+                                  const int *slot_ptr, const int *slot_idx, bool presum, const double *Rp, const double2 *Xe,
+                                  const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
+  if (n_own <= 0) return;
+  if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
+  hipLaunchKernelGGL(hc_sum_kernel, dim3(n_own), dim3(256), 0, s, own_rt, pl.R_pad, nzc, Hp, slot_ptr, slot_idx, Hc);
+  if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 4);
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 4);
 }
 

@@ -111,30 +111,61 @@ def test_pair_rows_match_the_reference_membership_rule(newton, etypes):
     assert gp["npairs"] >= got["npairs"]
 
 
-def test_sk_gemm_kernel_does_not_spill():
+def test_sk_gemm_chunk_loop_does_not_spill():
     """the dominant kernel sits at the 256-register budget of two waves per SIMD; a change that tips the NFW = 5 bodies over it
     makes the allocator spill inside the chunk loop (round 3: -15 % at the 16384 / 262144 size, invisible in the parity tests).
-    Cross-compile the kernels for gfx950 (no GPU needed) and read the compiler's resource remarks."""
+    Cross-compile the kernels for gfx950 (no GPU needed), read the compiler's resource remarks and the assembly: no SGPR spill,
+    and no scratch access in any loop that multiplies (a basic block of a loop whose blocks hold MFMA instructions).  The
+    projecting epilogue of a segment (sk_project_out) may park a few of the NEXT segment's constants in scratch: once per
+    segment, outside the chunk loop -- bounded here."""
     import os
     import re
     import shutil
     import subprocess
+    import tempfile
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         import pytest
         pytest.skip("no hipcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "lammps-user-conp2_amd", "csrc", "conp_kernels.hip")
-    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", src, "-o", os.devnull,
-                        "-I" + os.path.join(root, "include"), "-Rpass-analysis=kernel-resource-usage"],
-                       capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", asm,
+                            "-I" + os.path.join(root, "include"), "-Rpass-analysis=kernel-resource-usage"],
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        text = open(asm).read()
     blocks = re.split(r"remark: Function Name: ", p.stderr)
     sk = [b for b in blocks if b.startswith("_ZN4conp14sk_gemm_kernel")]
     assert len(sk) == 1
     scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", sk[0]).group(1))
-    vspill = int(re.search(r"VGPRs Spill: (\d+)", sk[0]).group(1))
     sspill = int(re.search(r"SGPRs Spill: (\d+)", sk[0]).group(1))
     vgprs = int(re.search(r" VGPRs: (\d+)", sk[0]).group(1))
-    assert (scratch, vspill, sspill) == (0, 0, 0), (scratch, vspill, sspill)
+    assert sspill == 0 and scratch <= 128, (scratch, sspill)
     assert vgprs <= 256
+    # the kernel's body, cut into basic blocks with the loop each belongs to (the compiler's own annotations)
+    m = re.search(r"^_ZN4conp14sk_gemm_kernel\w*:[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    assert m
+    loop_of, body_of, cur = {}, {}, None
+    lines = m.group(1).split("\n")
+    for k, ln in enumerate(lines):
+        lab = re.match(r"^(\.LBB\d+_\d+):(.*)$", ln)
+        if lab:
+            cur = lab.group(1)
+            body_of[cur] = []
+            note = lab.group(2) + " " + (lines[k + 1] if k + 1 < len(lines) else "")
+            hdr = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", note)
+            if hdr:
+                loop_of[cur] = (hdr.group(1), int(hdr.group(2)))
+            elif "This Inner Loop Header" in note or "This Loop Header" in note:
+                d = re.search(r"Header: Depth=(\d+)", note)
+                loop_of[cur] = (cur[2:], int(d.group(1)) if d else 1)
+        elif cur:
+            body_of[cur].append(ln)
+    mfma_loops = {loop_of[b][0] for b, body in body_of.items()
+                  if b in loop_of and loop_of[b][1] >= 2 and any("v_mfma_f64" in x for x in body)}
+    assert mfma_loops, "no chunk loop found"
+    bad = [b for b, body in body_of.items() if b in loop_of and loop_of[b][0] in mfma_loops and any("scratch_" in x for x in body)]
+    assert not bad, bad
+
