@@ -643,7 +643,8 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
       if (f < 3) {
         // not earlier: the registers are the ones this row fragment's accumulators free.  (Requesting them right after the
         // multiplies above, to have the class loop in between, makes the allocator spill hundreds of registers; pulling the
-        // wave's weights into L2 with throw-away loads during the segment's last chunk changed nothing: A/B 240.8 vs 240.6 us.)
+        // wave's weights into L2 with throw-away loads during the segment's last chunk changed nothing: A/B 240.8 vs 240.6 us;
+        // parking the weights of fragments 2 and 3 in the dead accumulators of 0 and 1: 450 spilled registers.)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int g = 0; g < NFW; ++g)
@@ -1211,6 +1212,7 @@ __global__ __launch_bounds__(1024) void b_zc_dot_kernel(int n_own, const int *__
   for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {
     const int cls = e / nrow, rowl = e - cls * nrow;
     const double *h = Hc4 + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 5] * 128 + blockIdx.y * 32 + (rowl & 31);
+    if (nslot == 1) { H[rowl * nzc + cls] = h[0]; continue; }          // already summed (hc_sum_kernel)
     const double h03 = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);       // slots = column slices of the reduction (4 or 8)
     H[rowl * nzc + cls] = nslot == 4 ? h03 : h03 + ((h[4 * hp] + h[5 * hp]) + (h[6 * hp] + h[7 * hp]));
   }
@@ -1290,6 +1292,7 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {      // class-major Hc4: coalesced runs of rows, classes in use only
     const int cls = e / nrow, rowl = e - cls * nrow;
     const double *h = Hc4 + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 7] * 128 + (rowl & 127);
+    if (nslot == 1) { H[rowl * nzc + cls] = h[0]; continue; }          // already summed (hc_sum_kernel)
     const double h03 = (h[0] + h[hp]) + (h[2 * hp] + h[3 * hp]);       // slots = column slices of the reduction (4 or 8)
     H[rowl * nzc + cls] = nslot == 4 ? h03 : h03 + ((h[4 * hp] + h[5 * hp]) + (h[6 * hp] + h[7 * hp]));
   }
@@ -1468,15 +1471,15 @@ void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const
 
 // planar electrodes, sk_gemm in projecting mode: Hp = the segments' pieces; slot lists per owned row tile.  fin: the dot kernel
 // adds the pieces itself (presum: hc_sum first -- many pieces per tile, every block of the dot kernel would re-add them all);
-// otherwise hc_sum -> slot 0 of Hc (the other slots stay zero) -> b_zc_dot.
+// otherwise hc_sum -> slot 0 of Hc -> b_zc_dot.
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
                                   const int *slot_ptr, const int *slot_idx, bool presum, const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
   if (n_own <= 0) return;
   if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
   hipLaunchKernelGGL(hc_sum_kernel, dim3(n_own), dim3(256), 0, s, own_rt, pl.R_pad, nzc, Hp, slot_ptr, slot_idx, Hc);
-  if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 4);
-  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 4);
+  if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 1);
+  else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 1);
 }
 
 // ================================================================================================
