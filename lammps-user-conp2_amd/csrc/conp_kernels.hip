@@ -589,7 +589,9 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
   // (global address space spelled out: the pointers come out of memory behind an asm barrier, the compiler would use FLAT loads,
   //  which count on the LDS counter too -- every wait for an LDS read then waits for the weights in flight)
   typedef __attribute__((address_space(1))) const double *gcd_t;
-  gcd_t wp = (gcd_t)(wfull + ((unsigned)c.it.rt * 128 + 64 * rh + fk) * cpad + colb);             // + (16 f + 4 r) * cpad
+  // (the 'a' and 'b' rows of a planar vector carry the same weight, KPlan::wfull: both row halves read the 'a' rows -- the second
+  //  wave of a column group finds the lines in L2)
+  gcd_t wp = (gcd_t)(wfull + ((unsigned)c.it.rt * 128 + fk) * cpad + colb);                       // + (16 f + 4 r) * cpad
   gcd_t tzg = (gcd_t)tzt;
   // the weights of row fragment f + 1 are requested as soon as those of f have been used; the tile's z-class phases go through LDS
   double wv[NFW > 0 ? NFW : 1][4];
