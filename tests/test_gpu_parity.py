@@ -655,6 +655,31 @@ def test_device_row_regrouping_keeps_the_list_order(deck, newton, monkeypatch):
     assert np.array_equal(res[0][0], res[1][0])
 
 
+@pytest.mark.parametrize("deck,mode", [("il_onelayer", "ffield"), ("il_twolayer", "ffield"), ("dilute", "slab")])
+def test_projecting_epilogue_equals_the_partial_tile_path(deck, mode, monkeypatch):
+    """planar electrodes: a segment of sk_gemm projects its partial tile on the z classes before it leaves the registers and the
+    pieces are added afterwards; the comparison path (CONP_SK_PARTIALS) adds the partial tiles and projects the sum -- the same
+    terms re-associated.  The structure factors, which the projecting update never forms, are re-formed on request through the
+    partial-tile kernels: the same bits as the comparison path's."""
+    s = systems.deck(deck, mode, etypes=(deck != "dilute"))
+    at, alist, blist = neighbor.build_lists(s)
+    res = []
+    for partials in (False, True):
+        if partials:
+            monkeypatch.setenv("CONP_SK_PARTIALS", "1")
+        fx = FixConp(s)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.b_cal(at)
+        b = fx.vectors()[0].copy()
+        sr, si = fx.sfac()
+        res.append((b, sr.copy(), si.copy(), fx.info().n_zclasses))
+        fx.close()
+    assert res[0][3] == res[1][3] > 0
+    assert rel_err(res[0][0], res[1][0]) < 1e-12
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
 def _gpu_shard_worker(rank, world, port, out):
     import os, sys
     import torch
