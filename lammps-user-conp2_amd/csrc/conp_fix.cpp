@@ -245,13 +245,12 @@ struct conp_fix {
       d_pp_tw2, d_pp_re, d_pp_im, d_pp_ew, d_eta_ij, d_fo_ij, d_u0_i, d_diag_atom, d_setzvec;
   DevBuf<double2> d_Xt, d_Yt, d_Zt, d_Xe, d_Ye;      // d_Xe / d_Ye: electrode atoms' axis phases [k][ne_pad] (once per run)
   DevBuf<int> d_type, d_atom2eleall, d_elyte_idx, d_p_ikx, d_p_iky, d_p_sgn, d_sf_row_a, d_sf_col_c, d_k_sign, d_k_p, d_k_m,
-      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_seg_idx, d_hslot_ptr, d_hslot_idx, d_rt_slot, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of, d_ele_csr_row;
+      d_elecheck, d_zclass, d_nb_act, d_rt_mine, d_own_rt, d_own_pv, d_ele_pairs, d_a_chunk_group, d_ct_ptr, d_seg_ptr, d_seg_idx, d_hslot_ptr, d_hslot_idx, d_b_rowptr, d_b_ele, d_b_oth, d_a_rowptr, d_a_ele, d_a_oth, d_a_col, d_bl_ilist, d_bl_numneigh, d_bl_first, d_bl_neigh, d_pp_egrid, d_ipiv, d_info, d_cg_done, d_iota, d_ele_csr_ptr, d_ele_csr_of, d_ele_csr_row;
   bool left_stale = false;          // the fused GEMV + charge write leaves the fix scalar's group-1 sum to refresh_scalar()
   double left_potdiff = 0.0;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
   DevBuf<SkProj> d_skproj;
-  DevBuf<unsigned> d_hticket;
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   bool b_bound = false, q_bound = false;         // conp_fix_bind_device_buffers gave us the host's vectors
@@ -690,29 +689,8 @@ struct conp_fix {
   bool sk_projects() const {
     return nzc > 0 && nzc <= sk_hc_max_classes() && !args.pppm && !sk_partials && !no_fuse;
   }
-  // who adds a row tile's pieces: its last segment inside sk_gemm (many pieces per tile: the full chip on the headline sizes), the
-  // dot kernel (few: the decks), or hc_sum (CONP_HC_PRESUM comparison switch)
-  bool hc_in_launch() const { return !hc_presum_env && hslots > 16 * (int)own_rt_h.size(); }
-  bool skproj_dirty = true;
-  void upload_skproj() {
-    std::vector<int> rt_slot(plan.n_row_tiles, -1);
-    for (size_t k = 0; k < own_rt_h.size(); ++k) rt_slot[own_rt_h[k]] = (int)k;
-    d_rt_slot.upload(rt_slot, stream);
-    d_hticket.reserve(std::max<size_t>(1, own_rt_h.size())); d_hticket.zero(stream);
-    SkProj pj{};
-    pj.wfull = d_wfull.p; pj.tzt = d_TzcT.p; pj.nzc = nzc; pj.cpad = plan.C_pad;
-    pj.ticket = hc_in_launch() ? d_hticket.p : nullptr;
-    pj.rt_slot = d_rt_slot.p; pj.slot_ptr = d_hslot_ptr.p; pj.slot_idx = d_hslot_idx.p;
-    pj.hpart = d_Hpart.p; pj.hc = d_Hc.p; pj.r_pad = plan.R_pad;
-    d_skproj.upload(std::vector<SkProj>{pj}, stream);
-    skproj_dirty = false;
-  }
   void reserve_partials(bool tiles_too = false) {
-    if (sk_projects()) {
-      const double *before = d_Hpart.p;
-      d_Hpart.reserve(std::max<size_t>(1, items_h.size()) * sk_hc_stride());
-      if (d_Hpart.p != before) skproj_dirty = true;
-    }
+    if (sk_projects()) d_Hpart.reserve(std::max<size_t>(1, items_h.size()) * sk_hc_stride());
     if (!sk_projects() || tiles_too)
       if ((size_t)items_h.size() * 128 * 320 > d_Gpart.n) { d_Gpart.reserve((size_t)items_h.size() * 128 * 320); d_Gpart.zero(stream); }
   }
@@ -907,7 +885,6 @@ struct conp_fix {
     hslots = (int)hidx.size();
     if (hidx.empty()) hidx.push_back(0);
     d_hslot_ptr.upload(hptr, stream); d_hslot_idx.upload(hidx, stream);
-    skproj_dirty = true;
   }
 
   void gather_xele(const conp_atoms *at) {
@@ -980,7 +957,7 @@ struct conp_fix {
         for (int t = 0; t < plan.C_pad; ++t)
           for (int c = 0; c < nzc; ++c) TzcT[(size_t)c * plan.C_pad + t] = Tzc[(size_t)t * 64 + c];
         d_TzcT.upload(TzcT, stream);
-        skproj_dirty = true;            // (the parameter block points at buffers that build_items may still (re)allocate)
+        d_skproj.upload(std::vector<SkProj>{SkProj{d_wfull.p, d_TzcT.p, nzc, plan.C_pad}}, stream);
         d_Hc.reserve((size_t)8 * plan.R_pad * 64); d_Hc.zero(stream);     // 8 slots: the reduction's column slices (b_hc: 4, the rest stay 0)
       }
     }
@@ -1516,7 +1493,6 @@ struct conp_fix {
       use_fin = ride && nzc > 0 && zc_final_fits((int)own_rt_h.size(), nzc);
       const bool proj = sk_projects();
       reserve_partials();
-      if (proj && skproj_dirty) upload_skproj();
       prof.begin("sk_gemm", stream);
       launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, d_seg_idx.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                      proj ? d_Hpart.p : d_Gpart.p, proj ? d_skproj.p : nullptr);
@@ -1525,7 +1501,7 @@ struct conp_fix {
       if (proj) {
         // planar electrodes: the segments left their projected pieces (128 x nzc each); the dot kernel adds them per row tile
         // (a launch of its own first when there are many: every block of the dot kernel would re-add them all)
-        const int presum = hc_in_launch() ? 2 : (hc_presum_env ? (atoi(hc_presum_env) != 0) : hslots > 16 * (int)own_rt_h.size());
+        const bool presum = hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 16 * (int)own_rt_h.size();
         prof.begin("reduce_project", stream);
         launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Hpart.p, d_hslot_ptr.p, d_hslot_idx.p,
                                      presum, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);

@@ -22,16 +22,7 @@ struct DevPlan {              // device copy of KPlan geometry
 struct SkItem { int rt, ct, nba, c0, c1; unsigned nbf; };   // one sk_gemm segment: tile + chunk range [c0, c1) of 16 atoms;
                                                           // nbf = active 8-kz column fragments per 16-row fragment, 4 x 8 bit
 // parameter block of sk_gemm's projecting epilogue (device memory): weights [R_pad][C_pad], z-class phases class-major [nzc][C_pad]
-struct SkProj {
-  const double *wfull, *tzt; int nzc, cpad;
-  // in-launch sum of a row tile's pieces by its last segment (ticket == nullptr: the pieces are added by hc_sum / the dot kernel)
-  unsigned *ticket;                   // [owned row tiles], zero between updates
-  const int *rt_slot;                 // [n_row_tiles] -> index of the row tile in the owned list, -1 otherwise
-  const int *slot_ptr, *slot_idx;     // the owned row tiles' segment lists
-  const double *hpart;                // the pieces
-  double *hc;                         // class-major Hc table [64][r_pad], slot 0
-  int r_pad;
-};
+struct SkProj { const double *wfull, *tzt; int nzc, cpad; };
 struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
@@ -106,7 +97,7 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 int sk_hc_stride();           // doubles per segment of sk_gemm's projected output
 int sk_hc_max_classes();      // most z classes the projecting mode takes
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
-                                  const int *slot_ptr, const int *slot_idx, int presum /*0 dot kernel adds, 1 hc_sum, 2 already added in sk_gemm*/, const double *Rp, const double2 *Xe,
+                                  const int *slot_ptr, const int *slot_idx, bool presum, const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);

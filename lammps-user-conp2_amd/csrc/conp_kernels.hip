@@ -659,8 +659,7 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
   for (unsigned o = t; o < (unsigned)nzc * 128; o += 512) {
     const double2 *src = reinterpret_cast<const double2 *>(Lp + 4 * o);
     const double2 v0 = src[0], v1 = src[1];
-    // (write-through store: the row tile's last segment may add the pieces inside this launch, sk_sum_pieces)
-    __hip_atomic_store(hout + o, (v0.x + v0.y) + (v1.x + v1.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hout[o] = (v0.x + v0.y) + (v1.x + v1.y);
   }
   __syncthreads();          // (the next segment's prologue writes panels into this memory)
 }
@@ -745,65 +744,6 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
 #endif
 }
 
-
-// The segment that finishes LAST on a row tile adds the tile's pieces (all column tiles, all splits; list order, whoever is last:
-// the bits do not depend on the arrival order) into slot 0 of the class-major Hc table -- no launch of its own for that
-// (hc_sum_kernel: 5.3 us + a kernel boundary at the headline size).  Hand-off without cache-wide fences (the per-XCD L2s are not
-// coherent; MI355X_MICROARCH.md, inter-workgroup visibility): the pieces are write-through (sc1) stores, every storing wave drains
-// its stores (vmcnt 0) before the workgroup's barrier, ONE agent-scope ticket add per segment, sc1 loads by the last arriver,
-// which also re-arms the ticket for the next update.  Called by all threads of the workgroup after the segment's epilogue.
-__device__ __forceinline__ void sk_sum_pieces(const SkProj *pp, int rt, char *smem) {
-  const __attribute__((address_space(4))) SkProj *cp = (const __attribute__((address_space(4))) SkProj *)pp;
-  const int k = cp->rt_slot[rt];
-  if (k < 0) return;                                   // (wave-uniform: not a row tile of this rank's dot kernel)
-  unsigned *flag = reinterpret_cast<unsigned *>(smem);
-  const unsigned t = threadIdx.x;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int s0 = cp->slot_ptr[k], s1 = cp->slot_ptr[k + 1];
-  if (t == 0) {
-    const unsigned old = __hip_atomic_fetch_add(cp->ticket + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned last = old + 1u == (unsigned)(s1 - s0);
-    if (last) __hip_atomic_store(cp->ticket + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[0] = last;
-  }
-  __syncthreads();
-  const unsigned last = flag[0];
-  __syncthreads();                                     // (flag[] is panel memory: the next segment's prologue writes there)
-  if (!last) return;
-  const int nzc = cp->nzc, nout = 128 * nzc;
-  // output o = (class, row); with two classes the 512 threads split every list in two halves (added: first half + second half)
-  const int nparts = nout <= 256 ? 2 : 1;
-  double *part = reinterpret_cast<double *>(smem) + 64;
-  const double *hp = cp->hpart;
-  const int *sidx = cp->slot_idx;
-  for (int o0 = 0; o0 < nout; o0 += 512 / nparts) {
-    const int o = o0 + (int)(t % (512 / nparts)), h = (int)(t / (512 / nparts));
-    const int a = s0 + (s1 - s0) * h / nparts, b = s0 + (s1 - s0) * (h + 1) / nparts;
-    double acc = 0.0;
-    if (o < nout) {
-      int sl = a;
-      for (; sl + 8 <= b; sl += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(hp + (size_t)sidx[sl + u] * (SK_HC * 128) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      }
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        v[u] = sl + u < b ? __hip_atomic_load(hp + (size_t)sidx[sl + u] * (SK_HC * 128) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    if (nparts == 2) {
-      if (h == 1) part[t - 256] = acc;
-      __syncthreads();
-      if (h == 0) acc += part[t];
-    }
-    if (h == 0 && o < nout) cp->hc[(size_t)(o >> 7) * cp->r_pad + (size_t)rt * 128 + (o & 127)] = acc;
-    __syncthreads();
-  }
-}
 
 // Persistent-style launch: workgroup w runs the segments seg_idx[seg_ptr[w] .. seg_ptr[w+1]-1] (host: equal cost per workgroup,
 // a segment boundary may fall inside a tile -- "stream-K" over the atom chunks).
@@ -902,11 +842,6 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
     if (late) { SK_BODY_NFW(true) } else { SK_BODY_NFW(false) }
 #undef SK_BODY_NFW
 #undef SK_BODY_F0
-    if (proj) {
-      const SkProj *pq = proj;                         // (opaque copy: keeps the parameter block's loads here)
-      asm volatile("" : "+s"(pq));
-      if (((const __attribute__((address_space(4))) SkProj *)pq)->ticket) sk_sum_pieces(pq, c.it.rt, smem);
-    }
 #ifdef SK_STAMP
     if (t == 0 && sg < 4096) {
       unsigned long long *o = sk_seg_buf + (size_t)sg * 4;
@@ -1249,7 +1184,12 @@ __device__ __forceinline__ double hc_slot_sum(const double *__restrict__ h, cons
 }
 
 // the segments' Hc pieces of every owned row tile added into slot 0 of Hc4 (class-major, [64][R_pad]) for the consumers that read
-// that table (b_zc_dot_kernel: row quarters of ALL tiles per block); one block per owned row tile
+// that table (b_zc_dot_kernel: row quarters of ALL tiles per block); one block per owned row tile.
+// (Built, measured and removed: the same sum by the LAST segment to finish on a row tile, inside sk_gemm -- write-through stores of
+//  the pieces, vmcnt(0), barrier, one agent-scope ticket add per segment, sc1 loads by the last arriver.  This launch (5.3 us + a
+//  kernel boundary) went away and sk_gemm grew by 5.7-6.4 us: every workgroup pays the atomic's round trip behind its epilogue and
+//  eight late ones add 39 pieces each on the kernel's critical path.  0.2884 vs 0.2890 ms per update: nothing.  The same for
+//  sym_finish inside sym_gemv: 25.6 us instead of 23.1.)
 __global__ __launch_bounds__(256) void hc_sum_kernel(const int *__restrict__ own_rt, int R_pad, int nzc, const double *__restrict__ Hp,
                                                      const int *__restrict__ slot_ptr, const int *__restrict__ slot_idx,
                                                      double *__restrict__ Hc4) {
@@ -1536,16 +1476,15 @@ void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 4);
 }
 
-// planar electrodes, sk_gemm in projecting mode: Hp = the segments' pieces; slot lists per owned row tile.  presum 0 (fin only): the
-// dot kernel adds the pieces itself; 1: hc_sum first (many pieces per tile, every block of the dot kernel would re-add them all);
-// 2: the row tile's last segment has added them inside sk_gemm (SkProj::ticket);
+// planar electrodes, sk_gemm in projecting mode: Hp = the segments' pieces; slot lists per owned row tile.  fin: the dot kernel
+// adds the pieces itself (presum: hc_sum first -- many pieces per tile, every block of the dot kernel would re-add them all);
 // otherwise hc_sum -> slot 0 of Hc -> b_zc_dot.
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
-                                  const int *slot_ptr, const int *slot_idx, int presum, const double *Rp, const double2 *Xe,
+                                  const int *slot_ptr, const int *slot_idx, bool presum, const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
   if (n_own <= 0) return;
-  if (fin && presum == 0) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
-  if (presum != 2) hipLaunchKernelGGL(hc_sum_kernel, dim3(n_own), dim3(256), 0, s, own_rt, pl.R_pad, nzc, Hp, slot_ptr, slot_idx, Hc);
+  if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
+  hipLaunchKernelGGL(hc_sum_kernel, dim3(n_own), dim3(256), 0, s, own_rt, pl.R_pad, nzc, Hp, slot_ptr, slot_idx, Hc);
   if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 1);
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 1);
 }
@@ -1775,9 +1714,6 @@ __global__ __launch_bounds__(256, 4) void sym_gemv_kernel(int ne_pad, const doub
   }
   if (!direct && bi != bj) yp[(size_t)bi * ne_pad + bj * SG_T + tid] = acc_t;
 }
-// (The finishing step inside this launch -- every 128-row block finished by the last of the nb workgroups that contribute to it,
-//  ticket + write-through hand-off as in sk_sum_pieces -- was built and measured: 25.6 us for the pair instead of 23.1; 528
-//  workgroups each pay an atomic round trip, and 32 late ones do serially what a launch of 64 blocks does at once.  Removed.)
 
 // y[row] = sum of the row's nb slots (fixed order), q = y + dV setq (+ qinit); then the charge write of gemv_finish_kernel's tail:
 // the block's rows own a contiguous run of the CSR atom list, walked by all threads (row of an entry: atoms_row)

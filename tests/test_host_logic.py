@@ -114,10 +114,10 @@ def test_pair_rows_match_the_reference_membership_rule(newton, etypes):
 def test_sk_gemm_chunk_loop_does_not_spill():
     """the dominant kernel sits at the 256-register budget of two waves per SIMD; a change that tips the NFW = 5 bodies over it
     makes the allocator spill inside the chunk loop (round 3: -15 % at the 16384 / 262144 size, invisible in the parity tests).
-    Cross-compile the kernels for gfx950 (no GPU needed), read the compiler's resource remarks and the assembly: no SGPR spill,
-    and no scratch access in any loop that multiplies (a basic block of a loop whose blocks hold MFMA instructions).  The
-    projecting epilogue of a segment (sk_project_out) may park a few of the NEXT segment's constants in scratch: once per
-    segment, outside the chunk loop -- bounded here."""
+    Cross-compile the kernels for gfx950 (no GPU needed), read the compiler's resource remarks and the assembly: no scratch
+    access and no SGPR spill traffic (v_readlane / v_writelane) in any loop that multiplies (a basic block of a loop whose blocks
+    hold MFMA instructions).  The epilogue of a segment (sk_project_out, sk_sum_pieces) may park a few of the NEXT segment's
+    constants: once per segment, outside the chunk loop -- bounded here."""
     import os
     import re
     import shutil
@@ -142,7 +142,7 @@ def test_sk_gemm_chunk_loop_does_not_spill():
     scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", sk[0]).group(1))
     sspill = int(re.search(r"SGPRs Spill: (\d+)", sk[0]).group(1))
     vgprs = int(re.search(r" VGPRs: (\d+)", sk[0]).group(1))
-    assert sspill == 0 and scratch <= 128, (scratch, sspill)
+    assert sspill <= 32 and scratch <= 128, (scratch, sspill)
     assert vgprs <= 256
     # the kernel's body, cut into basic blocks with the loop each belongs to (the compiler's own annotations)
     m = re.search(r"^_ZN4conp14sk_gemm_kernel\w*:[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
@@ -166,6 +166,8 @@ def test_sk_gemm_chunk_loop_does_not_spill():
     mfma_loops = {loop_of[b][0] for b, body in body_of.items()
                   if b in loop_of and loop_of[b][1] >= 2 and any("v_mfma_f64" in x for x in body)}
     assert mfma_loops, "no chunk loop found"
-    bad = [b for b, body in body_of.items() if b in loop_of and loop_of[b][0] in mfma_loops and any("scratch_" in x for x in body)]
+    spill_ops = ("scratch_", "v_readlane_b32", "v_writelane_b32")      # VGPR spills; SGPR spills go through VGPR lanes
+    bad = [b for b, body in body_of.items()
+           if b in loop_of and loop_of[b][0] in mfma_loops and any(op in x for x in body for op in spill_ops)]
     assert not bad, bad
 
