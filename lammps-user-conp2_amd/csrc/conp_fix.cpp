@@ -762,8 +762,10 @@ struct conp_fix {
     // one workgroup per CU, except for small problems: sk_reduce walks a tile's splits serially (~1 us per split), so a tile
     // is cut into more than 16 segments only when a segment still holds >= 8 chunks (measured on the decks: il_onelayer
     // 57 -> 52 us per update with 32 instead of 256 workgroups)
+    // With the projecting epilogue (planar electrodes) a segment leaves 8 KB, not a partial tile, and the dot kernel adds up to 32
+    // pieces per row tile itself: twice as many workgroups pay (il_onelayer 30.9 -> 29.4 us per update with 64; 128: 30.0).
     int nwg = std::max(1, num_cus);
-    nwg = std::min(nwg, std::max((int)(16 * nt), (int)((nt * (size_t)nchunks + 7) / 8)));
+    nwg = std::min(nwg, std::max((int)((sk_projects() ? 32 : 16) * nt), (int)((nt * (size_t)nchunks + 7) / 8)));
     nwg = std::max(1, nwg);
     if (exp_switch("CONP_SK_NWG")) nwg = std::max(1, atoi(exp_switch("CONP_SK_NWG")));
     // MFMA work of a tile ~ mean over its 4 row fragments of their active kz blocks (per-fragment sphere culling)
@@ -960,6 +962,8 @@ struct conp_fix {
         d_skproj.upload(std::vector<SkProj>{SkProj{d_wfull.p, d_TzcT.p, nzc, plan.C_pad}}, stream);
         d_Hc.reserve((size_t)8 * plan.R_pad * 64); d_Hc.zero(stream);     // 8 slots: the reduction's column slices (b_hc: 4, the rest stay 0)
       }
+      // the stream-K schedule was cut before the electrodes' geometry was known: planar electrodes take more, smaller shares
+      if (sk_projects() && !tiles_h.empty() && nl_pad > 0) { build_items(); reserve_partials(); }
     }
     sync();
   }
@@ -1501,7 +1505,7 @@ struct conp_fix {
       if (proj) {
         // planar electrodes: the segments left their projected pieces (128 x nzc each); the dot kernel adds them per row tile
         // (a launch of its own first when there are many: every block of the dot kernel would re-add them all)
-        const bool presum = hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 16 * (int)own_rt_h.size();
+        const bool presum = hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size();
         prof.begin("reduce_project", stream);
         launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Hpart.p, d_hslot_ptr.p, d_hslot_idx.p,
                                      presum, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);

@@ -660,7 +660,7 @@ def test_projecting_epilogue_equals_the_partial_tile_path(deck, mode, monkeypatc
     """planar electrodes: a segment of sk_gemm projects its partial tile on the z classes before it leaves the registers and the
     pieces are added afterwards; the comparison path (CONP_SK_PARTIALS) adds the partial tiles and projects the sum -- the same
     terms re-associated.  The structure factors, which the projecting update never forms, are re-formed on request through the
-    partial-tile kernels: the same bits as the comparison path's."""
+    partial-tile kernels (the two paths cut the atom axis into different shares: equal to rounding, not bit for bit)."""
     s = systems.deck(deck, mode, etypes=(deck != "dilute"))
     at, alist, blist = neighbor.build_lists(s)
     res = []
@@ -677,7 +677,7 @@ def test_projecting_epilogue_equals_the_partial_tile_path(deck, mode, monkeypatc
         fx.close()
     assert res[0][3] == res[1][3] > 0
     assert rel_err(res[0][0], res[1][0]) < 1e-12
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert rel_err(res[0][1], res[1][1]) < 1e-12 and rel_err(res[0][2], res[1][2]) < 1e-12
 
 
 def _gpu_shard_worker(rank, world, port, out):
