@@ -293,7 +293,23 @@ struct conp_fix {
     return rp;
   }
 
-  void sync() { HIP_TRY(hipStreamSynchronize(stream)); }
+  // The wait at the end of a host-buffer update: the runtime's blocking synchronisation wakes the thread tens of microseconds after
+  // the stream drained; polling the stream for the first two milliseconds (an update takes 0.03 - 20 ms) returns within a few.
+  // Longer waits (setup, large systems) fall back to the blocking call: no core is burnt for them.
+  const bool sync_block = exp_switch("CONP_SYNC_BLOCK") != nullptr;      // comparison switch: always the blocking call
+  const bool results_by_copy = exp_switch("CONP_RESULTS_COPY") != nullptr;      // comparison switch: charges / scalars back by hipMemcpyAsync
+  void sync() {
+    if (!sync_block) {
+      const double t0 = now_s();
+      for (;;) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIP_TRY(e);
+        if (now_s() - t0 > 2e-3) break;
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
 
   // ---------------------------------------------------------------------------------------------
   void init_device() {
@@ -1760,8 +1776,19 @@ struct conp_fix {
     }
     double t0 = time_host ? now_s() : 0.0;
     double *qe = pinned((size_t)ne_pad + 8);
-    HIP_TRY(hipMemcpyAsync(qe, d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
-    finish_scalar(potdiff);                 // one synchronisation for the charges and the scalars
+    if (results_by_copy) {
+      HIP_TRY(hipMemcpyAsync(qe, d_qele.p, ne * sizeof(double), hipMemcpyDeviceToHost, stream));
+      finish_scalar(potdiff);               // one synchronisation for the charges and the scalars
+    } else {
+      // charges and scalars stored into the page-locked staging area by ONE kernel (which also forms the fix scalar's group-1 sum):
+      // no copy-engine transfer at the end of the update
+      double *h = qe + ne_pad;
+      launch_results_out(stream, ne, d_elecheck.p, d_eleallq, d_scalars.p, left_stale, d_qele.p, qe, h);
+      left_stale = false;
+      sync();
+      scalar_output = (args.conq || args.cond) ? h[3] : potdiff * totsetq + h[1];
+      slabcorr = h[2];
+    }
     collect_b_times();
     if (time_host) { const double t1 = now_s(); th[3] += t1 - t0; t0 = t1; }
     // owned and ghost electrode atoms :1153-1158, through the (atom, row) list of the last post_neighbor (the atom arrays keep

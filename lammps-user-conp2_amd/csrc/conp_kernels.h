@@ -148,6 +148,8 @@ void launch_post_force(hipStream_t s, int inum, const int *ilist, const int *num
                        const double *q, const int *type, const int *atom2eleall, RealParams rp, double qqrd2e, double *f,
                        double *acc /*[9]: eng_coul, virial[6], sum q^2 of owned electrode atoms, contributing pairs*/, bool clear_f);
 void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v, double *out);
+void launch_results_out(hipStream_t s, int ne, const int *elecheck, const double *v, double *scal, bool do_left, const double *qele,
+                        double *host_q /*page-locked host memory*/, double *host_scal);
 
 // ---- once-per-run matrix work ------------------------------------------------------------------
 int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk, int nranks);

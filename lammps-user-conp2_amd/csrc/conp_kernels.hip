@@ -1992,6 +1992,35 @@ void launch_left_sum(hipStream_t s, int ne, const int *elecheck, const double *v
   hipLaunchKernelGGL(left_sum_kernel, dim3(1), dim3(1024), 0, s, ne, elecheck, v, out);
 }
 
+// The end of a host-buffer update: the group-1 sum (left_sum_kernel's, same tree) AND the results on their way to the host --
+// the electrode charges and the four scalars are stored straight into page-locked host memory by this kernel (posted PCIe writes,
+// 32 KB at Ne = 4096) instead of two copy-engine transfers behind it (each ~10 us of latency on this runtime).
+__global__ __launch_bounds__(1024) void results_out_kernel(int ne, const int *__restrict__ elecheck, const double *__restrict__ v,
+                                                           double *__restrict__ scal /*[4] device*/, int do_left,
+                                                           const double *__restrict__ qele, double *__restrict__ host_q,
+                                                           double *__restrict__ host_scal /*[4]*/) {
+  __shared__ double red[16];
+  if (do_left) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < ne; i += 1024) if (elecheck[i] == 1) s += v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int k = 0; k < 16; ++k) tot += red[k];
+      scal[1] = tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) host_scal[threadIdx.x] = scal[threadIdx.x];
+  for (int i = threadIdx.x; i < ne; i += 1024) host_q[i] = qele[i];
+}
+void launch_results_out(hipStream_t s, int ne, const int *elecheck, const double *v, double *scal, bool do_left, const double *qele,
+                        double *host_q, double *host_scal) {
+  hipLaunchKernelGGL(results_out_kernel, dim3(1), dim3(1024), 0, s, ne, elecheck, v, scal, do_left ? 1 : 0, qele, host_q, host_scal);
+}
+
 // ================================================================================================
 // 6. once-per-run: Ewald A matrix.
 //    k-space (km_ewald.cpp:584-645):  A_ij = sum_{r,t} w(r,t) Rp[r][i] Tz[t][i] Rp[r][j] Tz[t][j]   for i > j
