@@ -15,7 +15,17 @@
 #include "force.h"
 #endif
 
+#include "conp_mpi_comm.h"
+
 using namespace LAMMPS_NS;
+
+/* the same MPI-backed callbacks as fix_conp_hip.cpp / kspacemodule_hip.cpp (ctx = &world): conp_mpi_comm.h */
+static int pp_allreduce_sum(void *ctx, double *buf, int64_t n) { return conp_glue::cb_allreduce_sum(ctx, buf, n); }
+static int pp_allreduce_max_int(void *ctx, int *buf, int n) { return conp_glue::cb_allreduce_max_int(ctx, buf, n); }
+static int pp_allgather_int(void *ctx, int value, int *out) { return conp_glue::cb_allgather_int(ctx, value, out); }
+static int pp_allgatherv(void *ctx, const void *send, int64_t nbytes, void *recv, const int64_t *counts, const int64_t *displs) {
+  return conp_glue::cb_allgatherv(ctx, send, nbytes, recv, counts, displs);
+}
 
 PPPMConpHip::PPPMConpHip(LAMMPS *lmp) : PPPM(lmp), KSpaceModule(), h(nullptr), first(true) {}
 
@@ -42,7 +52,8 @@ conp_atoms PPPMConpHip::view() {
 void PPPMConpHip::conp_setup(bool lowmem) {
   lowmemflag = lowmem;
   if (fixconp == nullptr) error->all(FLERR, "pppm/conp/hip: register_fix() must precede conp_setup()");
-  if (comm->nprocs > 1) error->all(FLERR, "pppm/conp/hip: the device mesh is not sharded over MPI ranks yet (use the Ewald provider)");
+  /* several MPI ranks: the mesh is not sharded -- rank 0 owns it; the ranks' charged electrolyte atoms are gathered per update
+   * like for the Ewald provider, the electrode vector is summed over the ranks (pppm_conp.cpp:114,122 shard the mesh instead) */
   if (h == nullptr) {
     conp_fix_args fa;
     std::memset(&fa, 0, sizeof(fa));
@@ -59,8 +70,16 @@ void PPPMConpHip::conp_setup(bool lowmem) {
     env.ntypes = atom->ntypes;
     cutsq0.assign((size_t)(atom->ntypes + 1) * (atom->ntypes + 1), 0.0);
     env.cutsq = cutsq0.data();
-    env.device = 0; env.rank = 0; env.nranks = 1;
+    env.device = comm->nprocs > 1 ? -(2 + conp_glue::node_local_rank(world)) : 0;     // ranks of a NODE spread over its GPUs
+    env.rank = comm->me; env.nranks = comm->nprocs;
     fail_if(conp_fix_create(&fa, &env, &h));
+    if (comm->nprocs > 1) {
+      conp_comm cc;
+      cc.ctx = &world; cc.rank = comm->me; cc.nranks = comm->nprocs;
+      cc.allreduce_sum = pp_allreduce_sum; cc.allreduce_max_int = pp_allreduce_max_int;
+      cc.allgather_int = pp_allgather_int; cc.allgatherv = pp_allgatherv;
+      fail_if(conp_fix_set_comm(h, &cc));
+    }
   }
 }
 
@@ -98,6 +117,7 @@ void PPPMConpHip::b_cal(double *bbb) {          /* spread, Poisson solve, stenci
 }
 
 double PPPMConpHip::compute_particle_potential(int i) {
+  if (comm->nprocs > 1) error->all(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
   conp_atoms at = view();
   double u = 0.0;
   fail_if(conp_pppm_compute_particle_potential(h, &at, i, &u));
@@ -105,6 +125,7 @@ double PPPMConpHip::compute_particle_potential(int i) {
 }
 
 void PPPMConpHip::compute_group_potential(int groupbit, double *recv) {
+  if (comm->nprocs > 1) error->all(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
   conp_atoms at = view();
   sel.resize(atom->nlocal);
   for (int i = 0; i < atom->nlocal; ++i) sel[i] = (atom->mask[i] & groupbit) ? 1 : 0;
@@ -112,6 +133,7 @@ void PPPMConpHip::compute_group_potential(int groupbit, double *recv) {
 }
 
 void PPPMConpHip::total_density(double *density_brick) {
+  if (comm->nprocs > 1) error->all(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
   conp_atoms at = view();
   fail_if(conp_pppm_make_rho(h, &at, density_brick, nullptr, nullptr));
 }

@@ -223,11 +223,15 @@ def test_pppm_keyword_takes_the_mesh_from_the_kspace_style(tmp_path):
     fx.close()
 
 
-@pytest.mark.parametrize("name,axis,nranks", [("small_slab", 0, 2), ("dilute_ffield_etypes", 2, 2), ("small_ffield", 1, 3)])
-def test_several_mpi_ranks_match_one_rank(tmp_path, name, axis, nranks):
+@pytest.mark.parametrize("name,axis,nranks,pppm", [("small_slab", 0, 2, False), ("dilute_ffield_etypes", 2, 2, False),
+                                                   ("small_ffield", 1, 3, False), ("dilute_ffield_etypes", 1, 2, True)])
+def test_several_mpi_ranks_match_one_rank(tmp_path, name, axis, nranks, pppm):
     """FixConpHip on a spatially decomposed system (fix_conp.cpp:409, 641-648; km_ewald.cpp:782-786 are the reference's multi-rank
     sites): N rank threads, each with the owned atoms, ghosts and half lists of its slab, the collectives through the glue's
-    MPI-backed conp_comm callbacks (here the MPI mock).  Charges per tag, and the fix scalar on every rank, equal the one-rank run."""
+    MPI-backed conp_comm callbacks (here the MPI mock).  Charges per tag, and the fix scalar on every rank, equal the one-rank run.
+    pppm: the `pppm` keyword under several ranks -- the mesh lives on rank 0, the ranks' electrolyte atoms are gathered per update."""
+    mesh = (27, 24, 144, 5) if pppm else None
+    kw = dict(extra_args=["pppm"], pppm_mesh=mesh[:3], pppm_order=mesh[3]) if pppm else {}
     s = {"small_slab": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0, mode="slab"),
          "small_ffield": lambda: systems.small_random(ne_side=4, n_elyte=96, lz=60.0),
          "dilute_ffield_etypes": lambda: systems.deck("dilute", "ffield", etypes=True)}[name]()
@@ -240,7 +244,7 @@ def test_several_mpi_ranks_match_one_rank(tmp_path, name, axis, nranks):
 
     # one rank, ctypes path
     at, alist, blist = neighbor.build_lists(s)
-    fx = FixConp(s)
+    fx = FixConp(s, **kw)
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
     fx.setup_pre_force(at, 0, s.potdiff)
@@ -259,9 +263,10 @@ def test_several_mpi_ranks_match_one_rank(tmp_path, name, axis, nranks):
     for r, (atr, al, bl) in enumerate(parts):
         case = str(tmp_path / f"case{r}.txt")
         steps = [(0, s.potdiff, 0, None), (1, 0.7, 0, moved(atr)), (2, 0.7, 1, None)]
-        tokens = fix_command_for(s)
+        tokens = fix_command_for(s, extra=["pppm"]) if pppm else fix_command_for(s)
         tokens[6] = "v_dv"                               # the potential difference changes from step to step: an equal-style variable
-        write_case(case, s, atr, [al] if al is bl else [al, bl], tokens, steps, variable=("dv", s.potdiff))
+        write_case(case, s, atr, [al] if al is bl else [al, bl], tokens, steps, variable=("dv", s.potdiff),
+                   **(dict(mesh=mesh) if pppm else {}))
         cases.append(case)
     res, proc = run_driver(cases, str(tmp_path))
     assert res["rc"] == 0 and res["error"] is None, proc.stdout[-3000:] + proc.stderr[-2000:]
