@@ -1389,14 +1389,14 @@ struct conp_fix {
       // iteration's update alone before the read-back; same arithmetic, same bits as the two-launch form
       auto step = [&](int it, int mode) {
         launch_cg_step(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_ap.p, d_cg_scal.p, args.tolerance,
-                       d_cg_done.p, it, hist_dev, mode);
+                       d_cg_done.p, it, hist_dev, mode, results_by_copy ? nullptr : ctl, 16 + it + 1);
       };
       step(1, 1);                                            // iter = the iteration whose matvec is in flight
       while (true) {
         const int last = std::min(args.maxiter - 1, iter + batch - 1);
         for (; iter < last; ++iter) step(iter + 1, 2);
-        step(iter, 4);
-        HIP_TRY(hipMemcpyAsync(ctl, d_cg_scal.p, (size_t)(16 + iter + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        step(iter, 4);                                        // (stores the control block into `ctl` itself)
+        if (results_by_copy) HIP_TRY(hipMemcpyAsync(ctl, d_cg_scal.p, (size_t)(16 + iter + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
         sync();
         done = ctl[8] != 0.0;
         if (done || iter + 1 >= args.maxiter) break;

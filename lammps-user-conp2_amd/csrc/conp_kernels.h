@@ -184,6 +184,7 @@ void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *re
 // one launch per CG iteration (update of iteration iter - 1 repeated by every workgroup + its rows of the matvec); see the kernel
 bool cg_step_fits(int n);
 void launch_cg_step(hipStream_t s, int n, const double *A, const double *b, double *q, double *res2 /*[2][n]*/, double *p2 /*[2][n]*/,
-                    double *ap2 /*[2][n]*/, double *scal, double tolerance, int *done, int iter, double *hist, int mode);
+                    double *ap2 /*[2][n]*/, double *scal, double tolerance, int *done, int iter, double *hist, int mode,
+                    double *host_ctl = nullptr /*page-locked host memory: mode 4 stores n_ctl doubles of scal there*/, int n_ctl = 0);
 
 }  // namespace conp

@@ -2479,11 +2479,18 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
                                                        double *__restrict__ q, double *__restrict__ res2, double *__restrict__ p2,
                                                        double *__restrict__ ap2, double *__restrict__ scal, double tolerance,
                                                        int *__restrict__ done, int iter, double *__restrict__ hist, int mode,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, double *__restrict__ host_ctl, int n_ctl) {
   extern __shared__ __attribute__((aligned(16))) char cg_smem[];
   double *pl = reinterpret_cast<double *>(cg_smem);          // the direction of the matvec: [n]
   __shared__ double red[16];
-  if (mode != 1 && *done) return;                            // (the start launch clears the flag of the previous solve itself)
+  // mode 4 ends a batch: its one workgroup stores the control block (scalars, flag, net charge, residual history -- n_ctl doubles
+  // from scal) straight into page-locked host memory: the host's read-back needs no copy-engine transfer behind this launch
+  auto to_host = [&]() {
+    if (mode != 4 || !host_ctl) return;
+    __syncthreads();                                         // (scal[] entries written by thread 0 of this workgroup above)
+    for (int i = threadIdx.x; i < n_ctl; i += 1024) host_ctl[i] = scal[i];
+  };
+  if (mode != 1 && *done) { to_host(); return; }             // (the start launch clears the flag of the previous solve itself)
   const bool writer = blockIdx.x == 0;
   const int k_upd = mode == 4 ? iter : iter - 1;             // the iteration whose update this launch applies (modes 2, 4)
   const int so = mode == 4 ? (iter + 1) & 1 : iter & 1;      // set written: the state entering iteration k_upd + 1
@@ -2592,13 +2599,14 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
         qs = block_sum_1024(qs, red);
         if (threadIdx.x == 0) { *done = 1; scal[6] = (double)k_upd; scal[7] = qs; scal[8] = 1.0; }
       }
+      to_host();
       return;
     }
   } else {
     const double *p_i = p2 + (size_t)(iter & 1) * n;
     for (int i = threadIdx.x; i < n; i += 1024) pl[i] = p_i[i];
   }
-  if (mode == 4) return;
+  if (mode == 4) { to_host(); return; }
   __syncthreads();
   // 16 waves: up to 16 rows per workgroup; small matrices take 8 so that more CUs pull on the matrix (Ne = 1664: 208 instead of 104)
   const int wv = threadIdx.x >> 6;
@@ -2612,13 +2620,13 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
 bool cg_step_fits(int n) { return n > 0 && (size_t)n * sizeof(double) <= 128 * 1024; }
 
 void launch_cg_step(hipStream_t s, int n, const double *A, const double *b, double *q, double *res2, double *p2, double *ap2,
-                    double *scal, double tolerance, int *done, int iter, double *hist, int mode) {
+                    double *scal, double tolerance, int *done, int iter, double *hist, int mode, double *host_ctl, int n_ctl) {
   const size_t lds = (size_t)n * sizeof(double);
   static DynLdsCache granted{};
   ensure_dyn_lds(cg_step_kernel, lds, granted);
   const int rpb = n <= 4096 ? 8 : 16;
   hipLaunchKernelGGL(cg_step_kernel, dim3(mode == 4 ? 1 : (n + rpb - 1) / rpb), dim3(1024), lds, s, n, A, b, q, res2, p2, ap2, scal, tolerance,
-                     done, iter, hist, mode, rpb);
+                     done, iter, hist, mode, rpb, mode == 4 ? host_ctl : nullptr, n_ctl);
 }
 
 }  // namespace conp
