@@ -1397,8 +1397,10 @@ struct conp_fix {
         for (; iter < last; ++iter) step(iter + 1, 2);
         step(iter, 4);                                        // (stores the control block into `ctl` itself)
         if (results_by_copy) HIP_TRY(hipMemcpyAsync(ctl, d_cg_scal.p, (size_t)(16 + iter + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (spec_dq) scatter_device(spec_dq, spec_pot, false);      // update_direct: speculative charge write
         sync();
         done = ctl[8] != 0.0;
+        if (spec_dq && done) spec_done = true;
         if (done || iter + 1 >= args.maxiter) break;
         ++iter;
         step(iter, 3);
@@ -1720,9 +1722,9 @@ struct conp_fix {
   }
 
   // fix_conp.cpp:1149-1159: charges for owned + ghost electrode atoms, scalar output
-  void scatter_device(double *d_q_atoms, double potdiff) {
+  void scatter_device(double *d_q_atoms, double potdiff, bool labelled = true) {
     const int ne = idx.elenum_all;
-    prof.begin("charge_write", stream);
+    if (labelled) prof.begin("charge_write", stream);
     if (args.cond) {
       // fix cond (fix_cond.cpp:58-126): vmult once (cond_setup2), then the potential from the cell dipole
       if (!cond_ready) {
@@ -1753,7 +1755,7 @@ struct conp_fix {
       launch_charge_finish(stream, ne, n_ele_atoms, d_ele_pairs.p, d_elecheck.p, d_eleallq, d_elesetq.p,
                            args.qinit ? d_eleinitq.p : nullptr, potdiff, nullptr, d_qele.p, d_q_atoms, d_scalars.p + 1);
     }
-    prof.end(stream);
+    if (labelled) prof.end(stream);
     HIP_TRY(hipGetLastError());
   }
 
@@ -1878,10 +1880,20 @@ struct conp_fix {
     b_cal_device(dx, dq, true);
     if (can_fuse_solve()) { solve_scatter_fused(dq, potdiff); return; }
     allreduce_b();
+    // CG on one rank: the charge write is enqueued behind every batch of iterations BEFORE the host reads the convergence flag
+    // (cg()): the device does not idle through the read-back and a launch from cold; a batch that did not converge just wrote
+    // intermediate charges, which the next batch's write replaces
+    const bool spec = args.minimizer == CONP_SOLVER_CG && env.nranks <= 1 && !nccl && !args.conq && !args.cond && !cg_no_spec;
+    if (spec) { spec_dq = dq; spec_pot = potdiff; spec_done = false; }
     solve_device();
+    spec_dq = nullptr;
     allgather_q();
-    scatter_device(dq, potdiff);
+    if (!(spec && spec_done)) scatter_device(dq, potdiff);
   }
+  const bool cg_no_spec = exp_switch("CONP_CG_NO_SPEC") != nullptr;      // comparison switch: charge write after the read-back
+  double *spec_dq = nullptr;
+  double spec_pot = 0.0;
+  bool spec_done = false;
   void update_device(const double *dx, double *dq, double potdiff) {
     // (the legacy default stream cannot be captured)
     const bool can = !graph_off && stream != nullptr && !prof.on && args.minimizer == CONP_SOLVER_INV && runstage >= 3 &&
