@@ -655,13 +655,15 @@ def test_device_row_regrouping_keeps_the_list_order(deck, newton, monkeypatch):
     assert np.array_equal(res[0][0], res[1][0])
 
 
-@pytest.mark.parametrize("deck,mode", [("il_onelayer", "ffield"), ("il_twolayer", "ffield"), ("dilute", "slab")])
+@pytest.mark.parametrize("deck,mode", [("il_onelayer", "ffield"), ("il_twolayer", "ffield"), ("dilute", "slab"),
+                                       ("small_tall_slab", None)])
 def test_projecting_epilogue_equals_the_partial_tile_path(deck, mode, monkeypatch):
     """planar electrodes: a segment of sk_gemm projects its partial tile on the z classes before it leaves the registers and the
     pieces are added afterwards; the comparison path (CONP_SK_PARTIALS) adds the partial tiles and projects the sum -- the same
     terms re-associated.  The structure factors, which the projecting update never forms, are re-formed on request through the
-    partial-tile kernels (the two paths cut the atom axis into different shares: equal to rounding, not bit for bit)."""
-    s = systems.deck(deck, mode, etypes=(deck != "dilute"))
+    partial-tile kernels (the two paths cut the atom axis into different shares: equal to rounding, not bit for bit).
+    small_tall_slab: two kz column tiles -- the comparison path is then sk_reduce + b_hc instead of the fused sk_reduce_hc."""
+    s = CASES[deck]() if mode is None else systems.deck(deck, mode, etypes=(deck != "dilute"))
     at, alist, blist = neighbor.build_lists(s)
     res = []
     for partials in (False, True):
