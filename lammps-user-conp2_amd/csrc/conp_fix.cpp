@@ -256,12 +256,14 @@ struct conp_fix {
   bool b_bound = false, q_bound = false;         // conp_fix_bind_device_buffers gave us the host's vectors
   int n_slab_part = 0;
   const bool no_fuse = exp_switch("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
+  const bool shard_by_cost = exp_switch("CONP_SHARD_COST_AXIS") != nullptr;   // comparison switch: rank shards = shares of the cost axis (round 2)
   const bool sk_partials = exp_switch("CONP_SK_PARTIALS") != nullptr;   // comparison switch: partial tiles + reducing launch, no projection in sk_gemm
   const char *hc_presum_env = exp_switch("CONP_HC_PRESUM");      // comparison switch: 1 / 0 = always / never add the pieces in a launch of their own
   // The host-buffer hooks report Ktime / Ctime (fix_conp.cpp:553-568).  By default they run the SAME kernels as the device hooks
   // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
   // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
   const bool time_split = exp_switch("CONP_TIME_SPLIT") != nullptr;
+  int table_c0 = 0, table_c1 = 0;  // chunk range (16 atoms each) whose phase tables this rank's sk_gemm reads
   int hslots = 0;                  // entries of the owned row tiles' segment lists (d_hslot_idx)
   bool g_current = true;           // d_G holds the last update's structure factors (false after a projecting update: conp_fix_get_sfac re-forms it)
   int max_nsplit = 0;              // most sk_gemm segments any tile is cut into (chooses sk_reduce's one- or two-level sum)
@@ -460,6 +462,16 @@ struct conp_fix {
           load[best] += -e.first;
         }
         for (size_t t = 0; t < all.size(); ++t) if (owner[all[t].rt] == env.rank) fhi[t] = 1.0;
+      } else if (!shard_by_cost) {
+        // Round 3: rank r takes the r-th N-th of the ATOMS of every tile (the axis the XCD-aware shares cut inside a rank, one level
+        // up).  Every rank has every tile with the same chunk count: equal work by construction, whatever the tiles' costs, and a
+        // rank needs the phase tables of ITS atoms only -- the phase kernel, replicated until now (12 us of an 89-us update on 8
+        // emulated ranks), shrinks with the share.  Each rank projects its partial structure factors for all rows; the
+        // all-reduce of b adds them, as it did for tiles that straddled a rank boundary.
+        for (size_t t = 0; t < all.size(); ++t) {
+          flo[t] = (double)env.rank / (double)env.nranks;
+          fhi[t] = (double)(env.rank + 1) / (double)env.nranks;
+        }
       } else {
         double W = 0.0;
         for (const auto &g : all) W += g.c;
@@ -775,6 +787,9 @@ struct conp_fix {
   void build_items() {
     const int nchunks = nl_pad / 16;
     const size_t nt = tiles_h.size();
+    // a segment that ends in the projecting epilogue costs about twice one that stores its partial tile (stamped build: 15 units;
+    // A/B on one rank: 5.74 / 9 / 12 equal within noise, 15 worse; on emulated ranks with 16 chunks per workgroup 12-14 is 7 % faster)
+    if (!exp_switch("CONP_SK_CSEG")) SK_CSEG = sk_projects() ? 12.0 : 5.74;
     // one workgroup per CU, except for small problems: sk_reduce walks a tile's splits serially (~1 us per split), so a tile
     // is cut into more than 16 segments only when a segment still holds >= 8 chunks (measured on the decks: il_onelayer
     // 57 -> 52 us per update with 32 instead of 256 workgroups)
@@ -843,23 +858,32 @@ struct conp_fix {
     };
     // this rank's chunk range of every tile (all of it on one rank; km_conp_setup); a tile may come out empty
     std::vector<int> clo(nt, 0), chi(nt, nchunks);
-    bool whole = true;
+    bool uniform = true;                   // every tile with the same chunk range (one rank: all of it; N ranks: the rank's atoms)
     for (size_t i = 0; i < nt; ++i) {
       clo[i] = (int)std::lround(tile_flo[i] * nchunks);
       chi[i] = (int)std::lround(tile_fhi[i] * nchunks);
-      whole = whole && clo[i] == 0 && chi[i] == nchunks;
+      uniform = uniform && clo[i] == clo[0] && chi[i] == chi[0];
     }
+    // the atoms whose phase tables this rank reads (elyte_phase fills those only)
+    table_c0 = nchunks; table_c1 = 0;
+    for (size_t i = 0; i < nt; ++i) if (chi[i] > clo[i]) { table_c0 = std::min(table_c0, clo[i]); table_c1 = std::max(table_c1, chi[i]); }
+    if (table_c1 <= table_c0) table_c0 = table_c1 = 0;
     // XCD-aware shares (the full chip on whole tiles): workgroups are dealt to the eight XCDs round-robin (w mod 8), each XCD has
     // its own L2 and the phase tables are blocked by atom chunk.  XCD x takes the x-th eighth of the atoms of EVERY tile, cut into
     // nwg / 8 shares for its workgroups w = x, x + 8, ...: equal work per XCD by construction, and an XCD pulls only its eighth of
     // the tables through the fabric (round 2: one axis over all tiles -- every XCD read ~70 % of the tables: 5.6 table volumes per
     // launch at the memory side, profiles/r03).  The block -> XCD map is not an architectural promise; nothing but the traffic
     // depends on it.
-    const bool xcd_aware = whole && nwg >= 64 && nwg % 8 == 0 && nchunks >= 64 && exp_switch("CONP_SK_FLAT") == nullptr;
+    // (XCD-aware shares put ~1.2 segments on a workgroup instead of ~1.03: worth it while a share is long -- 72 chunks on one rank --,
+    //  not when a rank's share leaves 8-16 chunks per workgroup and a segment's fixed cost is a fifth of it: emulated ranks,
+    //  tools/rank_emulation.py, N = 4: 80.9 vs 74.6 us, N = 8: 48.3 vs 41.2)
+    const int span = nt ? chi[0] - clo[0] : 0;
+    const bool long_shares = (size_t)span * nt >= (size_t)32 * nwg;
+    const bool xcd_aware = uniform && long_shares && nwg >= 64 && nwg % 8 == 0 && span >= 64 && exp_switch("CONP_SK_FLAT") == nullptr;
     if (xcd_aware) {
       std::vector<int> lo(nt), hi(nt);
       for (int x = 0; x < 8; ++x) {
-        for (size_t i = 0; i < nt; ++i) { lo[i] = (int)((long)nchunks * x / 8); hi[i] = (int)((long)nchunks * (x + 1) / 8); }
+        for (size_t i = 0; i < nt; ++i) { lo[i] = clo[0] + (int)((long)span * x / 8); hi[i] = clo[0] + (int)((long)span * (x + 1) / 8); }
         cut(lo, hi, nwg / 8, x, 8);
       }
     } else cut(clo, chi, nwg, 0, 1);
@@ -1506,7 +1530,7 @@ struct conp_fix {
       prof.begin("elyte_phase", stream);
       launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                          plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
-                         &n_slab_part, ride ? &pairs : nullptr, d_breal.p);
+                         &n_slab_part, ride ? &pairs : nullptr, d_breal.p, 16 * table_c0, 16 * table_c1);
       prof.end(stream);
       // with the pair sums in hand and a small z-class table the dot kernel can finish b itself: no b_real_combine launch
       fin = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 1, d_bk.p, slab,

@@ -90,7 +90,7 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int kzt, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part,
                         const BRowArgs *rows /*NULL, or: the real-space pair sums of these rows ride along, into breal_out*/,
-                        double *breal_out);
+                        double *breal_out, int j0 /*tables for the atoms [j0, j1) of the compact list only (a rank's share)*/, int j1);
 bool zc_final_fits(int n_own, int nzc);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, const int *seg_idx, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj = nullptr);

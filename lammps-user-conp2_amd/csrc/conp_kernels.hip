@@ -150,7 +150,8 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
                                                           double ux, double uy, double uz, int kxmax, int kymax, int nz,
                                                           int kzt, int nrz, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
                                                           double2 *__restrict__ Zs, double *__restrict__ qc,
-                                                          double *__restrict__ slab_part, BRowArgs ra, double *__restrict__ breal_out) {
+                                                          double *__restrict__ slab_part, BRowArgs ra, double *__restrict__ breal_out,
+                                                          int j0, int j1 /* atoms whose tables are wanted (a rank's share) */) {
 #pragma clang fp contract(off)
   if ((int)blockIdx.x >= 3 * nb) {
     const int row = ((int)blockIdx.x - 3 * nb) * (EP_THREADS / 64) + (threadIdx.x >> 6);
@@ -163,7 +164,18 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
   const int c = (int)blockIdx.x / nb, bx = (int)blockIdx.x - c * nb;
   const int j = bx * blockDim.x + threadIdx.x;
   double qz = 0.0;
-  if (j < nl_pad) {
+  // several ranks: tables only for this rank's atoms [j0, j1) (whole wavefronts of the others leave here); the compact charges and
+  // the slab sum's q z (z axis) cover all atoms on every rank
+  const bool tab = j >= j0 && j < j1;
+  if (j < nl_pad && !tab && c == 2) {
+    double xc = 0, qq = 0;
+    if (j < nl) {
+      const int i = elyte_idx[j];
+      xc = x[3 * i + c]; qq = q[i];
+    }
+    qc[j] = qq; qz = qq * xc;
+  }
+  if (j < nl_pad && tab) {
     double xc = 0, qq = 0;
     if (j < nl) {
       const int i = elyte_idx[j];
@@ -273,14 +285,14 @@ void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, 
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int kzt, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part, const BRowArgs *rows,
-                        double *breal_out) {
+                        double *breal_out, int j0, int j1) {
   const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS;
   *n_slab_part = nb;
   BRowArgs ra{};
   int nrb = 0;
   if (rows && breal_out) { ra = *rows; nrb = (ra.ne + EP_THREADS / 64 - 1) / (EP_THREADS / 64); }
   hipLaunchKernelGGL(elyte_phase_kernel, dim3(3 * nb + nrb), dim3(EP_THREADS), 0, s, nb, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
-                     kymax, nz, kzt, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out);
+                     kymax, nz, kzt, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out, j0, j1);
 }
 
 // ================================================================================================
