@@ -2,7 +2,7 @@
 # A/B of library builds on ONE box (boxes differ by 1-2 %): bash tools/ab_libs.sh [workload] name1 name2 ...   (name = "product" or
 # the NAME of lammps-user-conp2_amd/conp_amd/libconp_hip_NAME.so, e.g. a `make variant_NAME VDEF=...` build); two rounds each
 set -o pipefail
-W=headline; case "$1" in headline|big|headline_slab) W=$1; shift;; esac
+W=headline; case "$1" in headline|big|headline_slab|il_onelayer|il_twolayer|dilute) W=$1; shift;; esac
 D=lammps-user-conp2_amd/conp_amd
 for round in 1 2; do for n in "$@"; do
   L=$D/libconp_hip_$n.so; [ $n = product ] && L=$D/libconp_hip.so
