@@ -173,6 +173,8 @@ AUX_CONFIGS = [
     ("configs[2] il_twolayer cg+etypes", dict(workload="il_twolayer", solver="cg")),
     ("configs[3] il_onelayer pppm 40x45x180", dict(workload="il_onelayer", solver="inv", pppm=(40, 45, 180))),
     ("headline slab 3.0 (reference default geometry)", dict(workload="headline_slab", solver="inv", steps=100, warmup=10)),
+    # BASELINE configs[4]'s box (16384 electrode / 262144 electrolyte atoms) on ONE GPU: its 8-GPU half is the driver's scaling run
+    ("configs[4] 16384/262144 on one GPU", dict(workload="big", solver="inv", steps=20, warmup=3)),
 ]
 
 
