@@ -569,17 +569,31 @@ __device__ unsigned long long sk_seg_buf[4096 * 4];         // [segment][workgro
 // launch that summed and projected them (15 us) and their write-back go away; the segments' Hc pieces (8 KB each) are added in a
 // fixed order by whoever consumes them (hc_sum_kernel / b_zc_final_kernel).
 //   lane (fk, fr) of wave (rh, cg) holds G[16 (4 rh + f) + fk + 4 r][16 (4 g + cg) + fr]: it forms, per class, the sum over ITS
-//   columns (g) of w G Tzc for its 16 rows; the 16 lanes fr of a row are added by DPP shifts inside the register file (lane 15
-//   ends up with the total), the four column groups cg through 4 KB of LDS per class.  Two barriers per segment -- a first version
+//   columns (g) of w G Tzc for its 16 rows; the 16 lanes fr of a row are added by DPP exchanges inside the register file (a
+//   transposing butterfly, row16_sum4), the four column groups cg through 4 KB of LDS per class.  Two barriers per segment -- a first version
 //   went through LDS per row fragment (eight barriers, a dozen serialised LDS / memory waits per fragment): 8 us per segment.
 constexpr int SK_HC = 8;          // class stride of a segment's Hc piece: [SK_HC][128] doubles
 constexpr int SK_HC_MAX = 8;
-// v + (v of the lane CTRL's shift away in the 16-lane row, 0 beyond the row's edge)
+// the value the lane's partner under DPP control CTRL holds (row_mirror 0x140: lane ^ 15, row_half_mirror 0x141: lane ^ 7 inside
+// its half row, quad_perm [3,2,1,0] 0x1B: lane ^ 3, quad_perm [1,0,3,2] 0xB1: lane ^ 1)
 template <int CTRL>
-__device__ __forceinline__ double dpp_add(double v) {
+__device__ __forceinline__ double dpp_get(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
-  return v + __hiloint2double(hi, lo);
+  return __hiloint2double(hi, lo);
+}
+// four values per lane, each to be added over the 16 lanes of its row: a transposing butterfly -- a lane keeps the values whose
+// index has ITS lane bit and adds the partner's copy of them (2, then 1 exchange), then two plain exchange-adds: five instead of
+// 4 x 4.  Every lane of quad-group q = fr >> 2 ends up with the total of value q.  Fixed association: bitwise reproducible.
+__device__ __forceinline__ double row16_sum4(const double (&s)[4], unsigned fr) {
+  const bool b3 = fr & 8, b2 = fr & 4;
+  double k2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) k2[i] = (b3 ? s[2 + i] : s[i]) + dpp_get<0x140>(b3 ? s[i] : s[2 + i]);
+  double k = (b2 ? k2[1] : k2[0]) + dpp_get<0x141>(b2 ? k2[0] : k2[1]);
+  k += dpp_get<0x1B>(k);
+  k += dpp_get<0xB1>(k);
+  return k;
 }
 template <int NFW>
 __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&acc)[4][NFW > 0 ? NFW : 1], double *__restrict__ hout) {
@@ -640,18 +654,9 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[r] += acc[f][g][r] * tv;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[r] = dpp_add<0x111>(s[r]);      // row_shr:1
-          s[r] = dpp_add<0x112>(s[r]);      // row_shr:2
-          s[r] = dpp_add<0x114>(s[r]);      // row_shr:4
-          s[r] = dpp_add<0x118>(s[r]);      // row_shr:8 -> lane 15 of the row: all 16
-        }
       }
-      if (fr == 15) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lp[(zc * 128 + 16 * f + 4 * r) * 4] = s[r];
-      }
+      const double tot = row16_sum4(s, fr);            // every lane of quad-group fr >> 2: the row sum of value r = fr >> 2
+      if ((fr & 3) == 0) lp[(zc * 128 + 16 * f + 4 * (fr >> 2)) * 4] = tot;
     }
     if constexpr (NFW > 0) {
       if (f < 3) {
