@@ -250,6 +250,8 @@ struct conp_fix {
   double left_potdiff = 0.0;
   DevBuf<unsigned char> d_mask;
   DevBuf<SkItem> d_items;
+  DevBuf<SkWItem> d_witems;
+  int witems_maxseg = 1;
   DevBuf<SkProj> d_skproj;
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
@@ -707,7 +709,7 @@ struct conp_fix {
   void refresh_structure_factors() {
     if (g_current) return;
     reserve_partials(true);
-    launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, d_seg_idx.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
+    launch_sk_gemm(stream, dplan, d_witems.p, witems_maxseg, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                    d_Gpart.p);
     launch_sk_reduce(stream, dplan, d_tiles.p, (int)tiles_h.size(), max_nsplit, d_Gpart.p, d_G.p, d_Gw.p);
     g_current = true;
@@ -915,6 +917,17 @@ struct conp_fix {
     d_items.upload(items_h, stream);
     d_seg_ptr.upload(seg_ptr_h, stream);
     d_seg_idx.upload(seg_idx_h, stream);
+    // the kernel's own work list: one fixed-size row per workgroup (SkWItem)
+    witems_maxseg = 1;
+    for (int w = 0; w < nwg; ++w) witems_maxseg = std::max(witems_maxseg, (int)per_wg[w].size());
+    std::vector<SkWItem> wl((size_t)nwg * witems_maxseg, SkWItem{0, 0, 0, 0, 0, 0u, 0, 0});
+    for (int w = 0; w < nwg; ++w)
+      for (size_t k = 0; k < per_wg[w].size(); ++k) {
+        const int sg = per_wg[w][k];
+        const SkItem &it = items_h[sg];
+        wl[(size_t)w * witems_maxseg + k] = SkWItem{it.rt, it.ct, it.nba, it.c0, it.c1, it.nbf, sg, k == 0 ? (int)per_wg[w].size() : 0};
+      }
+    d_witems.upload(wl, stream);
     d_tiles.upload(tiles_h, stream);
     // per owned row tile: the segments that worked on it, over all its column tiles (sk_gemm's projected pieces are added in
     // this order: launch_project_zclass_pieces)
@@ -1540,7 +1553,7 @@ struct conp_fix {
       const bool proj = sk_projects();
       reserve_partials();
       prof.begin("sk_gemm", stream);
-      launch_sk_gemm(stream, dplan, d_items.p, d_seg_ptr.p, d_seg_idx.p, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
+      launch_sk_gemm(stream, dplan, d_witems.p, witems_maxseg, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                      proj ? d_Hpart.p : d_Gpart.p, proj ? d_skproj.p : nullptr);
       prof.end(stream);
       g_current = !proj;

@@ -23,6 +23,10 @@ struct SkItem { int rt, ct, nba, c0, c1; unsigned nbf; };   // one sk_gemm segme
                                                           // nbf = active 8-kz column fragments per 16-row fragment, 4 x 8 bit
 // parameter block of sk_gemm's projecting epilogue (device memory): weights [R_pad][C_pad], z-class phases class-major [nzc][C_pad]
 struct SkProj { const double *wfull, *tzt; int nzc, cpad; };
+// sk_gemm's work list, one fixed-size row per workgroup: the segments it runs, each with its index `sg` in the tile-major item order
+// (where its output goes); the first entry's nseg = how many are used.  One load replaces the seg_ptr -> seg_idx -> items chain at
+// the top of every workgroup (three dependent round trips before the first phase table can be requested).
+struct SkWItem { int rt, ct, nba, c0, c1; unsigned nbf; int sg, nseg; };
 struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
@@ -92,7 +96,7 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         const BRowArgs *rows /*NULL, or: the real-space pair sums of these rows ride along, into breal_out*/,
                         double *breal_out, int j0 /*tables for the atoms [j0, j1) of the compact list only (a rank's share)*/, int j1);
 bool zc_final_fits(int n_own, int nzc);
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, const int *seg_idx, int nwg, int nl_pad,
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems /*[nwg][maxseg]*/, int maxseg, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj = nullptr);
 int sk_hc_stride();           // doubles per segment of sk_gemm's projected output
 int sk_hc_max_classes();      // most z classes the projecting mode takes

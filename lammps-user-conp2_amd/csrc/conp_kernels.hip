@@ -771,10 +771,9 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
 }
 
 
-// Persistent-style launch: workgroup w runs the segments seg_idx[seg_ptr[w] .. seg_ptr[w+1]-1] (host: equal cost per workgroup,
+// Persistent-style launch: workgroup w runs the segments of row w of the work list (SkWItem; host: equal cost per workgroup,
 // a segment boundary may fall inside a tile -- "stream-K" over the atom chunks).
-__global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkItem *__restrict__ items,
-                                                         const int *__restrict__ seg_ptr, const int *__restrict__ seg_idx, int nl_pad,
+__global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWItem *__restrict__ witems, int maxseg, int nl_pad,
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
                                                          double *__restrict__ part, const SkProj *__restrict__ proj, int dbg) {
@@ -792,10 +791,13 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkIte
 #ifdef SK_STAMP
   unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int s0 = seg_ptr[blockIdx.x], s1 = seg_ptr[blockIdx.x + 1];
-  for (int sgi = s0; sgi < s1; ++sgi) {
-    const int sg = seg_idx[sgi];
-    c.it = items[sg];
+  const SkWItem *wi = witems + (size_t)blockIdx.x * maxseg;
+  SkWItem cur = wi[0];
+  const int nseg = cur.nseg;
+  for (int sgi = 0; sgi < nseg; ++sgi) {
+    if (sgi) cur = wi[sgi];
+    const int sg = cur.sg;
+    c.it = SkItem{cur.rt, cur.ct, cur.nba, cur.c0, cur.c1, cur.nbf};
     // the lane's constants are formed per segment from an opaque copy of the thread index: formed once at the top of the kernel
     // they would be live across the epilogue, which has no register to spare for them (they were spilled around it)
     {
@@ -908,7 +910,7 @@ int sk_hc_max_classes() { return SK_HC_MAX; }
 
 // proj == nullptr: partial tiles [segment][128 x 320] into `part`; otherwise (planar electrodes, at most sk_hc_max_classes() z
 // classes; proj = device copy of the parameter block) the segments' projected pieces [segment][sk_hc_stride()]
-void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const int *seg_ptr, const int *seg_idx, int nwg, int nl_pad,
+void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems, int maxseg, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj) {
   if (nwg <= 0) return;
   const size_t lds = SK_LDS_BYTES;
@@ -919,7 +921,7 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkItem *items, const
 #else
   const int dbg = 0;
 #endif
-  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, items, seg_ptr, seg_idx, nl_pad, Xt, Yt, Zs, qc, part, proj, dbg);
+  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, witems, maxseg, nl_pad, Xt, Yt, Zs, qc, part, proj, dbg);
 }
 
 // G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:
