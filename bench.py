@@ -261,7 +261,7 @@ def main():
         """plugs the HIP library into conp_amd.distributed.sharded_update (device tensors, RCCL collectives)"""
 
         def b_local(self):
-            fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())       # k-shard for all rows + own real-space rows -> d_b
+            fx.b_cal_device(d_x.data_ptr(), d_q.data_ptr())       # this rank's atoms' share of the k-space b for all rows + own real-space rows -> d_b
             return d_b.cpu() if rehearse else d_b
 
         def solve_rows(self, b):
@@ -392,7 +392,7 @@ def main():
                                accuracy_relative=s.accuracy_relative, mode="ffield" if s.ff_flag == 1 else "slab",
                                solver=args.solver, kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
                                blist_pairs=int(info.n_blist_pairs),
-                               parallelism=f"k-shard+row-shard x{world}" + (", RCCL inside libconp_hip" if lib_collectives else "")),
+                               parallelism=f"S(k): electrolyte atoms sharded (all k, all rows) + all-reduce(b); solve: electrode rows sharded + all-gather(q); x{world}" + (", RCCL inside libconp_hip" if lib_collectives else "")),
                    collectives=collectives,
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
                    ms_per_step_host_buffers_pcie=host_ms,

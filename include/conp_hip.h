@@ -304,6 +304,10 @@ int conp_fix_pre_force_device(conp_fix *fix, const double *d_x, double *d_q, dou
  * cheap enough to stay on inside a timed region (an event pair drains the queue around the kernel it brackets). */
 int conp_fix_profile(conp_fix *fix, int enable);
 int conp_fix_profile_read(conp_fix *fix, int *nkernels, const char **names /*[16]*/, double *avg_ms /*[16]*/, int *counts /*[16]*/);
+/* Diagnostic (no reference counterpart): with CONP_GUARD=1 in the environment every device buffer of the library sits between two
+ * 4-KB zones of a known byte pattern; this reads all zones back.  Returns the number of damaged zones (0 = no kernel has stored
+ * outside its buffers so far), -1 when guard zones are off; conp_last_error() names the damaged buffers. */
+int conp_debug_check_guards(void);
 
 
 /* ---- the fix's log file (fix_conp.cpp:119 `outf`) ----

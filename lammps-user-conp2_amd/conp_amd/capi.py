@@ -91,7 +91,7 @@ SYMBOLS = [
     "conp_host_ktables", "conp_host_index", "conp_host_pair_rows", "conp_fix_write_matrix_file", "conp_fix_read_matrix_file",
     "conp_fix_set_stream",
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
-    "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read",
+    "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read", "conp_debug_check_guards",
     "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
     "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl", "conp_rccl_available", "conp_fix_comm_destroy_rccl",
     "conp_pppm_make_rho", "conp_pppm_compute_group_potential", "conp_pppm_compute_particle_potential",

@@ -1,6 +1,7 @@
 """One charge update across N processes (one GPU each): the exchange choreography of SURVEY.md 8e.
 
-    b_local  = this rank's k-shard of the k-space b (all rows) + its rows of the real-space b (+ slab on rank 0)
+    b_local  = the k-space b (all rows) of this rank's share of the electrolyte ATOMS (atom_shard) + its rows of the real-space b
+               (+ slab on rank 0)
     b        = all_reduce(b_local, SUM)                       Ne doubles
     q[rows]  = S[rows, :] @ b                                 this rank's electrode rows
     q        = all_gather(q[rows])                            Ne doubles
@@ -21,19 +22,20 @@ def row_range(ne: int, rank: int, world: int):
     return r0, min(ne, r0 + per)
 
 
-def my_row_tiles(n_row_tiles: int, rank: int, world: int, costs=None):
-    """Row tiles (rings of planar k-vectors) go heaviest first to the least loaded rank (lowest rank on ties) -- the rule of
-    conp_fix.cpp km_conp_setup, where a tile's cost is its number of active kz blocks.  With equal costs (the default here:
-    the CPU model of the exchange only needs SOME disjoint cover, b is a sum over tiles) this is round-robin."""
-    costs = [1] * n_row_tiles if costs is None else list(costs)
-    order = sorted(range(n_row_tiles), key=lambda t: (-costs[t], t))
-    load = [0] * world
-    owner = [0] * n_row_tiles
-    for t in order:
-        r = min(range(world), key=lambda k: (load[k], k))
-        owner[t] = r
-        load[r] += costs[t]
-    return [t for t in range(n_row_tiles) if owner[t] == rank]
+def atom_shard(n_elyte: int, rank: int, world: int):
+    """The k-shard of the product (conp_fix.cpp km_conp_setup + build_items, round 3 on): rank r multiplies the r-th N-th of the ATOMS
+    of every (row tile, column tile) of the structure-factor contraction -- the compact list of charged electrolyte atoms
+    (`electrode_check == 0 && q != 0`, km_ewald.cpp:686, in local order), cut in chunks of 16 atoms on the list padded to a multiple
+    of 32; the boundaries are round(r / N * chunks), the expression both neighbours evaluate, so the ranges meet exactly.  Every rank
+    projects its partial structure factors on ALL electrode rows; the all-reduce of b adds the pieces (the sum over atoms is linear).
+    Returns the half-open range [j0, j1) of positions in the compact list (j1 clipped to the list's length)."""
+    nl_pad = max(32, (n_elyte + 31) // 32 * 32)
+    nchunks = nl_pad // 16
+    # C's lround: half away from zero (Python's round() rounds half to even)
+    lround = lambda v: int(v + 0.5) if v >= 0 else -int(-v + 0.5)
+    c0 = lround(rank / world * nchunks)
+    c1 = lround((rank + 1) / world * nchunks)
+    return min(n_elyte, 16 * c0), min(n_elyte, 16 * c1)
 
 
 def sharded_update(backend, ne: int, rank: int, world: int, group=None):

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,18 +39,76 @@ struct ConpError : std::runtime_error {
       throw ConpError(CONP_ERR_NO_DEVICE, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
   } while (0)
 
+// CONP_GUARD=1 (diagnostic; tests/test_gpu_guard.py): every device buffer of the library is allocated with a 4-KB zone of a
+// known byte pattern before and after it, and conp_debug_check_guards() reads all zones back -- an out-of-range STORE of any kernel
+// shows up as a damaged zone with the buffer's size, instead of as silent corruption of a neighbouring allocation or as an abort
+// of the HIP runtime somewhere else (round 3 had one abort whose message was lost).  Off: no cost.
+struct GuardZones {
+  static constexpr size_t G = 4096;
+  static constexpr int PATTERN = 0xA5;
+  std::mutex m;
+  std::map<const void *, size_t> live;       // raw allocation -> payload bytes
+  static bool on() { static const bool v = getenv("CONP_GUARD") != nullptr; return v; }
+  static GuardZones &get() { static GuardZones g; return g; }
+  void add(const void *raw, size_t bytes) { std::lock_guard<std::mutex> l(m); live[raw] = bytes; }
+  void drop(const void *raw) { std::lock_guard<std::mutex> l(m); live.erase(raw); }
+  // number of damaged zones; `what` names the first few
+  int check(std::string &what) {
+    std::lock_guard<std::mutex> l(m);
+    (void)hipDeviceSynchronize();
+    int bad = 0;
+    std::vector<unsigned char> h(2 * G);
+    for (const auto &kv : live) {
+      const char *raw = static_cast<const char *>(kv.first);
+      if (hipMemcpy(h.data(), raw, G, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(h.data() + G, raw + G + kv.second, G, hipMemcpyDeviceToHost) != hipSuccess) { ++bad; what += " [unreadable zone]"; continue; }
+      for (int side = 0; side < 2; ++side) {
+        size_t first = G;
+        for (size_t i = 0; i < G; ++i) if (h[side * G + i] != PATTERN) { first = i; break; }
+        if (first == G) continue;
+        ++bad;
+        if (bad <= 4) {
+          char line[160];
+          std::snprintf(line, sizeof line, " [buffer of %zu bytes: zone %s it damaged from byte %zu]", kv.second, side ? "behind" : "before", first);
+          what += line;
+        }
+      }
+    }
+    return bad;
+  }
+};
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  void free_() {
+    if (!p) return;
+    if (GuardZones::on()) {
+      char *raw = reinterpret_cast<char *>(p) - GuardZones::G;
+      GuardZones::get().drop(raw);
+      (void)hipFree(raw);
+    } else (void)hipFree(p);
+    p = nullptr;
+  }
+  ~DevBuf() { free_(); }
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   void reserve(size_t count) {
     if (count <= n) return;
-    if (p) { (void)hipFree(p); p = nullptr; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    free_();
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (GuardZones::on()) {
+      constexpr size_t G = GuardZones::G;
+      const size_t padded = (bytes + 15) / 16 * 16;
+      char *raw = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&raw), padded + 2 * G));
+      HIP_TRY(hipMemset(raw, GuardZones::PATTERN, G));
+      HIP_TRY(hipMemset(raw + G + padded, GuardZones::PATTERN, G));
+      GuardZones::get().add(raw, padded);
+      p = reinterpret_cast<T *>(raw + G);
+    } else HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), bytes));
     n = count;
   }
   void upload(const T *h, size_t count, hipStream_t s) {
@@ -58,7 +117,7 @@ struct DevBuf {
   }
   void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
   void zero(hipStream_t s) { if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() { free_(); n = 0; }
 };
 
 // per-kernel timing with HIP events on the library's stream (bench.py's roofline leg)
@@ -253,6 +312,7 @@ struct conp_fix {
   DevBuf<SkWItem> d_witems;
   int witems_maxseg = 1;
   DevBuf<SkProj> d_skproj;
+  SkProj skproj_h{};
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   bool b_bound = false, q_bound = false;         // conp_fix_bind_device_buffers gave us the host's vectors
@@ -522,6 +582,9 @@ struct conp_fix {
     d_ct_ptr.upload(ct_ptr_h, stream);
     sync();
     kspace_ready = true;
+    // the electrode tables, the z-class tables and sk_gemm's projection block (d_skproj: raw pointers into d_wfull / d_TzcT, the
+    // plan's C_pad) belong to the plan that was just replaced: whoever needs them next rebuilds them (km_a_read)
+    tables_current = false;
   }
 
   // fix_conp.cpp:393-424 linalg_init
@@ -953,30 +1016,31 @@ struct conp_fix {
     ele_comm(mine.data(), 3, xele_h.data());           // km_ewald.cpp:510-531 gathers the electrode tables the same way
   }
 
-  // km_ewald.cpp:134-145 a_read: electrode phase tables (electrodes are immobile: filled once, appendix D)
+  // km_ewald.cpp:134-145 a_read: electrode phase tables (electrodes are immobile: filled once, appendix D).
+  // sincos_a_ele / sincos_a_comm_eleall (km_ewald.cpp:426-531) on the device (conp_tables.hip): the host computes the 3 Ne seed pairs
+  // (cos, sin)(unitk_c x_ic) with libm (conp_host.cpp electrode_seeds: the reference's own calls, every table entry keeps its bits) and the
+  // kernels run the recurrences and the (kx, +-ky) products straight into Xe / Ye / Tz / Rp.
+  bool tables_current = false;   // false after km_conp_setup re-planned: tables, z classes and the projection block are rebuilt
+  DevBuf<double> d_seeds;
+  DevBuf<int> d_zrep;
   void km_a_read(const conp_atoms *at) {
     const int ne = idx.elenum_all;
     gather_xele(at);
-    electrode_trig(kt, ne, xele_h.data(), csk_h, snk_h);
-    std::vector<double> Rp, Tz, z(ne_pad, 0.0);
-    electrode_plan_tables(kt, plan, ne, ne_pad, csk_h, snk_h, Rp, Tz);
+    // (function scope: the uploads are asynchronous, the vectors must live until the sync() at the end)
+    std::vector<double> seeds, z(ne_pad, 0.0);
+    std::vector<int> zclass(ne_pad, 0), rep;
+    electrode_seeds(kt, ne, xele_h.data(), seeds);        // km_ewald.cpp:440-442, compiled like the reference (conp_host.cpp)
     for (int i = 0; i < ne; ++i) z[i] = xele_h[3 * (size_t)i + 2];
-    d_Rp.upload(Rp, stream); d_Tz.upload(Tz, stream); d_ele_z.upload(z, stream);
-    // axis phases of the electrode atoms, k-major: the planar fast path of the projection rebuilds Rp's rows from them per
-    // update instead of streaming the table (row 0 = (1, 0); rows of padding atoms stay zero).  (Function scope: the uploads
-    // are asynchronous, the vectors must live until the sync() at the end.)
-    std::vector<double2> xe, ye;
-    {
-      const int kflat = kt.kcount_flat, d0 = kt.kcount_dims[0], d1 = kt.kcount_dims[1];
-      xe.assign((size_t)(d0 + 2) * ne_pad, make_double2(0.0, 0.0));     // row kxmax + 1: all zero -- padding planar vectors point there
-      ye.assign((size_t)(d1 + 1) * ne_pad, make_double2(0.0, 0.0));
-      for (int i = 0; i < ne; ++i) {
-        xe[i] = make_double2(1.0, 0.0); ye[i] = make_double2(1.0, 0.0);
-        for (int k = 1; k <= d0; ++k) xe[(size_t)k * ne_pad + i] = make_double2(csk_h[(size_t)i * kflat + k - 1], snk_h[(size_t)i * kflat + k - 1]);
-        for (int k = 1; k <= d1; ++k) ye[(size_t)k * ne_pad + i] = make_double2(csk_h[(size_t)i * kflat + d0 + k - 1], snk_h[(size_t)i * kflat + d0 + k - 1]);
-      }
-      d_Xe.upload(xe, stream); d_Ye.upload(ye, stream);
-    }
+    d_seeds.upload(seeds, stream); d_ele_z.upload(z, stream);
+    // padding rows / atoms stay zero (row kxmax + 1 of Xe: padding planar vectors point there)
+    d_Xe.reserve((size_t)(plan.kxmax + 2) * ne_pad); d_Ye.reserve((size_t)(plan.kymax + 1) * ne_pad);
+    d_Rp.reserve((size_t)plan.R_pad * ne_pad); d_Tz.reserve((size_t)plan.C_pad * ne_pad);
+    HIP_TRY(hipMemsetAsync(d_Xe.p, 0, (size_t)(plan.kxmax + 2) * ne_pad * sizeof(double2), stream));
+    HIP_TRY(hipMemsetAsync(d_Ye.p, 0, (size_t)(plan.kymax + 1) * ne_pad * sizeof(double2), stream));
+    HIP_TRY(hipMemsetAsync(d_Rp.p, 0, (size_t)plan.R_pad * ne_pad * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(d_Tz.p, 0, (size_t)plan.C_pad * ne_pad * sizeof(double), stream));
+    launch_ele_tables(stream, dplan, plan.kzt, ne, ne_pad, d_seeds.p, d_Xe.p, d_Ye.p, d_Tz.p, d_Rp.p);
+    csk_h.clear(); snk_h.clear();                    // conp_fix_get_ele_trig reads the device tables back on request
     if (args.pppm) {   // aaa_map_rho (pppm_conp.cpp:318-344): stencil weights and lower-left mesh index of every electrode atom
       std::vector<int> eg((size_t)ne * 3);
       std::vector<double> ew((size_t)ne * 24, 0.0);
@@ -992,7 +1056,6 @@ struct conp_fix {
     // z classes: atoms with bitwise equal z share their Tz column
     {
       std::map<double, int> cls;
-      std::vector<int> zclass(ne_pad, 0), rep;
       for (int i = 0; i < ne; ++i) {
         auto it = cls.find(z[i]);
         if (it == cls.end()) { it = cls.emplace(z[i], (int)cls.size()).first; rep.push_back(i); }
@@ -1003,22 +1066,20 @@ struct conp_fix {
       // b_zc_dot keeps Hc for 32 rows of every row tile and every class in LDS
       if ((size_t)plan.n_row_tiles * 32 * (size_t)nzc * sizeof(double) > 96 * 1024) nzc = 0;
       if (nzc > 0) {
-        std::vector<double> Tzc((size_t)plan.C_pad * 64, 0.0);
-        for (int t = 0; t < plan.C_pad; ++t)
-          for (int c = 0; c < nzc; ++c) Tzc[(size_t)t * 64 + c] = Tz[(size_t)t * ne_pad + rep[c]];
-        d_Tzc.upload(Tzc, stream); d_zclass.upload(zclass, stream);
-        // class-major copy for sk_gemm's projecting epilogue (16 adjacent columns of one class per load)
-        std::vector<double> TzcT((size_t)std::max(nzc, 1) * plan.C_pad, 0.0);
-        for (int t = 0; t < plan.C_pad; ++t)
-          for (int c = 0; c < nzc; ++c) TzcT[(size_t)c * plan.C_pad + t] = Tzc[(size_t)t * 64 + c];
-        d_TzcT.upload(TzcT, stream);
-        d_skproj.upload(std::vector<SkProj>{SkProj{d_wfull.p, d_TzcT.p, nzc, plan.C_pad}}, stream);
+        d_zclass.upload(zclass, stream); d_zrep.upload(rep, stream);
+        d_Tzc.reserve((size_t)plan.C_pad * 64); d_TzcT.reserve((size_t)std::max(nzc, 1) * plan.C_pad);
+        d_Tzc.zero(stream); d_TzcT.zero(stream);
+        // Tzc[t][c] = Tz[t][representative of class c]; class-major copy for sk_gemm's projecting epilogue
+        launch_ele_zclass(stream, plan.C_pad, ne_pad, nzc, d_zrep.p, d_Tz.p, d_Tzc.p, d_TzcT.p);
+        skproj_h = SkProj{d_wfull.p, d_TzcT.p, nzc, plan.C_pad};      // (a member: the asynchronous upload reads it after this returns)
+        d_skproj.upload(&skproj_h, 1, stream);
         d_Hc.reserve((size_t)8 * plan.R_pad * 64); d_Hc.zero(stream);     // 8 slots: the reduction's column slices (b_hc: 4, the rest stay 0)
       }
       // the stream-K schedule was cut before the electrodes' geometry was known: planar electrodes take more, smaller shares
       if (sk_projects() && !tiles_h.empty() && nl_pad > 0) { build_items(); reserve_partials(); }
     }
     sync();
+    tables_current = true;
   }
 
   // Library-owned page-locked staging for the host-buffer hooks: the charges and scalars come back in ONE place with one
@@ -1514,7 +1575,7 @@ struct conp_fix {
     const int ne = idx.elenum_all;
     const double *ex = decomposed ? d_xg.p : dx, *eq = decomposed ? d_qg.p : dq;
     const int *eidx = decomposed ? d_iota.p : d_elyte_idx.p;
-    if (!kspace_ready || d_Rp.n == 0 || d_b == nullptr)
+    if (!kspace_ready || !tables_current || d_b == nullptr)
       throw ConpError(CONP_ERR_STATE, "b_cal before the k tables / electrode phase tables exist (setup_post_neighbor, a_cal)");
     if (timed) {
       for (auto &e : ev_b) if (!e) HIP_TRY(hipEventCreate(&e));
@@ -1729,6 +1790,8 @@ struct conp_fix {
   // the fused solve reads packed lower-triangle tiles, half the bytes of the row-by-row product.  Packed once per matrix
   // (spk_of: the matrix generation it was made from).  CONP_GEMV_FULL: comparison switch, always the row-by-row product.
   long s_generation = 0, spk_of = -1;
+  bool spk_symmetric = false;       // the matrix generation spk_of passed the symmetry test of the packing pass
+  DevBuf<unsigned long long> d_symstat;
   bool use_sym_gemv() const {
     static const bool off = exp_switch("CONP_GEMV_FULL") != nullptr;
     return !off && idx.elenum_all >= 2048;
@@ -1739,9 +1802,23 @@ struct conp_fix {
       if (spk_of != s_generation) {
         d_Spk.reserve(sym_packed_doubles(ne_pad));
         d_yp.reserve((size_t)(ne_pad / 128) * ne_pad);
-        launch_sym_pack(stream, ne, ne_pad, d_A.p, d_Spk.p);
+        d_symstat.reserve(2);
+        launch_sym_pack(stream, ne, ne_pad, d_A.p, d_Spk.p, d_symstat.p);
+        // once per matrix: is it symmetric?  The library's own projected inverse is (to ~1e-16 of its largest entry); a matrix
+        // from a file or from conp_fix_set_matrix need not be, and the reference multiplies full rows -- such a matrix keeps the
+        // row-by-row product below instead of being symmetrised without a word.
+        unsigned long long st[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(st, d_symstat.p, sizeof st, hipMemcpyDeviceToHost, stream));
+        sync();
+        double mx, md;
+        std::memcpy(&mx, &st[0], sizeof mx); std::memcpy(&md, &st[1], sizeof md);
+        spk_symmetric = md <= 1e-10 * mx;
         spk_of = s_generation;
+        if (!spk_symmetric)
+          mesgf("conp/hip: the solve matrix is not symmetric (max |S_ij - S_ji| = %.3g, max |S_ij| = %.3g): full rows are multiplied\n", md, mx);
       }
+    }
+    if (use_sym_gemv() && spk_symmetric) {
       prof.begin("gemv_charge", stream);
       launch_sym_gemv_finish(stream, ne, ne_pad, d_Spk.p, d_b, d_yp.p, d_eleallq, d_elesetq.p, args.qinit ? d_eleinitq.p : nullptr,
                              potdiff, d_ele_csr_ptr.p, d_ele_csr_of.p, d_ele_csr_row.p, d_qele.p, d_q_atoms);
@@ -1876,7 +1953,7 @@ struct conp_fix {
   // fix_conp.cpp:677-695 b_cal / update_bk
   void b_cal(const conp_atoms *at) {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
-    if (d_Rp.n == 0) km_a_read(at);      // electrode phase tables (kspmod->a_read) not built yet: b_cal before a_cal
+    if (!tables_current) km_a_read(at);      // electrode phase tables (kspmod->a_read) not built yet: b_cal before a_cal
     double t0 = time_host ? now_s() : 0.0;
     if (elyte_list_stale(at)) { sync(); build_elyte_list(at); }       // km_ewald.cpp:686 is evaluated every step
     if (time_host) { const double t1 = now_s(); th[0] += t1 - t0; t0 = t1; }
@@ -2235,7 +2312,7 @@ int conp_km_a_cal(conp_fix *f, const conp_atoms *at, double *aaa) {
 int conp_km_b_cal(conp_fix *f, const conp_atoms *at, double *bbb) {
   CONP_GUARD_BEGIN
   f->drop_graph();
-  if (f->d_Rp.n == 0) f->km_a_read(at);
+  if (!f->tables_current) f->km_a_read(at);
   if (at->nlocal + at->nghost != f->nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
   if (f->elyte_list_stale(at)) { f->sync(); f->build_elyte_list(at); }
   f->upload_xq(at);
@@ -2341,9 +2418,34 @@ int conp_fix_get_sfac(conp_fix *f, double *sr, double *si) {
 int conp_fix_get_ele_trig(conp_fix *f, double *csk, double *snk) {
   CONP_GUARD_BEGIN
   f->drop_graph();
-  if (f->csk_h.empty()) throw ConpError(CONP_ERR_STATE, "electrode tables not built (a_cal / a_read first)");
-  std::memcpy(csk, f->csk_h.data(), f->csk_h.size() * sizeof(double));
-  std::memcpy(snk, f->snk_h.data(), f->snk_h.size() * sizeof(double));
+  if (!f->tables_current) throw ConpError(CONP_ERR_STATE, "electrode tables not built (a_cal / a_read first)");
+  // a read-back of the DEVICE tables into the reference's layout csk / snk[i][kflat] (km_ewald.cpp:426-477): x axis, y axis, z axis,
+  // then the (kx, +-ky) pairs -- what the kernels of every later step actually read
+  const KTables &kt = f->kt;
+  const KPlan &pl = f->plan;
+  const int ne = f->idx.elenum_all, np_ = f->ne_pad, kflat = kt.kcount_flat;
+  const int d0 = kt.kcount_dims[0], d1 = kt.kcount_dims[1], d2 = kt.kcount_dims[2];
+  std::vector<double2> xe((size_t)(d0 + 2) * np_), ye((size_t)(d1 + 1) * np_);
+  std::vector<double> rp((size_t)pl.R_pad * np_), tz((size_t)pl.C_pad * np_);
+  HIP_TRY(hipMemcpyAsync(xe.data(), f->d_Xe.p, xe.size() * sizeof(double2), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipMemcpyAsync(ye.data(), f->d_Ye.p, ye.size() * sizeof(double2), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipMemcpyAsync(rp.data(), f->d_Rp.p, rp.size() * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipMemcpyAsync(tz.data(), f->d_Tz.p, tz.size() * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->sync();
+  for (int i = 0; i < ne; ++i) {
+    double *c = csk + (size_t)i * kflat, *s = snk + (size_t)i * kflat;
+    for (int k = 1; k <= d0; ++k) { c[k - 1] = xe[(size_t)k * np_ + i].x; s[k - 1] = xe[(size_t)k * np_ + i].y; }
+    for (int k = 1; k <= d1; ++k) { c[d0 + k - 1] = ye[(size_t)k * np_ + i].x; s[d0 + k - 1] = ye[(size_t)k * np_ + i].y; }
+    for (int m = 1; m <= d2; ++m) {
+      c[d0 + d1 + m - 1] = tz[(size_t)pl.col_c(m) * np_ + i];
+      s[d0 + d1 + m - 1] = tz[(size_t)pl.col_s(m) * np_ + i];
+    }
+    for (int fl = d0 + d1 + d2; fl < kflat; ++fl) {
+      const int p = pl.flat2p[fl];
+      c[fl] = rp[(size_t)pl.row_a(p) * np_ + i];
+      s[fl] = rp[(size_t)pl.row_b(p) * np_ + i];
+    }
+  }
   CONP_GUARD_END
 }
 
@@ -2771,6 +2873,17 @@ const char *conp_fix_log_drain(conp_fix *f) {
   f->logdrain.swap(f->logbuf);
   f->logbuf.clear();
   return f->logdrain.c_str();
+}
+
+// CONP_GUARD=1: reads back the guard zones around every device buffer of the library (all handles of this process).  Returns the
+// number of damaged zones (0: every kernel so far stayed inside its buffers), -1 when guard zones are off; conp_last_error()
+// then names the buffers' sizes.
+int conp_debug_check_guards(void) {
+  if (!GuardZones::on()) return -1;
+  std::string what;
+  const int bad = GuardZones::get().check(what);
+  if (bad) g_last_error = "guard zones damaged:" + what;
+  return bad;
 }
 
 int conp_fix_profile(conp_fix *f, int enable) {

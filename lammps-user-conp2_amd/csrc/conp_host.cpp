@@ -312,60 +312,21 @@ void PppmPlan::build(int nx_, int ny_, int nz_, int order_, double g, double sla
 // ------------------------------------------------------------------------------------------------
 // electrode phase tables
 // ------------------------------------------------------------------------------------------------
-void electrode_trig(const KTables &kt, int ne, const double *xele, std::vector<double> &csk, std::vector<double> &snk) {
-  const int kflat = kt.kcount_flat;
-  csk.assign((size_t)ne * kflat, 0.0);
-  snk.assign((size_t)ne * kflat, 0.0);
-  for (int i = 0; i < ne; ++i) {
-    double *c = csk.data() + (size_t)i * kflat, *s = snk.data() + (size_t)i * kflat;
-    int kf = 0;
-    for (int ic = 0; ic < 3; ++ic) {           // km_ewald.cpp:436-458 : libm cos/sin then angle-addition recurrence
-      const double xdotk = kt.unitk[ic] * xele[3 * i + ic];
-      c[kf] = std::cos(xdotk);
-      s[kf] = std::sin(xdotk);
-      for (int m = 1; m < kt.kcount_dims[ic]; ++m) {
-        c[kf + m] = c[kf + m - 1] * c[kf] - s[kf + m - 1] * s[kf];
-        s[kf + m] = s[kf + m - 1] * c[kf] + c[kf + m - 1] * s[kf];
-      }
-      kf += kt.kcount_dims[ic];
+// The seeds of km_ewald.cpp:440-442: (cos, sin)(unitk_c * x_ic) for the three axes, [6][ne] = cx, sx, cy, sy, cz, sz.  Everything
+// else of sincos_a_ele (the recurrences, the (kx, +-ky) products) runs on the device from these (conp_tables.hip).
+// This function lives in THIS translation unit on purpose: it is compiled by g++ like the oracle and like a LAMMPS build of the
+// reference, which turn the cos / sin pair of one argument into one sincos() call.  The same two lines compiled by hipcc's host
+// clang call cos() and sin() separately, and glibc's sin() / cos() differ from its sincos() in the last bit for about 7 arguments
+// in 10 000 (measured; on il_onelayer 186 of the 111 488 table entries moved) -- the tables would no longer be bit-identical to
+// the reference's.
+void electrode_seeds(const KTables &kt, int ne, const double *xele, std::vector<double> &seeds) {
+  seeds.assign((size_t)6 * std::max(ne, 1), 0.0);
+  for (int ic = 0; ic < 3; ++ic)
+    for (int i = 0; i < ne; ++i) {
+      const double xdotk = kt.unitk[ic] * xele[3 * (size_t)i + ic];
+      seeds[(size_t)(2 * ic) * ne + i] = std::cos(xdotk);
+      seeds[(size_t)(2 * ic + 1) * ne + i] = std::sin(xdotk);
     }
-    for (int m = 0; m < kt.kcount_dims[3]; ++m, kf += 2) {   // :464-477
-      const int kx = kt.kxvecs[kf] - 1, ky = kt.kyvecs[kf] + kt.kcount_dims[0] - 1;
-      c[kf] = c[kx] * c[ky] - s[kx] * s[ky];
-      s[kf] = c[kx] * s[ky] + s[kx] * c[ky];
-      c[kf + 1] = c[kx] * c[ky] + s[kx] * s[ky];
-      s[kf + 1] = -c[kx] * s[ky] + s[kx] * c[ky];
-    }
-  }
-}
-
-void electrode_plan_tables(const KTables &kt, const KPlan &plan, int ne, int ne_pad, const std::vector<double> &csk,
-                           const std::vector<double> &snk, std::vector<double> &Rp, std::vector<double> &Tz) {
-  const int kflat = kt.kcount_flat;
-  Rp.assign((size_t)plan.R_pad * ne_pad, 0.0);
-  Tz.assign((size_t)plan.C_pad * ne_pad, 0.0);
-  const int zoff = kt.kcount_dims[0] + kt.kcount_dims[1];
-  for (int i = 0; i < ne; ++i) {
-    Rp[(size_t)plan.row_a(0) * ne_pad + i] = 1.0;   // origin: cos 0
-    Tz[(size_t)plan.col_c(0) * ne_pad + i] = 1.0;   // m = 0
-  }
-  // a transpose ([atom][k] -> [k][atom]): atoms in blocks of 8, so that the 8 source rows stay in cache while f runs and every
-  // destination write is one full cache line
-  std::vector<size_t> dst_c(kflat), dst_s(kflat);
-  std::vector<char> is_planar(kflat);
-  for (int f = 0; f < kflat; ++f) {
-    const int p = plan.flat2p[f];
-    is_planar[f] = p >= 0;
-    if (p >= 0) { dst_c[f] = (size_t)plan.row_a(p) * ne_pad; dst_s[f] = (size_t)plan.row_b(p) * ne_pad; }
-    else { const int m = f - zoff + 1; dst_c[f] = (size_t)plan.col_c(m) * ne_pad; dst_s[f] = (size_t)plan.col_s(m) * ne_pad; }
-  }
-  for (int i0 = 0; i0 < ne; i0 += 8) {
-    const int i1 = std::min(ne, i0 + 8);
-    for (int f = 0; f < kflat; ++f) {
-      double *dc = (is_planar[f] ? Rp.data() : Tz.data()) + dst_c[f], *ds = (is_planar[f] ? Rp.data() : Tz.data()) + dst_s[f];
-      for (int i = i0; i < i1; ++i) { dc[i] = csk[(size_t)i * kflat + f]; ds[i] = snk[(size_t)i * kflat + f]; }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -97,12 +97,9 @@ struct PppmPlan {
   void rho1d(double dx, double *w) const;   // PPPM::compute_rho1d, one axis
 };
 
-// electrode phase tables.  csk/snk: [ne][kcount_flat] exactly as km_ewald.cpp:426-477 (lowmem) computes them;
-// Rp: [R_pad][ne_pad] planar cos/sin rows in G's row layout, Tz: [C_pad][ne_pad] z cos/sin in G's col layout.
-void electrode_trig(const KTables &kt, int ne, const double *xele /*[ne][3]*/, std::vector<double> &csk,
-                    std::vector<double> &snk);
-void electrode_plan_tables(const KTables &kt, const KPlan &plan, int ne, int ne_pad, const std::vector<double> &csk,
-                           const std::vector<double> &snk, std::vector<double> &Rp, std::vector<double> &Tz);
+// electrode phase tables: the host's share is the 3 Ne seed pairs (cos, sin)(unitk_c x_ic) of km_ewald.cpp:440-442, [6][ne] = cx, sx,
+// cy, sy, cz, sz; the recurrences and products of sincos_a_ele (:443-477) run on the device (conp_tables.hip)
+void electrode_seeds(const KTables &kt, int ne, const double *xele /*[ne][3]*/, std::vector<double> &seeds);
 
 // ------------------------------------------------------------------------------------------------
 // RankOps: the collectives FixConp::post_neighbor / linalg_init make on `world` (fix_conp.cpp:415, 492, 523, 535).  The default

@@ -617,10 +617,10 @@ bool launch_inverse(hipStream_t s, int n, double *M, double *work, int *piv_all 
   return used_multi;
 }
 
-// exact symmetry test: *flag_dev (device int) = 1 / 0
+// exact symmetry test: *flag_dev (device int) = non-zero / 0
 void launch_symmetry_check(hipStream_t s, int n, const double *M, int *flag_dev) {
-  const int one = 1;
-  (void)hipMemcpyAsync(flag_dev, &one, sizeof(int), hipMemcpyHostToDevice, s);
+  // (a memset, not an asynchronous copy out of a stack variable that is gone when this returns)
+  (void)hipMemsetAsync(flag_dev, 1, sizeof(int), s);
   const size_t tot = (size_t)n * n;
   hipLaunchKernelGGL(inv_symmetry_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, M, flag_dev);
 }

@@ -127,7 +127,8 @@ void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1
                            const double *breal = nullptr /*pair sums formed earlier in this update, or NULL: formed here*/);
 // the same GEMV + charge write with the matrix taken as symmetric: packed lower-triangle tiles, half the bytes (conp_kernels.hip)
 size_t sym_packed_doubles(int ne_pad);
-void launch_sym_pack(hipStream_t s, int ne, int ne_pad, const double *S, double *Spk);
+// stat [2] (device): receives the bit patterns of max |S_ij| and max |S_ij - S_ji| -- how symmetric the matrix is
+void launch_sym_pack(hipStream_t s, int ne, int ne_pad, const double *S, double *Spk, unsigned long long *stat);
 void launch_sym_gemv_finish(hipStream_t s, int n, int ne_pad, const double *Spk, const double *b, double *yp /*[ne_pad / 128][ne_pad]*/,
                             double *y, const double *elesetq, const double *eleinitq, double potdiff, const int *atoms_ptr,
                             const int *atoms_of, const int *atoms_row /*row of every CSR entry*/, double *q_ele, double *q_atoms);
@@ -156,6 +157,12 @@ void launch_results_out(hipStream_t s, int ne, const int *elecheck, const double
                         double *host_q /*page-locked host memory*/, double *host_scal);
 
 // ---- once-per-run matrix work ------------------------------------------------------------------
+// electrode phase tables on the device (conp_tables.hip; km_ewald.cpp:426-531).  seeds: [6][ne] = (cos, sin)(unitk_c x_ic) per axis,
+// from the host's libm; the target buffers must be zeroed (padding rows and atoms stay zero).
+void launch_ele_tables(hipStream_t s, const DevPlan &pl, int kzt, int ne, int ne_pad, const double *seeds, double2 *Xe /*[kxmax+2][ne_pad]*/,
+                       double2 *Ye /*[kymax+1][ne_pad]*/, double *Tz /*[C_pad][ne_pad]*/, double *Rp /*[R_pad][ne_pad]*/);
+// Tzc[t][c] = Tz[t][rep[c]] ([C_pad][64]) and its class-major copy TzcT ([nzc][C_pad])
+void launch_ele_zclass(hipStream_t s, int C_pad, int ne_pad, int nzc, const int *rep, const double *Tz, double *Tzc, double *TzcT);
 int a_kspace_nsplit(int ne_pad, int num_cus, int nchunk, int nranks);
 // planar electrodes: the same matrix through the z-class factorisation (contraction over the planar rows only)
 void launch_a_kspace_zclass(hipStream_t s, const DevPlan &pl, int ne, int ne_pad, int nzc, const double *Rp, const double *Tzc,

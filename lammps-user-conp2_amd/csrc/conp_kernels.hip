@@ -1665,132 +1665,193 @@ void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, 
 // to rounding (~1e-16 relative).  The product below uses its LOWER triangle for both halves -- the matrix (S_lower + S_lower^T -
 // diag), equal to S within that rounding -- packed once per run as 128 x 128 tiles (tile (bi, bj <= bi) at bi (bi + 1) / 2 + bj,
 // row-major inside; the diagonal tiles hold both mirrored halves): 4 Ne^2 bytes per update instead of 8 Ne^2.
-// One workgroup per tile: the tile passes through LDS in two halves of 64 rows; 128 threads form the direct products
-// (rows of block bi against b[block bj]), 128 the transposed ones (columns -> rows of block bj against b[block bi]).  Every
-// (row block, source tile) pair owns one slot of yp[nb][ne_pad]: nothing is added across workgroups, the finishing kernel sums
+// The packing pass also measures how symmetric the matrix IS (max |S_ij - S_ji| against max |S_ij|): a matrix that came from a file
+// or from conp_fix_set_matrix need not be, and the reference multiplies full rows (ddot_, fix_conp.cpp:1135-1139) -- the caller
+// keeps the row-by-row product for such a matrix instead of symmetrising it silently.
+//
+// Round 4: the tile never touches LDS.  One workgroup per tile, four wavefronts of 32 rows; lane l of a wavefront loads the columns
+// (2 l, 2 l + 1) of each of its rows -- 32 coalesced 16-byte loads per lane, all requested at once, the whole tile in flight:
+//   transposed product (rows of block bj): acc_t += S[r][cols] * b_i[r] in registers, b_i[r] wavefront-uniform; the four
+//     wavefronts' partial columns are added through 4 KB of LDS in a fixed order;
+//   direct product (rows of block bi): p_r = S[r][2l] b_j[2l] + S[r][2l+1] b_j[2l+1], then the 32 row sums over the 64 lanes by a
+//     transposing butterfly (a lane keeps the half of its values that carries ITS lane bit and adds the partner's copy: 16 + 8 + 4
+//     + 2 + 1 + 1 = 32 exchange-adds instead of 32 x 6) -- lane l ends up with the sum of row l >> 1.
+// Round 3 staged the tile through LDS in four 32-row quarters: its 16-byte writes into odd-stride rows cost 3.1 bank-conflict cycles
+// per LDS instruction (SQ_LDS_BANK_CONFLICT 1 081 344 on 348 736 instructions) and eight barriers per tile: 16.2 us, 4.3 TB/s.
+// Every (row block, source tile) pair owns one slot of yp[nb][ne_pad]: nothing is added across workgroups, the finishing kernel sums
 // a row's nb slots in a fixed order -> bitwise reproducible.
 constexpr int SG_T = 128;                 // tile edge
-constexpr int SG_LD = SG_T + 1;           // LDS row stride (odd: conflict-free row- and column-wise)
-__global__ __launch_bounds__(256) void sym_pack_kernel(int ne, const double *__restrict__ S, double *__restrict__ Spk) {
+__device__ __forceinline__ unsigned long long f64_bits_abs(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
+__global__ __launch_bounds__(256) void sym_pack_kernel(int ne, const double *__restrict__ S, double *__restrict__ Spk,
+                                                       unsigned long long *__restrict__ stat /*[2]: bits of max |S_ij|, max |S_ij - S_ji|*/) {
   int t = blockIdx.x, bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
   const int bj = t - bi * (bi + 1) / 2;
   double *out = Spk + (size_t)t * SG_T * SG_T;
+  double mx = 0.0, md = 0.0;
   for (int e = threadIdx.x; e < SG_T * SG_T; e += 256) {
     const int r = e >> 7, c = e & 127;
     int i = bi * SG_T + r, j = bj * SG_T + c;
     if (j > i) { const int k = i; i = j; j = k; }            // diagonal tile, upper half: the mirrored lower element
-    out[e] = (i < ne && j < ne) ? S[(size_t)i * ne + j] : 0.0;
+    double v = 0.0;
+    if (i < ne && j < ne) {
+      v = S[(size_t)i * ne + j];
+      const double u = S[(size_t)j * ne + i];
+      mx = fmax(mx, fmax(fabs(v), fabs(u)));
+      md = fmax(md, fabs(v - u));
+    }
+    out[e] = v;
   }
+  // (non-negative doubles order like their bit patterns: an integer atomicMax is exact and order-independent)
+  for (int off = 32; off > 0; off >>= 1) { mx = fmax(mx, __shfl_down(mx, off, 64)); md = fmax(md, __shfl_down(md, off, 64)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(stat, f64_bits_abs(mx)); atomicMax(stat + 1, f64_bits_abs(md)); }
 }
 
-__global__ __launch_bounds__(256, 4) void sym_gemv_kernel(int ne_pad, const double *__restrict__ Spk, const double *__restrict__ b,
+// sum over the 64 lanes of each of the 16 values of `p`: lane l returns the total of p[l >> 2] (the four lanes of a quad hold it).
+// Fixed association: bitwise reproducible.
+__device__ __forceinline__ double wave_sum16_transposed(double (&p)[16], unsigned lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool hi = lane & 32;
+    const double keep = hi ? p[8 + i] : p[i], send = hi ? p[i] : p[8 + i];
+    p[i] = keep + __shfl_xor(send, 32, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool hi = lane & 16;
+    const double keep = hi ? p[4 + i] : p[i], send = hi ? p[i] : p[4 + i];
+    p[i] = keep + __shfl_xor(send, 16, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bool hi = lane & 8;
+    const double keep = hi ? p[2 + i] : p[i], send = hi ? p[i] : p[2 + i];
+    p[i] = keep + __shfl_xor(send, 8, 64);
+  }
+  {
+    const bool hi = lane & 4;
+    const double keep = hi ? p[1] : p[0], send = hi ? p[0] : p[1];
+    p[0] = keep + __shfl_xor(send, 4, 64);
+  }
+  p[0] += __shfl_xor(p[0], 2, 64);
+  return p[0] + __shfl_xor(p[0], 1, 64);
+}
+
+// (two passes of 16 rows per wavefront, the second pass's loads requested when the first pass's values have been used: ~110
+//  registers, four workgroups per CU -- all 528 tiles of the headline size resident at once.  With all 32 rows of a wavefront in flight
+//  the kernel needs 204 registers: two workgroups per CU, 512 slots for 528 tiles, a second round for sixteen of them.)
+__global__ __launch_bounds__(256, 4) void sym_gemv_kernel(int ne, int ne_pad, const double *__restrict__ Spk, const double *__restrict__ b,
                                                           double *__restrict__ yp /*[nb][ne_pad]*/) {
-  // the tile passes through LDS in four quarters of 32 rows (33 KB, 64 data registers: four workgroups per CU -- all 528 tiles of
-  // the headline size are resident at once; with 64-row halves two fitted per CU and sixteen tiles ran in a second round)
-  __shared__ double L[32 * SG_LD];
   __shared__ double bi_s[SG_T], bj_s[SG_T];
+  __shared__ double tr[4][SG_T];
   int t = blockIdx.x, bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
   const int bj = t - bi * (bi + 1) / 2;
-  const int tid = threadIdx.x;
-  const double2 *tile = reinterpret_cast<const double2 *>(Spk + (size_t)t * SG_T * SG_T);
-  // two quarters are requested up front (8 x 16 bytes per thread each), quarter qd + 2 when quarter qd goes into LDS: the second
-  // half of the tile arrives while the first is being multiplied (everything up front made the launch one burst of 67 MB
-  // followed by an LDS tail)
-  double2 v[2][8];                                 // quarter qd lives in v[qd & 1]
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double2 *tile = reinterpret_cast<const double2 *>(Spk + (size_t)t * SG_T * SG_T) + (size_t)(32 * wave) * 64 + lane;
+  double2 v[16];
 #pragma unroll
-  for (int qd = 0; qd < 2; ++qd)
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[qd][u] = tile[2048 * qd + tid + 256 * u];
-  if (tid < SG_T) bi_s[tid] = b[bi * SG_T + tid]; else bj_s[tid - SG_T] = b[bj * SG_T + tid - SG_T];
-  double acc_t = 0.0;                              // transposed: thread tid < 128 owns column tid
-  const bool direct = tid >= SG_T;
-  // direct: row dr of the quarter, columns 32 m + 8 dh + n (m < 4, n < 8): conflict-free row-wise reads with the odd stride
-  const int u_ = tid - SG_T, dr = u_ >> 2, dh = u_ & 3;
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e2 = tid + 256 * u;                // double2 index inside the quarter: row = e2 >> 6, column pair = e2 & 63
-      const int r = e2 >> 6, c = (e2 & 63) * 2;
-      L[r * SG_LD + c] = v[qd & 1][u].x; L[r * SG_LD + c + 1] = v[qd & 1][u].y;
-    }
-    if (qd + 2 < 4) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[qd & 1][u] = tile[2048 * (qd + 2) + tid + 256 * u];
-    }
-    __syncthreads();
-    if (!direct) {
-      if (bi != bj) {
-        const double *bb = bi_s + 32 * qd;
-#pragma unroll 16
-        for (int r = 0; r < 32; ++r) acc_t = fma(L[r * SG_LD + tid], bb[r], acc_t);
-      }
-    } else {
-      double a = 0.0;
-      const double *row = L + dr * SG_LD;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 8; ++n) { const int c = 32 * m + 8 * dh + n; a = fma(row[c], bj_s[c], a); }
-      a += __shfl_xor(a, 1, 64);                   // the four column groups of the row (adjacent lanes), fixed order
-      a += __shfl_xor(a, 2, 64);
-      if (dh == 0) yp[(size_t)bj * ne_pad + bi * SG_T + 32 * qd + dr] = a;
-    }
+  for (int r = 0; r < 16; ++r) v[r] = tile[r * 64];
+  // b beyond Ne reads as zero: a bound b vector holds Ne entries only (conp_fix_bind_device_buffers), the packed tiles are zero
+  // there, and 0 * (whatever lies behind the host's buffer) must not become NaN
+  {
+    const int i = (tid < SG_T ? bi : bj) * SG_T + (int)(tid & (SG_T - 1));
+    (tid < SG_T ? bi_s : bj_s)[tid & (SG_T - 1)] = i < ne ? b[i] : 0.0;
   }
-  if (!direct && bi != bj) yp[(size_t)bi * ne_pad + bj * SG_T + tid] = acc_t;
+  __syncthreads();
+  // (both b blocks come out of LDS behind the barrier: with b_j in registers the compiler forms the direct products above the barrier
+  //  and has to carry the loaded rows across it for the transposed ones -- spills)
+  const double bj0 = bj_s[2 * lane], bj1 = bj_s[2 * lane + 1];
+  double at0 = 0.0, at1 = 0.0;
+  double *ydir = yp + (size_t)bj * ne_pad + bi * SG_T + 32 * wave + (lane >> 2);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    double p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = fma(v[r].y, bj1, v[r].x * bj0);
+      const double br = bi_s[32 * wave + 16 * h + r];      // wavefront-uniform: one broadcast read
+      at0 = fma(v[r].x, br, at0);
+      at1 = fma(v[r].y, br, at1);
+    }
+    if (h == 0) {
+      // the second pass's loads reuse the first pass's registers: the offset is made opaque BEHIND the first pass's last use of
+      // them (left alone the compiler requests all 32 rows at the top and spills)
+      unsigned off2 = 16 * 64;
+      asm volatile("" : "+v"(off2) : "v"(at0), "v"(at1));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = tile[off2 + r * 64];
+    }
+    const double rs = wave_sum16_transposed(p, lane);
+    if ((lane & 3) == 0) ydir[16 * h] = rs;
+  }
+  if (bi != bj) {
+    tr[wave][2 * lane] = at0; tr[wave][2 * lane + 1] = at1;
+    __syncthreads();
+    if (tid < SG_T) yp[(size_t)bi * ne_pad + bj * SG_T + tid] = (tr[0][tid] + tr[1][tid]) + (tr[2][tid] + tr[3][tid]);
+  }
 }
 
 // y[row] = sum of the row's nb slots (fixed order), q = y + dV setq (+ qinit); then the charge write of gemv_finish_kernel's tail:
-// the block's rows own a contiguous run of the CSR atom list, walked by all threads (row of an entry: atoms_row)
-constexpr int SF_T = 64;                  // rows per finishing block: 64 blocks at Ne = 4096
-__global__ __launch_bounds__(SF_T) void sym_finish_kernel(int n, int ne_pad, int nb, const double *__restrict__ yp, double *__restrict__ y,
+// the block's rows own a contiguous run of the CSR atom list, walked by all threads (row of an entry: atoms_row).
+// Four threads per row: thread g adds the slots g, g + 4, g + 8, ... in order -- exactly the partial sum s4[g] of the 4-wide loop the
+// one-thread form ran (round 3), combined as (s0 + s1) + (s2 + s3): the same bits, a quarter of the dependent loads per thread.
+constexpr int SF_R = 32;                  // rows per finishing block: 128 blocks of 128 threads at Ne = 4096
+__global__ __launch_bounds__(4 * SF_R) void sym_finish_kernel(int n, int ne_pad, int nb, const double *__restrict__ yp, double *__restrict__ y,
                                                          const double *__restrict__ elesetq, const double *__restrict__ eleinitq,
                                                          double potdiff, const int *__restrict__ atoms_ptr,
                                                          const int *__restrict__ atoms_of, const int *__restrict__ atoms_row,
                                                          double *__restrict__ q_ele, double *__restrict__ q_atoms) {
-  __shared__ double vq[SF_T];
-  const int row0 = blockIdx.x * SF_T, row = row0 + threadIdx.x;
+  __shared__ double part[4][SF_R];
+  __shared__ double vq[SF_R];
+  const int rl = threadIdx.x & (SF_R - 1), g = threadIdx.x / SF_R;
+  const int row0 = blockIdx.x * SF_R, row = row0 + rl;
+  const int rend = row0 + SF_R < n ? row0 + SF_R : n;
+  // the block's run of the atom list and this row's constants are requested before the slots: their latency hides behind the sums
+  int k0 = 0, k1 = 0;
+  if (q_atoms) { k0 = atoms_ptr[row0]; k1 = atoms_ptr[rend]; }
+  double sq = 0.0, iq = 0.0;
+  if (g == 0 && row < n) { sq = elesetq[row]; if (eleinitq) iq = eleinitq[row]; }
+  double s = 0.0;
   if (row < n) {
-    // 32 slots in flight per round (the loads are the kernel: one dependent round trip per four slots took 7 us); additions in
-    // the order of a 4-wide loop -> the same bits whatever nb
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < nb; k0 += 32) {
-      double w[32];
+    for (int kb = g; kb < nb; kb += 32) {              // eight slots in flight per thread
+      double w[8];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) w[u] = k0 + u < nb ? yp[(size_t)(k0 + u) * ne_pad + row] : 0.0;
+      for (int u = 0; u < 8; ++u) w[u] = kb + 4 * u < nb ? yp[(size_t)(kb + 4 * u) * ne_pad + row] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 32; ++u) s4[u & 3] += w[u];
+      for (int u = 0; u < 8; ++u) s += w[u];
     }
-    const double r = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
+  part[g][rl] = s;
+  __syncthreads();
+  if (g == 0 && row < n) {
+    const double r = (part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl]);
     double v;
     {
 #pragma clang fp contract(off)
-      v = r + potdiff * elesetq[row];
-      if (eleinitq) v += eleinitq[row];
+      v = r + potdiff * sq;
+      if (eleinitq) v += iq;
     }
     y[row] = r; q_ele[row] = v;
-    vq[threadIdx.x] = v;
+    vq[rl] = v;
   }
   __syncthreads();
   if (!q_atoms) return;
-  const int rend = row0 + SF_T < n ? row0 + SF_T : n;
-  for (int k = atoms_ptr[row0] + threadIdx.x; k < atoms_ptr[rend]; k += SF_T) q_atoms[atoms_of[k]] = vq[atoms_row[k] - row0];
+  for (int k = k0 + (int)threadIdx.x; k < k1; k += 4 * SF_R) q_atoms[atoms_of[k]] = vq[atoms_row[k] - row0];
 }
 
 size_t sym_packed_doubles(int ne_pad) { const size_t nb = ne_pad / SG_T; return nb * (nb + 1) / 2 * SG_T * SG_T; }
-void launch_sym_pack(hipStream_t s, int ne, int ne_pad, const double *S, double *Spk) {
+void launch_sym_pack(hipStream_t s, int ne, int ne_pad, const double *S, double *Spk, unsigned long long *stat) {
   const int nb = ne_pad / SG_T;
-  hipLaunchKernelGGL(sym_pack_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, ne, S, Spk);
+  (void)hipMemsetAsync(stat, 0, 2 * sizeof(unsigned long long), s);
+  hipLaunchKernelGGL(sym_pack_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, ne, S, Spk, stat);
 }
 void launch_sym_gemv_finish(hipStream_t s, int n, int ne_pad, const double *Spk, const double *b, double *yp, double *y,
                             const double *elesetq, const double *eleinitq, double potdiff, const int *atoms_ptr, const int *atoms_of,
                             const int *atoms_row, double *q_ele, double *q_atoms) {
   const int nb = ne_pad / SG_T;
-  hipLaunchKernelGGL(sym_gemv_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, ne_pad, Spk, b, yp);
-  hipLaunchKernelGGL(sym_finish_kernel, dim3((n + SF_T - 1) / SF_T), dim3(SF_T), 0, s, n, ne_pad, nb, (const double *)yp, y, elesetq, eleinitq,
+  hipLaunchKernelGGL(sym_gemv_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, n, ne_pad, Spk, b, yp);
+  hipLaunchKernelGGL(sym_finish_kernel, dim3((n + SF_R - 1) / SF_R), dim3(4 * SF_R), 0, s, n, ne_pad, nb, (const double *)yp, y, elesetq, eleinitq,
                      potdiff, atoms_ptr, atoms_of, atoms_row, q_ele, q_atoms);
 }
 

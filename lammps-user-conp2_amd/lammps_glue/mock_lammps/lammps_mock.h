@@ -17,7 +17,7 @@ namespace LAMMPS_NS {
 typedef int tagint;
 typedef int64_t bigint;
 
-class Error { public: [[noreturn]] void all(const char *, int, const std::string &); void warning(const char *, int, const std::string &); };
+class Error { public: [[noreturn]] void all(const char *, int, const std::string &); [[noreturn]] void one(const char *, int, const std::string &); void warning(const char *, int, const std::string &); };
 class Memory {};
 class Atom { public: int nlocal, nghost, ntypes, nmax = 0; bigint natoms; double **x, **f, *q; int *type, *mask, *molecule = nullptr; tagint *tag; int map(tagint);
              int *map_array = nullptr; int map_size = 0; };

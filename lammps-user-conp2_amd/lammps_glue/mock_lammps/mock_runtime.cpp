@@ -78,6 +78,7 @@ void Error::all(const char *file, int line, const std::string &msg) {
   (void)file; (void)line;
   throw std::runtime_error(msg);
 }
+void Error::one(const char *file, int line, const std::string &msg) { all(file, line, msg); }   // (LAMMPS: MPI_Abort from the calling rank alone)
 void Error::warning(const char *, int, const std::string &msg) { std::fprintf(stderr, "WARNING: %s\n", msg.c_str()); }
 
 int Atom::map(tagint t) { return (t >= 0 && t < map_size) ? map_array[t] : -1; }

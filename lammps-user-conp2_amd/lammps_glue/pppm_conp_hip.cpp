@@ -117,7 +117,8 @@ void PPPMConpHip::b_cal(double *bbb) {          /* spread, Poisson solve, stenci
 }
 
 double PPPMConpHip::compute_particle_potential(int i) {
-  if (comm->nprocs > 1) error->all(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
+  // (a per-atom call: not every rank need make it -- error->one, the collective error->all would leave the others waiting in MPI)
+  if (comm->nprocs > 1) error->one(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
   conp_atoms at = view();
   double u = 0.0;
   fail_if(conp_pppm_compute_particle_potential(h, &at, i, &u));

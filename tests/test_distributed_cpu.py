@@ -1,6 +1,7 @@
-"""world_size-2 gloo test (CPU): the k-shard + row-shard decomposition and its two collectives reproduce the
-single-rank charge update.  The per-rank arithmetic comes from the CPU oracle (the HIP path cannot run here); the
-choreography is the one bench.py uses on GPUs (conp_amd/distributed.py)."""
+"""world_size-2 / -3 gloo test (CPU): the product's decomposition -- every rank contracts ITS share of the electrolyte atoms for all
+k-vectors and projects on all electrode rows (conp_amd/distributed.py atom_shard = conp_fix.cpp build_items), rows of the solve
+sharded -- and its two collectives reproduce the single-rank charge update.  The per-rank arithmetic comes from the CPU oracle (the
+HIP path cannot run here); the choreography is the one bench.py uses on GPUs (conp_amd/distributed.py)."""
 import os
 import sys
 
@@ -18,7 +19,7 @@ def _worker(rank, world, port, out):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     from conp_amd import neighbor, systems
-    from conp_amd.distributed import my_row_tiles, row_range, sharded_update
+    from conp_amd.distributed import atom_shard, row_range, sharded_update
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = oracle_py.load()
@@ -35,21 +36,19 @@ def _worker(rank, world, port, out):
     ks = fo.ks
     ne = fo.sizes()["elenum_all"]
     csk, snk = fo.trig()
-    sr, si = ks.sincos_b(at.x, q, at.echeck, at.nlocal)
-    # planar vector of every k (same rule as KPlan: sorted by |k_p|^2, 64 per row tile)
-    kx, ky = ks.kxvecs, ks.kyvecs
-    planar = sorted({(int(a), int(b)) for a, b in zip(kx, ky)} | {(0, 0)},
-                    key=lambda p: (p[0] * ks.unitk[0]) ** 2 + (p[1] * ks.unitk[1]) ** 2)
-    tile_of = {p: i // 64 for i, p in enumerate(planar)}
-    n_tiles = (len(planar) + 63) // 64
-    mine = set(my_row_tiles(n_tiles, rank, world))
-    keep = np.array([tile_of[(int(a), int(b))] in mine for a, b in zip(kx, ky)])
+    # this rank's share of the compact electrolyte list (km_ewald.cpp:686: electrode_check == 0 && q != 0, local order): the
+    # structure factors of ITS atoms only -- the other atoms' charges read as zero, which is exactly the list filter
+    elyte = np.nonzero((at.echeck[:at.nlocal] == 0) & (q[:at.nlocal] != 0))[0]
+    j0, j1 = atom_shard(len(elyte), rank, world)
+    q_mine = np.zeros_like(q)
+    q_mine[elyte[j0:j1]] = q[elyte[j0:j1]]
+    sr, si = ks.sincos_b(at.x, q_mine, at.echeck, at.nlocal)
     r0, r1 = row_range(ne, rank, world)
     m = fo.maps()
 
     class Backend:
         def b_local(self):
-            bk = ks.bbb(csk, snk, np.where(keep, sr, 0.0), np.where(keep, si, 0.0))     # this rank's k-shard, all rows
+            bk = ks.bbb(csk, snk, sr, si)               # all k-vectors, all rows, this rank's atoms
             if rank == 0 and s.slabflag:
                 xele = np.zeros((ne, 3)); loc = {int(t): i for i, t in enumerate(at.tag[:at.nlocal])}
                 for ia, t in enumerate(m["eleall2tag"]):
@@ -71,7 +70,7 @@ def _worker(rank, world, port, out):
     fo.pre_force(s.potdiff)
     b_ref, q_ref, _ = fo.vectors()
     out[rank] = (float(np.abs(b.numpy() - b_ref).max() / np.abs(b_ref).max()),
-                 float(np.abs(q_all.numpy() - q_ref).max() / np.abs(q_ref).max()), n_tiles, len(mine))
+                 float(np.abs(q_all.numpy() - q_ref).max() / np.abs(q_ref).max()), len(elyte), j0, j1)
     fo.close()
     dist.destroy_process_group()
 
@@ -84,6 +83,9 @@ def test_sharded_update_matches_single_rank(world):
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert len(out) == world
     for rank in range(world):
-        eb, eq, n_tiles, nmine = out[rank]
+        eb, eq, n_elyte, j0, j1 = out[rank]
         assert eb < 1e-12 and eq < 1e-11, (rank, eb, eq)
-    assert sum(out[r][3] for r in range(world)) == out[0][2]   # every row tile owned exactly once
+    # the ranks' atom ranges tile the compact list exactly once, in rank order
+    assert out[0][3] == 0 and out[world - 1][4] == out[0][2]
+    for rank in range(1, world):
+        assert out[rank][3] == out[rank - 1][4]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-rank compute time of the sharded update WITHOUT the collectives: one process builds the handle of rank r of N
 (conp_env.rank / nranks) on the single GPU and times b_cal_device + solve_device + scatter_device.  Used to see how the
-k-shard / row-shard scales before an N-GPU node is available; the two 32-KB RCCL collectives come on top.
+atom-shard (structure factors) / row-shard (solve) scales before an N-GPU node is available; the two 32-KB RCCL collectives come on top.
 Runs against the PRODUCT library: the three device entry points below contain no collective (the host would make them between
 the calls), so no emulation switch is involved.
 usage: python tools/rank_emulation.py [--workload NAME] [--json PATH] [N ...]
@@ -78,7 +78,7 @@ def main():
         doc = {}
         if os.path.exists(jpath):
             doc = json.load(open(jpath))
-        doc["_about"] = ("per-rank COMPUTE time of the k-shard / row-shard update, one process per emulated rank on ONE MI355X "
+        doc["_about"] = ("per-rank COMPUTE time of the atom-shard (structure factors) / row-shard (solve) update, one process per emulated rank on ONE MI355X "
                          "(tools/rank_emulation.py); the two Ne-double collectives (all-reduce b, all-gather q) are not in these "
                          "numbers; NOT a hardware scaling curve")
         doc[s.name] = record
