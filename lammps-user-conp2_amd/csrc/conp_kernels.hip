@@ -498,8 +498,26 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, 
 // Straight-line form of the same phase: all four k-steps unrolled, the sphere cut F0 a template parameter -- no loop, no branch,
 // no scalar bookkeeping between MFMAs.  The (k-step, lane)-dependent 32-byte group of the swizzle costs one address register per
 // k-step and operand side (8 in all, XORed with the buffer bit once per chunk); fragment / column-group offsets are immediates.
+// The first reads of a chunk's MFMA phase -- the A value of row fragment 0 and the wave's NFW B values of k-step 0 -- can be
+// requested apart from the phase itself (SkPre): a LATE wave requests them BEFORE it builds the next panel, so that they queue
+// ahead of the build's fourteen LDS writes (LDS operations of a wave complete in order) and the first MFMAs do not wait for the
+// write drain behind the build.
+template <int NFW>
+struct SkPre { double a0; double bf[NFW > 0 ? NFW : 1]; };
+template <int NFW>
+__device__ __forceinline__ void sk_mfma_prefetch(const SkCtx &c, const char *smem, unsigned buf, SkPre<NFW> &pre) {
+  if constexpr (NFW > 0) {
+    constexpr unsigned FB = 64 * SK_LD * 8;
+    const unsigned q = c.pq;
+    pre.a0 = SK_LDS_F64((c.base_a ^ buf) + q);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NFW; ++g) { pre.bf[g] = SK_LDS_F64((c.base_b ^ buf) + q + g * FB); __builtin_amdgcn_sched_barrier(0); }
+  }
+}
 template <int NFW, int F0>
-__device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
+__device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1],
+                                                const SkPre<NFW> *pre = nullptr) {
   if constexpr (NFW > 0) {
     constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
     unsigned aa[4], ab[4];
@@ -510,10 +528,16 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
       ab[ks] = (c.base_b ^ buf) + q;
     }
     double bf[NFW], a0, a1;
-    a0 = SK_LDS_F64(aa[0]);
-    __builtin_amdgcn_sched_barrier(0);
+    if (pre) {
+      a0 = pre->a0;
 #pragma unroll
-    for (int g = 0; g < NFW; ++g) { bf[g] = SK_LDS_F64(ab[0] + g * FB); __builtin_amdgcn_sched_barrier(0); }
+      for (int g = 0; g < NFW; ++g) bf[g] = pre->bf[g];
+    } else {
+      a0 = SK_LDS_F64(aa[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NFW; ++g) { bf[g] = SK_LDS_F64(ab[0] + g * FB); __builtin_amdgcn_sched_barrier(0); }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kn = (ks + 1) & 3;
@@ -542,8 +566,16 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
 #endif
 #if SK_MFMA_LOOP
 #define SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc) sk_mfma_chunk<NFW>(c, smem, buf, acc)
+#define SK_LATE_PREFETCH 0
 #else
 #define SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc) sk_mfma_chunk_u<NFW, F0>(c, smem, buf, acc)
+// Measured and left off (round 4, one box, `make variant_pre VDEF=-DSK_LATE_PREFETCH=1`): the late waves' first operand reads requested
+// ahead of their panel build -- sk_gemm 243.5 vs 238.6 us at the headline size, 734 vs 734 us in the slab geometry.  The reads
+// queue ahead of the build's LDS writes as intended, but NFW + 1 more live registers through the build and a wait for them in
+// front of it cost more than the write drain they skip.
+#ifndef SK_LATE_PREFETCH
+#define SK_LATE_PREFETCH 0
+#endif
 #endif
 // Ablation switches (phases of the kernel turned off, TIMING ONLY, results are garbage) exist in the diagnostic build
 // -DSK_ABLATE only (`make ablate`, tools/sk_ablate.sh); in the product build the tests below fold to constants.
@@ -726,11 +758,20 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
 #if SK_LATE_MODE == 1
       // full stagger: build first, multiply second
       SK_STAMP_T(st_a);
+#if SK_LATE_PREFETCH
+      // (the phase's first operand reads go out ahead of the build's LDS writes: sk_mfma_prefetch)
+      SkPre<NFW> pre;
+      if (!(SK_DBG(c, 2))) sk_mfma_prefetch<NFW>(c, smem, buf, pre);
+#endif
       if (more && !(SK_DBG(c, 1))) sk_build_panel(c, raw, nxt);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
       if (ch + 2 < c.it.c1 && !(SK_DBG(c, 4))) sk_load_raw(c, ch + 2, raw);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_load, st_b, st_a);
+#if SK_LATE_PREFETCH
+      if (!(SK_DBG(c, 2))) sk_mfma_chunk_u<NFW, F0>(c, smem, buf, acc, &pre);
+#else
       if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc);
+#endif
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_mfma, st_a, st_b);
 #else
 #error "only the full stagger (SK_LATE_MODE 1) is kept: half stagger measured 264 vs 260 us (DESIGN.md)"
