@@ -38,6 +38,15 @@ def make_workload(name):
         return systems.synthetic_fast(n_cells_x=32, n_cells_y=16, lz=600.0, n_elyte=32768, cutoff=16.0,
                                       accuracy_relative=1e-7, g_ewald=0.21218, mode="slab", seed=12345,
                                       name="synthetic graphene/IL 4096 electrode + 32768 electrolyte, slab 3.0")
+    if name == "headline_rough":     # the same box with ROUGH electrodes: every electrode atom its own z (jitter as tests/test_gpu_parity.py `rough`),
+        # no z classes -> the general path of the update: partial tiles + sk_reduce + b_project, what the reference's tests/cond2 deck needs
+        s = systems.synthetic_fast(n_cells_x=32, n_cells_y=16, lz=600.0, n_elyte=32768, cutoff=16.0,
+                                   accuracy_relative=1e-7, g_ewald=0.21218, mode="ffield", seed=12345,
+                                   name="synthetic graphene/IL 4096 rough electrode + 32768 electrolyte, ffield")
+        rng = np.random.default_rng(4)
+        ele = s.echeck != 0
+        s.x[ele, 2] += rng.uniform(-0.05, 0.05, size=int(ele.sum()))
+        return s
     if name == "big":
         return systems.synthetic_fast(n_cells_x=64, n_cells_y=32, lz=1200.0, n_elyte=262144, cutoff=12.0,
                                       accuracy_relative=1e-6, g_ewald=0.2554, mode="ffield", seed=12345,
@@ -173,6 +182,10 @@ AUX_CONFIGS = [
     ("configs[2] il_twolayer cg+etypes", dict(workload="il_twolayer", solver="cg")),
     ("configs[3] il_onelayer pppm 40x45x180", dict(workload="il_onelayer", solver="inv", pppm=(40, 45, 180))),
     ("headline slab 3.0 (reference default geometry)", dict(workload="headline_slab", solver="inv", steps=100, warmup=10)),
+    # the GENERAL path of the update (rough electrodes: no z classes -> partial tiles, sk_reduce, b_project; once per run the (planar, kz)
+    # SYRK): the headline box with jittered electrode z, and the reference's own rough deck tests/cond2 (2 x 1248 electrode atoms)
+    ("headline, rough electrodes (general projection path)", dict(workload="headline_rough", solver="inv", steps=100, warmup=10)),
+    ("tests/cond2 deck (rough electrodes)", dict(workload="cond2", solver="inv")),
     # BASELINE configs[4]'s box (16384 electrode / 262144 electrolyte atoms) on ONE GPU: its 8-GPU half is the driver's scaling run
     ("configs[4] 16384/262144 on one GPU", dict(workload="big", solver="inv", steps=20, warmup=3)),
 ]

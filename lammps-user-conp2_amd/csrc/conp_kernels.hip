@@ -1259,15 +1259,42 @@ __device__ __forceinline__ double hc_slot_sum(const double *__restrict__ h, cons
 //  kernel boundary) went away and sk_gemm grew by 5.7-6.4 us: every workgroup pays the atomic's round trip behind its epilogue and
 //  eight late ones add 39 pieces each on the kernel's critical path.  0.2884 vs 0.2890 ms per update: nothing.  The same for
 //  sym_finish inside sym_gemv: 25.6 us instead of 23.1.)
+// Eight threads per element (round 4): thread u of an element's octet loads the pieces 8 g + u of every group g of eight at once
+// (39 pieces at the headline size: five loads in flight, ONE round trip -- the one-thread form walked five dependent rounds), the
+// octet's lanes add a group by a butterfly -- ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)), hc_slot_sum's tree, additions
+// commute -- and the groups are added in list order: the same bits as hc_slot_sum.
+constexpr int HCS_MAXG = 16;                 // groups of eight pieces a thread keeps in flight per pass
 __global__ __launch_bounds__(256) void hc_sum_kernel(const int *__restrict__ own_rt, int R_pad, int nzc, const double *__restrict__ Hp,
                                                      const int *__restrict__ slot_ptr, const int *__restrict__ slot_idx,
                                                      double *__restrict__ Hc4) {
-  const int k = blockIdx.x, rt = own_rt[k];
+  const int per = (128 * nzc + 31) / 32;             // blocks per row tile (32 elements each)
+  const int k = blockIdx.x / per, rt = own_rt[k];
   const int s0 = slot_ptr[k], s1 = slot_ptr[k + 1];
-  for (int e = threadIdx.x; e < 128 * nzc; e += 256) {
-    const int cls = e >> 7, row = e & 127;
-    Hc4[(size_t)cls * R_pad + (size_t)rt * 128 + row] = hc_slot_sum(Hp + cls * 128 + row, slot_idx, s0, s1, (size_t)SK_HC * 128);
+  const int u = threadIdx.x & 7;
+  const int e = (blockIdx.x - k * per) * 32 + (threadIdx.x >> 3);
+  const bool live = e < 128 * nzc;
+  const int cls = live ? e >> 7 : 0, row = e & 127;
+  const double *h = Hp + cls * 128 + row;
+  double acc = 0.0;
+  const int ng = (s1 - s0) / 8 + 1;                  // hc_slot_sum: the full groups, then one zero-padded group (possibly all zero)
+  for (int gb = 0; gb < ng; gb += HCS_MAXG) {
+    double v[HCS_MAXG];
+#pragma unroll
+    for (int g = 0; g < HCS_MAXG; ++g) {
+      const int sidx = s0 + 8 * (gb + g) + u;
+      v[g] = (live && sidx < s1) ? h[(size_t)slot_idx[sidx] * (SK_HC * 128)] : 0.0;
+    }
+#pragma unroll
+    for (int g = 0; g < HCS_MAXG; ++g) {
+      if (gb + g >= ng) break;                        // (uniform over the block)
+      double t = v[g];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      acc += t;
+    }
   }
+  if (live && u == 0) Hc4[(size_t)cls * R_pad + (size_t)rt * 128 + row] = acc;
 }
 
 // grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16.
@@ -1345,6 +1372,9 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   const size_t hp = (size_t)R_pad * 64;
   // the slab scalar by the first wave, with b_real_combine's summation tree (the 16 finishing threads are lanes of that wave)
   const double sc = (ra.slab && threadIdx.x < 64) ? b_slab_scalar(ra, threadIdx.x) : 0.0;
+  // what the finishing threads add at the very end is requested now (it was one more dependent round trip behind the last barrier)
+  double fin_z = 0.0, fin_r = 0.0;
+  if (w == 0 && i < ra.ne) { if (ra.slab) fin_z = ra.ele_z[i]; fin_r = ra.breal[i]; }
   // the first 8 row tiles' phases are requested BEFORE the Hc table is staged: the two latencies overlap instead of adding up --
   // at the headline size that is everything this thread reads
   double2 xe0[8], ye0[8];
@@ -1416,8 +1446,8 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
 #pragma unroll
     for (int k = 0; k < 64; k += 4) tot += (red[k][a] + red[k + 1][a]) + (red[k + 2][a] + red[k + 3][a]);
     double v = -tot;
-    if (ra.slab) v -= ra.ele_z[i] * sc;
-    v += ra.breal[i];
+    if (ra.slab) v -= fin_z * sc;
+    v += fin_r;
     ra.b_out[i] = v;
     if (ra.slab && i == 0 && ra.slab_out) *ra.slab_out = sc;
   }
@@ -1553,7 +1583,7 @@ void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, 
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
   if (n_own <= 0) return;
   if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
-  hipLaunchKernelGGL(hc_sum_kernel, dim3(n_own), dim3(256), 0, s, own_rt, pl.R_pad, nzc, Hp, slot_ptr, slot_idx, Hc);
+  hipLaunchKernelGGL(hc_sum_kernel, dim3(n_own * ((128 * nzc + 31) / 32)), dim3(256), 0, s, own_rt, pl.R_pad, nzc, Hp, slot_ptr, slot_idx, Hc);
   if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 1);
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 1);
 }
