@@ -328,7 +328,8 @@ struct conp_fix {
   int table_c0 = 0, table_c1 = 0;  // chunk range (16 atoms each) whose phase tables this rank's sk_gemm reads
   int hslots = 0;                  // entries of the owned row tiles' segment lists (d_hslot_idx)
   bool g_current = true;           // d_G holds the last update's structure factors (false after a projecting update: conp_fix_get_sfac re-forms it)
-  int max_nsplit = 0;              // most sk_gemm segments any tile is cut into (chooses sk_reduce's one- or two-level sum)
+  int max_nsplit = 0;              // most output slots any tile of the plan has (chooses sk_reduce's one- or two-level sum)
+  int n_slots = 0;                 // output slots of sk_gemm: one per (segment, row tile of the plan its band touches)
   DevPlan dplan{};
   Profiler prof;
 
@@ -473,7 +474,8 @@ struct conp_fix {
              env.qqrd2e, env.dielectric);
     plan.build(kt);
     // padding planar rows point at the all-zero X row kxmax+1 (they then contribute nothing)
-    std::vector<int> ikx(plan.n_row_tiles * 64, plan.kxmax + 1), iky(plan.n_row_tiles * 64, 0), sgn(plan.n_row_tiles * 64, 1);
+    // (96 more than the plan's row tiles hold: a band of sk_gemm may run up to five row fragments past the last planar vector)
+    std::vector<int> ikx(plan.n_row_tiles * 64 + 96, plan.kxmax + 1), iky(plan.n_row_tiles * 64 + 96, 0), sgn(plan.n_row_tiles * 64 + 96, 1);
     for (int p = 0; p < plan.np; ++p) { ikx[p] = plan.p_ikx[p]; iky[p] = plan.p_iky[p]; sgn[p] = plan.p_sgn[p]; }
     d_p_ikx.upload(ikx, stream); d_p_iky.upload(iky, stream); d_p_sgn.upload(sgn, stream);
     d_wfull.upload(plan.wfull, stream);
@@ -783,9 +785,16 @@ struct conp_fix {
     return nzc > 0 && nzc <= sk_hc_max_classes() && !args.pppm && !sk_partials && !no_fuse;
   }
   void reserve_partials(bool tiles_too = false) {
+    const size_t ns = std::max<size_t>(1, (size_t)n_slots);
     if (sk_projects()) d_Hpart.reserve(std::max<size_t>(1, items_h.size()) * sk_hc_stride());
-    if (!sk_projects() || tiles_too)
-      if ((size_t)items_h.size() * 128 * 320 > d_Gpart.n) { d_Gpart.reserve((size_t)items_h.size() * 128 * 320); d_Gpart.zero(stream); }
+    if (!sk_projects() || tiles_too) {
+      // partial tiles: fragments beyond a tile's sphere cut are never written -- all zero from the start, finite ever after.  A
+      // projecting handle cuts bands that straddle row tiles: a slot then holds the fragments of ONE band, the others must read as
+      // zero -- it asks for partial tiles only for conp_fix_get_sfac, and clears them every time.
+      const bool grew = ns * 128 * 320 > d_Gpart.n;
+      if (grew) d_Gpart.reserve(ns * 128 * 320);
+      if (grew || sk_projects()) d_Gpart.zero(stream);
+    }
   }
   bool elyte_list_stale(const conp_atoms *at) {
     size_t k = 0;
@@ -851,7 +860,71 @@ struct conp_fix {
   double SK_CSEG = exp_switch("CONP_SK_CSEG") ? atof(exp_switch("CONP_SK_CSEG")) : 5.74;
   void build_items() {
     const int nchunks = nl_pad / 16;
-    const size_t nt = tiles_h.size();
+    // this rank's chunk range of every tile (all of it on one rank; km_conp_setup); a tile may come out empty
+    const size_t ntiles = tiles_h.size();
+    std::vector<int> tclo(ntiles, 0), tchi(ntiles, nchunks);
+    bool uniform = true;                   // every tile with the same chunk range (one rank: all of it; N ranks: the rank's atoms)
+    for (size_t i = 0; i < ntiles; ++i) {
+      tclo[i] = (int)std::lround(tile_flo[i] * nchunks);
+      tchi[i] = (int)std::lround(tile_fhi[i] * nchunks);
+      uniform = uniform && tclo[i] == tclo[0] && tchi[i] == tchi[0];
+    }
+    // BANDS (round 4).  sk_gemm's unit of work is a band of planar vectors x a column tile: rf consecutive row fragments (16 planar
+    // vectors each) of the plan.  A wave holds 20 accumulator fragments either as 4 row x 5 column fragments -- a row tile of the
+    // plan, what every band was until round 3 -- or as 5 x 4: a column tile that uses at most 16 of its 20 column fragments (the
+    // headline box: nz = 126; the slab geometry: 15 per tile) is cut into bands of FIVE row fragments, 80 planar vectors instead of
+    // 64 per panel and barrier: 33 row fragments = 5 x 5 + 2 x 4 -> 7 bands instead of 9 tiles (the ninth a runt of 9 vectors that
+    // paid a tile's full per-chunk cost), and 80 instead of 64 MFMAs per wave and chunk where the sphere is full.  A band that
+    // straddles two row tiles of the plan writes one output slot per tile (zero rows where the other band writes): everything
+    // behind sk_gemm still sees row tiles.  Only the projecting mode takes bands of five (its slots are 8-KB pieces; partial tiles
+    // would double sk_reduce's reads); CONP_SK_BANDS4: comparison switch, bands = row tiles everywhere.
+    struct Band { int g0, rf, ct; unsigned long long nbf; int clo, chi; };
+    std::vector<Band> bands;
+    {
+      std::map<std::pair<int, int>, size_t> tile_at;
+      for (size_t i = 0; i < ntiles; ++i) tile_at[{tiles_h[i].rt, tiles_h[i].ct}] = i;
+      const bool five = sk_projects() && uniform && ntiles > 0 && exp_switch("CONP_SK_BANDS4") == nullptr;
+      for (int ct = 0; ct < plan.n_col_tiles; ++ct) {
+        const int nfr = 4 * plan.n_row_tiles;
+        std::vector<int> nfa(nfr + 8, 0);
+        int n = 0;
+        for (int g = 0; g < nfr; ++g) {
+          auto it = tile_at.find({g >> 2, ct});
+          if (it == tile_at.end()) continue;
+          nfa[g] = (int)((tiles_h[it->second].nbf >> (8 * (g & 3))) & 255u);
+          if (nfa[g] > 0) n = g + 1;
+        }
+        if (n == 0) continue;
+        if (!five) {
+          for (int rt = 0; 4 * rt < n; ++rt) {
+            auto it = tile_at.find({rt, ct});
+            if (it == tile_at.end()) continue;
+            bands.push_back(Band{4 * rt, 4, ct, (unsigned long long)tiles_h[it->second].nbf, tclo[it->second], tchi[it->second]});
+          }
+          continue;
+        }
+        // fewest bands covering the fragments [0, n) with pieces of 4 or 5 (5 only where no fragment has more than 16 column
+        // fragments), then the least padding behind n; ties: fives first (the early, full fragments)
+        std::vector<int> best(n + 6, 1 << 20), pad(n + 6, 1 << 20), take(n + 6, 0);
+        for (int i = n + 5; i >= 0; --i) {
+          if (i >= n) { best[i] = 0; pad[i] = i - n; continue; }
+          for (int rf : {5, 4}) {
+            bool ok = true;
+            if (rf == 5) for (int f = 0; f < 5; ++f) ok = ok && nfa[i + f] <= 16;
+            if (!ok) continue;
+            const int j = std::min(i + rf, n + 5);
+            if (best[j] + 1 < best[i] || (best[j] + 1 == best[i] && pad[j] < pad[i])) { best[i] = best[j] + 1; pad[i] = pad[j]; take[i] = rf; }
+          }
+        }
+        const size_t t0 = tile_at.begin()->second;
+        for (int i = 0; i < n; i += take[i]) {
+          unsigned long long nbf = 0;
+          for (int f = 0; f < take[i]; ++f) nbf |= (unsigned long long)(i + f < nfr ? nfa[i + f] : 0) << (8 * f);
+          bands.push_back(Band{i, take[i], ct, nbf, tclo[t0], tchi[t0]});
+        }
+      }
+    }
+    const size_t nt = bands.size();
     // a segment that ends in the projecting epilogue costs about twice one that stores its partial tile (stamped build: 15 units;
     // A/B on one rank: 5.74 / 9 / 12 equal within noise, 15 worse; on emulated ranks with 16 chunks per workgroup 12-14 is 7 % faster)
     if (!exp_switch("CONP_SK_CSEG")) SK_CSEG = sk_projects() ? 12.0 : 5.74;
@@ -864,11 +937,12 @@ struct conp_fix {
     nwg = std::min(nwg, std::max((int)((sk_projects() ? 32 : 16) * nt), (int)((nt * (size_t)nchunks + 7) / 8)));
     nwg = std::max(1, nwg);
     if (exp_switch("CONP_SK_NWG")) nwg = std::max(1, atoi(exp_switch("CONP_SK_NWG")));
-    // MFMA work of a tile ~ mean over its 4 row fragments of their active kz blocks (per-fragment sphere culling)
-    auto cost = [&](const SkTile &t) {
+    // MFMA work of a band ~ its row fragments' active column fragments (per-fragment sphere culling), in the unit the constants were
+    // fitted in: kz blocks of 16 of a four-fragment tile (two column fragments each)
+    auto cost = [&](const Band &t) {
       double sum = 0.0;
-      for (int f = 0; f < 4; ++f) sum += (double)((t.nbf >> (8 * f)) & 255u);
-      return 0.125 * sum + SK_C0;                 // in kz blocks of 16 (the unit the constants were fitted in): two column fragments each
+      for (int f = 0; f < t.rf; ++f) sum += (double)((t.nbf >> (8 * f)) & 255u);
+      return 0.125 * sum + SK_C0;
     };
     struct Seg { int tile, c0, c1, wg; };
     std::vector<Seg> segs;
@@ -877,7 +951,7 @@ struct conp_fix {
     auto cut = [&](const std::vector<int> &clo, const std::vector<int> &chi, int nshare, int wg0, int wgstride) {
       // work left from (tile ti, chunk ch) to the end, without segment starts
       std::vector<double> tail(nt + 1, 0.0);
-      for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + std::max(0, chi[i] - clo[i]) * cost(tiles_h[i]);
+      for (size_t i = nt; i-- > 0;) tail[i] = tail[i + 1] + std::max(0, chi[i] - clo[i]) * cost(bands[i]);
       size_t total = 0;
       for (size_t i = 0; i < nt; ++i) total += (size_t)std::max(0, chi[i] - clo[i]);
       // a segment shorter than this costs more in start-up than it carries -- but only where shares are long: a small system's
@@ -890,11 +964,11 @@ struct conp_fix {
         if (ti >= nt) continue;
         const bool last = w + 1 == nshare;
         // equal shares of what is left, counting one segment start per remaining workgroup and one per tile boundary ahead
-        const double left = tail[ti] - (ch - clo[ti]) * cost(tiles_h[ti]) + SK_CSEG * ((double)(nshare - w) + (double)(nt - 1 - ti));
+        const double left = tail[ti] - (ch - clo[ti]) * cost(bands[ti]) + SK_CSEG * ((double)(nshare - w) + (double)(nt - 1 - ti));
         double budget = left / (nshare - w) - SK_CSEG;
         bool first = true;
         while (ti < nt) {
-          const double c = cost(tiles_h[ti]);
+          const double c = cost(bands[ti]);
           const int avail = chi[ti] - ch;
           int take;
           if (last) take = avail;
@@ -921,14 +995,8 @@ struct conp_fix {
         }
       }
     };
-    // this rank's chunk range of every tile (all of it on one rank; km_conp_setup); a tile may come out empty
     std::vector<int> clo(nt, 0), chi(nt, nchunks);
-    bool uniform = true;                   // every tile with the same chunk range (one rank: all of it; N ranks: the rank's atoms)
-    for (size_t i = 0; i < nt; ++i) {
-      clo[i] = (int)std::lround(tile_flo[i] * nchunks);
-      chi[i] = (int)std::lround(tile_fhi[i] * nchunks);
-      uniform = uniform && clo[i] == clo[0] && chi[i] == chi[0];
-    }
+    for (size_t i = 0; i < nt; ++i) { clo[i] = bands[i].clo; chi[i] = bands[i].chi; }
     // the atoms whose phase tables this rank reads (elyte_phase fills those only)
     table_c0 = nchunks; table_c1 = 0;
     for (size_t i = 0; i < nt; ++i) if (chi[i] > clo[i]) { table_c0 = std::min(table_c0, clo[i]); table_c1 = std::max(table_c1, chi[i]); }
@@ -959,7 +1027,8 @@ struct conp_fix {
     std::vector<std::vector<int>> per_wg(nwg);
     for (const Seg &g : segs) {
       per_wg[g.wg].push_back((int)items_h.size());
-      items_h.push_back(SkItem{tiles_h[g.tile].rt, tiles_h[g.tile].ct, tiles_h[g.tile].nba, g.c0, g.c1, tiles_h[g.tile].nbf});
+      const Band &bd = bands[g.tile];
+      items_h.push_back(SkItem{bd.g0, bd.rf, bd.ct, g.c0, g.c1, bd.nbf});
     }
     seg_ptr_h.assign(nwg + 1, 0);
     seg_idx_h.clear();
@@ -969,13 +1038,33 @@ struct conp_fix {
     }
     seg_ptr_h[nwg] = (int)seg_idx_h.size();
     if (seg_idx_h.empty()) seg_idx_h.push_back(0);
-    // tiles -> their segments (contiguous in items_h)
-    size_t it = 0;
-    max_nsplit = 0;
-    for (auto &tl : tiles_h) {
-      tl.item0 = (int)it; tl.nsplit = 0;
-      while (it < items_h.size() && items_h[it].rt == tl.rt && items_h[it].ct == tl.ct) { ++it; ++tl.nsplit; }
-      max_nsplit = std::max(max_nsplit, tl.nsplit);
+    // OUTPUT SLOTS: one per (segment, row tile of the plan the segment's band has fragments in), numbered tile-major so that a
+    // tile's slots are item0 .. item0 + nsplit - 1 for the kernels that add them (sk_reduce, hc_sum, the dot kernel)
+    std::vector<int> seg_sga(items_h.size(), -1), seg_sgb(items_h.size(), -1);
+    {
+      std::map<std::pair<int, int>, size_t> tile_at;
+      for (size_t i = 0; i < tiles_h.size(); ++i) tile_at[{tiles_h[i].rt, tiles_h[i].ct}] = i;
+      std::vector<std::vector<std::pair<int, int>>> of_tile(tiles_h.size());       // (segment, side)
+      for (size_t sgm = 0; sgm < items_h.size(); ++sgm) {
+        const SkItem &it = items_h[sgm];
+        for (int side = 0; side < 2; ++side) {
+          const int rt = (it.g0 >> 2) + side;
+          bool any = false;                       // does the band hold a real fragment of this row tile?
+          for (int f = 0; f < it.rf; ++f) any = any || (((it.g0 + f) >> 2) == rt && ((it.nbf >> (8 * f)) & 255u) != 0);
+          auto at_ = tile_at.find({rt, it.ct});
+          if (side == 0 && at_ == tile_at.end()) throw ConpError(CONP_ERR_STATE, "sk_gemm schedule: a band starts in a row tile without work");
+          if (at_ == tile_at.end() || (side == 1 && !any)) continue;
+          of_tile[at_->second].push_back({(int)sgm, side});
+        }
+      }
+      int slot = 0;
+      max_nsplit = 0;
+      for (size_t i = 0; i < tiles_h.size(); ++i) {
+        tiles_h[i].item0 = slot; tiles_h[i].nsplit = (int)of_tile[i].size();
+        for (const auto &e : of_tile[i]) (e.second ? seg_sgb : seg_sga)[e.first] = slot++;
+        max_nsplit = std::max(max_nsplit, tiles_h[i].nsplit);
+      }
+      n_slots = slot;
     }
     d_items.upload(items_h, stream);
     d_seg_ptr.upload(seg_ptr_h, stream);
@@ -983,27 +1072,52 @@ struct conp_fix {
     // the kernel's own work list: one fixed-size row per workgroup (SkWItem)
     witems_maxseg = 1;
     for (int w = 0; w < nwg; ++w) witems_maxseg = std::max(witems_maxseg, (int)per_wg[w].size());
-    std::vector<SkWItem> wl((size_t)nwg * witems_maxseg, SkWItem{0, 0, 0, 0, 0, 0u, 0, 0});
+    std::vector<SkWItem> wl((size_t)nwg * witems_maxseg, SkWItem{0, 4, 0, 0, 0, 0, 0, -1, 0, 0, 0ull});
     for (int w = 0; w < nwg; ++w)
       for (size_t k = 0; k < per_wg[w].size(); ++k) {
         const int sg = per_wg[w][k];
         const SkItem &it = items_h[sg];
-        wl[(size_t)w * witems_maxseg + k] = SkWItem{it.rt, it.ct, it.nba, it.c0, it.c1, it.nbf, sg, k == 0 ? (int)per_wg[w].size() : 0};
+        wl[(size_t)w * witems_maxseg + k] = SkWItem{it.g0, it.rf, it.ct, it.c0, it.c1, sg, seg_sga[sg], seg_sgb[sg], k == 0 ? (int)per_wg[w].size() : 0, 0, it.nbf};
       }
     d_witems.upload(wl, stream);
     d_tiles.upload(tiles_h, stream);
-    // per owned row tile: the segments that worked on it, over all its column tiles (sk_gemm's projected pieces are added in
-    // this order: launch_project_zclass_pieces)
+    // projecting mode: a segment leaves ONE band-local piece (slot = its index; a band's segments are contiguous).  hc_sum_kernel
+    // adds a band's pieces and maps its rows to the plan's; when every band IS a row tile of the plan (rf = 4, aligned: the decks,
+    // CONP_SK_BANDS4) the dot kernel may add a row tile's few pieces itself, from the per-row-tile lists below
+    bands_aligned = true;
+    for (const Band &bd : bands) if (bd.rf != 4 || (bd.g0 & 3)) bands_aligned = false;
+    {
+      // per row fragment of the plan: the pieces that hold it, column tile after column tile, segment after segment (the order
+      // the sums are formed in: fixed by the schedule, not by which workgroup finishes first)
+      n_frags = 4 * plan.n_row_tiles;
+      std::vector<std::vector<int2>> of_frag(n_frags);
+      for (size_t sgm = 0; sgm < items_h.size(); ++sgm) {
+        const SkItem &it = items_h[sgm];
+        for (int f = 0; f < it.rf; ++f)
+          if (it.g0 + f < n_frags && ((it.nbf >> (8 * f)) & 255u) != 0)
+            of_frag[it.g0 + f].push_back(make_int2((int)(sgm * (size_t)sk_hc_stride()) + 16 * f, it.rf));
+      }
+      std::vector<int> fptr(n_frags + 1, 0);
+      std::vector<int2> fent;
+      for (int g = 0; g < n_frags; ++g) { fent.insert(fent.end(), of_frag[g].begin(), of_frag[g].end()); fptr[g + 1] = (int)fent.size(); }
+      if (fent.empty()) fent.push_back(make_int2(0, 4));
+      if (items_h.size() * (size_t)sk_hc_stride() > 0x7fffffffull) throw ConpError(CONP_ERR_STATE, "sk_gemm schedule: piece offsets exceed 31 bits");
+      d_frag_ptr.upload(fptr, stream); d_frag_ents.upload(fent, stream);
+    }
     std::vector<int> hptr(own_rt_h.size() + 1, 0), hidx;
     for (size_t k = 0; k < own_rt_h.size(); ++k) {
-      for (const auto &tl : tiles_h)
-        if (tl.rt == own_rt_h[k]) for (int i = 0; i < tl.nsplit; ++i) hidx.push_back(tl.item0 + i);
+      if (bands_aligned)
+        for (size_t sgm = 0; sgm < items_h.size(); ++sgm) if ((items_h[sgm].g0 >> 2) == own_rt_h[k]) hidx.push_back((int)sgm);
       hptr[k + 1] = (int)hidx.size();
     }
-    hslots = (int)hidx.size();
+    hslots = bands_aligned ? (int)hidx.size() : (int)items_h.size();
     if (hidx.empty()) hidx.push_back(0);
     d_hslot_ptr.upload(hptr, stream); d_hslot_idx.upload(hidx, stream);
   }
+  bool bands_aligned = true;       // every band of sk_gemm's schedule is a row tile of the plan
+  int n_frags = 0;
+  DevBuf<int> d_frag_ptr;
+  DevBuf<int2> d_frag_ents;
 
   void gather_xele(const conp_atoms *at) {
     const int ne = idx.elenum_all;
@@ -1621,10 +1735,11 @@ struct conp_fix {
       if (proj) {
         // planar electrodes: the segments left their projected pieces (128 x nzc each); the dot kernel adds them per row tile
         // (a launch of its own first when there are many: every block of the dot kernel would re-add them all)
-        const bool presum = hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size();
+        const bool presum = !bands_aligned || (hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size());
         prof.begin("reduce_project", stream);
         launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Hpart.p, d_hslot_ptr.p, d_hslot_idx.p,
-                                     presum, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p, use_fin ? &fin : nullptr);
+                                     presum, d_frag_ptr.p, d_frag_ents.p, n_frags, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p,
+                                     use_fin ? &fin : nullptr);
         prof.end(stream);
       } else if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
         // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)

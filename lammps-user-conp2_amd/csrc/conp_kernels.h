@@ -19,15 +19,19 @@ struct DevPlan {              // device copy of KPlan geometry
   const double *wfull;                // [R_pad][C_pad]
 };
 
-struct SkItem { int rt, ct, nba, c0, c1; unsigned nbf; };   // one sk_gemm segment: tile + chunk range [c0, c1) of 16 atoms;
-                                                          // nbf = active 8-kz column fragments per 16-row fragment, 4 x 8 bit
+// One sk_gemm segment: a BAND of planar vectors x one column tile x a chunk range [c0, c1) of 16 atoms.  A band = rf consecutive row
+// fragments (16 planar vectors each) g0 .. g0 + rf - 1 of the plan, rf = 4 (up to 20 column fragments, e.g. one row tile of the plan)
+// or 5 (up to 16 column fragments): 20 accumulator fragments per wave either way.  nbf = active 8-kz column fragments per row
+// fragment, rf x 8 bit.
+struct SkItem { int g0, rf, ct, c0, c1; unsigned long long nbf; };
 // parameter block of sk_gemm's projecting epilogue (device memory): weights [R_pad][C_pad], z-class phases class-major [nzc][C_pad]
 struct SkProj { const double *wfull, *tzt; int nzc, cpad; };
-// sk_gemm's work list, one fixed-size row per workgroup: the segments it runs, each with its index `sg` in the tile-major item order
-// (where its output goes); the first entry's nseg = how many are used.  One load replaces the seg_ptr -> seg_idx -> items chain at
-// the top of every workgroup (three dependent round trips before the first phase table can be requested).
-struct SkWItem { int rt, ct, nba, c0, c1; unsigned nbf; int sg, nseg; };
-struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile): its items are item0 .. item0+nsplit-1
+// sk_gemm's work list, one fixed-size row per workgroup: the segments it runs, each with its output slots -- one per row tile of the
+// plan the band touches (sga: row tile g0 >> 2, sgb: the next one or -1), numbered tile-major (SkTile::item0), for the partial-tile
+// mode; sg = the segment's own index, the slot of its band-local piece in the projecting mode -- and the first entry's nseg = how
+// many are used.  One load replaces the seg_ptr -> seg_idx -> items chain at the top of every workgroup.
+struct SkWItem { int g0, rf, ct, c0, c1, sg, sga, sgb, nseg, pad_; unsigned long long nbf; };
+struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile) of the plan: its output slots are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
   double g_ewald, eta, cut_coulsq;    // cut_coulsq already min(cut_coul^2, (5.8/g)^2)  fix_conp.cpp:1237-1240
@@ -101,7 +105,9 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems /*[n
 int sk_hc_stride();           // doubles per segment of sk_gemm's projected output
 int sk_hc_max_classes();      // most z classes the projecting mode takes
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
-                                  const int *slot_ptr, const int *slot_idx, bool presum, const double *Rp, const double2 *Xe,
+                                  const int *slot_ptr, const int *slot_idx, bool presum /*hc_sum first: many pieces, or bands that are
+                                  not row tiles of the plan*/, const int *frag_ptr /*[nfrag + 1]*/, const int2 *frag_ents /*per row fragment of the plan: its pieces
+                                  (offset of the fragment's first 'a' row, the band's rf)*/, int nfrag, const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);

@@ -338,8 +338,12 @@ constexpr int SK_J = 16;
 // writes are a permutation of one 128-byte row: conflict-free ds_write_b64.  (The first version padded rows to 17 doubles:
 // clean for the paired form only -- every single ds_read_b64 had a 2-way conflict, SQ_LDS_BANK_CONFLICT ~ 1 per LDS instruction.)
 constexpr int SK_LD = SK_J;
-constexpr int SK_NF = 128 + 320;
-constexpr int SK_PANEL = SK_NF * SK_LD;          // doubles per buffer (57,344 bytes)
+// rows of a panel: 32 RF operand rows of the band's planar vectors (RF = 4 or 5 row fragments per half: 'a' rows then 'b' rows), then
+// the z features, 16 per column fragment.  A band of RF = 4 takes up to 20 column fragments (128 + 320 rows), a band of RF = 5 up to
+// 16 (160 + 256); the z build writes whole groups of five fragments per thread, so the RF = 5 layout may spill into rows 416..479 --
+// inside the buffer, read by nobody.
+constexpr int SK_NF = 160 + 320;
+constexpr int SK_PANEL = SK_NF * SK_LD;          // doubles per buffer (61,440 bytes)
 constexpr unsigned SK_BUF1 = 65536;              // byte offset of the second buffer: switching buffers is one XOR of a byte address
 constexpr size_t SK_LDS_BYTES = SK_BUF1 + (size_t)SK_PANEL * sizeof(double);
 
@@ -364,15 +368,16 @@ __device__ __forceinline__ unsigned sk_part_off(int rowl, int col) {
 
 struct SkRaw {        // raw inputs of one thread for one chunk
   double2 X0, Y0, X1, Y1, Zseed, Zst;     // Zseed: phase at the thread's first kz of the column tile, Zst: the 8-kz rotation
+  double2 X2, Y2;                         // RF = 5 bands: the fifth row fragment's vector of the threads gs < 16 (the early waves)
 };
 
 struct SkCtx {        // per-thread constants of one work item
   SkItem it;
   int nl_pad, nz;
   int gj, gs;                       // generation role: atom gj of the chunk, sub-index gs 0..31
-  unsigned xy0, xy1, zoff;          // (row * 16 + gj) inside a chunk block of the phase tables: X in the low, Y in the high half-word
+  unsigned xy0, xy1, xy2, zoff;     // (row * 16 + gj) inside a chunk block of the phase tables: X in the low, Y in the high half-word
   unsigned nrx16, nry16, nrz16;                // rows per chunk block * 16 (X, Y, Z tables)
-  bool neg0, neg1;                  // ky < 0: flips the sign of sin(ky y)
+  bool neg0, neg1, neg2;            // ky < 0: flips the sign of sin(ky y)
   bool zact;                        // this thread's kz values reach into an active column fragment
   unsigned za;                      // doubles offset of (cos feature of the thread's first kz, atom gj) in a panel (swizzled)
   int dsin;                         // from a cos feature to its sin feature
@@ -386,30 +391,41 @@ struct SkCtx {        // per-thread constants of one work item
   const double *qc;
   const SkProj *proj;               // projected output (planar electrodes, sk_project_out) when not null
   int dbg;
+  int nfr;                          // row fragments (16 planar vectors each) the plan has: 4 n_row_tiles (a band's padding lies beyond)
 };
 
+template <bool THIRD>
 __device__ __forceinline__ void sk_load_raw(const SkCtx &c, int ch, SkRaw &r) {
   // blocked tables: element (row, atom) of chunk ch at (ch * NR + row) * 16 + (atom & 15); the row offsets already hold row * 16 + gj
   const unsigned bx = (unsigned)ch * c.nrx16, by = (unsigned)ch * c.nry16, bz = (unsigned)ch * c.nrz16;
   r.X0 = c.Xt[bx + (c.xy0 & 0xffffu)]; r.Y0 = c.Yt[by + (c.xy0 >> 16)];
   r.X1 = c.Xt[bx + (c.xy1 & 0xffffu)]; r.Y1 = c.Yt[by + (c.xy1 >> 16)];
+  if constexpr (THIRD) { r.X2 = c.Xt[bx + (c.xy2 & 0xffffu)]; r.Y2 = c.Yt[by + (c.xy2 >> 16)]; }
   if (c.zact) { r.Zst = c.Zs[bz + c.gj]; r.Zseed = c.Zs[bz + c.zoff]; }
 }
 
+// RF row fragments per half: 'a' rows 0 .. 16 RF - 1, 'b' rows 16 RF .. 32 RF - 1, z features from row 32 RF.  THIRD: this thread
+// (gs < 16 of an RF = 5 band) also builds planar vector 64 + gs, the fifth row fragment.
+template <int RF, bool THIRD>
 __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, double *pn) {
   // (kx, sg*ky): q cos = (q cx) cy - (q sx)(sg sy) ; q sin = (q cx)(sg sy) + (q sx) cy   (km_ewald.cpp:739-747); the X table
   // already carries q, padding rows read an all-zero X row
   // sg is +1 or -1 (0 only on padding rows, whose X row is all zero anyway): a sign flip, not an FP64 multiply
-  // features gs, 32 + gs, 64 + gs, 96 + gs share their low four bits: one swizzled column for all four
+  // features gs, 32 + gs, 64 + gs (a) and 16 RF + the same (b) share their low four bits: one swizzled column for all of them
   {
     const double sy = c.neg0 ? -r.Y0.y : r.Y0.y;
     pn[c.wa] = r.X0.x * r.Y0.x - r.X0.y * sy;
-    pn[c.wa + 64 * SK_LD] = r.X0.x * sy + r.X0.y * r.Y0.x;
+    pn[c.wa + 16 * RF * SK_LD] = r.X0.x * sy + r.X0.y * r.Y0.x;
   }
   {
     const double sy = c.neg1 ? -r.Y1.y : r.Y1.y;
     pn[c.wa + 32 * SK_LD] = r.X1.x * r.Y1.x - r.X1.y * sy;
-    pn[c.wa + 96 * SK_LD] = r.X1.x * sy + r.X1.y * r.Y1.x;
+    pn[c.wa + (32 + 16 * RF) * SK_LD] = r.X1.x * sy + r.X1.y * r.Y1.x;
+  }
+  if constexpr (THIRD) {
+    const double sy = c.neg2 ? -r.Y2.y : r.Y2.y;
+    pn[c.wa + 64 * SK_LD] = r.X2.x * r.Y2.x - r.X2.y * sy;
+    pn[c.wa + (64 + 16 * RF) * SK_LD] = r.X2.x * sy + r.X2.y * r.Y2.x;
   }
   if (c.zact) {
     // thread (gs = 8 q + r, gj) owns the kz values 40 q + r + 8 u (u < 5) of the column tile: column fragments 5 q + u, position r.
@@ -456,8 +472,8 @@ __device__ __forceinline__ void sk_build_panel(const SkCtx &c, const SkRaw &r, d
 // kz cut never grows with f; a fragment whose cut is shorter still than NFW - 1 multiplies a few zero-weight columns: G entries
 // no listed k reads).  One wave-uniform branch per row fragment instead of one per MFMA.
 #define SK_LDS_F64(byte_addr) (*reinterpret_cast<const double *>(smem + (byte_addr)))
-template <int NFW>
-__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1]) {
+template <int RF, int NFW>
+__device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[RF][NFW > 0 ? NFW : 1]) {
   if constexpr (NFW > 0) {
     constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;        // bytes between row fragments / between this wave's column fragments
     const unsigned ba = c.base_a ^ buf, bb = c.base_b ^ buf;
@@ -477,16 +493,16 @@ __device__ __forceinline__ void sk_mfma_chunk(const SkCtx &c, const char *smem, 
       const unsigned qn = (unsigned)(((ks + 1) & 3) << 5) ^ c.pq;       // the group of the next k-step (wraps after the last)
       const unsigned an = ba + qn, bn = bb + qn, ac = ba + q;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        a1 = f < 3 ? SK_LDS_F64(ac + (f + 1) * FA) : SK_LDS_F64(an);
+      for (int f = 0; f < RF; ++f) {
+        a1 = f < RF - 1 ? SK_LDS_F64(ac + (f + 1) * FA) : SK_LDS_F64(an);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g + 1 < NFW; ++g) {
           acc[f][g] = MFMA_F64(a0, bf[g], acc[f][g]);
-          if (f == 3) { bf[g] = SK_LDS_F64(bn + g * FB); __builtin_amdgcn_sched_barrier(0); }
+          if (f == RF - 1) { bf[g] = SK_LDS_F64(bn + g * FB); __builtin_amdgcn_sched_barrier(0); }
         }
         if (f < c.f0) acc[f][NFW - 1] = MFMA_F64(a0, bf[NFW - 1], acc[f][NFW - 1]);      // wave-uniform
-        if (f == 3) bf[NFW - 1] = SK_LDS_F64(bn + (NFW - 1) * FB);
+        if (f == RF - 1) bf[NFW - 1] = SK_LDS_F64(bn + (NFW - 1) * FB);
         __builtin_amdgcn_sched_barrier(0);
         a0 = a1;
       }
@@ -515,8 +531,8 @@ __device__ __forceinline__ void sk_mfma_prefetch(const SkCtx &c, const char *sme
     for (int g = 0; g < NFW; ++g) { pre.bf[g] = SK_LDS_F64((c.base_b ^ buf) + q + g * FB); __builtin_amdgcn_sched_barrier(0); }
   }
 }
-template <int NFW, int F0>
-__device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[4][NFW > 0 ? NFW : 1],
+template <int RF, int NFW, int F0>
+__device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[RF][NFW > 0 ? NFW : 1],
                                                 const SkPre<NFW> *pre = nullptr) {
   if constexpr (NFW > 0) {
     constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
@@ -542,17 +558,17 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
     for (int ks = 0; ks < 4; ++ks) {
       const int kn = (ks + 1) & 3;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
+      for (int f = 0; f < RF; ++f) {
         // the last row fragment of the last k-step has nothing left to fetch
-        if (!(ks == 3 && f == 3)) a1 = f < 3 ? SK_LDS_F64(aa[ks] + (f + 1) * FA) : SK_LDS_F64(aa[kn]);
+        if (!(ks == 3 && f == RF - 1)) a1 = f < RF - 1 ? SK_LDS_F64(aa[ks] + (f + 1) * FA) : SK_LDS_F64(aa[kn]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g + 1 < NFW; ++g) {
           acc[f][g] = MFMA_F64(a0, bf[g], acc[f][g]);
-          if (f == 3 && ks < 3) { bf[g] = SK_LDS_F64(ab[kn] + g * FB); __builtin_amdgcn_sched_barrier(0); }
+          if (f == RF - 1 && ks < 3) { bf[g] = SK_LDS_F64(ab[kn] + g * FB); __builtin_amdgcn_sched_barrier(0); }
         }
         if (f < F0) acc[f][NFW - 1] = MFMA_F64(a0, bf[NFW - 1], acc[f][NFW - 1]);
-        if (f == 3 && ks < 3) bf[NFW - 1] = SK_LDS_F64(ab[kn] + (NFW - 1) * FB);
+        if (f == RF - 1 && ks < 3) bf[NFW - 1] = SK_LDS_F64(ab[kn] + (NFW - 1) * FB);
         __builtin_amdgcn_sched_barrier(0);
         a0 = a1;
       }
@@ -565,10 +581,10 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
 #define SK_MFMA_LOOP 0
 #endif
 #if SK_MFMA_LOOP
-#define SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc) sk_mfma_chunk<NFW>(c, smem, buf, acc)
+#define SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc) sk_mfma_chunk<RF, NFW>(c, smem, buf, acc)
 #define SK_LATE_PREFETCH 0
 #else
-#define SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc) sk_mfma_chunk_u<NFW, F0>(c, smem, buf, acc)
+#define SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc) sk_mfma_chunk_u<RF, NFW, F0>(c, smem, buf, acc)
 // Measured and left off (round 4, one box, `make variant_pre VDEF=-DSK_LATE_PREFETCH=1`): the late waves' first operand reads requested
 // ahead of their panel build -- sk_gemm 243.5 vs 238.6 us at the headline size, 734 vs 734 us in the slab geometry.  The reads
 // queue ahead of the build's LDS writes as intended, but NFW + 1 more live registers through the build and a wait for them in
@@ -613,7 +629,8 @@ __device__ unsigned long long sk_seg_buf[4096 * 4];         // [segment][workgro
 //   columns (g) of w G Tzc for its 16 rows; the 16 lanes fr of a row are added by DPP exchanges inside the register file (a
 //   transposing butterfly, row16_sum4), the four column groups cg through 4 KB of LDS per class.  Two barriers per segment -- a first version
 //   went through LDS per row fragment (eight barriers, a dozen serialised LDS / memory waits per fragment): 8 us per segment.
-constexpr int SK_HC = 8;          // class stride of a segment's Hc piece: [SK_HC][128] doubles
+constexpr int SK_HC = 8;          // classes a segment's piece has room for
+constexpr int SK_HC_ROWS = 160;   // rows it has room for: 32 RF of the widest band
 constexpr int SK_HC_MAX = 8;
 // the value the lane's partner under DPP control CTRL holds (row_mirror 0x140: lane ^ 15, row_half_mirror 0x141: lane ^ 7 inside
 // its half row, quad_perm [3,2,1,0] 0x1B: lane ^ 3, quad_perm [1,0,3,2] 0xB1: lane ^ 1)
@@ -636,8 +653,11 @@ __device__ __forceinline__ double row16_sum4(const double (&s)[4], unsigned fr) 
   k += dpp_get<0xB1>(k);
   return k;
 }
-template <int NFW>
-__device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&acc)[4][NFW > 0 ? NFW : 1], double *__restrict__ hout) {
+// The piece of a segment is BAND-LOCAL: [nzc][32 RF rows] (the band's 'a' rows, then its 'b' rows), class stride 32 RF -- for a
+// band that is a row tile of the plan (RF = 4, g0 a multiple of 4) exactly the [class][128] piece the dot kernel adds itself;
+// hc_sum_kernel maps a band's rows to the plan's.
+template <int RF, int NFW>
+__device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&acc)[RF][NFW > 0 ? NFW : 1], double *__restrict__ hout) {
   double *L = reinterpret_cast<double *>(smem);
   // everything this needs is derived HERE, behind opaque copies of the thread index and the parameter block's address: left to
   // itself the compiler forms the lane's offsets and loads the parameters at the top of the kernel and carries them through the
@@ -658,7 +678,11 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
   typedef __attribute__((address_space(1))) const double *gcd_t;
   // (the 'a' and 'b' rows of a planar vector carry the same weight, KPlan::wfull: both row halves read the 'a' rows -- the second
   //  wave of a column group finds the lines in L2)
-  gcd_t wp = (gcd_t)(wfull + ((unsigned)c.it.rt * 128 + fk) * cpad + colb);                       // + (16 f + 4 r) * cpad
+  // row fragment f of the band is fragment g0 + f of the plan: rows (g >> 2) * 128 + (g & 3) * 16 .. of wfull (a band's padding
+  // fragments lie beyond the plan: they read the last fragment's weights and hold zero accumulators)
+  const unsigned g0 = (unsigned)c.it.g0, glast = (unsigned)c.nfr - 1;
+  auto wrow = [&](unsigned f) { const unsigned g = g0 + f < glast ? g0 + f : glast; return (g >> 2) * 128 + (g & 3) * 16; };
+  gcd_t wp = (gcd_t)(wfull + fk * cpad + colb);                                                   // + (wrow(f) + 4 r) * cpad
   gcd_t tzg = (gcd_t)tzt;
   // the weights of row fragment f + 1 are requested as soon as those of f have been used; the tile's z-class phases go through LDS
   double wv[NFW > 0 ? NFW : 1][4];
@@ -666,19 +690,19 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
 #pragma unroll
     for (int g = 0; g < NFW; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wv[g][r] = wp[(unsigned)(4 * r) * cpad + 64 * g];
+      for (int r = 0; r < 4; ++r) wv[g][r] = wp[(wrow(0) + (unsigned)(4 * r)) * cpad + 64 * g];
   }
   double *Tl = L;                                                                                 // [nzc][320]
-  double *Lp = L + SK_HC_MAX * 320;                                                               // [nzc][128 rows][4 cg]
+  double *Lp = L + SK_HC_MAX * 320;                                                               // [nzc][32 RF rows][4 cg]
   for (unsigned e = t; e < (unsigned)nzc * 320; e += 512) {
     const unsigned zc = e / 320, cc = e - zc * 320;
     Tl[e] = tzg[zc * cpad + (unsigned)c.it.ct * 320 + cc];
   }
   const double *tl = Tl + 16 * cg + fr;                                                           // + zc * 320 + 64 g
-  double *lp = Lp + (64 * rh + fk) * 4 + cg;                                                      // + (zc * 128 + 16 f + 4 r) * 4
+  double *lp = Lp + (16 * RF * rh + fk) * 4 + cg;                                                 // + (zc * 32 RF + 16 f + 4 r) * 4
   __syncthreads();
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
+  for (int f = 0; f < RF; ++f) {
     // (w G) in place: the accumulators are done with
     if constexpr (NFW > 0) {
 #pragma unroll
@@ -697,10 +721,10 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
         }
       }
       const double tot = row16_sum4(s, fr);            // every lane of quad-group fr >> 2: the row sum of value r = fr >> 2
-      if ((fr & 3) == 0) lp[(zc * 128 + 16 * f + 4 * (fr >> 2)) * 4] = tot;
+      if ((fr & 3) == 0) lp[(zc * 32 * RF + 16 * f + 4 * (fr >> 2)) * 4] = tot;
     }
     if constexpr (NFW > 0) {
-      if (f < 3) {
+      if (f < RF - 1) {
         // not earlier: the registers are the ones this row fragment's accumulators free.  (Requesting them right after the
         // multiplies above, to have the class loop in between, makes the allocator spill hundreds of registers; pulling the
         // wave's weights into L2 with throw-away loads during the segment's last chunk changed nothing: A/B 240.8 vs 240.6 us;
@@ -709,12 +733,12 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
 #pragma unroll
         for (int g = 0; g < NFW; ++g)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) wv[g][r] = wp[(unsigned)(16 * (f + 1) + 4 * r) * cpad + 64 * g];
+          for (int r = 0; r < 4; ++r) wv[g][r] = wp[(wrow(f + 1) + (unsigned)(4 * r)) * cpad + 64 * g];
       }
     }
   }
   __syncthreads();
-  for (unsigned o = t; o < (unsigned)nzc * 128; o += 512) {
+  for (unsigned o = t; o < (unsigned)nzc * 32 * RF; o += 512) {
     const double2 *src = reinterpret_cast<const double2 *>(Lp + 4 * o);
     const double2 v0 = src[0], v1 = src[1];
     hout[o] = (v0.x + v0.y) + (v1.x + v1.y);
@@ -725,11 +749,14 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
 // One segment = (tile, chunk range).  Between two barriers the workgroup multiplies chunk c (panel buffer c&1) and
 // builds chunk c+1 (other buffer).  The two waves of a SIMD (w and w+4) do this in OPPOSITE order -- waves 0-3
 // multiply first, waves 4-7 build first -- so one wave's operand generation overlaps its partner's MFMAs.
-template <int NFW, bool late, int F0>
-__device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out) {
-  d4 acc[4][NFW > 0 ? NFW : 1];
+template <int RF, int NFW, bool late, int F0>
+__device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA, double *outB, double *outP) {
+  // the fifth row fragment's planar vectors (64 + gs, gs < 16) are built by the threads gs < 16: the EARLY waves, which wait at the
+  // barrier for the late ones anyway
+  constexpr bool THIRD = RF == 5 && !late;
+  d4 acc[RF][NFW > 0 ? NFW : 1];
 #pragma unroll
-  for (int f = 0; f < 4; ++f)
+  for (int f = 0; f < RF; ++f)
 #pragma unroll
     for (int g = 0; g < (NFW > 0 ? NFW : 1); ++g) acc[f][g] = (d4){0.0, 0.0, 0.0, 0.0};
   SkRaw raw;
@@ -737,9 +764,9 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
   unsigned long long st_a = 0, st_b = 0, s_pro = 0, s_load = 0, s_mfma = 0, s_build = 0, s_bar = 0, s_epi = 0;
 #endif
   SK_STAMP_T(st_a);
-  sk_load_raw(c, c.it.c0, raw);
-  sk_build_panel(c, raw, reinterpret_cast<double *>(smem));
-  if (late && c.it.c0 + 1 < c.it.c1) sk_load_raw(c, c.it.c0 + 1, raw);
+  sk_load_raw<THIRD>(c, c.it.c0, raw);
+  sk_build_panel<RF, THIRD>(c, raw, reinterpret_cast<double *>(smem));
+  if (late && c.it.c0 + 1 < c.it.c1) sk_load_raw<THIRD>(c, c.it.c0 + 1, raw);
   __syncthreads();
   SK_STAMP_T(st_b); SK_STAMP_ADD(s_pro, st_a, st_b);
   unsigned buf = 0;                                    // byte offset of the panel being multiplied: 0 or SK_BUF1
@@ -748,11 +775,11 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
     const bool more = ch + 1 < c.it.c1;
     if (!late) {
       SK_STAMP_T(st_a);
-      if (more && !(SK_DBG(c, 4))) sk_load_raw(c, ch + 1, raw);
+      if (more && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 1, raw);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_load, st_a, st_b);
-      if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc);
+      if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_mfma, st_b, st_a);
-      if (more && !(SK_DBG(c, 1))) sk_build_panel(c, raw, nxt);
+      if (more && !(SK_DBG(c, 1))) sk_build_panel<RF, THIRD>(c, raw, nxt);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
     } else {
 #if SK_LATE_MODE == 1
@@ -763,14 +790,14 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
       SkPre<NFW> pre;
       if (!(SK_DBG(c, 2))) sk_mfma_prefetch<NFW>(c, smem, buf, pre);
 #endif
-      if (more && !(SK_DBG(c, 1))) sk_build_panel(c, raw, nxt);
+      if (more && !(SK_DBG(c, 1))) sk_build_panel<RF, THIRD>(c, raw, nxt);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
-      if (ch + 2 < c.it.c1 && !(SK_DBG(c, 4))) sk_load_raw(c, ch + 2, raw);
+      if (ch + 2 < c.it.c1 && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 2, raw);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_load, st_b, st_a);
 #if SK_LATE_PREFETCH
-      if (!(SK_DBG(c, 2))) sk_mfma_chunk_u<NFW, F0>(c, smem, buf, acc, &pre);
+      if (!(SK_DBG(c, 2))) sk_mfma_chunk_u<RF, NFW, F0>(c, smem, buf, acc, &pre);
 #else
-      if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(NFW, F0, c, smem, buf, acc);
+      if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc);
 #endif
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_mfma, st_a, st_b);
 #else
@@ -786,20 +813,26 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *out)
   if (SK_DBG(c, 16)) return;
   SK_STAMP_T(st_a);
   if (c.proj) {
-    sk_project_out<NFW>(c, smem, acc, out);
+    sk_project_out<RF, NFW>(c, smem, acc, outP);
   } else {
     // one lane-dependent offset, made opaque per segment: left to itself the compiler hoists all store addresses out of the
-    // segment loop and spills them
+    // segment loop and spills them.  Row fragment f of the band is fragment (g0 + f) & 3 of row tile (g0 + f) >> 2: the partial
+    // tile of the first row tile the band touches (outA) or of the next one (outB; null: the band's padding, nothing to store)
     unsigned lane_off = (unsigned)(((4 * c.rh * 20 + c.cg) << 8) + 2 * (16 * c.fk + c.fr));
     asm volatile("" : "+v"(lane_off));
-    double2 *o = reinterpret_cast<double2 *>(out + lane_off);
+    const unsigned g0 = (unsigned)c.it.g0;
 #pragma unroll
-    for (int g = 0; g < NFW; ++g)
+    for (int f = 0; f < RF; ++f) {
+      const unsigned g = g0 + (unsigned)f;
+      double *ob = (g >> 2) == (g0 >> 2) ? outA : outB;
+      if (!ob) continue;                                        // (uniform)
+      double2 *o = reinterpret_cast<double2 *>(ob + lane_off) + (((g & 3) * 20) << 7);
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        st_d2(o + ((f * 20 + 4 * g) << 7), make_double2(acc[f][g][0], acc[f][g][1]), SK_PART_NT);
-        st_d2(o + ((f * 20 + 4 * g) << 7) + 64, make_double2(acc[f][g][2], acc[f][g][3]), SK_PART_NT);
+      for (int gg = 0; gg < NFW; ++gg) {
+        st_d2(o + ((4 * gg) << 7), make_double2(acc[f][gg][0], acc[f][gg][1]), SK_PART_NT);
+        st_d2(o + ((4 * gg) << 7) + 64, make_double2(acc[f][gg][2], acc[f][gg][3]), SK_PART_NT);
       }
+    }
   }
 #ifdef SK_STAMP
   SK_STAMP_T(st_b); SK_STAMP_ADD(s_epi, st_a, st_b);
@@ -838,7 +871,9 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
   for (int sgi = 0; sgi < nseg; ++sgi) {
     if (sgi) cur = wi[sgi];
     const int sg = cur.sg;
-    c.it = SkItem{cur.rt, cur.ct, cur.nba, cur.c0, cur.c1, cur.nbf};
+    c.it = SkItem{cur.g0, cur.rf, cur.ct, cur.c0, cur.c1, cur.nbf};
+    const int rf = __builtin_amdgcn_readfirstlane(cur.rf);      // row fragments per half of this band: 4 or 5
+    c.nfr = 4 * pl.n_row_tiles;
     // the lane's constants are formed per segment from an opaque copy of the thread index: formed once at the top of the kernel
     // they would be live across the epilogue, which has no register to spare for them (they were spilled around it)
     {
@@ -847,23 +882,24 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
       c.gj = tt & 15; c.gs = tt >> 4;
       c.fr = tt & 15; c.fk = (tt >> 4) & 3;
       c.wa = (unsigned)(c.gs * SK_LD + (c.gj ^ (c.gs & 15)));
-      c.za = (unsigned)((128 + 16 * 5 * (c.gs >> 3) + (c.gs & 7)) * SK_LD + (c.gj ^ (c.gs & 7)));
+      c.za = (unsigned)((32 * rf + 16 * 5 * (c.gs >> 3) + (c.gs & 7)) * SK_LD + (c.gj ^ (c.gs & 7)));
       c.dsin = 8 * SK_LD + ((c.gj & 8) ? -8 : 8);
-      c.base_a = ((unsigned)(64 * c.rh + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
-      c.base_b = ((unsigned)(128 + 16 * c.cg + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
+      c.base_a = ((unsigned)(16 * rf * c.rh + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
+      c.base_b = ((unsigned)(32 * rf + 16 * c.cg + c.fr) * SK_LD + (unsigned)((c.fk ^ c.fr) & 3)) * 8u;
       c.pq = (unsigned)(c.fr >> 2) << 5;
     }
     // per row fragment f (16 planar vectors) only the leading nff_f column fragments (8 kz each) are inside the cut-off sphere;
-    // the tile's count is the largest of them (<= 2 nba; an odd count leaves the last fragment of the last kz block unwritten:
+    // the band's count is the largest of them (an odd count leaves the last fragment of the last kz block unwritten:
     // the partial buffer is zeroed when allocated, those columns carry no listed k and zero weight)
     int nfrag = 0;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { const int nff = (int)((c.it.nbf >> (8 * f)) & 255u); nfrag = nff > nfrag ? nff : nfrag; }
+    for (int f = 0; f < 5; ++f) { const int nff = f < rf ? (int)((c.it.nbf >> (8 * f)) & 255u) : 0; nfrag = nff > nfrag ? nff : nfrag; }
     const int nfw = (nfrag - c.cg + 3) >> 2;            // fragments of this wave: fi = 4 g + cg < nfrag   (wave-uniform)
-    // f0 = the first row fragment whose cut leaves out this wave's last column fragment (4: none)
-    int f0 = 4;
+    // f0 = the first row fragment whose cut leaves out this wave's last column fragment (rf: none)
+    int f0 = rf;
 #pragma unroll
-    for (int f = 3; f >= 0; --f) {
+    for (int f = 4; f >= 0; --f) {
+      if (f >= rf) continue;
       const int nff = (int)((c.it.nbf >> (8 * f)) & 255u);
       const int n = (nff - c.cg + 3) >> 2;
       if (n < nfw) f0 = f;
@@ -873,50 +909,86 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
     //  all following fragments are short too -- which the loop above does: f0 is the smallest f with a short cut, so any longer
     //  cut behind it would be wrong; fall back to no culling then)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < 5; ++f) {
+      if (f >= rf) continue;
       const int nff = (int)((c.it.nbf >> (8 * f)) & 255u);
-      if (f >= f0 && ((nff - c.cg + 3) >> 2) >= nfw) f0 = 4;
+      if (f >= f0 && ((nff - c.cg + 3) >> 2) >= nfw) f0 = rf;
     }
     c.f0 = __builtin_amdgcn_readfirstlane(f0);
-    const int p0 = c.it.rt * 64 + c.gs, p1 = p0 + 32;
+    // planar vectors of this thread: 16 g0 + gs, + 32, and -- fifth row fragment, threads gs < 16 -- + 64 (the host pads the
+    // vector tables past the plan's end with vectors that read the all-zero X row)
+    const int p0 = c.it.g0 * 16 + c.gs, p1 = p0 + 32, p2 = p0 + 64;
     // (a table has at most kmax + 2 < 4096 rows of 16: the offsets fit in 16 bits)
     c.xy0 = ((unsigned)pl.p_ikx[p0] * 16 + c.gj) | (((unsigned)pl.p_iky[p0] * 16 + c.gj) << 16);
     c.xy1 = ((unsigned)pl.p_ikx[p1] * 16 + c.gj) | (((unsigned)pl.p_iky[p1] * 16 + c.gj) << 16);
     c.neg0 = pl.p_sgn[p0] < 0; c.neg1 = pl.p_sgn[p1] < 0;             // (padding vectors read the all-zero X row)
+    c.xy2 = 0; c.neg2 = false;
+    if (rf == 5 && c.gs < 16) {
+      c.xy2 = ((unsigned)pl.p_ikx[p2] * 16 + c.gj) | (((unsigned)pl.p_iky[p2] * 16 + c.gj) << 16);
+      c.neg2 = pl.p_sgn[p2] < 0;
+    }
     c.zact = 40 * (c.gs >> 3) + (c.gs & 7) < 8 * nfrag;     // the thread's first kz lies in an active column fragment
     c.zoff = (unsigned)(1 + c.it.ct * 32 + c.gs) * 16 + c.gj;
-    // projecting: `part` takes the segment's piece [SK_HC][128] instead of its partial tile
-    double *out = part + (size_t)sg * (proj ? SK_HC * 128 : 128 * 320);
+    // output: projecting -- ONE band-local piece per segment (slot = the segment's index cur.sg); else partial tiles, one per row
+    // tile of the plan the band touches (cur.sga: row tile g0 >> 2; cur.sgb: the next one, -1 when the band ends inside the first
+    // or its tail is padding)
+    double *outA = nullptr, *outB = nullptr, *outP = nullptr;
+    if (proj) outP = part + (size_t)cur.sg * (SK_HC * SK_HC_ROWS);            // projecting: the segment's band-local piece
+    else {
+      outA = part + (size_t)cur.sga * (128 * 320);
+      if (cur.sgb >= 0) outB = part + (size_t)cur.sgb * (128 * 320);
+    }
 #ifdef SK_STAMP
     const unsigned long long sg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // one body per (column fragments of this wave, stagger role, sphere cut): the MFMA phase is straight-line code.  f0 = 4 (no
-    // culling) is always correct -- culled fragments only hold G entries that no listed k reads -- and serves as the default.
-#define SK_BODY_F0(N, L)                                       \
-  switch (c.f0) {                                              \
-    case 1: sk_body<N, L, 1>(c, smem, out); break;             \
-    case 2: sk_body<N, L, 2>(c, smem, out); break;             \
-    case 3: sk_body<N, L, 3>(c, smem, out); break;             \
-    default: sk_body<N, L, 4>(c, smem, out); break;            \
+    // one body per (row fragments of the band, column fragments of this wave, stagger role, sphere cut): the MFMA phase is
+    // straight-line code.  f0 = rf (no culling) is always correct -- culled fragments only hold G entries that no listed k reads --
+    // and serves as the default.  RF = 4 bands take up to 5 column fragments per wave, RF = 5 bands up to 4 (20 accumulator
+    // fragments either way).
+#define SK_BODY_F0_4(N, L)                                            \
+  switch (c.f0) {                                                     \
+    case 1: sk_body<4, N, L, 1>(c, smem, outA, outB, outP); break;          \
+    case 2: sk_body<4, N, L, 2>(c, smem, outA, outB, outP); break;          \
+    case 3: sk_body<4, N, L, 3>(c, smem, outA, outB, outP); break;          \
+    default: sk_body<4, N, L, 4>(c, smem, outA, outB, outP); break;         \
   }
-#define SK_BODY_NFW(L)                                         \
-  switch (nfw) {                                               \
-    case 5: SK_BODY_F0(5, L) break;                            \
-    case 4: SK_BODY_F0(4, L) break;                            \
-    case 3: SK_BODY_F0(3, L) break;                            \
-    case 2: SK_BODY_F0(2, L) break;                            \
-    case 1: SK_BODY_F0(1, L) break;                            \
-    default: sk_body<0, L, 4>(c, smem, out); break;            \
+#define SK_BODY_F0_5(N, L)                                            \
+  switch (c.f0) {                                                     \
+    case 1: sk_body<5, N, L, 1>(c, smem, outA, outB, outP); break;          \
+    case 2: sk_body<5, N, L, 2>(c, smem, outA, outB, outP); break;          \
+    case 3: sk_body<5, N, L, 3>(c, smem, outA, outB, outP); break;          \
+    case 4: sk_body<5, N, L, 4>(c, smem, outA, outB, outP); break;          \
+    default: sk_body<5, N, L, 5>(c, smem, outA, outB, outP); break;         \
+  }
+#define SK_BODY_NFW(L)                                                \
+  if (rf == 5) {                                                      \
+    switch (nfw) {                                                    \
+      case 4: SK_BODY_F0_5(4, L) break;                               \
+      case 3: SK_BODY_F0_5(3, L) break;                               \
+      case 2: SK_BODY_F0_5(2, L) break;                               \
+      case 1: SK_BODY_F0_5(1, L) break;                               \
+      default: sk_body<5, 0, L, 5>(c, smem, outA, outB, outP); break;       \
+    }                                                                 \
+  } else {                                                            \
+    switch (nfw) {                                                    \
+      case 5: SK_BODY_F0_4(5, L) break;                               \
+      case 4: SK_BODY_F0_4(4, L) break;                               \
+      case 3: SK_BODY_F0_4(3, L) break;                               \
+      case 2: SK_BODY_F0_4(2, L) break;                               \
+      case 1: SK_BODY_F0_4(1, L) break;                               \
+      default: sk_body<4, 0, L, 4>(c, smem, outA, outB, outP); break;       \
+    }                                                                 \
   }
     if (late) { SK_BODY_NFW(true) } else { SK_BODY_NFW(false) }
 #undef SK_BODY_NFW
-#undef SK_BODY_F0
+#undef SK_BODY_F0_4
+#undef SK_BODY_F0_5
 #ifdef SK_STAMP
     if (t == 0 && sg < 4096) {
       unsigned long long *o = sk_seg_buf + (size_t)sg * 4;
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));      // which XCD this workgroup landed on
-      o[0] = ((unsigned long long)blockIdx.x << 32) | ((xcc & 15u) << 16) | (unsigned)c.it.rt; o[1] = c.it.nbf; o[2] = (unsigned)(c.it.c1 - c.it.c0);
+      o[0] = ((unsigned long long)blockIdx.x << 32) | ((xcc & 15u) << 16) | (unsigned)c.it.g0; o[1] = c.it.nbf; o[2] = (unsigned)(c.it.c1 - c.it.c0);
       o[3] = __builtin_amdgcn_s_memrealtime() - sg_t0;
     }
 #endif
@@ -946,7 +1018,7 @@ extern "C" int conp_debug_sk_stamps(unsigned long long *out /*[1024*8*8]*/, int 
 }
 #endif
 
-int sk_hc_stride() { return SK_HC * 128; }
+int sk_hc_stride() { return SK_HC * SK_HC_ROWS; }
 int sk_hc_max_classes() { return SK_HC_MAX; }
 
 // proj == nullptr: partial tiles [segment][128 x 320] into `part`; otherwise (planar electrodes, at most sk_hc_max_classes() z
@@ -1263,38 +1335,43 @@ __device__ __forceinline__ double hc_slot_sum(const double *__restrict__ h, cons
 // (39 pieces at the headline size: five loads in flight, ONE round trip -- the one-thread form walked five dependent rounds), the
 // octet's lanes add a group by a butterfly -- ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)), hc_slot_sum's tree, additions
 // commute -- and the groups are added in list order: the same bits as hc_slot_sum.
+// One row fragment g of the plan (16 planar vectors: rows 16 (g & 3) + i and 64 + the same of row tile g >> 2) per blockIdx.y.  In
+// every column tile the fragment belongs to one band of sk_gemm's schedule -- not the same band from tile to tile, the cut differs --
+// and every segment of that band left a band-local piece [class][32 rf rows]: the host lists them per fragment (frag_ptr / ents: the
+// offset of the fragment's first 'a' row in the piece, and the band's rf), column tile after column tile, segment after segment.
 constexpr int HCS_MAXG = 16;                 // groups of eight pieces a thread keeps in flight per pass
-__global__ __launch_bounds__(256) void hc_sum_kernel(const int *__restrict__ own_rt, int R_pad, int nzc, const double *__restrict__ Hp,
-                                                     const int *__restrict__ slot_ptr, const int *__restrict__ slot_idx,
-                                                     double *__restrict__ Hc4) {
-  const int per = (128 * nzc + 31) / 32;             // blocks per row tile (32 elements each)
-  const int k = blockIdx.x / per, rt = own_rt[k];
-  const int s0 = slot_ptr[k], s1 = slot_ptr[k + 1];
+__global__ __launch_bounds__(256) void hc_sum_kernel(const int *__restrict__ frag_ptr, const int2 *__restrict__ ents, int R_pad, int nzc,
+                                                     const double *__restrict__ Hp, double *__restrict__ Hc4) {
+  const int g = blockIdx.y;
+  const int s0 = frag_ptr[g], s1 = frag_ptr[g + 1];
   const int u = threadIdx.x & 7;
-  const int e = (blockIdx.x - k * per) * 32 + (threadIdx.x >> 3);
-  const bool live = e < 128 * nzc;
-  const int cls = live ? e >> 7 : 0, row = e & 127;
-  const double *h = Hp + cls * 128 + row;
+  const int e = blockIdx.x * 32 + (threadIdx.x >> 3);          // element of the fragment: (class, half, i)
+  const bool live = e < 32 * nzc;
+  const int cls = live ? e >> 5 : 0, half = (e >> 4) & 1, i = e & 15;
   double acc = 0.0;
   const int ng = (s1 - s0) / 8 + 1;                  // hc_slot_sum: the full groups, then one zero-padded group (possibly all zero)
   for (int gb = 0; gb < ng; gb += HCS_MAXG) {
     double v[HCS_MAXG];
 #pragma unroll
-    for (int g = 0; g < HCS_MAXG; ++g) {
-      const int sidx = s0 + 8 * (gb + g) + u;
-      v[g] = (live && sidx < s1) ? h[(size_t)slot_idx[sidx] * (SK_HC * 128)] : 0.0;
+    for (int k = 0; k < HCS_MAXG; ++k) {
+      const int sidx = s0 + 8 * (gb + k) + u;
+      v[k] = 0.0;
+      if (live && sidx < s1) {
+        const int2 en = ents[sidx];                  // x: offset of the fragment's first 'a' row in its piece, y: the band's rf
+        v[k] = Hp[(size_t)en.x + (size_t)(cls * 32 * en.y + half * 16 * en.y + i)];
+      }
     }
 #pragma unroll
-    for (int g = 0; g < HCS_MAXG; ++g) {
-      if (gb + g >= ng) break;                        // (uniform over the block)
-      double t = v[g];
+    for (int k = 0; k < HCS_MAXG; ++k) {
+      if (gb + k >= ng) break;                        // (uniform over the block)
+      double t = v[k];
       t += __shfl_xor(t, 1, 64);
       t += __shfl_xor(t, 2, 64);
       t += __shfl_xor(t, 4, 64);
       acc += t;
     }
   }
-  if (live && u == 0) Hc4[(size_t)cls * R_pad + (size_t)rt * 128 + row] = acc;
+  if (live && u == 0) Hc4[(size_t)cls * R_pad + (size_t)(g >> 2) * 128 + 64 * half + 16 * (g & 3) + i] = acc;
 }
 
 // grid = (ne_pad/64 atom blocks, 4 row quarters) -> partial slot blockIdx.y of bk; 16 waves: wave w takes rows r = w mod 16.
@@ -1392,7 +1469,7 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
     // Hc4 = the segments' projected pieces (sk_project_out): the pieces of a row tile are added here, in list order
     for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {
       const int cls = e / nrow, rowl = e - cls * nrow, k = rowl >> 7;
-      H[rowl * nzc + cls] = hc_slot_sum(Hc4 + cls * 128 + (rowl & 127), slot_idx, slot_ptr[k], slot_ptr[k + 1], (size_t)SK_HC * 128);
+      H[rowl * nzc + cls] = hc_slot_sum(Hc4 + cls * 128 + (rowl & 127), slot_idx, slot_ptr[k], slot_ptr[k + 1], (size_t)SK_HC * SK_HC_ROWS);
     }
   } else
   for (int e = threadIdx.x; e < nrow * nzc; e += 1024) {      // class-major Hc4: coalesced runs of rows, classes in use only
@@ -1579,11 +1656,12 @@ void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const
 // adds the pieces itself (presum: hc_sum first -- many pieces per tile, every block of the dot kernel would re-add them all);
 // otherwise hc_sum -> slot 0 of Hc -> b_zc_dot.
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
-                                  const int *slot_ptr, const int *slot_idx, bool presum, const double *Rp, const double2 *Xe,
+                                  const int *slot_ptr, const int *slot_idx, bool presum, const int *frag_ptr, const int2 *frag_ents, int nfrag,
+                                  const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
   if (n_own <= 0) return;
   if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
-  hipLaunchKernelGGL(hc_sum_kernel, dim3(n_own * ((128 * nzc + 31) / 32)), dim3(256), 0, s, own_rt, pl.R_pad, nzc, Hp, slot_ptr, slot_idx, Hc);
+  if (nfrag > 0) hipLaunchKernelGGL(hc_sum_kernel, dim3(nzc, nfrag), dim3(256), 0, s, frag_ptr, frag_ents, pl.R_pad, nzc, Hp, Hc);
   if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 1);
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 1);
 }
