@@ -592,6 +592,19 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
 #ifndef SK_LATE_PREFETCH
 #define SK_LATE_PREFETCH 0
 #endif
+// issue priority of the LATE waves (build first, multiply second: they arrive last at every barrier, the early waves wait ~a
+// quarter of a chunk for them): SK_PRIO > 0 raises them above their SIMD partner -- 3 through their build, SK_PRIO through their
+// multiply phase -- the early waves stay at 0
+#ifndef SK_PRIO
+#define SK_PRIO 0
+#endif
+// the same for the EARLY waves (multiply first): 1 = raised through their multiply phase only, 2 = through multiply and build.
+// Measured on one box (tools/ab_libs.sh, sk_gemm us, headline / slab geometry): late waves raised (SK_PRIO 1 / 2) 243.5 / 243.6 vs
+// 237.9 and 709 / 709 vs 680 -- worse; early waves raised through the multiply phase (SK_PRIO_E 1) 238.2 vs 237.6 and 675.7 vs 678.4;
+// through multiply and build (2) 236.5 and 673.4: the product's setting.
+#ifndef SK_PRIO_E
+#define SK_PRIO_E 2
+#endif
 #endif
 // Ablation switches (phases of the kernel turned off, TIMING ONLY, results are garbage) exist in the diagnostic build
 // -DSK_ABLATE only (`make ablate`, tools/sk_ablate.sh); in the product build the tests below fold to constants.
@@ -775,16 +788,25 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA
     const bool more = ch + 1 < c.it.c1;
     if (!late) {
       SK_STAMP_T(st_a);
+#if SK_PRIO_E
+      __builtin_amdgcn_s_setprio(SK_PRIO_E);
+#endif
       if (more && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 1, raw);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_load, st_a, st_b);
       if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_mfma, st_b, st_a);
+#if SK_PRIO_E == 1
+      __builtin_amdgcn_s_setprio(0);            // (variant 1: the early waves' build at the base priority; 2 / 3: raised throughout)
+#endif
       if (more && !(SK_DBG(c, 1))) sk_build_panel<RF, THIRD>(c, raw, nxt);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
     } else {
 #if SK_LATE_MODE == 1
       // full stagger: build first, multiply second
       SK_STAMP_T(st_a);
+#if SK_PRIO
+      __builtin_amdgcn_s_setprio(3);
+#endif
 #if SK_LATE_PREFETCH
       // (the phase's first operand reads go out ahead of the build's LDS writes: sk_mfma_prefetch)
       SkPre<NFW> pre;
@@ -794,6 +816,9 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
       if (ch + 2 < c.it.c1 && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 2, raw);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_load, st_b, st_a);
+#if SK_PRIO
+      __builtin_amdgcn_s_setprio(SK_PRIO);
+#endif
 #if SK_LATE_PREFETCH
       if (!(SK_DBG(c, 2))) sk_mfma_chunk_u<RF, NFW, F0>(c, smem, buf, acc, &pre);
 #else
@@ -988,7 +1013,7 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
       unsigned long long *o = sk_seg_buf + (size_t)sg * 4;
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));      // which XCD this workgroup landed on
-      o[0] = ((unsigned long long)blockIdx.x << 32) | ((xcc & 15u) << 16) | (unsigned)c.it.g0; o[1] = c.it.nbf; o[2] = (unsigned)(c.it.c1 - c.it.c0);
+      o[0] = ((unsigned long long)blockIdx.x << 32) | ((xcc & 15u) << 16) | (unsigned)c.it.g0; o[1] = c.it.nbf; o[2] = (unsigned long long)(unsigned)(c.it.c1 - c.it.c0) | ((unsigned long long)c.it.rf << 32);
       o[3] = __builtin_amdgcn_s_memrealtime() - sg_t0;
     }
 #endif

@@ -8,15 +8,19 @@ import numpy as np
 
 path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/sk_segments.txt"
 d = np.loadtxt(path)
-wg, rt, chunks, us, xcc = d[:, 0], d[:, 1], d[:, 6], d[:, 7], d[:, 8]
-nb = d[:, 2:6].mean(axis=1) / 2.0
-# us = a*chunks*nb + (a*C0)*chunks + (a*CSEG)
-X = np.stack([chunks * nb, chunks, np.ones_like(chunks)], 1)
+wg, g0, rf, chunks, us, xcc = d[:, 0], d[:, 1], d[:, 7], d[:, 8], d[:, 9], d[:, 10]
+nb = d[:, 2:7].sum(axis=1) / 8.0           # the cost model's unit: 0.125 x the band's active column fragments
+# us = a*chunks*nb + (a*C0_4)*chunks*[rf = 4] + (a*C0_5)*chunks*[rf = 5] + (a*CSEG)
+X = np.stack([chunks * nb, chunks * (rf == 4), chunks * (rf == 5), np.ones_like(chunks)], 1)
 coef, *_ = np.linalg.lstsq(X, us, rcond=None)
-a, ac0, acseg = coef
+a, ac4, ac5, acseg = coef
 res = us - X @ coef
-print(f"segments {len(us)}: a = {a:.4f} us per chunk per kz block, C0 = {ac0 / a:.3f}, CSEG = {acseg / a:.2f} (in chunk-block units); "
-      f"rms residual {res.std():.2f} us of mean {us.mean():.1f} us")
+print(f"segments {len(us)}: a = {a:.4f} us per chunk per unit, C0 (bands of 4) = {ac4 / a:.3f}, C0 (bands of 5) = {ac5 / a:.3f}, "
+      f"CSEG = {acseg / a:.2f} (in chunk units); rms residual {res.std():.2f} us of mean {us.mean():.1f} us")
+for band in sorted(set(zip(g0, rf))):
+    m = (g0 == band[0]) & (rf == band[1])
+    print(f"  band g0 {int(band[0]):3d} rf {int(band[1])}: {m.sum():3d} segments, units {nb[m].mean():5.2f}, us per chunk {np.mean(us[m] / chunks[m]):6.3f}, "
+          f"mean residual {res[m].mean():+.2f} us")
 for x in range(8):
     m = xcc == x
     if m.any():

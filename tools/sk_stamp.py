@@ -61,19 +61,20 @@ if hasattr(lib, "conp_debug_sk_clock") and lib.conp_debug_sk_clock(ck.ctypes.dat
           "kernel length per workgroup: median %.1f us" % (np.median(dc[ok] / dr[ok]) * 100.0, np.median(dr[ok]) / 100.0))
 fx.close()
 
-# per-segment lengths (the stream-K cost model of conp_fix.cpp build_items is fitted to these): workgroup, row tile, active kz
-# blocks per row fragment, chunks, microseconds
+# per-segment lengths (the stream-K cost model of conp_fix.cpp build_items is fitted to these): workgroup, first row fragment of
+# the band, active column fragments per row fragment (five slots), row fragments of the band, chunks, microseconds, XCD
 fx2 = None
 sg = np.zeros(4096 * 4, dtype=np.uint64)
 if hasattr(lib, "conp_debug_sk_segs") and lib.conp_debug_sk_segs(sg.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0:
     sg = sg.reshape(4096, 4)
-    sg = sg[sg[:, 2] > 0]
+    sg = sg[(sg[:, 2] & np.uint64(0xffffffff)) > 0]
     out = os.path.join(ROOT, "gpurun_out", "sk_segments.txt")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
-        f.write("# wg rt nbf0 nbf1 nbf2 nbf3 chunks us xcc\n")
+        f.write("# wg g0 nbf0 nbf1 nbf2 nbf3 nbf4 rf chunks us xcc\n")
         for r in sg:
             nbf = int(r[1])
-            f.write("%d %d %d %d %d %d %d %.2f %d\n" % (int(r[0]) >> 32, int(r[0]) & 0xffff, nbf & 255, (nbf >> 8) & 255, (nbf >> 16) & 255,
-                                                      (nbf >> 24) & 255, int(r[2]), float(r[3]) / 100.0, (int(r[0]) >> 16) & 15))
+            f.write("%d %d %d %d %d %d %d %d %d %.2f %d\n" % (int(r[0]) >> 32, int(r[0]) & 0xffff, nbf & 255, (nbf >> 8) & 255, (nbf >> 16) & 255,
+                                                            (nbf >> 24) & 255, (nbf >> 32) & 255, int(r[2]) >> 32, int(r[2]) & 0xffffffff,
+                                                            float(r[3]) / 100.0, (int(r[0]) >> 16) & 15))
     print(f"  {len(sg)} segments -> {out}")
