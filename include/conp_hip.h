@@ -304,6 +304,23 @@ int conp_fix_pre_force_device(conp_fix *fix, const double *d_x, double *d_q, dou
  * cheap enough to stay on inside a timed region (an event pair drains the queue around the kernel it brackets). */
 int conp_fix_profile(conp_fix *fix, int enable);
 int conp_fix_profile_read(conp_fix *fix, int *nkernels, const char **names /*[16]*/, double *avg_ms /*[16]*/, int *counts /*[16]*/);
+/* ---- page-locked host memory (optional; no reference counterpart: the reference has no device) ----
+ * The host-buffer hooks copy x, q (and, at a re-neighbour, the flattened neighbour list) out of the host's arrays.  Out of
+ * PAGEABLE memory such a copy is staged by the runtime and blocks the calling thread (about 70 us for the 1.2 MB of x, q at the
+ * headline size); out of page-locked memory it is an asynchronous DMA transfer that overlaps the enqueue of the update's kernels.
+ *   conp_fix_pin_host_arrays   page-locks the host's OWN arrays in place: x [3 n] and q [n], n >= nlocal + nghost of the calls
+ *       that follow.  The host promises that both stay where they are, and allocated, until conp_fix_unpin_host_arrays (or the
+ *       handle's destruction).  LAMMPS: atom->x / atom->q move only when the per-atom arrays grow, which happens between
+ *       pre_exchange and post_neighbor of a re-neighbouring step -- the glue unpins in pre_exchange and pins again in
+ *       post_neighbor.  Arrays that were not pinned (or other pointers than the pinned ones) take the staged copy as before:
+ *       same results either way.  A runtime that refuses the registration returns CONP_ERR_NO_DEVICE and changes nothing.
+ *   conp_host_alloc / conp_host_free   page-locked memory for arrays the host BUILDS for the hooks (the glue's flattened
+ *       neighbour list: conp_neighlist.first / .neigh). */
+int conp_fix_pin_host_arrays(conp_fix *fix, const double *x, const double *q, int n);
+int conp_fix_unpin_host_arrays(conp_fix *fix);
+void *conp_host_alloc(size_t bytes);
+void conp_host_free(void *p);
+
 /* Diagnostic (no reference counterpart): with CONP_GUARD=1 in the environment every device buffer of the library sits between two
  * 4-KB zones of a known byte pattern; this reads all zones back.  Returns the number of damaged zones (0 = no kernel has stored
  * outside its buffers so far), -1 when guard zones are off; conp_last_error() names the damaged buffers. */

@@ -92,6 +92,7 @@ SYMBOLS = [
     "conp_fix_set_stream",
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read", "conp_debug_check_guards",
+    "conp_fix_pin_host_arrays", "conp_fix_unpin_host_arrays", "conp_host_alloc", "conp_host_free",
     "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
     "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl", "conp_rccl_available", "conp_fix_comm_destroy_rccl",
     "conp_pppm_make_rho", "conp_pppm_compute_group_potential", "conp_pppm_compute_particle_potential",
@@ -114,6 +115,12 @@ def load_library():
     lib.conp_fix_create.argtypes = [C.POINTER(conp_fix_args), C.POINTER(conp_env), C.POINTER(vp)]
     lib.conp_fix_destroy.argtypes = [vp]
     lib.conp_fix_destroy.restype = None
+    lib.conp_fix_pin_host_arrays.argtypes = [vp, dp, dp, C.c_int]
+    lib.conp_fix_unpin_host_arrays.argtypes = [vp]
+    lib.conp_host_alloc.argtypes = [C.c_size_t]
+    lib.conp_host_alloc.restype = C.c_void_p
+    lib.conp_host_free.argtypes = [C.c_void_p]
+    lib.conp_host_free.restype = None
     lib.conp_fix_init_list.argtypes = [vp, C.c_int, C.POINTER(conp_neighlist)]
     for n in ("conp_fix_setup_post_neighbor", "conp_fix_post_neighbor", "conp_fix_linalg_setup", "conp_fix_a_cal",
               "conp_fix_b_cal"):
@@ -497,6 +504,15 @@ class FixConp:
             return True
         self.lib.conp_fix_comm_destroy_rccl(self.h)
         return False
+
+    def pin_host_arrays(self, at):
+        """page-lock at.x / at.q in place (conp_fix_pin_host_arrays): the host-buffer hooks then upload by asynchronous DMA"""
+        self._pinned = (at.x, at.q)                 # keep them alive and in place
+        self._check(self.lib.conp_fix_pin_host_arrays(self.h, _dptr(at.x), _dptr(at.q), int(at.nlocal + at.nghost)))
+
+    def unpin_host_arrays(self):
+        self._check(self.lib.conp_fix_unpin_host_arrays(self.h))
+        self._pinned = None
 
     # -- device-resident path --------------------------------------------------------------------
     def set_stream(self, stream_ptr: int):

@@ -325,6 +325,7 @@ struct conp_fix {
   // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
   // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
   const bool time_split = exp_switch("CONP_TIME_SPLIT") != nullptr;
+  const bool no_ride = exp_switch("CONP_NO_RIDE") != nullptr;      // comparison switch: the real-space pair sums in a launch of their own (b_real_combine)
   int table_c0 = 0, table_c1 = 0;  // chunk range (16 atoms each) whose phase tables this rank's sk_gemm reads
   int hslots = 0;                  // entries of the owned row tiles' segment lists (d_hslot_idx)
   bool g_current = true;           // d_G holds the last update's structure factors (false after a projecting update: conp_fix_get_sfac re-forms it)
@@ -341,6 +342,7 @@ struct conp_fix {
     prof.collect();
     drop_graph();
     if (nccl) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(nccl); nccl = nullptr; }
+    if (pin_x || pin_q) { (void)hipStreamSynchronize(stream); if (pin_x) (void)hipHostUnregister(const_cast<double *>(pin_x)); if (pin_q) (void)hipHostUnregister(const_cast<double *>(pin_q)); }
     if (h_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_pin); }
     if (h_np) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_np); }
     for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -1243,9 +1245,37 @@ struct conp_fix {
     if (ghost_mode)
       launch_ghost_fill(stream, at->nlocal, at->nghost, d_ghost_owner.p, d_ghost_img.p, env.xprd, env.yprd, env.zprd, d_x.p, d_q.p);
   }
+  // conp_fix_pin_host_arrays: the host's own x / q arrays, page-locked in place (asynchronous DMA straight out of them)
+  const double *pin_x = nullptr, *pin_q = nullptr;
+  int pin_n = 0;
+  void unpin_host() {
+    if (pin_x || pin_q) sync();                       // no transfer out of them may be in flight
+    if (pin_x) (void)hipHostUnregister(const_cast<double *>(pin_x));
+    if (pin_q) (void)hipHostUnregister(const_cast<double *>(pin_q));
+    pin_x = pin_q = nullptr; pin_n = 0;
+  }
+  void pin_host(const double *x, const double *q, int n) {
+    if (x == pin_x && q == pin_q && n <= pin_n) return;
+    unpin_host();
+    if (!x || !q || n <= 0) return;
+    if (hipHostRegister(const_cast<double *>(x), (size_t)n * 3 * sizeof(double), hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      throw ConpError(CONP_ERR_NO_DEVICE, "conp_fix_pin_host_arrays: the runtime refused to page-lock x (the staged copy stays in use)");
+    }
+    if (hipHostRegister(const_cast<double *>(q), (size_t)n * sizeof(double), hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipHostUnregister(const_cast<double *>(x));
+      throw ConpError(CONP_ERR_NO_DEVICE, "conp_fix_pin_host_arrays: the runtime refused to page-lock q (the staged copy stays in use)");
+    }
+    pin_x = x; pin_q = q; pin_n = n;
+  }
   void upload_xq_n(const conp_atoms *at, int nup) {
     const size_t nx = (size_t)nup * 3, nq = (size_t)nup;
-    if (nx + nq <= STAGE_MAX) {
+    if (at->x == pin_x && at->q == pin_q && nup <= pin_n) {
+      // page-locked by the host: two asynchronous DMA transfers, nothing staged, nothing blocks
+      HIP_TRY(hipMemcpyAsync(d_x.p, at->x, nx * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(d_q.p, at->q, nq * sizeof(double), hipMemcpyHostToDevice, stream));
+    } else if (nx + nq <= STAGE_MAX) {
       // results live in the first ne_pad + 8 doubles (update_charge); uploads behind them
       double *st = pinned((size_t)ne_pad + 8 + nx + nq) + ne_pad + 8;
       sync();                                          // the previous update's transfers out of the staging area are done
@@ -1714,7 +1744,7 @@ struct conp_fix {
       // host-buffer hooks were asked to time the two halves of b_cal separately (CONP_TIME_SPLIT; Ktime / Ctime, fix_conp.cpp:553-568)
       BRowArgs pairs = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 0,
                                  nullptr, 0, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
-      ride = !no_fuse && !(timed && time_split);
+      ride = !no_fuse && !(timed && time_split) && !no_ride;
       prof.begin("elyte_phase", stream);
       launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                          plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
@@ -2989,6 +3019,30 @@ const char *conp_fix_log_drain(conp_fix *f) {
   f->logbuf.clear();
   return f->logdrain.c_str();
 }
+
+int conp_fix_pin_host_arrays(conp_fix *f, const double *x, const double *q, int n) {
+  CONP_GUARD_BEGIN
+  if (!f) throw ConpError(CONP_ERR_ARG, "null argument");
+  f->drop_graph();
+  f->pin_host(x, q, n);
+  CONP_GUARD_END
+}
+
+int conp_fix_unpin_host_arrays(conp_fix *f) {
+  CONP_GUARD_BEGIN
+  if (!f) throw ConpError(CONP_ERR_ARG, "null argument");
+  f->drop_graph();
+  f->unpin_host();
+  CONP_GUARD_END
+}
+
+void *conp_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void conp_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 // CONP_GUARD=1: reads back the guard zones around every device buffer of the library (all handles of this process).  Returns the
 // number of damaged zones (0: every kernel so far stayed inside its buffers), -1 when guard zones are off; conp_last_error()

@@ -57,7 +57,7 @@ FixConpHip::~FixConpHip() {
   if (outf) fclose(outf);
 }
 
-int FixConpHip::setmask() { return POST_NEIGHBOR | PRE_FORCE | POST_FORCE | END_OF_STEP; }   // :233-241
+int FixConpHip::setmask() { return PRE_EXCHANGE | POST_NEIGHBOR | PRE_FORCE | POST_FORCE | END_OF_STEP; }   // :233-241 (+ PRE_EXCHANGE: un-pinning)
 
 void FixConpHip::init() {
   coulpair = force->pair_match("coul", 0);                                 // :252-258
@@ -167,15 +167,42 @@ conp_atoms FixConpHip::view() {
   return a;
 }
 
+void FixConpHip::PinnedInts::reserve(size_t want) {
+  if (want <= cap) return;
+  const size_t ncap = want + want / 2 + 64;
+  int *np_ = static_cast<int *>(conp_host_alloc(ncap * sizeof(int)));
+  if (!np_) throw std::bad_alloc();
+  if (n) std::memcpy(np_, p, n * sizeof(int));
+  conp_host_free(p);
+  p = np_; cap = ncap;
+}
+
+// atom->x / atom->q page-locked in place between re-neighbourings (include/conp_hip.h "page-locked host memory"): the per-step
+// upload of pre_force is then an asynchronous DMA transfer straight out of LAMMPS' arrays.  They move only when the per-atom arrays
+// grow (Atom::avec->grow), which happens inside a re-neighbouring step after pre_exchange: un-pinned there, pinned again in
+// post_neighbor with whatever the arrays are then.  A refusal leaves the staged copy in use -- not an error.
+void FixConpHip::pin_atoms() {
+  const int nall = atom->nlocal + atom->nghost;
+  const double *x = nall ? &atom->x[0][0] : nullptr;
+  const int n = atom->nmax > nall ? atom->nmax : nall;
+  if (x == pinned_x && atom->q == pinned_q && n == pinned_n) return;
+  pinned_x = pinned_q = nullptr; pinned_n = 0;
+  if (conp_fix_pin_host_arrays(h, x, atom->q, n) == CONP_OK) { pinned_x = x; pinned_q = atom->q; pinned_n = n; }
+}
+
+void FixConpHip::pre_exchange() {
+  if (h && pinned_x) { (void)conp_fix_unpin_host_arrays(h); pinned_x = pinned_q = nullptr; pinned_n = 0; }
+}
+
 // LAMMPS pages firstneigh; the library wants it flat (once per re-neighbour, not per step)
-void FixConpHip::push_list(int which, NeighList *l, std::vector<int> &first, std::vector<int> &neigh) {
+void FixConpHip::push_list(int which, NeighList *l, PinnedInts &first, PinnedInts &neigh) {
   const int nall = atom->nlocal + atom->nghost;
   first.assign(nall, 0);
   neigh.clear();
   for (int ii = 0; ii < l->inum; ++ii) {
     const int i = l->ilist[ii];
-    first[i] = (int)neigh.size();
-    neigh.insert(neigh.end(), l->firstneigh[i], l->firstneigh[i] + l->numneigh[i]);
+    first.data()[i] = (int)neigh.size();
+    neigh.append(l->firstneigh[i], l->firstneigh[i] + l->numneigh[i]);
   }
   if (neigh.empty()) neigh.push_back(0);
   conp_neighlist v;
@@ -194,6 +221,7 @@ void FixConpHip::setup_post_neighbor() {                                   // :3
   else { push_list(0, alist, first_a, neigh_a); push_list(1, blist, first_b, neigh_b); }
   conp_atoms a = view();
   fail_if(conp_fix_setup_post_neighbor(h, &a));
+  pin_atoms();
 }
 
 void FixConpHip::setup_pre_force(int) {                                    // :387-391
@@ -207,6 +235,7 @@ void FixConpHip::post_neighbor() {                                         // :4
   push_list(alist == blist ? 2 : 1, blist, first_b, neigh_b);
   conp_atoms a = view();
   fail_if(conp_fix_post_neighbor(h, &a));
+  pin_atoms();
 }
 
 void FixConpHip::pre_force(int) {                                          // :543-573

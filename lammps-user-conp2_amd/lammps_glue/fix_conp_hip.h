@@ -33,6 +33,7 @@ class FixConpHip : public Fix {
   void init_list(int, class NeighList *) override;
   void setup_post_neighbor() override;
   void setup_pre_force(int) override;
+  void pre_exchange() override;
   void post_neighbor() override;
   void pre_force(int) override;
   void post_force(int) override;
@@ -51,9 +52,28 @@ class FixConpHip : public Fix {
   bool postforceflag;
   std::vector<std::vector<std::string>> pending_modify;
   std::vector<double> cutsq_flat;
-  std::vector<int> echeck, first_a, first_b, neigh_a, neigh_b;
+  // the flattened neighbour lists live in page-locked memory (conp_host_alloc): the library's upload at a re-neighbour is an
+  // asynchronous DMA transfer, not a staged copy
+  struct PinnedInts {
+    int *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~PinnedInts() { conp_host_free(p); }
+    void reserve(size_t want);
+    void assign(size_t count, int v) { reserve(count); n = count; for (size_t i = 0; i < count; ++i) p[i] = v; }
+    void clear() { n = 0; }
+    void append(const int *b, const int *e) { const size_t k = (size_t)(e - b); reserve(n + k); for (size_t i = 0; i < k; ++i) p[n + i] = b[i]; n += k; }
+    void push_back(int v) { reserve(n + 1); p[n++] = v; }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    int *data() { return p; }
+  };
+  std::vector<int> echeck;
+  PinnedInts first_a, first_b, neigh_a, neigh_b;
+  const double *pinned_x = nullptr, *pinned_q = nullptr;
+  int pinned_n = 0;
   conp_atoms view();
-  void push_list(int which, class NeighList *l, std::vector<int> &first, std::vector<int> &neigh);
+  void pin_atoms();
+  void push_list(int which, class NeighList *l, PinnedInts &first, PinnedInts &neigh);
   double potdiff_now();
   void fail_if(int status);
   void flush_log();

@@ -284,7 +284,7 @@ int run_case(const char *path, bool provider, int me, int nprocs, MockCommRank *
       fix.setup_pre_force(0);
       first = false;
     } else {
-      if (reneigh) fix.post_neighbor();
+      if (reneigh) { fix.pre_exchange(); fix.post_neighbor(); }      // Verlet::run: pre_exchange ... neighbor->build ... post_neighbor
       fix.pre_force(0);
     }
     std::fill(fs.begin(), fs.end(), 0.0);

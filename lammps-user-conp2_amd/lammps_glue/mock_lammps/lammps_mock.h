@@ -74,7 +74,7 @@ class Compute : protected Pointers {
   virtual double memory_usage() { return 0.0; }
 };
 
-namespace FixConst { enum { POST_NEIGHBOR = 1 << 3, PRE_FORCE = 1 << 5, POST_FORCE = 1 << 7, END_OF_STEP = 1 << 10 }; }
+namespace FixConst { enum { PRE_EXCHANGE = 1 << 1, POST_NEIGHBOR = 1 << 3, PRE_FORCE = 1 << 5, POST_FORCE = 1 << 7, END_OF_STEP = 1 << 10 }; }
 
 class Fix : protected Pointers {
  public:
@@ -90,6 +90,7 @@ class Fix : protected Pointers {
   virtual void init_list(int, NeighList *) {}
   virtual void setup_post_neighbor() {}
   virtual void setup_pre_force(int) {}
+  virtual void pre_exchange() {}
   virtual void post_neighbor() {}
   virtual void pre_force(int) {}
   virtual void post_force(int) {}

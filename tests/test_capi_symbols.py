@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_every_declared_symbol_is_exported():
     hdr = open(os.path.join(ROOT, "include", "conp_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|double|void|int64_t|const char \*)\s*(conp_[a-z_0-9]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|double|void \*|void|int64_t|const char \*)\s*(conp_[a-z_0-9]+)\s*\(", hdr, re.M))
     lib = capi.load_library()
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing

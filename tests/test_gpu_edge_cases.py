@@ -164,3 +164,30 @@ def test_charge_switched_on_between_reneighbourings(oracle):
     ele = at.echeck != 0
     assert rel_err(at.q[ele], o.q[ele]) < 1e-8
     fx.close(); o.fx.close()
+
+
+def test_page_locked_host_arrays_give_the_same_update():
+    """conp_fix_pin_host_arrays: x, q uploaded by asynchronous DMA straight out of the host's arrays instead of the staged copy --
+    bitwise the same charges, also after the arrays were unpinned again, and other arrays than the pinned ones fall back"""
+    s = systems.deck("il_onelayer", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    q_ref = at.q.copy()
+    ele = at.echeck != 0
+    at.q[ele] = 0.0
+    fx.pin_host_arrays(at)
+    fx.pre_force(at, 1, s.potdiff)
+    assert np.array_equal(at.q, q_ref)
+    other = neighbor.Atoms(nlocal=at.nlocal, nghost=at.nghost, x=at.x.copy(), q=at.q.copy(), type=at.type, tag=at.tag, echeck=at.echeck,
+                           owner=at.owner)
+    other.q[ele] = 0.0
+    fx.pre_force(other, 2, s.potdiff)                   # not the pinned arrays: the staged copy
+    assert np.array_equal(other.q, q_ref)
+    fx.unpin_host_arrays()
+    at.q[ele] = 0.0
+    fx.pre_force(at, 3, s.potdiff)
+    assert np.array_equal(at.q, q_ref)
+    fx.close()

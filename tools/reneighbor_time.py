@@ -32,13 +32,21 @@ def main():
     for k in range(n):
         fx.pre_force(at, k + 1, s.potdiff)
     t4 = time.perf_counter()
+    fx.pin_host_arrays(at)
+    fx.pre_force(at, n + 1, s.potdiff)
+    tp = time.perf_counter()
+    for k in range(n):
+        fx.pre_force(at, k + 1, s.potdiff)
+    print(f"{wl}: pre_force with the host arrays page-locked in place {(time.perf_counter() - tp) / n * 1e3:.3f} ms")
+    fx.unpin_host_arrays()
+    t4b = time.perf_counter()
     for k in range(n):
         fx.post_force(at)
     t5 = time.perf_counter()
     for k in range(n):
         fx.post_force_step(at, n)            # the step of the last pre_force: x, q are resident
     t6 = time.perf_counter()
-    print(f"{wl}: post_force (host buffers) {(t5 - t4) / n * 1e3:.3f} ms, same step as pre_force {(t6 - t5) / n * 1e3:.3f} ms")
+    print(f"{wl}: post_force (host buffers) {(t5 - t4b) / n * 1e3:.3f} ms, same step as pre_force {(t6 - t5) / n * 1e3:.3f} ms")
     print(f"{wl}: nall {at.nall}, blist pairs {blist.npairs}: post_neighbor {(t3 - t2) / n * 1e3:.3f} ms, "
           f"pre_force (host buffers) {(t4 - t3) / n * 1e3:.3f} ms   [python list build: {t1 - t0:.1f} s, not part of the library]")
     fx.close()
