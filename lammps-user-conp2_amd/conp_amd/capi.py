@@ -115,12 +115,13 @@ def load_library():
     lib.conp_fix_create.argtypes = [C.POINTER(conp_fix_args), C.POINTER(conp_env), C.POINTER(vp)]
     lib.conp_fix_destroy.argtypes = [vp]
     lib.conp_fix_destroy.restype = None
-    lib.conp_fix_pin_host_arrays.argtypes = [vp, dp, dp, C.c_int]
-    lib.conp_fix_unpin_host_arrays.argtypes = [vp]
-    lib.conp_host_alloc.argtypes = [C.c_size_t]
-    lib.conp_host_alloc.restype = C.c_void_p
-    lib.conp_host_free.argtypes = [C.c_void_p]
-    lib.conp_host_free.restype = None
+    if hasattr(lib, "conp_fix_pin_host_arrays"):      # (comparison builds of earlier rounds, loaded through CONP_LIB, lack these)
+        lib.conp_fix_pin_host_arrays.argtypes = [vp, dp, dp, C.c_int]
+        lib.conp_fix_unpin_host_arrays.argtypes = [vp]
+        lib.conp_host_alloc.argtypes = [C.c_size_t]
+        lib.conp_host_alloc.restype = C.c_void_p
+        lib.conp_host_free.argtypes = [C.c_void_p]
+        lib.conp_host_free.restype = None
     lib.conp_fix_init_list.argtypes = [vp, C.c_int, C.POINTER(conp_neighlist)]
     for n in ("conp_fix_setup_post_neighbor", "conp_fix_post_neighbor", "conp_fix_linalg_setup", "conp_fix_a_cal",
               "conp_fix_b_cal"):

@@ -2707,7 +2707,39 @@ namespace {
 void need_pppm(conp_fix *f) {
   if (!f->args.pppm || f->dpppm.nfft <= 0)
     throw ConpError(CONP_ERR_STATE, "Compute requires a compatible KSpace provider like pppm/conp");   // compute_potential_atom.cpp:110
-  if (f->decomposed) throw ConpError(CONP_ERR_STATE, "the PPPM mesh is not sharded: one rank");
+}
+// Spatially decomposed ranks: the mesh potentials and density bricks are those of ALL atoms.  Every rank gathers the charged owned
+// atoms of all ranks of the wanted kind -- (x, q), one conp_comm gather, like the per-update gather of the electrolyte -- and spreads
+// them onto its own copy of the whole mesh: a REPLICATED mesh (the reference's ranks own bricks of it and exchange ghost planes,
+// pppm_conp.cpp:114,122 GridComm; the mesh of the `pppm` mode is 10^5..10^6 points, a fraction of a millisecond on one GPU), so the
+// collective call gives every rank the same brick and the potentials of its own atoms.  Returns the number of gathered atoms; the
+// device arrays are d_xg / d_qg, indexed by d_iota.
+int pppm_gather_all(conp_fix *f, const conp_atoms *at, int kind) {
+  std::vector<double> pack;
+  for (int i = 0; i < at->nlocal; ++i) {
+    if (at->q[i] == 0) continue;
+    if (kind == 0 && at->echeck[i] != 0) continue;
+    if (kind == 1 && at->echeck[i] == 0) continue;
+    pack.push_back(at->x[3 * (size_t)i]); pack.push_back(at->x[3 * (size_t)i + 1]); pack.push_back(at->x[3 * (size_t)i + 2]);
+    pack.push_back(at->q[i]);
+  }
+  std::vector<int> counts(f->env.nranks, 0);
+  f->rc.allgather_int((int)(pack.size() / 4), counts.data());
+  int n = 0;
+  for (int v : counts) n += v;
+  std::vector<double> all((size_t)std::max(n, 1) * 4), xs((size_t)std::max(n, 1) * 3), qs(std::max(n, 1));
+  if (pack.empty()) pack.resize(4);
+  f->rc.gatherv(pack.data(), counts, 4, all.data());
+  for (int k = 0; k < n; ++k) {
+    xs[3 * (size_t)k] = all[4 * (size_t)k]; xs[3 * (size_t)k + 1] = all[4 * (size_t)k + 1]; xs[3 * (size_t)k + 2] = all[4 * (size_t)k + 2];
+    qs[k] = all[4 * (size_t)k + 3];
+  }
+  std::vector<int> iota(std::max(n, 1));
+  for (int k = 0; k < n; ++k) iota[k] = k;
+  f->d_iota.upload(iota, f->stream);
+  f->d_xg.upload(xs, f->stream); f->d_qg.upload(qs, f->stream);
+  f->sync();                       // (the host vectors go out of scope)
+  return n;
 }
 // index lists of the owned atoms that carry charge, by kind (0 electrolyte, 1 electrode, 2 all), and x, q on the device
 int pppm_list(conp_fix *f, const conp_atoms *at, int kind, DevBuf<int> &d_idx) {
@@ -2732,9 +2764,14 @@ void pppm_upload(conp_fix *f, const conp_atoms *at) {
 void pppm_total_potential(conp_fix *f, const conp_atoms *at) {
   DevBuf<int> d_idx;
   pppm_upload(f, at);
-  const int n = pppm_list(f, at, 2, d_idx);
   f->d_pp_scratch.reserve(2048);
-  launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+  if (f->decomposed) {
+    const int n = pppm_gather_all(f, at, 2);
+    launch_pppm_density(f->stream, f->dpppm, n, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
+  } else {
+    const int n = pppm_list(f, at, 2, d_idx);
+    launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+  }
   launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p); f->pp_im_clean = false;
   HIP_TRY(hipGetLastError());
   f->sync();                       // d_idx goes out of scope
@@ -2752,15 +2789,25 @@ int conp_pppm_make_rho(conp_fix *f, const conp_atoms *at, double *density, doubl
   std::vector<double> e(nf), l(nf);
   {
     DevBuf<int> d_idx;
-    const int n = pppm_list(f, at, 1, d_idx);          // ele_make_rho (pppm_conp.cpp:385-426)
-    launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_ele.p, f->d_pp_scratch.p);
+    if (f->decomposed) {
+      const int n = pppm_gather_all(f, at, 1);
+      launch_pppm_density(f->stream, f->dpppm, n, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_ele.p, f->d_pp_scratch.p);
+    } else {
+      const int n = pppm_list(f, at, 1, d_idx);          // ele_make_rho (pppm_conp.cpp:385-426)
+      launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_ele.p, f->d_pp_scratch.p);
+    }
     HIP_TRY(hipMemcpyAsync(e.data(), f->d_pp_ele.p, nf * sizeof(double), hipMemcpyDeviceToHost, f->stream));
     f->sync();
   }
   {
     DevBuf<int> d_idx;
-    const int n = pppm_list(f, at, 0, d_idx);          // elyte_make_rho (:172-228)
-    launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    if (f->decomposed) {
+      const int n = pppm_gather_all(f, at, 0);
+      launch_pppm_density(f->stream, f->dpppm, n, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    } else {
+      const int n = pppm_list(f, at, 0, d_idx);          // elyte_make_rho (:172-228)
+      launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    }
     HIP_TRY(hipMemcpyAsync(l.data(), f->d_pp_re.p, nf * sizeof(double), hipMemcpyDeviceToHost, f->stream));
     f->sync();
   }
@@ -2843,7 +2890,11 @@ int conp_compute_potential_atom(conp_fix *f, const conp_atoms *at, const conp_ne
     if (all.empty()) all.push_back(0);
     d_idx.upload(all, f->stream);
     f->d_pp_scratch.reserve(2048);
-    launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    if (f->decomposed) {           // all ranks' charged atoms on this rank's copy of the mesh (pppm_gather_all)
+      const int ng = pppm_gather_all(f, at, 2);
+      launch_pppm_density(f->stream, f->dpppm, ng, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    } else
+      launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
     launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p); f->pp_im_clean = false;
     std::vector<int> idx;
     for (int i = 0; i < at->nlocal; ++i) if (sel[i]) idx.push_back(i);
@@ -2868,6 +2919,7 @@ int conp_compute_potential_atom(conp_fix *f, const conp_atoms *at, const conp_ne
       const double pi2vol = 2 * 3.14159265358979323846 / volume;
       double slabcorr = 0.0, qsum = 0.0;
       for (int i = 0; i < at->nlocal; ++i) { slabcorr += 2 * pi2vol * at->q[i] * at->x[3 * (size_t)i + 2]; qsum += at->q[i]; }
+      { double two[2] = {slabcorr, qsum}; f->rc.sum(two, 2); slabcorr = two[0]; qsum = two[1]; }      // MPI_Allreduce :331, :337
       for (int i = 0; i < at->nlocal; ++i)
         if (sel[i]) {
           const double z = at->x[3 * (size_t)i + 2];

@@ -2625,6 +2625,16 @@ void launch_inv_project_apply(hipStream_t s, int n, double *A, const double *ain
 //    scal: [0] lresnorm [1] lgamma [2] netr [3] ptap [4] alpha [5] beta [6] converged-iteration [7] net charge at
 //          convergence [8] converged flag (0/1), followed in the same buffer by hist[iter] = lresnorm of every iteration
 // ================================================================================================
+// two sums at once, each with block_sum_1024's tree (same bits), one pair of barriers instead of two
+__device__ __forceinline__ void block_sum2_1024(double &a, double &b, double *red /*[32]*/) {
+  a = wave_sum(a); b = wave_sum(b);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[16 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0;
+  for (int k = 0; k < 16; ++k) { ta += red[k]; tb += red[16 + k]; }
+  a = ta; b = tb;
+}
 __device__ double block_sum_1024(double v, double *red) {
   v = wave_sum(v);
   __syncthreads();
@@ -2657,7 +2667,7 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restri
                                                          double *__restrict__ p, const double *__restrict__ ap,
                                                          double *__restrict__ scal, double tolerance, int *__restrict__ done,
                                                          int iter, double *__restrict__ hist) {
-  __shared__ double red[16];
+  __shared__ double red[32];
   if (*done) return;
   double ptap = 0;
   for (int i = threadIdx.x; i < n; i += 1024) ptap += p[i] * ap[i];
@@ -2670,8 +2680,7 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restri
     const double r = res[i] - alpha * ap[i];
     res[i] = r; lg += r * r; netr += r;
   }
-  lg = block_sum_1024(lg, red);
-  netr = block_sum_1024(netr, red);
+  block_sum2_1024(lg, netr, red);
   const double ave = netr / n;
   lg -= netr * ave;
   const double beta = lg / gamma;
@@ -2695,6 +2704,17 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restri
 __device__ __forceinline__ double cg_row_dot(int n, const double *__restrict__ srow, const double *p, int lane) {
   double s0 = 0.0;
   int j = lane;
+  if (n <= 2048) {
+    // a deck-sized row (Ne = 832 / 1664): ALL of the lane's elements requested at once -- one round trip instead of three or four
+    // dependent ones (the tails below walk the last steps one load at a time); the additions stay in column order: the same bits
+    // (the vector comes out of LDS in the one-launch form: only the matrix row is kept in registers)
+    double a[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) { const int jj = lane + 64 * u; a[u] = jj < n ? srow[jj] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) if (lane + 64 * u < n) s0 = fma(a[u], p[lane + 64 * u], s0);
+    return s0;
+  }
   for (; j + 960 < n; j += 1024) {           // sixteen steps' loads in flight: a deck-sized row (Ne = 1664) is two round trips
     double a[16], x[16];
 #pragma unroll
@@ -2745,7 +2765,7 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
                                                        int rows_per_block, double *__restrict__ host_ctl, int n_ctl) {
   extern __shared__ __attribute__((aligned(16))) char cg_smem[];
   double *pl = reinterpret_cast<double *>(cg_smem);          // the direction of the matvec: [n]
-  __shared__ double red[16];
+  __shared__ double red[32];
   // mode 4 ends a batch: its one workgroup stores the control block (scalars, flag, net charge, residual history -- n_ctl doubles
   // from scal) straight into page-locked host memory: the host's read-back needs no copy-engine transfer behind this launch
   auto to_host = [&]() {
@@ -2822,8 +2842,7 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
         lg += r * r; netr += r;
       }
     }
-    lg = block_sum_1024(lg, red);
-    netr = block_sum_1024(netr, red);
+    block_sum2_1024(lg, netr, red);
     const double ave = netr / n;
     lg -= netr * ave;
     const double beta = lg / gamma;

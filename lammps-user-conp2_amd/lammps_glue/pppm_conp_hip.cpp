@@ -117,8 +117,8 @@ void PPPMConpHip::b_cal(double *bbb) {          /* spread, Poisson solve, stenci
 }
 
 double PPPMConpHip::compute_particle_potential(int i) {
-  // (a per-atom call: not every rank need make it -- error->one, the collective error->all would leave the others waiting in MPI)
-  if (comm->nprocs > 1) error->one(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
+  // (several MPI ranks: every rank gathers all ranks' charged atoms onto its own copy of the mesh -- a COLLECTIVE call, like the
+  //  reference's, whose PPPM::compute fills u_brick on all ranks before anybody asks for a potential)
   conp_atoms at = view();
   double u = 0.0;
   fail_if(conp_pppm_compute_particle_potential(h, &at, i, &u));
@@ -126,7 +126,6 @@ double PPPMConpHip::compute_particle_potential(int i) {
 }
 
 void PPPMConpHip::compute_group_potential(int groupbit, double *recv) {
-  if (comm->nprocs > 1) error->all(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
   conp_atoms at = view();
   sel.resize(atom->nlocal);
   for (int i = 0; i < atom->nlocal; ++i) sel[i] = (atom->mask[i] & groupbit) ? 1 : 0;
@@ -134,7 +133,6 @@ void PPPMConpHip::compute_group_potential(int groupbit, double *recv) {
 }
 
 void PPPMConpHip::total_density(double *density_brick) {
-  if (comm->nprocs > 1) error->all(FLERR, "pppm/conp/hip: mesh potentials and density bricks need all atoms on the mesh's rank (one MPI rank)");
   conp_atoms at = view();
   fail_if(conp_pppm_make_rho(h, &at, density_brick, nullptr, nullptr));
 }

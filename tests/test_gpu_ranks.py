@@ -51,7 +51,16 @@ def _decomposed_worker(rank, world, port, name, axis, solver, out):
     f, ek, ec, vir = fx.post_force(at)
     S = fx.matrix() if solver != "cg" else None             # collective: the row-sharded inverse is re-assembled
     m = fx.maps()
-    out[rank] = dict(q0=q0, q1=q1, sc0=sc0, sc1=fx.compute_scalar(), ek=ek, S=S, eleall2tag=m["eleall2tag"].copy(),
+    mesh = None
+    if solver == "pppm":
+        # PPPMCONP's coupling beyond b under decomposition (pppm_conp.cpp:385-534): the density brick of ALL atoms and the mesh
+        # potentials of this rank's electrode atoms -- collective calls, every rank gathers all charged atoms onto its mesh copy
+        nfft = 27 * 24 * 144
+        rho, rho_e, rho_l = fx.pppm_make_rho(at, nfft)
+        sel = (at.echeck[:at.nlocal] != 0).astype(np.int32)
+        pot = fx.pppm_group_potential(at, sel)
+        mesh = dict(rho=rho, rho_e=rho_e, pot={int(t): float(v) for t, v, e in zip(at.tag[:at.nlocal], pot, sel) if e})
+    out[rank] = dict(q0=q0, q1=q1, sc0=sc0, sc1=fx.compute_scalar(), ek=ek, S=S, eleall2tag=m["eleall2tag"].copy(), mesh=mesh,
                      info=(fx.info().elenum, fx.info().elenum_all, fx.info().n_elyte_charged))
     fx.close()
     dist.destroy_process_group()
@@ -83,6 +92,12 @@ def test_decomposed_ranks_match_one_rank(name, axis, world, solver):
     S1 = fx.matrix()
     tags1 = fx.maps()["eleall2tag"]
     n_charged = fx.info().n_elyte_charged
+    mesh1 = None
+    if solver == "pppm":
+        rho, rho_e, _ = fx.pppm_make_rho(at, 27 * 24 * 144)
+        sel = (at.echeck[:at.nlocal] != 0).astype(np.int32)
+        pot = fx.pppm_group_potential(at, sel)
+        mesh1 = dict(rho=rho, rho_e=rho_e, pot={int(t): float(v) for t, v, e in zip(at.tag[:at.nlocal], pot, sel) if e})
     fx.close()
     mgr = mp.Manager(); out = mgr.dict()
     port = 29600 + (os.getpid() + 7 * axis + world) % 300
@@ -100,6 +115,18 @@ def test_decomposed_ranks_match_one_rank(name, axis, world, solver):
     scale = max(abs(v) for v in q0.values())
     assert max(abs(allq0[t] - q0[t]) for t in q0) < tol * scale
     assert max(abs(allq1[t] - q1[t]) for t in q1) < tol * scale
+    if solver == "pppm":
+        # every rank holds the whole mesh: the same bricks as one rank (the spread adds in another order: f64 atomics), and the
+        # potentials of its own electrode atoms
+        allpot = {}
+        for r in range(world):
+            mr = out[r]["mesh"]
+            assert rel_err(mr["rho"], mesh1["rho"]) < 1e-12 and rel_err(mr["rho_e"], mesh1["rho_e"]) < 1e-12
+            assert not (set(mr["pot"]) & set(allpot))
+            allpot.update(mr["pot"])
+        assert sorted(allpot) == sorted(mesh1["pot"])
+        pscale = max(abs(v) for v in mesh1["pot"].values())
+        assert max(abs(allpot[t] - mesh1["pot"][t]) for t in allpot) < 1e-10 * pscale
     if solver != "cg":
         # the projected inverse in the ranks' own (rank-major) numbering == the one-rank matrix permuted by tag
         pos1 = {int(t): i for i, t in enumerate(tags1)}
