@@ -2704,17 +2704,9 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(int n, double *__restri
 __device__ __forceinline__ double cg_row_dot(int n, const double *__restrict__ srow, const double *p, int lane) {
   double s0 = 0.0;
   int j = lane;
-  if (n <= 2048) {
-    // a deck-sized row (Ne = 832 / 1664): ALL of the lane's elements requested at once -- one round trip instead of three or four
-    // dependent ones (the tails below walk the last steps one load at a time); the additions stay in column order: the same bits
-    // (the vector comes out of LDS in the one-launch form: only the matrix row is kept in registers)
-    double a[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) { const int jj = lane + 64 * u; a[u] = jj < n ? srow[jj] : 0.0; }
-#pragma unroll
-    for (int u = 0; u < 32; ++u) if (lane + 64 * u < n) s0 = fma(a[u], p[lane + 64 * u], s0);
-    return s0;
-  }
+  // (Measured and removed, round 4: ALL of a deck-sized row's elements requested at once -- 26 loads per lane, one round trip
+  //  instead of three -- made the iteration SLOWER, 84.5 vs 79.9 us per solve on il_twolayer: the matrix comes out of L2, the loads
+  //  of a later batch overlap the products of an earlier one, and one 26-deep batch serialises them.)
   for (; j + 960 < n; j += 1024) {           // sixteen steps' loads in flight: a deck-sized row (Ne = 1664) is two round trips
     double a[16], x[16];
 #pragma unroll
