@@ -377,13 +377,16 @@ def main():
             t_ms = timed_prof["sk_gemm"][0]
             ach = flops / (t_ms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pj = os.path.join(ROOT, "profiles", "r03_bench_headline_summary.json")
-            if args.workload == "headline" and world == 1 and os.path.exists(pj):
+            # the newest committed profile of this command (profiles/rNN_bench_headline_summary.json)
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_headline_summary.json")))
+            pj = cands[-1] if cands else ""
+            if args.workload == "headline" and world == 1 and pj and os.path.exists(pj):
                 pm = json.load(open(pj)).get("pmc", {}).get("sk_gemm_kernel", {})
                 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                     # rocprofv3 reports KiB; FETCH_SIZE x2: gfx950 counts 16-B-per-lane streams at half (MI355X_MICROARCH.md, HBM)
                     traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-                    traffic_src = "profiles/r03_bench_headline_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    traffic_src = f"profiles/{os.path.basename(pj)} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             roofline = dict(bound="mfma", kernel="sk_gemm_kernel (v_mfma_f64_16x16x4_f64)", achieved=ach, peak=FP64_PEAK_TFLOPS,
                             unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=t_ms, launches_averaged=timed_prof["sk_gemm"][1],
@@ -391,7 +394,7 @@ def main():
                             algorithmic_flops_per_launch=flops, survey_count_tflops=2 * ach,
                             note="achieved uses 4 flop per (k, atom); SURVEY 8d's reference-loop count (8 per k) would double it")
         # the HBM-bound member of the update: the GEMV with the projected inverse streams 8 Ne^2 / N bytes once (HIP events of the
-        # per-kernel pass; rocprofv3's kernel-only duration is ~2 us shorter, profiles/r03_bench_headline_summary.txt)
+        # per-kernel pass; rocprofv3's kernel-only duration is ~2 us shorter, profiles/r04_bench_headline_summary.txt)
         hbm_member = None
         if "gemv_charge" in prof and prof["gemv_charge"][0] > 0:
             t_s = prof["gemv_charge"][0] * 1e-3

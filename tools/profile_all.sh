@@ -2,7 +2,7 @@
 # Every workload of profiles/rNN_*: the headline and the BASELINE configs under rocprofv3 (tools/profile_gpu.sh each), summaries
 # gathered in gpurun_out/profiles_new/ (copy what is to be judged into profiles/).   bash tools/profile_all.sh [round tag]
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 DST=gpurun_out/profiles_new; mkdir -p $DST
 run() {   # name, bench args
   local name=$1; shift
@@ -14,5 +14,6 @@ run() {   # name, bench args
   echo "== $name done" >&2
 }
 run bench_headline && run il_onelayer --workload il_onelayer && run il_twolayer_cg --workload il_twolayer --solver cg \
-  && run il_onelayer_pppm --workload il_onelayer --pppm 40 45 180 && run headline_slab --workload headline_slab
+  && run il_onelayer_pppm --workload il_onelayer --pppm 40 45 180 && run headline_slab --workload headline_slab \
+  && run headline_rough --workload headline_rough
 ls -la $DST
