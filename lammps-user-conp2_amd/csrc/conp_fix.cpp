@@ -50,30 +50,42 @@ struct GuardZones {
   std::map<const void *, size_t> live;       // raw allocation -> payload bytes
   static bool on() { static const bool v = getenv("CONP_GUARD") != nullptr; return v; }
   static GuardZones &get() { static GuardZones g; return g; }
+  int bad_freed = 0;                         // damaged zones found when a buffer was released (checked then: the zones go with it)
+  std::string what_freed;
   void add(const void *raw, size_t bytes) { std::lock_guard<std::mutex> l(m); live[raw] = bytes; }
-  void drop(const void *raw) { std::lock_guard<std::mutex> l(m); live.erase(raw); }
-  // number of damaged zones; `what` names the first few
+  void drop(const void *raw) {
+    std::lock_guard<std::mutex> l(m);
+    auto it = live.find(raw);
+    if (it == live.end()) return;
+    (void)hipDeviceSynchronize();
+    bad_freed += check_one(static_cast<const char *>(raw), it->second, what_freed, bad_freed);
+    live.erase(it);
+  }
+  static int check_one(const char *raw, size_t bytes, std::string &what, int already) {
+    std::vector<unsigned char> h(2 * G);
+    if (hipMemcpy(h.data(), raw, G, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(h.data() + G, raw + G + bytes, G, hipMemcpyDeviceToHost) != hipSuccess) { what += " [unreadable zone]"; return 1; }
+    int bad = 0;
+    for (int side = 0; side < 2; ++side) {
+      size_t first = G;
+      for (size_t i = 0; i < G; ++i) if (h[side * G + i] != PATTERN) { first = i; break; }
+      if (first == G) continue;
+      ++bad;
+      if (already + bad <= 4) {
+        char line[160];
+        std::snprintf(line, sizeof line, " [buffer of %zu bytes: zone %s it damaged from byte %zu]", bytes, side ? "behind" : "before", first);
+        what += line;
+      }
+    }
+    return bad;
+  }
+  // number of damaged zones, of live buffers and of buffers released since the process started; `what` names the first few
   int check(std::string &what) {
     std::lock_guard<std::mutex> l(m);
     (void)hipDeviceSynchronize();
-    int bad = 0;
-    std::vector<unsigned char> h(2 * G);
-    for (const auto &kv : live) {
-      const char *raw = static_cast<const char *>(kv.first);
-      if (hipMemcpy(h.data(), raw, G, hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(h.data() + G, raw + G + kv.second, G, hipMemcpyDeviceToHost) != hipSuccess) { ++bad; what += " [unreadable zone]"; continue; }
-      for (int side = 0; side < 2; ++side) {
-        size_t first = G;
-        for (size_t i = 0; i < G; ++i) if (h[side * G + i] != PATTERN) { first = i; break; }
-        if (first == G) continue;
-        ++bad;
-        if (bad <= 4) {
-          char line[160];
-          std::snprintf(line, sizeof line, " [buffer of %zu bytes: zone %s it damaged from byte %zu]", kv.second, side ? "behind" : "before", first);
-          what += line;
-        }
-      }
-    }
+    int bad = bad_freed;
+    what = what_freed;
+    for (const auto &kv : live) bad += check_one(static_cast<const char *>(kv.first), kv.second, what, bad);
     return bad;
   }
 };

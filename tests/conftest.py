@@ -38,3 +38,18 @@ def _torch_owns_the_gpu_first():
     except Exception:
         pass
     yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """CONP_GUARD=1 python -m pytest tests -m gpu: the whole suite with guard zones around every device buffer of the library
+    (conp_fix.cpp GuardZones) -- every zone, of live buffers and of every buffer released during the session, must be intact"""
+    if not os.environ.get("CONP_GUARD"):
+        return
+    from conp_amd import capi
+    lib = capi.load_library()
+    lib.conp_debug_check_guards.restype = int
+    bad = lib.conp_debug_check_guards()
+    msg = lib.conp_last_error().decode() if bad > 0 else ""
+    print(f"\nCONP_GUARD: {bad} damaged guard zone(s) {msg}")
+    if bad != 0:
+        session.exitstatus = 1

@@ -31,8 +31,14 @@ cases = [("dilute", "ffield", (), "conp", None), ("il_onelayer", "ffield", (), "
          ("il_twolayer", "ffield", ("cg",), "conp", None),            # the shape round 3's abort happened at (Ne = 1664, CG, etypes)
          ("il_twolayer", "slab", (), "conq", None), ("cond2", "ffield", (), "conp", None),        # rough electrodes: general projection
          ("il_onelayer", "ffield", ("pppm",), "conp", (40, 45, 180, 5))]
+# a mid-size synthetic box whose planar vectors fill several bands of FIVE row fragments (straddling the plan's row tiles), projecting
+# mode + the structure-factor getter's two-slot partial tiles, symmetric solve with Ne not a multiple of its tile
+cases.append(("synthetic", "ffield", (), "conp", None))
 for deck, mode, extra, style, mesh in cases:
-    s = systems.deck(deck, mode, etypes=(deck != "dilute"), shuffle_seed=3)
+    if deck == "synthetic":
+        s = systems.synthetic_fast(n_cells_x=22, n_cells_y=13, lz=120.0, n_elyte=2048, cutoff=10.0, accuracy_relative=1e-5, g_ewald=0.30)
+    else:
+        s = systems.deck(deck, mode, etypes=(deck != "dilute"), shuffle_seed=3)
     at, alist, blist = neighbor.build_lists(s)
     kw = dict(pppm_mesh=mesh[:3], pppm_order=mesh[3]) if mesh else dict()
     fx = FixConp(s, extra_args=list(extra), style=style, **kw)
