@@ -592,6 +592,13 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
 #ifndef SK_LATE_PREFETCH
 #define SK_LATE_PREFETCH 0
 #endif
+// Early waves: first operand reads ahead of the next chunk's table loads.  Measured (tools/ab_libs.sh, one box each): in every body,
+// sk_gemm 235.9 -> 234.2 us at the headline size, 677 us either way in the slab geometry -- but four chunk loops of the bodies that
+// hold all 20 accumulator fragments then spill (tests/test_host_logic.py); restricted to the bodies with headroom: 235.2 vs 235.0 us,
+// and 17.24 vs 17.15 ms at 16384 / 262144.  Left off.
+#ifndef SK_EARLY_PREFETCH
+#define SK_EARLY_PREFETCH 0
+#endif
 // issue priority of the LATE waves (build first, multiply second: they arrive last at every barrier, the early waves wait ~a
 // quarter of a chunk for them): SK_PRIO > 0 raises them above their SIMD partner -- 3 through their build, SK_PRIO through their
 // multiply phase -- the early waves stay at 0
@@ -791,9 +798,16 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA
 #if SK_PRIO_E
       __builtin_amdgcn_s_setprio(SK_PRIO_E);
 #endif
+      // the phase's first operand reads go out BEFORE the next chunk's table loads are issued: the loads' address arithmetic and
+      // issue (6-8 instructions per thread) then run in the shadow of the LDS round trip instead of in front of it.  Not in the
+      // bodies that hold all 20 accumulator fragments: NFW + 1 more live registers there mean spills inside the chunk loop
+      constexpr bool EPRE = SK_EARLY_PREFETCH && !SK_MFMA_LOOP && RF * NFW < 20;
+      SkPre<NFW> pre;
+      if constexpr (EPRE) { if (!(SK_DBG(c, 2))) sk_mfma_prefetch<NFW>(c, smem, buf, pre); }
       if (more && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 1, raw);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_load, st_a, st_b);
-      if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc);
+      if constexpr (EPRE) { if (!(SK_DBG(c, 2))) sk_mfma_chunk_u<RF, NFW, F0>(c, smem, buf, acc, &pre); }
+      else { if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc); }
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_mfma, st_b, st_a);
 #if SK_PRIO_E == 1
       __builtin_amdgcn_s_setprio(0);            // (variant 1: the early waves' build at the base priority; 2 / 3: raised throughout)
