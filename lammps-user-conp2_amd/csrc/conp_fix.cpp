@@ -700,6 +700,7 @@ struct conp_fix {
     const int ne = idx.elenum_all;
     if (grew) {
       ne_pad = (ne + 127) / 128 * 128;
+      tables_current = false;          // the electrode tables are [..][ne_pad] of the OLD electrode count: whoever needs them next rebuilds them
       d_A.reserve((size_t)ne * ne);
       // electrode rows in blocks of ceil(Ne / nranks): rank r's rows start at r * rows_per, so that an all-gather of rows_per
       // values per rank lands every row at its own index (the buffers hold nranks * rows_per >= Ne entries)

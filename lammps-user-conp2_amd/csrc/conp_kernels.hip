@@ -1241,77 +1241,91 @@ void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int 
 
 // ================================================================================================
 // 3. k-space b vector (km_ewald.cpp:789-825):  b_i = - sum_{r,t} Rp[r][i] * (w G)[r][t] * Tz[t][i]
-//    Workgroup = 16 waves, 32 electrode atoms (2 column fragments) x the row tiles of one `half`
-//    (row tiles alternate between the two halves; the halves' sums are added by b_real_combine -- two terms, so the
-//    result does not depend on arrival order).  H = (w G)(16-row fragment) x Tz(slice in LDS) on MFMA, Hadamard
+//    Workgroup = 16 waves, 64 electrode atoms (4 column fragments) x the units of one of four `parts`
+//    (the parts' sums are added by b_real_combine as (k0 + k1) + (k2 + k3): a fixed order).  H = (w G)(16-row fragment) x Tz(slice in LDS) on MFMA, Hadamard
 //    with Rp and column sum in the epilogue.  (w G) arrives fragment-major: every A operand is one contiguous
 //    512-byte load.  Only the leading 8*nba k-steps of a row tile carry weight.
 // ================================================================================================
+// Round 4: 64 electrode atoms per workgroup (four column fragments: every A operand load feeds four MFMAs -- the 32-atom form re-read
+// (w G) from L2 once per 32 atoms, 333 MB per launch at the headline size) and four PARTS instead of two halves (the units of a
+// column tile -- (row tile, row fragment) pairs -- are dealt to the parts one by one: 256 workgroups at Ne = 4096; all four slots of
+// bk_part are written).  The Tz slice of 64 atoms is staged in two halves of 160 columns (80 KB), as four [160][16] blocks -- the
+// same conflict-free fragment reads as before; a unit's product with each half is multiplied with Rp and added on its own (the
+// projection is linear in H).
 __global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, int n_col_tiles, const int *__restrict__ ct_ptr,
                                                          const SkTile *__restrict__ tiles, const double *__restrict__ Gwf,
                                                          const double *__restrict__ Rp, const double *__restrict__ Tz,
                                                          double *__restrict__ bk_part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *tz0 = reinterpret_cast<double *>(smem);         // [320][16]  atoms i0 .. i0+15
-  double *tz1 = tz0 + 320 * 16;                            // [320][16]  atoms i0+16 .. i0+31
-  double *red = tz1 + 320 * 16;                            // [16 waves][32]
-  const int half = blockIdx.y;
-  const int i0 = blockIdx.x * 32;
+  double *tz = reinterpret_cast<double *>(smem);          // [4 atom fragments][160 columns][16 atoms]
+  double *red = tz + 4 * 160 * 16;                         // [16 waves][64]
+  const int part = blockIdx.y;
+  const int i0 = blockIdx.x * 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  double part0 = 0.0, part1 = 0.0;
+  double psum[4] = {0.0, 0.0, 0.0, 0.0};
   for (int ct = 0; ct < n_col_tiles; ++ct) {
     const int tb = ct_ptr[ct], te = ct_ptr[ct + 1];
     if (te <= tb) continue;
-    __syncthreads();
-    for (int e = t; e < 320 * 32; e += 1024) {
-      const int col = e >> 5, a = e & 31;
-      const double v = Tz[(size_t)(ct * 320 + col) * ne_pad + i0 + a];
-      if (a < 16) tz0[col * 16 + a] = v; else tz1[col * 16 + a - 16] = v;
-    }
-    __syncthreads();
-    // units of this half: tiles tb + half, tb + half + 2, ... x 8 row fragments; dealt round-robin to the 16 waves
-    const int nth = (te - tb - half + 1) / 2;
-    for (int u = wave; u < 8 * nth; u += 16) {
-      const SkTile tl = tiles[tb + half + 2 * (u >> 3)];
-      const int rf = tl.rt * 8 + (u & 7);
-      d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-      const double *ap = Gwf + ((size_t)rf * (C_pad / 4) + (size_t)ct * 80) * 64 + lane;
-      const double *bp0 = tz0 + fk * 16 + fr, *bp1 = tz1 + fk * 16 + fr;
-      const int nks = 8 * tl.nba;
-#pragma unroll 4
-      for (int ts = 0; ts < nks; ++ts) {
-        const double a = ap[(size_t)ts * 64];
-        acc0 = MFMA_F64(a, bp0[64 * ts], acc0);
-        acc1 = MFMA_F64(a, bp1[64 * ts], acc1);
+    int nba_max = 0;
+    for (int k = tb; k < te; ++k) nba_max = tiles[k].nba > nba_max ? tiles[k].nba : nba_max;      // (uniform: a handful of tiles)
+    for (int h = 0; h < 2; ++h) {                        // columns [160 h, 160 h + 160) of the tile = k-steps [40 h, 40 h + 40)
+      if (40 * h >= 8 * nba_max) break;
+      __syncthreads();
+      for (int e = t; e < 160 * 64; e += 1024) {
+        const int col = e >> 6, a = e & 63;
+        tz[((a >> 4) * 160 + col) * 16 + (a & 15)] = Tz[(size_t)(ct * 320 + 160 * h + col) * ne_pad + i0 + a];
       }
+      __syncthreads();
+      // units of this part: u_all = part, part + 4, ... over the 8 (te - tb) (tile, row fragment) pairs; dealt to the 16 waves
+      const int nu = 8 * (te - tb);
+      for (int u = part + 4 * wave; u < nu; u += 64) {
+        const SkTile tl = tiles[tb + (u >> 3)];
+        const int rf = tl.rt * 8 + (u & 7);
+        const int ks0 = 40 * h, ks1 = 8 * tl.nba < 40 * (h + 1) ? 8 * tl.nba : 40 * (h + 1);
+        if (ks1 <= ks0) continue;
+        d4 acc[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double *rp = Rp + (size_t)(16 * rf + fk + 4 * r) * ne_pad + i0 + fr;
-        part0 += rp[0] * acc0[r];
-        part1 += rp[16] * acc1[r];
+        for (int c = 0; c < 4; ++c) acc[c] = (d4){0.0, 0.0, 0.0, 0.0};
+        const double *ap = Gwf + ((size_t)rf * (C_pad / 4) + (size_t)ct * 80) * 64 + lane;
+        const double *bp = tz + fk * 16 + fr;
+#pragma unroll 4
+        for (int ts = ks0; ts < ks1; ++ts) {
+          const double a = ap[(size_t)ts * 64];
+          const double *bq = bp + 64 * (ts - ks0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = MFMA_F64(a, bq[c * 160 * 16], acc[c]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double *rp = Rp + (size_t)(16 * rf + fk + 4 * r) * ne_pad + i0 + fr;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) psum[c] += rp[16 * c] * acc[c][r];
+        }
       }
     }
   }
-  part0 += __shfl_xor(part0, 16, 64); part0 += __shfl_xor(part0, 32, 64);
-  part1 += __shfl_xor(part1, 16, 64); part1 += __shfl_xor(part1, 32, 64);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { psum[c] += __shfl_xor(psum[c], 16, 64); psum[c] += __shfl_xor(psum[c], 32, 64); }
   __syncthreads();
-  if (lane < 16) { red[wave * 32 + lane] = part0; red[wave * 32 + 16 + lane] = part1; }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * 64 + 16 * c + lane] = psum[c];
+  }
   __syncthreads();
-  if (t < 32) {
+  if (t < 64) {
     double sum = 0.0;
-    for (int w = 0; w < 16; ++w) sum += red[w * 32 + t];
-    bk_part[(size_t)half * ne_pad + i0 + t] = -sum;
-    bk_part[(size_t)(2 + half) * ne_pad + i0 + t] = 0.0;     // slots 2, 3 belong to the planar fast path
+    for (int w = 0; w < 16; ++w) sum += red[w * 64 + t];
+    bk_part[(size_t)part * ne_pad + i0 + t] = -sum;
   }
 }
 
 void launch_b_project(hipStream_t s, const DevPlan &pl, int ne_pad, const int *ct_ptr, const SkTile *tiles, const double *Gwf,
                       const double *Rp, const double *Tz, double *bk_part) {
-  const size_t lds = ((size_t)320 * 32 + 16 * 32) * sizeof(double);
+  const size_t lds = ((size_t)4 * 160 * 16 + 16 * 64) * sizeof(double);
   static DynLdsCache granted{};
   ensure_dyn_lds(b_project_kernel, lds, granted);
-  hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 32, 2), dim3(1024), lds, s, pl.C_pad, ne_pad, pl.n_col_tiles, ct_ptr, tiles,
+  hipLaunchKernelGGL(b_project_kernel, dim3(ne_pad / 64, 4), dim3(1024), lds, s, pl.C_pad, ne_pad, pl.n_col_tiles, ct_ptr, tiles,
                      Gwf, Rp, Tz, bk_part);
 }
 

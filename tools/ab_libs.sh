@@ -3,7 +3,7 @@
 # the NAME of lammps-user-conp2_amd/conp_amd/libconp_hip_NAME.so, e.g. a `make variant_NAME VDEF=...` build); two rounds each;
 # AB_ARGS: more bench.py flags, e.g. AB_ARGS='--solver cg'
 set -o pipefail
-W=headline; case "$1" in headline|big|headline_slab|il_onelayer|il_twolayer|dilute) W=$1; shift;; esac
+W=headline; case "$1" in headline|big|headline_slab|headline_rough|il_onelayer|il_twolayer|dilute|cond2) W=$1; shift;; esac
 D=lammps-user-conp2_amd/conp_amd
 for round in 1 2; do for n in "$@"; do
   L=$D/libconp_hip_$n.so; [ $n = product ] && L=$D/libconp_hip.so
