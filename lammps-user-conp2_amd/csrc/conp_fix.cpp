@@ -1746,12 +1746,22 @@ struct conp_fix {
     if (args.pppm) {
       // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
       prof.begin("pppm_b", stream);
+      // one rank: the real-space pair sums ride in the spread launch and the stencil gather completes the rows of b (slab term,
+      // pair sums): no b_real_combine launch behind the mesh (round 4; CONP_NO_RIDE / CONP_NO_FUSE / CONP_TIME_SPLIT: as before)
+      const bool pp_fin = env.nranks == 1 && !nccl && !decomposed && !no_fuse && !no_ride && !(timed && time_split);
+      BRowArgs pairs = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 0,
+                                 nullptr, 0, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
+      fin = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 1, d_bk.p, slab,
+                      d_ele_z.p, d_slab_part.p, 0, 4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
+      fin.breal = d_breal.p;
       if (env.rank == 0)
         launch_pppm_b(stream, dpppm, nl, eidx, ex, eq, ne, ne_pad, d_pp_egrid.p, d_pp_ew.p, d_pp_re.p, d_pp_im.p,
-                      d_slab_part.p, &n_slab_part, d_bk.p, &pp_im_clean);
+                      d_slab_part.p, &n_slab_part, d_bk.p, &pp_im_clean, pp_fin ? &pairs : nullptr, pp_fin ? d_breal.p : nullptr,
+                      pp_fin ? &fin : nullptr);
       else
         d_bk.zero(stream);
       prof.end(stream);
+      use_fin = pp_fin;
     } else {
       // the real-space pair sums depend on x, q only: they ride along in the phase kernel's launch (spare blocks) unless the
       // host-buffer hooks were asked to time the two halves of b_cal separately (CONP_TIME_SPLIT; Ktime / Ctime, fix_conp.cpp:553-568)

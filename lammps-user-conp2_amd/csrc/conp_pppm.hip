@@ -8,6 +8,7 @@
 #include <atomic>
 
 #include "conp_kernels.h"
+#include "conp_brow.hpp"
 
 namespace conp {
 
@@ -29,12 +30,22 @@ __device__ __forceinline__ void rho1d_dev(const double *__restrict__ coeff, int 
 // atom.  Orders above 6 (order^3 > 256) walk their stencil in several rounds of 256 threads.
 __host__ __device__ inline int spread_threads_per_atom(int order) { const int o3 = order * order * order; return o3 < 256 ? o3 : 256; }
 
+// Blocks beyond the spreading ones (nb_spread .. ): the real-space pair sums of the electrode rows (fix_conp.cpp:1313-1353), four
+// rows per block -- they depend on x, q only and ride along here (round 4) instead of costing a launch of their own behind the mesh.
 __global__ __launch_bounds__(256) void pppm_spread_kernel(PppmDev pd, int nl, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double *__restrict__ rho, double *__restrict__ slab_part,
-                                                          int npass) {
+                                                          int npass, int nb_spread, BRowArgs ra, double *__restrict__ breal_out) {
   __shared__ double coeff[64];
   __shared__ double red[4];
+  if ((int)blockIdx.x >= nb_spread) {
+    const int row = ((int)blockIdx.x - nb_spread) * 4 + (int)(threadIdx.x >> 6);
+    if (row < ra.ne) {
+      const double v = b_row_pairs(ra, row, threadIdx.x & 63);
+      if ((threadIdx.x & 63) == 0) breal_out[row] = v;
+    }
+    return;
+  }
   if (threadIdx.x < pd.order * pd.order) coeff[threadIdx.x] = pd.rho_coeff[threadIdx.x];
   __syncthreads();
   const int o2 = pd.order * pd.order, o3 = o2 * pd.order;
@@ -390,11 +401,15 @@ __global__ void pppm_greens_kernel(int nfft, double scaleinv, const double *__re
 // b_i = - sum over the order^3 stencil of w_x w_y w_z u (pppm_conp.cpp:278-299); weights/indices cached per electrode atom
 // like ele2rho / part2grid (aaa_map_rho :318-344).  One wavefront per electrode atom: lanes take (z, y) stencil rows, then a
 // shuffle reduction; slots 1..3 of bk are cleared here.
+// finish != 0 (round 4; one rank): the row of b is COMPLETED here -- slab term and the real-space pair sum (ra.breal, formed by the
+// spread launch's spare blocks) with b_row's operations -- instead of by b_real_combine in a launch of its own.
 __global__ __launch_bounds__(256) void pppm_gather_kernel(PppmDev pd, int ne, int ne_pad, const int *__restrict__ egrid /*[ne][3]*/,
                                                           const double *__restrict__ ew /*[ne][3][8]*/,
-                                                          const double *__restrict__ u, double *__restrict__ bk) {
+                                                          const double *__restrict__ u, double *__restrict__ bk, int finish, BRowArgs ra) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= ne) return;
+  // (every wave derives the slab scalar with the same summation tree, like b_real_combine_kernel)
+  const double sc = (finish && ra.slab) ? b_slab_scalar(ra, lane) : 0.0;
   const int gx = egrid[3 * i], gy = egrid[3 * i + 1], gz = egrid[3 * i + 2];
   const double *w = ew + (size_t)i * 24;
   const int o2 = pd.order * pd.order;
@@ -409,6 +424,7 @@ __global__ __launch_bounds__(256) void pppm_gather_kernel(PppmDev pd, int ne, in
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) { bk[i] = acc; bk[ne_pad + i] = 0.0; bk[2 * ne_pad + i] = 0.0; bk[3 * ne_pad + i] = 0.0; }
+  if (finish) b_row(ra, i, lane, sc);          // reads bk[i] .. bk[3 ne_pad + i] back as written by this lane 0: (k0 + 0) + (0 + 0) = k0
 }
 
 __global__ void zero_kernel(size_t n, double *p) {
@@ -514,7 +530,7 @@ static bool poisson_three_launches(hipStream_t s, const PppmDev &pd, double *re,
 // this rank's k-space b through the mesh: bk[0..ne) = PPPM b (slot 0), slots 1..3 zeroed
 void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_idx, const double *x, const double *q, int ne,
                    int ne_pad, const int *egrid, const double *ew, double *re, double *im, double *slab_part, int *n_slab_part,
-                   double *bk, bool *im_clean) {
+                   double *bk, bool *im_clean, const BRowArgs *pairs, double *breal_out, BRowArgs *fin) {
   const bool fused = mesh_smooth(pd);
   FftPlan fx, fy;
   // the density brick: `im` when the last backward pass left it all zero (*im_clean) -- one launch fewer per update
@@ -530,7 +546,11 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
   const int npass = (ngroups + 1023) / 1024;       // at most 1024 slab partial sums (launch_b_real_combine reads them per wave)
   const int nb = (ngroups + npass - 1) / npass;
   *n_slab_part = nb;
-  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, nl, elyte_idx, x, q, rho, slab_part, npass);
+  // pairs / fin != NULL: the real-space pair sums ride in the spread launch and the gather completes the rows of b (one rank)
+  BRowArgs ra{};
+  int nrb = 0;
+  if (pairs && breal_out) { ra = *pairs; nrb = (ra.ne + 3) / 4; }
+  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb + nrb), dim3(256), 0, s, pd, nl, elyte_idx, x, q, rho, slab_part, npass, nb, ra, breal_out);
   if (!(xy_fused && poisson_three_launches(s, pd, re, im, use_im, use_im))) {
     dft3(s, pd, -1.0, re, im, fused, gscale, use_im, false);
     if (!fused)
@@ -538,7 +558,9 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
     dft3(s, pd, +1.0, re, im, fused, gscale, false, use_im);
   }
   if (im_clean) *im_clean = use_im;
-  hipLaunchKernelGGL(pppm_gather_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, pd, ne, ne_pad, egrid, ew, re, bk);
+  BRowArgs fa{};
+  if (fin) { fin->n_slab_part = *n_slab_part; fa = *fin; }
+  hipLaunchKernelGGL(pppm_gather_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, pd, ne, ne_pad, egrid, ew, re, bk, fin ? 1 : 0, fa);
 }
 
 // ---- PPPM coupling beyond b (pppm_conp.cpp:385-534) ---------------------------------------------------------------------------
@@ -552,7 +574,7 @@ void launch_pppm_density(hipStream_t s, const PppmDev &pd, int n, const int *idx
   const int ngroups = (n + apb - 1) / apb;
   const int npass = (ngroups + 1023) / 1024;
   const int nb = (ngroups + npass - 1) / npass;
-  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, n, idx, x, q, rho, slab_scratch, npass);
+  hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb), dim3(256), 0, s, pd, n, idx, x, q, rho, slab_scratch, npass, nb, BRowArgs{}, nullptr);
 }
 
 // rho (in `re`) -> u_brick (in `re`): forward transform, greensfn / N, backward transform (elyte_poisson :230-267; the same

@@ -10,5 +10,5 @@ for round in 1 2; do for n in "$@"; do
   CONP_LIB=$PWD/$L python bench.py --workload $W --steps 60 --no-cpu-baseline --no-configs $AB_ARGS > gpurun_out/ab_$n.$round.json 2> gpurun_out/ab_$n.$round.err || exit 1
   python3 -c "
 import json,sys
-r=json.loads(open('gpurun_out/ab_$n.$round.json').read().strip().splitlines()[-1]); print('$n', $round, round(r['value'],1), round(r['ms_per_step'],4), round(r['roofline']['frac'],4), r['kernels_ms'])"
+r=json.loads(open('gpurun_out/ab_$n.$round.json').read().strip().splitlines()[-1]); print('$n', $round, round(r['value'],1), round(r['ms_per_step'],4), round(r['roofline']['frac'],4) if r.get('roofline') else '', r['kernels_ms'])"
 done; done
