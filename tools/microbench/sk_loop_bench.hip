@@ -35,8 +35,8 @@ __global__ __launch_bounds__(NT, 2) void loop_kernel(int iters, int f0, double *
 #pragma unroll
   for (int g = 0; g < NFW; ++g) rb[g] = 1e-4 * (lane + g);
   for (int it = 0; it < iters; ++it, buf ^= SK_BUF1) {
-    if constexpr (FORM == 0) sk_mfma_chunk<NFW>(c, smem, buf, acc);
-    else if constexpr (FORM == 1) sk_mfma_chunk_u<NFW, F0>(c, smem, buf, acc);
+    if constexpr (FORM == 0) sk_mfma_chunk<4, NFW>(c, smem, buf, acc);
+    else if constexpr (FORM == 1) sk_mfma_chunk_u<4, NFW, F0>(c, smem, buf, acc);
     else if constexpr (FORM == 2) {
 #pragma unroll 1
       for (int ks = 0; ks < 4; ++ks) {
