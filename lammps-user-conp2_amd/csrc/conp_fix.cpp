@@ -325,6 +325,8 @@ struct conp_fix {
   int witems_maxseg = 1;
   DevBuf<SkProj> d_skproj;
   SkProj skproj_h{};
+  DevBuf<SkFuse> d_skfuse;
+  SkFuse skfuse_h{};
   DevBuf<SkTile> d_tiles;
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   bool b_bound = false, q_bound = false;         // conp_fix_bind_device_buffers gave us the host's vectors
@@ -337,6 +339,7 @@ struct conp_fix {
   // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
   // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
   const bool time_split = exp_switch("CONP_TIME_SPLIT") != nullptr;
+  const bool no_phase_fuse = exp_switch("CONP_NO_PHASE_FUSE") != nullptr;      // comparison switch: always the stand-alone phase launch
   const bool no_ride = exp_switch("CONP_NO_RIDE") != nullptr;      // comparison switch: the real-space pair sums in a launch of their own (b_real_combine)
   int table_c0 = 0, table_c1 = 0;  // chunk range (16 atoms each) whose phase tables this rank's sk_gemm reads
   int hslots = 0;                  // entries of the owned row tiles' segment lists (d_hslot_idx)
@@ -1087,12 +1090,20 @@ struct conp_fix {
     // the kernel's own work list: one fixed-size row per workgroup (SkWItem)
     witems_maxseg = 1;
     for (int w = 0; w < nwg; ++w) witems_maxseg = std::max(witems_maxseg, (int)per_wg[w].size());
-    std::vector<SkWItem> wl((size_t)nwg * witems_maxseg, SkWItem{0, 4, 0, 0, 0, 0, 0, -1, 0, 0, 0ull});
+    std::vector<int> slab_slot_of(items_h.size(), -1);
+    n_slab_slots = 0; max_seg_chunks = 0;
+    for (size_t sgm = 0; sgm < items_h.size(); ++sgm) {          // items are band-major, chunk-ordered inside a band
+      max_seg_chunks = std::max(max_seg_chunks, items_h[sgm].c1 - items_h[sgm].c0);
+      if (items_h[sgm].g0 == 0 && items_h[sgm].ct == 0) slab_slot_of[sgm] = n_slab_slots++;
+    }
+    std::vector<SkWItem> wl((size_t)nwg * witems_maxseg, SkWItem{0, 4, 0, 0, 0, 0, 0, -1, 0, -1, 0ull});
     for (int w = 0; w < nwg; ++w)
       for (size_t k = 0; k < per_wg[w].size(); ++k) {
         const int sg = per_wg[w][k];
         const SkItem &it = items_h[sg];
-        wl[(size_t)w * witems_maxseg + k] = SkWItem{it.g0, it.rf, it.ct, it.c0, it.c1, sg, seg_sga[sg], seg_sgb[sg], k == 0 ? (int)per_wg[w].size() : 0, 0, it.nbf};
+        // (SkFuse: the segments of band 0 of column tile 0 tile the atoms once: they carry the slab term's sum of q z, in chunk order)
+        wl[(size_t)w * witems_maxseg + k] = SkWItem{it.g0, it.rf, it.ct, it.c0, it.c1, sg, seg_sga[sg], seg_sgb[sg], k == 0 ? (int)per_wg[w].size() : 0,
+                                                    slab_slot_of[sg], it.nbf};
       }
     d_witems.upload(wl, stream);
     d_tiles.upload(tiles_h, stream);
@@ -1129,6 +1140,7 @@ struct conp_fix {
     if (hidx.empty()) hidx.push_back(0);
     d_hslot_ptr.upload(hptr, stream); d_hslot_idx.upload(hidx, stream);
   }
+  int n_slab_slots = 0, max_seg_chunks = 0;      // SkFuse: segments that carry the slab sum; the longest segment (chunks)
   bool bands_aligned = true;       // every band of sk_gemm's schedule is a row tile of the plan
   int n_frags = 0;
   DevBuf<int> d_frag_ptr;
@@ -1768,11 +1780,32 @@ struct conp_fix {
       BRowArgs pairs = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 0,
                                  nullptr, 0, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
       ride = !no_fuse && !(timed && time_split) && !no_ride;
-      prof.begin("elyte_phase", stream);
-      launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
-                         plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
-                         &n_slab_part, ride ? &pairs : nullptr, d_breal.p, 16 * table_c0, 16 * table_c1);
-      prof.end(stream);
+      // small systems on one rank: no phase launch at all -- every sk_gemm segment computes the phase tables of its own atoms in
+      // front of its chunk loop, the pair sums ride in spare workgroups of that launch (SkFuse; CONP_NO_PHASE_FUSE: comparison switch)
+      const int nwg_sk = (int)seg_ptr_h.size() - 1;
+      const bool fuse_phase = ride && env.nranks == 1 && !nccl && !decomposed && nl_pad <= 4096 && max_seg_chunks <= 4 && n_slab_slots > 0 &&
+                              nwg_sk + (ne + 7) / 8 <= num_cus && !no_phase_fuse;
+      SkFuse fz;
+      std::memset(&fz, 0, sizeof fz);           // (padding bytes too: the block is compared bytewise below)
+      if (fuse_phase) {
+        fz.on = 1; fz.nl = nl; fz.kzt = plan.kzt; fz.nwg_sk = nwg_sk; fz.elyte_idx = eidx; fz.x = ex; fz.q = eq;
+        fz.ux = kt.unitk[0]; fz.uy = kt.unitk[1]; fz.uz = kt.unitk[2];
+        fz.Xt = d_Xt.p; fz.Yt = d_Yt.p; fz.Zs = d_Zt.p; fz.qc = d_qc.p; fz.slab_part = d_slab_part.p;
+        fz.rows = pairs; fz.breal_out = d_breal.p;
+        n_slab_part = n_slab_slots;
+        // the kernel reads the block from device memory: uploaded when its content changes (the host's x, q pointers are the same
+        // from step to step; a re-neighbour or other arrays change them)
+        if (d_skfuse.n == 0 || std::memcmp(&fz, &skfuse_h, sizeof fz) != 0) {
+          std::memcpy(&skfuse_h, &fz, sizeof fz);
+          d_skfuse.upload(&skfuse_h, 1, stream);
+        }
+      } else {
+        prof.begin("elyte_phase", stream);
+        launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
+                           plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
+                           &n_slab_part, ride ? &pairs : nullptr, d_breal.p, 16 * table_c0, 16 * table_c1);
+        prof.end(stream);
+      }
       // with the pair sums in hand and a small z-class table the dot kernel can finish b itself: no b_real_combine launch
       fin = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 1, d_bk.p, slab,
                       d_ele_z.p, d_slab_part.p, n_slab_part, 4.0 * 3.14159265358979323846 / kt.volume, d_b, d_scalars.p + 2);
@@ -1781,8 +1814,8 @@ struct conp_fix {
       const bool proj = sk_projects();
       reserve_partials();
       prof.begin("sk_gemm", stream);
-      launch_sk_gemm(stream, dplan, d_witems.p, witems_maxseg, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
-                     proj ? d_Hpart.p : d_Gpart.p, proj ? d_skproj.p : nullptr);
+      launch_sk_gemm(stream, dplan, d_witems.p, witems_maxseg, nwg_sk, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
+                     proj ? d_Hpart.p : d_Gpart.p, proj ? d_skproj.p : nullptr, fuse_phase ? d_skfuse.p : nullptr, ne);
       prof.end(stream);
       g_current = !proj;
       if (proj) {

@@ -30,7 +30,7 @@ struct SkProj { const double *wfull, *tzt; int nzc, cpad; };
 // plan the band touches (sga: row tile g0 >> 2, sgb: the next one or -1), numbered tile-major (SkTile::item0), for the partial-tile
 // mode; sg = the segment's own index, the slot of its band-local piece in the projecting mode -- and the first entry's nseg = how
 // many are used.  One load replaces the seg_ptr -> seg_idx -> items chain at the top of every workgroup.
-struct SkWItem { int g0, rf, ct, c0, c1, sg, sga, sgb, nseg, pad_; unsigned long long nbf; };
+struct SkWItem { int g0, rf, ct, c0, c1, sg, sga, sgb, nseg, slab_slot /*SkFuse: where this segment's sum of q z goes, or -1*/; unsigned long long nbf; };
 struct SkTile { int rt, ct, nba, item0, nsplit; unsigned nbf; };     // one (row tile, col tile) of the plan: its output slots are item0 .. item0+nsplit-1
 
 struct RealParams {           // real-space pair kernels
@@ -70,6 +70,21 @@ inline BRowArgs make_brow(int ne, int ne_pad, int row0, int row1, const int *row
   return a;
 }
 
+// Small systems (round 4): the phase tables of a segment's atoms are computed by the segment's own workgroup in front of its chunk
+// loop (sk_phase_prologue: the arithmetic of elyte_phase_kernel; several bands compute the same atoms' entries -- identical values
+// to identical addresses), the real-space pair sums ride in spare workgroups of the same launch: no elyte_phase launch at all.
+struct SkFuse {
+  int on;                         // 0: the tables were filled by elyte_phase_kernel
+  int nl, kzt, nwg_sk;            // charged electrolyte atoms; kz values per column tile; workgroups that run segments (the rest: pair rows)
+  const int *elyte_idx;
+  const double *x, *q;
+  double ux, uy, uz;
+  double2 *Xt, *Yt, *Zs;
+  double *qc, *slab_part;         // slab_part[SkWItem::slab_slot]: sum of q z over the segment's atoms (segments of band 0 of column tile 0)
+  BRowArgs rows;
+  double *breal_out;
+};
+
 struct PppmDev {              // device view of PppmPlan
   int nx, ny, nz, order, nlower, nfft;
   double shift, shiftone, delinv[3], delvolinv, boxlo[3];
@@ -103,7 +118,9 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         double *breal_out, int j0 /*tables for the atoms [j0, j1) of the compact list only (a rank's share)*/, int j1);
 bool zc_final_fits(int n_own, int nzc);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems /*[nwg][maxseg]*/, int maxseg, int nwg, int nl_pad,
-                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj = nullptr);
+                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj = nullptr,
+                    const SkFuse *fuse = nullptr /*small systems: phase tables and pair sums inside this launch (DEVICE copy of the block)*/,
+                    int fuse_rows = 0 /*its rows.ne*/);
 int sk_hc_stride();           // doubles per segment of sk_gemm's projected output
 int sk_hc_max_classes();      // most z classes the projecting mode takes
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,

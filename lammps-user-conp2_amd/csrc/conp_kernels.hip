@@ -804,15 +804,133 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA
 }
 
 
+// ---- small systems: the phase tables of a segment's atoms, computed by the segment's own workgroup (SkFuse) --------------------
+// The arithmetic is elyte_phase_kernel's, value for value (libm-grade sincos, the reference's angle-addition recurrence without
+// FMA contraction, the same rotation sequence for the z seeds); the decomposition differs: one thread per (atom, x axis), (atom, y
+// axis) and (atom, z axis, r) -- the eight z seeds r of an atom, which the stand-alone kernel keeps in flight in ONE thread, go to
+// eight threads here (a segment has ~48 atoms for 512 threads).  Several bands run over the same atoms: each writes the same values
+// to the same addresses.  The workgroup reads what IT wrote (one workgroup per CU, the CU's L1 was invalidated at the kernel's
+// start, the barrier behind this makes the stores visible inside the workgroup): no dependency on any other workgroup.
+// NOT inlined: a real call, once per segment.  Inlined, its live ranges (libm-grade sincos) are allocated together with the chunk
+// loops' and the allocator spilled inside them (35 VGPRs, 31 SGPRs); as a function it has a register file of its own.
+struct SkPlanDims { int kxmax, kymax, n_col_tiles; };
+__device__ __attribute__((noinline)) void sk_phase_prologue(SkPlanDims pl, const SkFuse *fzp, int c0, int c1, int slab_slot, char *smem) {
+#pragma clang fp contract(off)
+  // (arguments of a real call arrive in vector registers: made wave-uniform again here, so that the block is read by scalar loads)
+  {
+    const unsigned long long a = (unsigned long long)fzp;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    fzp = (const SkFuse *)(((unsigned long long)hi << 32) | lo);
+  }
+  c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
+  slab_slot = __builtin_amdgcn_readfirstlane(slab_slot);
+  pl.kxmax = __builtin_amdgcn_readfirstlane(pl.kxmax); pl.kymax = __builtin_amdgcn_readfirstlane(pl.kymax);
+  pl.n_col_tiles = __builtin_amdgcn_readfirstlane(pl.n_col_tiles);
+  const __attribute__((address_space(4))) SkFuse &fz = *(const __attribute__((address_space(4))) SkFuse *)fzp;
+  const int natoms = 16 * (c1 - c0);
+  const int NA = (natoms + 63) & ~63;               // items are kind-major in runs of NA: a wavefront has one kind
+  const int nrz = 1 + pl.n_col_tiles * 32;
+  double *qzs = reinterpret_cast<double *>(smem);   // [natoms] q z of the segment's atoms (slab term), summed by thread 0 in order
+  auto rot = [](double &cr, double &sr, double cw, double sw) {       // (cr, sr) *= (cw, sw), the reference's angle addition
+    const double cn = cr * cw - sr * sw;
+    const double sn = sr * cw + cr * sw;
+    cr = cn; sr = sn;
+  };
+  for (int it = threadIdx.x; it < 10 * NA; it += 512) {
+    const int kind = it / NA, al = it - kind * NA;   // kind 0: x axis, 1: y axis, 2 + r: z axis, seed r
+    if (al >= natoms) continue;
+    const int j = 16 * c0 + al;
+    const int c = kind < 2 ? kind : 2;
+    double xc = 0, qq = 0;
+    if (j < fz.nl) {
+      const int i = fz.elyte_idx[j];
+      xc = fz.x[3 * i + c]; qq = fz.q[i];
+    }
+    const double ang = (c == 0 ? fz.ux : (c == 1 ? fz.uy : fz.uz)) * xc;
+    double c1_, s1_;
+    sincos(ang, &s1_, &c1_);
+    if (c != 2) {
+      const int nrow = c == 0 ? pl.kxmax + 1 : pl.kymax + 1;
+      const int NR = c == 0 ? pl.kxmax + 2 : pl.kymax + 1;
+      double2 *t = (c == 0 ? fz.Xt : fz.Yt) + ((size_t)(j >> 4) * NR) * 16 + (j & 15);
+      const double sc = (c == 0) ? qq : 1.0;
+      if (c == 0) t[(size_t)(pl.kxmax + 1) * 16] = make_double2(0.0, 0.0);
+      t[0] = make_double2(sc, 0.0);
+      double cm = c1_, sm = s1_;
+      if (nrow > 1) t[16] = make_double2(sc * c1_, sc * s1_);
+      for (int m = 2; m < nrow; ++m) {
+        rot(cm, sm, c1_, s1_);
+        t[(size_t)m * 16] = make_double2(sc * cm, sc * sm);
+      }
+    } else {
+      const int r = kind - 2;
+      double2 *t = fz.Zs + ((size_t)(j >> 4) * nrz) * 16 + (j & 15);
+      // the chain 1, w, w^2, ... w^7 (this thread keeps w^r), w^8, w^40, w^kzt: the stand-alone kernel's sequence
+      double bc = 1.0, bs = 0.0, mc = 1.0, ms = 0.0;
+      for (int k = 1; k < 8; ++k) { rot(bc, bs, c1_, s1_); if (k == r) { mc = bc; ms = bs; } }
+      double c8 = bc, s8 = bs;
+      rot(c8, s8, c1_, s1_);
+      double c40 = c8, s40 = s8;
+      rot(c40, s40, c8, s8);
+      rot(c40, s40, c40, s40);
+      rot(c40, s40, c8, s8);
+      double ct_c = 1.0, ct_s = 0.0;
+      {
+        double pc = c8, ps = s8;
+        for (int e = fz.kzt >> 3; e; e >>= 1) {
+          if (e & 1) rot(ct_c, ct_s, pc, ps);
+          rot(pc, ps, pc, ps);
+        }
+      }
+      if (r == 0) {
+        t[0] = make_double2(c8, s8);
+        fz.qc[j] = qq;
+        qzs[al] = qq * xc;
+      }
+      for (int ct = 0; ct < pl.n_col_tiles; ++ct) {
+        double sc_ = mc, ss_ = ms;
+#pragma unroll
+        for (int q40 = 0; q40 < 4; ++q40) {
+          t[(size_t)(1 + 32 * ct + 8 * q40 + r) * 16] = make_double2(sc_, ss_);
+          if (q40 < 3) rot(sc_, ss_, c40, s40);
+        }
+        rot(mc, ms, ct_c, ct_s);
+      }
+    }
+  }
+  __syncthreads();
+  if (slab_slot >= 0 && threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int a = 0; a < natoms; ++a) tot += qzs[a];
+    fz.slab_part[slab_slot] = tot;
+  }
+  __syncthreads();          // (the panels are built into the memory the q z values sat in)
+}
+
 // Persistent-style launch: workgroup w runs the segments of row w of the work list (SkWItem; host: equal cost per workgroup,
 // a segment boundary may fall inside a tile -- "stream-K" over the atom chunks).
+// FUSE: the small-system variant (SkFuse: phase tables and pair sums inside this launch).  A variant of its own, so that the
+// other keeps the register allocation it was tuned to: with the prologue in the same function the allocator reloads one spilled
+// lane constant per chunk-loop iteration -- nothing for segments of <= 4 chunks, 15 % at the 16384 / 262144 size.
+template <bool FUSE>
 __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWItem *__restrict__ witems, int maxseg, int nl_pad,
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
-                                                         double *__restrict__ part, const SkProj *__restrict__ proj, int dbg) {
+                                                         double *__restrict__ part, const SkProj *__restrict__ proj, int dbg,
+                                                         const SkFuse *__restrict__ fzp /*device copy, or null*/, int nwg_sk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // panel buffer 0 at byte 0, buffer 1 at byte SK_BUF1
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (FUSE && (int)blockIdx.x >= nwg_sk) {
+    // spare workgroups of a small system's launch: the real-space pair sums of the electrode rows, one wavefront per row
+    const BRowArgs ra = fzp->rows;
+    const int row = ((int)blockIdx.x - nwg_sk) * 8 + wave;
+    if (row < ra.ne) {
+      const double v = b_row_pairs(ra, row, t & 63);
+      if ((t & 63) == 0) fzp->breal_out[row] = v;
+    }
+    return;
+  }
   SkCtx c;
   c.dbg = dbg;
   c.nl_pad = nl_pad; c.nz = pl.nz;
@@ -832,6 +950,8 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
     const int sg = cur.sg;
     c.it = SkItem{cur.g0, cur.rf, cur.ct, cur.c0, cur.c1, cur.nbf};
     const int rf = __builtin_amdgcn_readfirstlane(cur.rf);      // row fragments per half of this band: 4 or 5
+    // (small systems) the segment's phase tables first: before any per-lane constant of the chunk loop exists
+    if (FUSE) sk_phase_prologue(SkPlanDims{pl.kxmax, pl.kymax, pl.n_col_tiles}, fzp, cur.c0, cur.c1, cur.slab_slot, smem);
     c.nfr = 4 * pl.n_row_tiles;
     // the lane's constants are formed per segment from an opaque copy of the thread index: formed once at the top of the kernel
     // they would be live across the epilogue, which has no register to spare for them (they were spilled around it)
@@ -983,17 +1103,26 @@ int sk_hc_max_classes() { return SK_HC_MAX; }
 // proj == nullptr: partial tiles [segment][128 x 320] into `part`; otherwise (planar electrodes, at most sk_hc_max_classes() z
 // classes; proj = device copy of the parameter block) the segments' projected pieces [segment][sk_hc_stride()]
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems, int maxseg, int nwg, int nl_pad,
-                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj) {
+                    const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj,
+                    const SkFuse *fuse, int fuse_rows) {
   if (nwg <= 0) return;
+  // fuse: DEVICE copy of the parameter block (conp_fix.cpp uploads it when its content changes); fuse_rows: its rows.ne
+  const int extra = fuse ? (fuse_rows + 7) / 8 : 0;
   const size_t lds = SK_LDS_BYTES;
-  static DynLdsCache granted{};
-  ensure_dyn_lds(sk_gemm_kernel, lds, granted);
+  static DynLdsCache granted{}, granted_f{};
+  if (fuse) ensure_dyn_lds(sk_gemm_kernel<true>, lds, granted_f);
+  else ensure_dyn_lds(sk_gemm_kernel<false>, lds, granted);
 #ifdef SK_ABLATE
   static const int dbg = getenv("CONP_SK_DBG") ? atoi(getenv("CONP_SK_DBG")) : 0;   // diagnostic build only
 #else
   const int dbg = 0;
 #endif
-  hipLaunchKernelGGL(sk_gemm_kernel, dim3(nwg), dim3(512), lds, s, pl, witems, maxseg, nl_pad, Xt, Yt, Zs, qc, part, proj, dbg);
+  if (fuse)
+    hipLaunchKernelGGL(sk_gemm_kernel<true>, dim3(nwg + extra), dim3(512), lds, s, pl, witems, maxseg, nl_pad, Xt, Yt, Zs, qc, part, proj,
+                       dbg, fuse, nwg);
+  else
+    hipLaunchKernelGGL(sk_gemm_kernel<false>, dim3(nwg), dim3(512), lds, s, pl, witems, maxseg, nl_pad, Xt, Yt, Zs, qc, part, proj, dbg,
+                       fuse, nwg);
 }
 
 // G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:

@@ -137,7 +137,8 @@ def test_sk_gemm_chunk_loop_does_not_spill():
         assert p.returncode == 0, p.stderr[-2000:]
         text = open(asm).read()
     blocks = re.split(r"remark: Function Name: ", p.stderr)
-    sk = [b for b in blocks if b.startswith("_ZN4conp14sk_gemm_kernel")]
+    # (the instantiation every size but the small decks runs: sk_gemm_kernel<false>; <true> adds the fused phase prologue)
+    sk = [b for b in blocks if b.startswith("_ZN4conp14sk_gemm_kernelILb0E")]
     assert len(sk) == 1
     scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", sk[0]).group(1))
     sspill = int(re.search(r"SGPRs Spill: (\d+)", sk[0]).group(1))
@@ -145,7 +146,7 @@ def test_sk_gemm_chunk_loop_does_not_spill():
     assert sspill <= 32 and scratch <= 128, (scratch, sspill)
     assert vgprs <= 256
     # the kernel's body, cut into basic blocks with the loop each belongs to (the compiler's own annotations)
-    m = re.search(r"^_ZN4conp14sk_gemm_kernel\w*:[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    m = re.search(r"^_ZN4conp14sk_gemm_kernelILb0E\w*:[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
     assert m
     loop_of, body_of, cur = {}, {}, None
     lines = m.group(1).split("\n")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of comparison switches on ONE box: bash tools/ab_env.sh [workload] "NAME=VALUE" ...   ("-" = product defaults); two rounds
 set -o pipefail
-W=headline; case "$1" in headline|big|headline_slab|il_onelayer|il_twolayer) W=$1; shift;; esac
+W=headline; case "$1" in headline|big|headline_slab|headline_rough|il_onelayer|il_twolayer|dilute|cond2) W=$1; shift;; esac
 for round in 1 2; do for e in "$@"; do
   E="$e"; [ "$e" = "-" ] && E="CONP_X=0"
   env $E python bench.py --workload $W --steps 60 --no-cpu-baseline --no-configs > gpurun_out/ab_env.json 2> gpurun_out/ab_env.err || exit 1
