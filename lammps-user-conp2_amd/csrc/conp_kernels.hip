@@ -947,7 +947,6 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
   const int nseg = cur.nseg;
   for (int sgi = 0; sgi < nseg; ++sgi) {
     if (sgi) cur = wi[sgi];
-    const int sg = cur.sg;
     c.it = SkItem{cur.g0, cur.rf, cur.ct, cur.c0, cur.c1, cur.nbf};
     const int rf = __builtin_amdgcn_readfirstlane(cur.rf);      // row fragments per half of this band: 4 or 5
     // (small systems) the segment's phase tables first: before any per-lane constant of the chunk loop exists
@@ -1931,6 +1930,10 @@ void launch_gemv_finish(hipStream_t s, int n, const double *S, const double *b, 
 // per LDS instruction (SQ_LDS_BANK_CONFLICT 1 081 344 on 348 736 instructions) and eight barriers per tile: 16.2 us, 4.3 TB/s.
 // Every (row block, source tile) pair owns one slot of yp[nb][ne_pad]: nothing is added across workgroups, the finishing kernel sums
 // a row's nb slots in a fixed order -> bitwise reproducible.
+// (Tried in round 4: the finish inside this launch -- every workgroup announces itself at a counter per row block behind a
+//  __threadfence(), the last arrival of a block sums its slots.  Correct, and 82 us instead of 17.6 for the pair of launches: a
+//  device-scope release / acquire on gfx950 writes back and invalidates the XCD's whole L2, 528 workgroups do it one after the
+//  other.  A kernel boundary is the cheap device-wide fence here.)
 constexpr int SG_T = 128;                 // tile edge
 __device__ __forceinline__ unsigned long long f64_bits_abs(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 __global__ __launch_bounds__(256) void sym_pack_kernel(int ne, const double *__restrict__ S, double *__restrict__ Spk,
