@@ -311,3 +311,38 @@ def test_large_box_structure_factors_against_direct_sums():
         b_ref = -np.sum(2.0 * kt["ug"] * (e.real * sr + e.imag * si))
         assert b_g[ia] == pytest.approx(b_ref, rel=1e-9)
     fx.close()
+
+
+@pytest.mark.parametrize("mode", ["ffield", "slab"])
+def test_small_system_fused_phase_equals_the_separate_launch(monkeypatch, mode):
+    """il_onelayer takes the small-system form of sk_gemm (SkFuse: the phase tables of a segment's atoms and the pair sums inside the
+    launch, no elyte_phase launch).  The tables and the pair sums are the stand-alone kernels' arithmetic value for value: the b
+    vector and the charges must come out bit for bit as with CONP_NO_PHASE_FUSE=1 (ffield); in slab mode the slab sum is added in
+    another order (per segment, not per block of the phase kernel): equal to rounding."""
+    s = systems.deck("il_onelayer", mode, etypes=True, shuffle_seed=5)
+    at0, alist, blist = neighbor.build_lists(s)
+    out = {}
+    for sep in (False, True):
+        if sep:
+            monkeypatch.setenv("CONP_NO_PHASE_FUSE", "1")
+        at, _, _ = neighbor.build_lists(s)
+        fx = FixConp(s)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.setup_pre_force(at, 0, s.potdiff)
+        fx.profile(1)
+        fx.pre_force(at, 1, s.potdiff)
+        names = set(fx.profile_read())
+        fx.profile(0)
+        b, q, _ = fx.vectors()
+        out[sep] = (b.copy(), q.copy(), at.q.copy(), names)
+        fx.close()
+        if sep:
+            monkeypatch.delenv("CONP_NO_PHASE_FUSE")
+    assert "elyte_phase" not in out[False][3] and "elyte_phase" in out[True][3]
+    if mode == "ffield":
+        for k in range(3):
+            assert np.array_equal(out[False][k], out[True][k])
+    else:
+        for k in range(3):
+            assert rel_err(out[False][k], out[True][k]) < 1e-13
