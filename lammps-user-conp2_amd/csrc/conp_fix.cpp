@@ -302,7 +302,7 @@ struct conp_fix {
   std::string warning;
   double cond_vmult = 0.0;       // fix cond (fix_cond.cpp:58-68)
   bool cond_ready = false;
-  std::vector<int> atom2eleall_h, elyte_idx_h;
+  std::vector<int> elyte_idx_h;
   int bl_inum = 0;                 // owners in the ele-electrolyte list as uploaded for the post-force kernel
   size_t bl_nneigh = 0;            // length of its flattened neighbour array
   DevBuf<char> d_rows_scratch;
@@ -490,6 +490,7 @@ struct conp_fix {
     kt.build(env.g_ewald, env.accuracy, env.slab_volfactor, env.slabflag, env.xprd, env.yprd, env.zprd, qsqsum, natoms,
              env.qqrd2e, env.dielectric);
     plan.build(kt);
+    ++plan_gen;
     // padding planar rows point at the all-zero X row kxmax+1 (they then contribute nothing)
     // (96 more than the plan's row tiles hold: a band of sk_gemm may run up to five row fragments past the last planar vector)
     std::vector<int> ikx(plan.n_row_tiles * 64 + 96, plan.kxmax + 1), iky(plan.n_row_tiles * 64 + 96, 0), sgn(plan.n_row_tiles * 64 + 96, 1);
@@ -633,16 +634,50 @@ struct conp_fix {
     idx.linalg_init(at->nlocal, at->tag, &rc);
   }
 
+  // ---- uploads of a re-neighbour.  A hipMemcpyAsync out of pageable memory blocks the caller per call (the runtime stages it and
+  // waits); a re-neighbour makes a dozen of them.  They go through ONE page-locked arena instead: a memcpy into the arena, a real
+  // asynchronous transfer out of it, the host moves on to the next table; the arena is recycled at the next re-neighbour (this one
+  // ends with a stream synchronisation).  Arrays the host has page-locked itself (the glue's flattened lists; atom arrays
+  // between conp_fix_pin_host_arrays and _unpin_host_arrays) are transferred from where they lie.
+  char *ren_arena = nullptr;
+  size_t ren_cap = 0, ren_off = 0;
+  void ren_begin(size_t bytes_wanted) {
+    ren_off = 0;
+    if (bytes_wanted <= ren_cap) return;
+    if (ren_arena) { sync(); (void)hipHostFree(ren_arena); ren_arena = nullptr; ren_cap = 0; }
+    const size_t want = bytes_wanted + bytes_wanted / 4 + 4096;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ren_arena), want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ren_arena = nullptr; return; }
+    ren_cap = want;
+  }
+  static bool host_page_locked(const void *h) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, h) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+  }
+  template <class T>
+  void ren_upload(DevBuf<T> &d, const T *h, size_t count, bool locked = false) {
+    d.reserve(count);
+    if (!count) return;
+    const size_t bytes = count * sizeof(T), o = (ren_off + 63) & ~(size_t)63;
+    if (locked || o + bytes > ren_cap) { HIP_TRY(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream)); return; }
+    std::memcpy(ren_arena + o, h, bytes);
+    ren_off = o + bytes;
+    HIP_TRY(hipMemcpyAsync(d.p, ren_arena + o, bytes, hipMemcpyHostToDevice, stream));
+  }
+  template <class T>
+  void ren_upload(DevBuf<T> &d, const std::vector<T> &v) { ren_upload(d, v.data(), v.size()); }
+
   void upload_atoms_static(const conp_atoms *at) {
     nall = at->nlocal + at->nghost;
-    d_type.upload(at->type, nall, stream);
-    atom2eleall_h.assign(nall, -1);
-    for (int i = 0; i < nall; ++i)
-      if (at->echeck[i]) atom2eleall_h[i] = (at->tag[i] <= idx.maxtag_all) ? idx.tag2eleall[at->tag[i]] : -1;
-    d_atom2eleall.upload(atom2eleall_h, stream);
-    ele_pairs_h.clear();                       // (atom, eleall) for every owned or ghost electrode atom: the charge scatter list
-    for (int i = 0; i < nall; ++i)
-      if (atom2eleall_h[i] >= 0) { ele_pairs_h.push_back(i); ele_pairs_h.push_back(atom2eleall_h[i]); }
+    ren_upload(d_type, at->type, (size_t)nall);
+    // one pass: the (atom, eleall) pairs of every owned / ghost electrode atom -- the charge scatter list, and what the device
+    // fills its atom -> eleall table from (launch_atom2eleall below)
+    ele_pairs_h.clear();
+    for (int i = 0; i < nall; ++i) {
+      if (!at->echeck[i]) continue;
+      const int e = (at->tag[i] <= idx.maxtag_all) ? idx.tag2eleall[at->tag[i]] : -1;
+      if (e >= 0 && e < idx.elenum_all) { ele_pairs_h.push_back(i); ele_pairs_h.push_back(e); }
+    }
     n_ele_atoms = (int)(ele_pairs_h.size() / 2);
     {   // the same list by electrode row (CSR): the fused GEMV + charge write scatters row by row
       const int ne = idx.elenum_all;
@@ -653,10 +688,12 @@ struct conp_fix {
       for (int k = 0; k < n_ele_atoms; ++k) of[fill[ele_pairs_h[2 * (size_t)k + 1]]++] = ele_pairs_h[2 * (size_t)k];
       std::vector<int> rowof(of.size(), 0);
       for (int r = 0; r < ne; ++r) for (int k = ptr[r]; k < ptr[r + 1]; ++k) rowof[k] = r;
-      d_ele_csr_ptr.upload(ptr, stream); d_ele_csr_of.upload(of, stream); d_ele_csr_row.upload(rowof, stream);
+      ren_upload(d_ele_csr_ptr, ptr); ren_upload(d_ele_csr_of, of); ren_upload(d_ele_csr_row, rowof);
     }
     if (ele_pairs_h.empty()) { ele_pairs_h.push_back(0); ele_pairs_h.push_back(0); }
-    d_ele_pairs.upload(ele_pairs_h, stream);
+    ren_upload(d_ele_pairs, ele_pairs_h);
+    d_atom2eleall.reserve((size_t)std::max(nall, 1));
+    launch_atom2eleall(stream, nall, n_ele_atoms, d_ele_pairs.p, d_atom2eleall.p);
     d_x.reserve((size_t)nall * 3); d_q.reserve(nall);
   }
 
@@ -699,6 +736,32 @@ struct conp_fix {
       tm0 = t;
     };
     bool elyte_grew = false;
+    // The flattened half list goes to the device as it is: the post-force kernel walks it (one wavefront per owner), and the
+    // electrode rows of the real-space b are regrouped from it on the device (conp_rows.hip: count, scan, emit, stable sort).
+    // It is the bulk of what a re-neighbour sends (1.4 of 2.7 MB at the headline size, ~0.1 ms of PCIe time): its transfer is
+    // started FIRST and runs under the host's bookkeeping below.
+    {
+      size_t nneigh = 0;
+      int iown = 0;                       // list owners are owned atoms: the per-atom tables are needed up to the largest owner only
+      for (int ii = 0; ii < blist.inum; ++ii) {
+        const int i = blist.ilist[ii];
+        nneigh = std::max(nneigh, (size_t)blist.first[i] + (size_t)blist.numneigh[i]);
+        iown = std::max(iown, i + 1);
+      }
+      bl_inum = blist.inum;
+      bl_nneigh = nneigh;
+      // everything this re-neighbour uploads (bytes); an arena that turns out too small only means that the rest goes the
+      // blocking way
+      const size_t na = (size_t)at->nlocal + at->nghost;
+      ren_begin(sizeof(int) * (4 * na + 6 * (size_t)std::max(idx.elenum_all, 64) + (size_t)blist.inum + 2 * (size_t)iown + nneigh + 4096) + 64 * 32);
+      const bool locked = host_page_locked(blist.neigh) && host_page_locked(blist.ilist) && host_page_locked(blist.numneigh) &&
+                          host_page_locked(blist.first);
+      ren_upload(d_bl_neigh, blist.neigh, std::max<size_t>(nneigh, 1), locked);
+      ren_upload(d_bl_ilist, blist.ilist, (size_t)blist.inum, locked);
+      ren_upload(d_bl_numneigh, blist.numneigh, (size_t)std::max(iown, 1), locked);
+      ren_upload(d_bl_first, blist.first, (size_t)std::max(iown, 1), locked);
+    }
+    mark("list upload");
     const bool grew = idx.post_neighbor(at->nlocal, at->tag, at->echeck, &elyte_grew, &rc);
     const int ne = idx.elenum_all;
     if (grew) {
@@ -727,26 +790,8 @@ struct conp_fix {
     mark("atoms static");
     map_ghosts(at);
     mark("ghost map");
-    build_elyte_list(at);
+    build_elyte_list(at, true);
     mark("electrolyte list + schedule");
-    // the flattened half list goes to the device as it is: the post-force kernel walks it (one wavefront per owner), and the
-    // electrode rows of the real-space b are regrouped from it on the device (conp_rows.hip: count, scan, emit, stable sort)
-    {
-      size_t nneigh = 0;
-      int iown = 0;                       // list owners are owned atoms: the per-atom tables are needed up to the largest owner only
-      for (int ii = 0; ii < blist.inum; ++ii) {
-        const int i = blist.ilist[ii];
-        nneigh = std::max(nneigh, (size_t)blist.first[i] + (size_t)blist.numneigh[i]);
-        iown = std::max(iown, i + 1);
-      }
-      bl_inum = blist.inum;
-      bl_nneigh = nneigh;
-      d_bl_ilist.upload(blist.ilist, (size_t)blist.inum, stream);
-      d_bl_numneigh.upload(blist.numneigh, (size_t)std::max(iown, 1), stream);
-      d_bl_first.upload(blist.first, (size_t)std::max(iown, 1), stream);
-      d_bl_neigh.upload(blist.neigh, std::max<size_t>(nneigh, 1), stream);
-    }
-    mark("list upload");
     build_b_rows_device(at);
     mark("b rows (device)");
     nlocal_cur = at->nlocal;
@@ -760,7 +805,8 @@ struct conp_fix {
   // (which see atom->q) re-check the membership at every update -- elyte_list_stale() -- and rebuild the list when an atom's
   // charge has switched between zero and non-zero (fix atom/swap, charge-transfer fixes).  Device-resident hosts
   // (conp_fix_pre_force_device) announce such a change with conp_fix_post_neighbor.
-  void build_elyte_list(const conp_atoms *at) {
+  void build_elyte_list(const conp_atoms *at, bool inside_reneighbour = false) {
+    if (!inside_reneighbour) ren_off = 0;      // (the callers outside a re-neighbour have synchronised the stream: the arena is free)
     elyte_idx_h.clear();
     for (int i = 0; i < at->nlocal; ++i) if (at->echeck[i] == 0 && at->q[i] != 0) elyte_idx_h.push_back(i);
     nl_local = nl = (int)elyte_idx_h.size();
@@ -778,7 +824,7 @@ struct conp_fix {
     }
     // atoms are consumed in chunks of 32; the splits want an even share of chunks
     nl_pad = std::max(32, (nl + 31) / 32 * 32);
-    d_elyte_idx.upload(elyte_idx_h, stream);
+    ren_upload(d_elyte_idx, elyte_idx_h);
     build_items();
     d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
@@ -876,7 +922,18 @@ struct conp_fix {
   //  no effect at +-8 / 16 / 24 units, 244.1 - 244.5 us.  What is left is a +-2 % spread between XCDs.)
   double SK_C0 = exp_switch("CONP_SK_C0") ? atof(exp_switch("CONP_SK_C0")) : 1.37;
   double SK_CSEG = exp_switch("CONP_SK_CSEG") ? atof(exp_switch("CONP_SK_CSEG")) : 5.74;
+  // what the schedule was cut for: the same padded atom count, plan and output form give the same schedule -- a re-neighbour that
+  // changes none of them (the usual one) keeps the work list that is on the device
+  struct ItemsKey { int nl_pad = -1; long plan_gen = -1; bool proj = false; int nzc = -1; int nranks = 0; bool operator==(const ItemsKey &o) const {
+    return nl_pad == o.nl_pad && plan_gen == o.plan_gen && proj == o.proj && nzc == o.nzc && nranks == o.nranks; } };
+  ItemsKey items_key;
+  long plan_gen = 0;
   void build_items() {
+    {
+      const ItemsKey k{nl_pad, plan_gen, sk_projects(), nzc, env.nranks};
+      if (k == items_key && !items_h.empty()) return;
+      items_key = k;
+    }
     const int nchunks = nl_pad / 16;
     // this rank's chunk range of every tile (all of it on one rank; km_conp_setup); a tile may come out empty
     const size_t ntiles = tiles_h.size();

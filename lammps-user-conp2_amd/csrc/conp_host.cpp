@@ -355,14 +355,15 @@ bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool
   if (!ops) ops = &one;
   const int nprocs = ops->nranks();
   const int elytenum_old = elytenum, elenum_all_old = elenum_all;
-  int n = 0;
-  for (int i = 0; i < nlocal; ++i) if (echeck[i]) ++n;            // :480-484
-  elenum = n;
+  // (the reference walks the owned atoms three times, :480-484, :493-498, :528-533; here once -- the electrode atoms' local indices
+  //  in ascending order serve the other two walks)
+  ele_local.clear();
+  for (int i = 0; i < nlocal; ++i) if (echeck[i]) ele_local.push_back(i);
+  elenum = (int)ele_local.size();
   elytenum = nlocal - elenum;
   ele2tag.resize(elenum);
   ele2eleall.resize(elenum);
-  int j = 0;
-  for (int i = 0; i < nlocal; ++i) if (echeck[i]) ele2tag[j++] = tag[i];   // :493-498
+  for (int j = 0; j < elenum; ++j) ele2tag[j] = tag[ele_local[j]];
   elenum_list.assign(nprocs, 0); displs.assign(nprocs, 0);
   ops->allgather_int(elenum, elenum_list.data());                // MPI_Allgather :492
   elenum_all = 0;
@@ -379,13 +380,10 @@ bool EleIndex::post_neighbor(int nlocal, const int *tag, const int *echeck, bool
   }
   for (int i = 0; i < elenum_all; ++i) eleall2ele[i] = -1;       // :527
   eleall2ele[elenum_all] = -1;
-  j = 0;
-  for (int i = 0; i < nlocal; ++i)
-    if (echeck[i]) {
-      ele2eleall[j] = tag2eleall[tag[i]];
-      eleall2ele[ele2eleall[j]] = j;
-      ++j;
-    }
+  for (int j = 0; j < elenum; ++j) {
+    ele2eleall[j] = tag2eleall[tag[ele_local[j]]];
+    eleall2ele[ele2eleall[j]] = j;
+  }
   ops->allgatherv_int(ele2eleall.data(), elenum, elebuf2eleall.data(), elenum_list.data(), displs.data());   // :535
   if (elyte_grew) *elyte_grew = elytenum > elytenum_old;
   map_atoms(nlocal, tag);

@@ -124,6 +124,7 @@ struct EleIndex {
   std::vector<int> ele2tag, ele2eleall, tag2eleall, eleall2tag, eleall2ele, elecheck_eleall, elebuf2eleall;
   std::vector<int> elenum_list, displs;   // per rank: owned electrode atoms and their offsets in gathered buffers (:492-506)
   std::vector<int> tag2local;   // atom->map(tag) for owned atoms
+  std::vector<int> ele_local;   // local indices of the owned electrode atoms, ascending (scratch of post_neighbor)
   bool initialised = false;
 
   void linalg_init(int nlocal, const int *tag, RankOps *ops = nullptr);

@@ -169,6 +169,7 @@ void launch_cond_potdiff(hipStream_t s, int ne, const double *setzvec, const dou
                          int n_slab_part, double lz, double rightcharge, double vmult, double *out);
 void launch_conq_potdiff(hipStream_t s, const double *left, double rightcharge, double totsetq, int one_electrode, double *out);
 size_t b_rows_scratch_bytes(int ne, size_t nneigh);
+void launch_atom2eleall(hipStream_t s, int nall, int npairs, const int *pairs /*[npairs][2] = (atom, eleall)*/, int *atom2eleall /*[nall]*/);
 void launch_build_b_rows(hipStream_t s, int inum, size_t nneigh, const int *ilist, const int *numneigh, const int *first,
                          const int *neigh, const int *arow, int nlocal, int newton, int ne, void *scratch, size_t scratch_bytes,
                          int *row_ptr, int *ele, int *oth, unsigned *np_pinned /*page-locked host word: the number of pairs, valid

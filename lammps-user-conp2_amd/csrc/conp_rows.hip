@@ -177,4 +177,16 @@ void launch_build_b_rows(hipStream_t s, int inum, size_t nneigh, const int *ilis
   hipLaunchKernelGGL(rows_order_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, ne, row_ptr, key, val, ele, oth);
 }
 
+// atom2eleall[atom] = eleall row for the listed (atom, eleall) pairs, -1 everywhere else: built here from the pair list (a few
+// thousand entries) instead of uploaded ([nall] ints, 360 KB at the headline size, filled on the host at every re-neighbour)
+__global__ __launch_bounds__(256) void atom2eleall_kernel(int npairs, const int *__restrict__ pairs, int *__restrict__ atom2eleall) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < npairs) atom2eleall[pairs[2 * k]] = pairs[2 * k + 1];
+}
+void launch_atom2eleall(hipStream_t s, int nall, int npairs, const int *pairs, int *atom2eleall) {
+  if (nall <= 0) return;
+  (void)hipMemsetAsync(atom2eleall, 0xFF, (size_t)nall * sizeof(int), s);      // all bits set: -1
+  if (npairs > 0) hipLaunchKernelGGL(atom2eleall_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, npairs, pairs, atom2eleall);
+}
+
 }  // namespace conp
