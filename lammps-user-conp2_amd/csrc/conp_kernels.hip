@@ -1410,6 +1410,9 @@ __global__ __launch_bounds__(256) void b_hc_kernel(int C_pad, int n_col_tiles, c
 
 // sum of one Hc element over the segments slot_idx[s0 .. s1) that worked on its row tile (sk_project_out's pieces, `stride` doubles
 // apart), eight loads in flight, fixed association: bitwise reproducible
+// (Measured, round 4: sixteen in flight for b_zc_final_kernel on the decks -- 32 pieces per row tile, two round trips instead of
+//  four -- is SLOWER: 11.0 -> 11.4 us for hc + dot on il_onelayer, 13.4 -> 14.5 on il_twolayer; the kernel holds its first eight
+//  phases in flight meanwhile and 128 registers do not take both, 7 values spill.)
 __device__ __forceinline__ double hc_slot_sum(const double *__restrict__ h, const int *__restrict__ slot_idx, int s0, int s1, size_t stride) {
   double acc = 0.0;
   int s = s0;
