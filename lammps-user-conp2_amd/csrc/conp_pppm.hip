@@ -354,23 +354,109 @@ __device__ __forceinline__ void fft_axis_g(double2 *&in, double2 *&out, const do
   }
 }
 
+// one stencil weight (compute_rho1d, one k): the polynomial of rho1d_dev for that k alone
+__device__ __forceinline__ double rho1d_one(const double *__restrict__ coeff, int order, double dx, int k) {
+  double r = 0.0;
+  for (int l = order - 1; l >= 0; --l) r = coeff[l * order + k] + r * dx;
+  return r;
+}
+
+// real_in == 3 (round 4, deck-sized systems): the plane's workgroup spreads the charges ITSELF -- no density brick in memory, no
+// spreading launch, no clearing.  Every workgroup walks the charged electrolyte atoms (1280 on the decks: 2.5 per thread), keeps
+// those whose z stencil reaches its plane (~36) in a list, then all threads add the order^2 in-plane stencil points of the listed
+// atoms into the LDS plane (LDS atomics; the products are elyte_make_rho's, pppm_conp.cpp:216-225 -- the order in which a mesh
+// point's contributions arrive was unordered with the global atomics too).  slab_part[plane] = sum of q z over the plane's share
+// of the atom list (:301-314).  Blocks beyond the planes: the real-space pair sums, eight rows per block.
+struct PppmSpreadIn {
+  int nl;
+  const int *elyte_idx;
+  const double *x, *q;
+  double *slab_part;
+  double *breal_out;
+};
+
 // one workgroup per z-plane: x transforms of its ny lines, then y transforms of its nx lines.  real_in: im is not read.
 // real_in: 0 complex input; 1 real input in `re` (im not read); 2 real input in `im` (re not read) -- the b path spreads the charges
-// into `im`, which the previous update's last backward pass left all zero, so that no clearing launch is needed
+// into `im`, which the previous update's last backward pass left all zero, so that no clearing launch is needed; 3: see above
 __global__ __launch_bounds__(512) void pppm_fft_xy_kernel(int nx, int ny, double sign, FftPlan fpx, FftPlan fpy,
                                                           const double *__restrict__ twx, const double *__restrict__ twy,
                                                           double *__restrict__ re, double *__restrict__ im, int real_in,
-                                                          int out_flags /* 2: store the real part only, 4: ... and zeros into im */) {
+                                                          int out_flags /* 2: store the real part only, 4: ... and zeros into im */,
+                                                          PppmDev pd, PppmSpreadIn sp, BRowArgs ra) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (real_in == 3 && (int)blockIdx.x >= pd.nz) {
+    const int row = ((int)blockIdx.x - pd.nz) * 8 + (int)(threadIdx.x >> 6);
+    if (row < ra.ne) {
+      const double v = b_row_pairs(ra, row, threadIdx.x & 63);
+      if ((threadIdx.x & 63) == 0) sp.breal_out[row] = v;
+    }
+    return;
+  }
   const int np = nx * ny;
   double2 *b0 = reinterpret_cast<double2 *>(smem), *b1 = b0 + np;
   double *tx = reinterpret_cast<double *>(b1 + np), *ty = tx + 2 * nx;
   for (int t = threadIdx.x; t < 2 * nx; t += blockDim.x) tx[t] = twx[t];
   for (int t = threadIdx.x; t < 2 * ny; t += blockDim.x) ty[t] = twy[t];
   const size_t base = (size_t)blockIdx.x * np;
-  for (int e = threadIdx.x; e < np; e += blockDim.x)
-    b0[e] = real_in == 2 ? make_double2(im[base + e], 0.0) : make_double2(re[base + e], real_in ? 0.0 : im[base + e]);
-  __syncthreads();
+  if (real_in == 3) {
+    __shared__ double coeff[64];
+    __shared__ double red[8];
+    __shared__ int nhit_s;
+    const int p = blockIdx.x, o = pd.order, o2 = o * o;
+    int *hits = reinterpret_cast<int *>(b1);          // (b1 is the first stage's output: free until then)
+    const int cap = 4 * np;
+    if ((int)threadIdx.x < o2) coeff[threadIdx.x] = pd.rho_coeff[threadIdx.x];
+    if (threadIdx.x == 0) nhit_s = 0;
+    for (int e = threadIdx.x; e < np; e += blockDim.x) b0[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+    auto add_atom = [&](int i, int n, int m, int l) {      // stencil point (n, m, l) of atom i into the plane
+      const double qq = sp.q[i];
+      int g[3];
+      double d[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double xs = (sp.x[3 * i + c] - pd.boxlo[c]) * pd.delinv[c];
+        g[c] = static_cast<int>(xs + pd.shift) - 16384;
+        d[c] = g[c] + pd.shiftone - xs;
+      }
+      const int my = pwrap(m + pd.nlower + g[1], pd.ny), mx = pwrap(l + pd.nlower + g[0], pd.nx);
+      const double x0 = (pd.delvolinv * qq * rho1d_one(coeff, o, d[2], n)) * rho1d_one(coeff, o, d[1], m);
+      atomicAdd(&b0[my * nx + mx].x, x0 * rho1d_one(coeff, o, d[0], l));
+    };
+    // this plane's share of the slab sum: a contiguous run of the atom list
+    const int share = (sp.nl + pd.nz - 1) / pd.nz, lo = p * share, hi = lo + share < sp.nl ? lo + share : sp.nl;
+    double qz = 0.0;
+    for (int j = threadIdx.x; j < sp.nl; j += blockDim.x) {
+      const int i = sp.elyte_idx[j];
+      const double z = sp.x[3 * i + 2];
+      if (j >= lo && j < hi) qz += sp.q[i] * z;
+      const double zs = (z - pd.boxlo[2]) * pd.delinv[2];
+      const int gz = static_cast<int>(zs + pd.shift) - 16384;
+      const int n = pwrap(p - pd.nlower - gz, pd.nz);      // the stencil index of this plane for the atom, if it has one
+      if (n >= o) continue;
+      const int k = atomicAdd(&nhit_s, 1);
+      if (k < cap) hits[k] = j;
+      else for (int r2 = 0; r2 < o2; ++r2) add_atom(i, n, r2 / o, r2 % o);      // (list full: never at the sizes this mode is used for)
+    }
+    __syncthreads();
+    const int nh = nhit_s < cap ? nhit_s : cap;
+    for (int item = threadIdx.x; item < nh * o2; item += blockDim.x) {
+      const int a = item / o2, r2 = item - a * o2, m = r2 / o, l = r2 - m * o;
+      const int i = sp.elyte_idx[hits[a]];
+      const double zs = (sp.x[3 * i + 2] - pd.boxlo[2]) * pd.delinv[2];
+      const int gz = static_cast<int>(zs + pd.shift) - 16384;
+      add_atom(i, pwrap(p - pd.nlower - gz, pd.nz), m, l);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) qz += __shfl_down(qz, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = qz;
+    __syncthreads();
+    if (threadIdx.x == 0) sp.slab_part[p] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  } else {
+    for (int e = threadIdx.x; e < np; e += blockDim.x)
+      b0[e] = real_in == 2 ? make_double2(im[base + e], 0.0) : make_double2(re[base + e], real_in ? 0.0 : im[base + e]);
+    __syncthreads();
+  }
   double2 *in = b0, *out = b1;
   fft_axis_g(in, out, tx, fpx, nx, ny, 1, nx, true, sign);      // x: element (t = x, line = y) at [y * nx + x]
   fft_axis_g(in, out, ty, fpy, ny, nx, nx, 1, false, sign);     // y: element (t = y, line = x)
@@ -465,7 +551,7 @@ static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, doub
       static LdsGrant g{};
       grant_lds(pppm_fft_xy_kernel, lds, g);
       hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(512), lds, s, pd.nx, pd.ny, sign, fpx, fpy, pd.twid[0], pd.twid[1], re, im,
-                         sign < 0 ? (rho_in_im ? 2 : 1) : 0, 0);
+                         sign < 0 ? (rho_in_im ? 2 : 1) : 0, 0, pd, PppmSpreadIn{}, BRowArgs{});
       axis0 = 2;
     } else if (rho_in_im) {
       // (the caller only asks for this with a fused xy pass; keep the contract honest if a mesh ever does not qualify)
@@ -506,15 +592,24 @@ static void dft3(hipStream_t s, const PppmDev &pd, double sign, double *re, doub
 // rho -> u_brick in three launches when the mesh qualifies (2,3,5-smooth, a z-plane fits in LDS): x and y forward per plane (real
 // input from `re`, or from `im` when rho_in_im), z forward * greensfn / N * z backward per bundle of lines, x and y backward per
 // plane (real part only; zeros into `im` when zero_im).  Returns false (nothing launched) when the mesh does not qualify.
-static bool poisson_three_launches(hipStream_t s, const PppmDev &pd, double *re, double *im, bool rho_in_im, bool zero_im) {
+// sp != nullptr: no density brick at all -- the forward xy pass spreads the charges itself (real_in 3; pair rows in its spare blocks
+// when ra holds any)
+static bool poisson_three_launches(hipStream_t s, const PppmDev &pd, double *re, double *im, bool rho_in_im, bool zero_im,
+                                   const PppmSpreadIn *sp = nullptr, const BRowArgs *ra = nullptr) {
   FftPlan fpx, fpy, fpz;
   const size_t lds_xy = (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double);
   if (!(fft_factor(pd.nx, fpx) && fft_factor(pd.ny, fpy) && fft_factor(pd.nz, fpz) && lds_xy <= 128 * 1024)) return false;
   const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
   static LdsGrant gxy{}, gz{};
   grant_lds(pppm_fft_xy_kernel, lds_xy, gxy);
-  hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(512), lds_xy, s, pd.nx, pd.ny, -1.0, fpx, fpy, pd.twid[0], pd.twid[1], re, im,
-                     rho_in_im ? 2 : 1, 0);
+  if (sp) {
+    const BRowArgs rows = ra ? *ra : BRowArgs{};
+    const int nrb = ra ? (rows.ne + 7) / 8 : 0;
+    hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz + nrb), dim3(512), lds_xy, s, pd.nx, pd.ny, -1.0, fpx, fpy, pd.twid[0], pd.twid[1], re,
+                       im, 3, 0, pd, *sp, rows);
+  } else
+    hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(512), lds_xy, s, pd.nx, pd.ny, -1.0, fpx, fpy, pd.twid[0], pd.twid[1], re, im,
+                       rho_in_im ? 2 : 1, 0, pd, PppmSpreadIn{}, BRowArgs{});
   int xs = 0;
   while (xs < 4 && (size_t)pd.nz * 32 * (2u << xs) <= 64 * 1024) ++xs;
   const int XT = 1 << xs, nlines = pd.nx * pd.ny;
@@ -523,7 +618,7 @@ static bool poisson_three_launches(hipStream_t s, const PppmDev &pd, double *re,
   hipLaunchKernelGGL(pppm_fft_kernel, dim3((nlines + XT - 1) / XT), dim3(512), lds_z, s, pd.nx, pd.ny, pd.nz, 2, -1.0, fpz, pd.twid[2], re, im,
                      xs, 8, pd.greensfn, gscale);
   hipLaunchKernelGGL(pppm_fft_xy_kernel, dim3(pd.nz), dim3(512), lds_xy, s, pd.nx, pd.ny, +1.0, fpx, fpy, pd.twid[0], pd.twid[1], re, im, 0,
-                     zero_im ? 6 : 2);
+                     zero_im ? 6 : 2, pd, PppmSpreadIn{}, BRowArgs{});
   return true;
 }
 
@@ -536,8 +631,24 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
   // the density brick: `im` when the last backward pass left it all zero (*im_clean) -- one launch fewer per update
   const bool xy_fused = fused && fft_factor(pd.nx, fx) && fft_factor(pd.ny, fy) &&
                         (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double) <= 128 * 1024;
-  const bool use_im = xy_fused && im_clean != nullptr;
   const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
+  // deck-sized systems: the forward xy pass spreads the charges itself (CONP_PPPM_SPREAD_LAUNCH: comparison switch, the launch of its own)
+  const bool spread_launch = exp_switch("CONP_PPPM_SPREAD_LAUNCH") != nullptr;      // (read per call: the test flips it between two handles)
+  if (xy_fused && !spread_launch && nl <= 8192 && pd.nz <= 1024 && pd.order * pd.order <= 64) {
+    BRowArgs ra{};
+    const bool rows = pairs && breal_out;
+    if (rows) ra = *pairs;
+    const PppmSpreadIn sp{nl, elyte_idx, x, q, slab_part, breal_out};
+    if (poisson_three_launches(s, pd, re, im, false, false, &sp, rows ? &ra : nullptr)) {
+      *n_slab_part = pd.nz;
+      if (im_clean) *im_clean = false;           // (`im` holds the z pass's imaginary parts now)
+      BRowArgs fa{};
+      if (fin) { fin->n_slab_part = *n_slab_part; fa = *fin; }
+      hipLaunchKernelGGL(pppm_gather_kernel, dim3((ne + 3) / 4), dim3(256), 0, s, pd, ne, ne_pad, egrid, ew, re, bk, fin ? 1 : 0, fa);
+      return;
+    }
+  }
+  const bool use_im = xy_fused && im_clean != nullptr;
   double *rho = use_im ? im : re;
   if (!use_im || !*im_clean) hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, rho);
   if (!fused) hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, (size_t)pd.nfft, im);

@@ -43,6 +43,27 @@ def test_pppm_b_matches_oracle_and_ewald(oracle, deck, mode, mesh, order, acc):
     pp.close(); ks.close(); fx.close()
 
 
+def test_pppm_spread_inside_the_forward_pass_equals_the_spreading_launch(monkeypatch):
+    """deck-sized systems spread the charges in the forward xy pass's own workgroups (pppm_fft_xy_kernel, real_in 3); the density
+    brick + spreading launch stay for large systems and as CONP_PPPM_SPREAD_LAUNCH=1: same b up to the order in which a mesh point's
+    contributions arrive (unordered in both forms), slab geometry included (the slab sum is cut differently)"""
+    for mode, mesh in (("ffield", (40, 45, 180)), ("slab", (40, 45, 540))):
+        s = systems.deck("il_onelayer", mode, etypes=True)
+        at, alist, blist = neighbor.build_lists(s)
+        out = {}
+        for sep in (False, True):
+            if sep:
+                monkeypatch.setenv("CONP_PPPM_SPREAD_LAUNCH", "1")
+            fx = FixConp(s, extra_args=["pppm"], pppm_mesh=mesh, pppm_order=5)
+            fx.init_lists(alist, blist)
+            fx.setup_post_neighbor(at)
+            out[sep] = fx.km_b_cal(at).copy()
+            fx.close()
+            if sep:
+                monkeypatch.delenv("CONP_PPPM_SPREAD_LAUNCH")
+        assert rel_err(out[False], out[True]) < 1e-12
+
+
 def test_pppm_full_update_close_to_ewald():
     """whole charge update with the pppm keyword (A matrix from the Ewald provider as in pppm_conp.cpp:91-101)"""
     s = systems.deck("dilute", "ffield", etypes=True)
