@@ -1838,10 +1838,12 @@ struct conp_fix {
                                  nullptr, 0, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
       ride = !no_fuse && !(timed && time_split) && !no_ride;
       // small systems on one rank: no phase launch at all -- every sk_gemm segment computes the phase tables of its own atoms in
-      // front of its chunk loop, the pair sums ride in spare workgroups of that launch (SkFuse; CONP_NO_PHASE_FUSE: comparison switch)
+      // front of its chunk loop, the pair sums ride in spare workgroups of that launch (SkFuse; CONP_NO_PHASE_FUSE: comparison switch).
+      // A workgroup of this launch owns its CU (registers): the pair workgroups run on the CUs sk_gemm leaves free, in at most two
+      // rounds of ~5 us -- shorter than the ~13 us the sk_gemm workgroups take
       const int nwg_sk = (int)seg_ptr_h.size() - 1;
       const bool fuse_phase = ride && env.nranks == 1 && !nccl && !decomposed && nl_pad <= 4096 && max_seg_chunks <= 4 && n_slab_slots > 0 &&
-                              nwg_sk + (ne + 7) / 8 <= num_cus && !no_phase_fuse;
+                              nwg_sk < num_cus && (ne + 7) / 8 <= 2 * (num_cus - nwg_sk) && !no_phase_fuse;
       SkFuse fz;
       std::memset(&fz, 0, sizeof fz);           // (padding bytes too: the block is compared bytewise below)
       if (fuse_phase) {
