@@ -235,7 +235,11 @@ def main():
     s = make_workload(args.workload)
     at, alist, blist = neighbor.build_lists(s)
     fx = FixConp(s, device=dev_index, rank=rank, nranks=world, extra_args=(["pppm"] if args.pppm else []) + (["cg"] if args.solver == "cg" else []),
-                 pppm_mesh=tuple(args.pppm) if args.pppm else None)
+                 pppm_mesh=tuple(args.pppm) if args.pppm else None,
+                 # one rank: every ghost is a periodic image of an owned atom -- the host-buffer hooks upload the owned x, q only and
+                 # rebuild the ghosts on the device (conp_env.ghost_images, what FixConpHip sets); no effect on the device-resident
+                 # hooks `value` is measured on
+                 ghost_images=(world == 1))
     # multi-rank: the library makes its own RCCL communicator (rank 0's unique id travels through torch.distributed) and runs
     # the collectives on its own stream, in order with its kernels.  The rehearsal on a one-GPU box cannot (RCCL refuses two
     # ranks on one device): it keeps the Python choreography over gloo.
@@ -424,6 +428,7 @@ def main():
                    collectives=collectives,
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
                    ms_per_step_host_buffers_pcie=host_ms, ms_per_step_host_buffers_pcie_pageable=host_ms_pageable,
+                   host_buffers_ghost_images=bool(world == 1),
                    setup_s=dict(total=t_a1 - t_setup0, a_build_inverse_setq=t_a1 - t_a0),
                    kernels_ms={k: round(v[0], 5) for k, v in prof.items()},
                    ms_per_step_profiled_pass=dt_prof / n_prof * 1e3,

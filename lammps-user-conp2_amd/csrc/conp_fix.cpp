@@ -2215,10 +2215,12 @@ struct conp_fix {
     if (at->nlocal + at->nghost != nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
     if (!tables_current) km_a_read(at);      // electrode phase tables (kspmod->a_read) not built yet: b_cal before a_cal
     double t0 = time_host ? now_s() : 0.0;
-    if (elyte_list_stale(at)) { sync(); build_elyte_list(at); }       // km_ewald.cpp:686 is evaluated every step
-    if (time_host) { const double t1 = now_s(); th[0] += t1 - t0; t0 = t1; }
+    // the transfer of x, q is started first: the membership walk over the owned atoms below (30 us at the headline size) then runs
+    // while the DMA does -- neither depends on the other
     upload_xq(at);
     if (time_host) { const double t1 = now_s(); th[1] += t1 - t0; t0 = t1; }
+    if (elyte_list_stale(at)) { sync(); build_elyte_list(at); }       // km_ewald.cpp:686 is evaluated every step
+    if (time_host) { const double t1 = now_s(); th[0] += t1 - t0; t0 = t1; }
     if (decomposed) gather_elyte(at);
     b_cal_device(d_x.p, d_q.p, true, true);
     if (time_host) { const double t1 = now_s(); th[2] += t1 - t0; t0 = t1; }
