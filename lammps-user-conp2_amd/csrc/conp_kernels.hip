@@ -1326,6 +1326,9 @@ __global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, 
       }
       __syncthreads();
       // units of this part: u_all = part, part + 4, ... over the 8 (te - tb) (tile, row fragment) pairs; dealt to the 16 waves
+      // (18 units for 16 waves at the headline plan: two rounds, the second for two waves.  Measured, round 4: units cut into two
+      //  or four runs of k-steps so that the rounds are shorter -- halves 46.0-47.3 against 47.4-47.6 us, within the spread of one
+      //  box; quarters 52.2 us: every item pays the epilogue's sixteen Rp loads.  The balance is not what this kernel waits for.)
       const int nu = 8 * (te - tb);
       for (int u = part + 4 * wave; u < nu; u += 64) {
         const SkTile tl = tiles[tb + (u >> 3)];
