@@ -1328,7 +1328,9 @@ __global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, 
       // units of this part: u_all = part, part + 4, ... over the 8 (te - tb) (tile, row fragment) pairs; dealt to the 16 waves
       // (18 units for 16 waves at the headline plan: two rounds, the second for two waves.  Measured, round 4: units cut into two
       //  or four runs of k-steps so that the rounds are shorter -- halves 46.0-47.3 against 47.4-47.6 us, within the spread of one
-      //  box; quarters 52.2 us: every item pays the epilogue's sixteen Rp loads.  The balance is not what this kernel waits for.)
+      //  box; quarters 52.2 us: every item pays the epilogue's sixteen Rp loads.  Also measured: a host-made schedule that gives
+      //  every SIMD of every part about the same number of k-steps (longest unit first; a table of unit indices per wave) --
+      //  50.8-53.0 against 47.6-50.1 us.  The balance is not what this kernel waits for.)
       const int nu = 8 * (te - tb);
       for (int u = part + 4 * wave; u < nu; u += 64) {
         const SkTile tl = tiles[tb + (u >> 3)];
