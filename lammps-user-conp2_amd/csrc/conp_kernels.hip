@@ -1342,12 +1342,28 @@ __global__ __launch_bounds__(1024) void b_project_kernel(int C_pad, int ne_pad, 
         for (int c = 0; c < 4; ++c) acc[c] = (d4){0.0, 0.0, 0.0, 0.0};
         const double *ap = Gwf + ((size_t)rf * (C_pad / 4) + (size_t)ct * 80) * 64 + lane;
         const double *bp = tz + fk * 16 + fr;
-#pragma unroll 4
-        for (int ts = ks0; ts < ks1; ++ts) {
-          const double a = ap[(size_t)ts * 64];
-          const double *bq = bp + 64 * (ts - ks0);
+        // the A operands (one double per lane and k-step, straight from L2) are requested a group of eight k-steps ahead of the
+        // MFMAs that use them: the counters say the waves of this kernel wait for instructions' operands 44 % of their cycles with
+        // the matrix pipe 60 % busy, and the LDS is not what they wait for (SQ_WAIT_INST_LDS 0.2 %)
+        // (k-step counts are multiples of eight: 8 nba, phases of 40)
+        double an[8];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = MFMA_F64(a, bq[c * 160 * 16], acc[c]);
+        for (int i = 0; i < 8; ++i) an[i] = ap[(size_t)(ks0 + i) * 64];
+#pragma unroll 1
+        for (int tg = ks0; tg < ks1; tg += 8) {
+          double ac[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ac[i] = an[i];
+          if (tg + 8 < ks1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) an[i] = ap[(size_t)(tg + 8 + i) * 64];
+          }
+          const double *bq = bp + 64 * (tg - ks0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F64(ac[i], bq[64 * i + c * 160 * 16], acc[c]);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
