@@ -2812,7 +2812,9 @@ __device__ __forceinline__ double cg_row_dot(int n, const double *__restrict__ s
   //  instead of three -- made the iteration SLOWER, 84.5 vs 79.9 us per solve on il_twolayer: the matrix comes out of L2, the loads
   //  of a later batch overlap the products of an earlier one, and one 26-deep batch serialises them.  Also measured, no effect:
   //  the row's first sixteen elements requested at the top of cg_step_kernel, ahead of the vector update it repeats -- 79.4 vs
-  //  79.4-80.8 us: the launch is not waiting for the matrix.)
+  //  79.4-80.8 us: the launch is not waiting for the matrix.  A third: the update's vectors and the two scalars of the iteration
+  //  requested together with the convergence flag at the head of cg_step_kernel instead of behind it -- 78.7-79.4 against
+  //  77.2-77.5 us: not the head's dependent loads either.)
   for (; j + 960 < n; j += 1024) {           // sixteen steps' loads in flight: a deck-sized row (Ne = 1664) is two round trips
     double a[16], x[16];
 #pragma unroll
