@@ -405,6 +405,17 @@ __global__ __launch_bounds__(512) void pppm_fft_xy_kernel(int nx, int ny, double
     const int p = blockIdx.x, o = pd.order, o2 = o * o;
     int *hits = reinterpret_cast<int *>(b1);          // (b1 is the first stage's output: free until then)
     const int cap = 4 * np;
+    // this thread's atoms (up to 16: nl <= 8192) and their z are requested BEFORE the plane is cleared and the barrier behind it:
+    // two dependent trips to memory that used to start behind that barrier
+    int ai[16];
+    double az[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = (int)threadIdx.x + 512 * u;
+      ai[u] = j < sp.nl ? sp.elyte_idx[j] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) az[u] = ai[u] >= 0 ? sp.x[3 * ai[u] + 2] : 0.0;
     if ((int)threadIdx.x < o2) coeff[threadIdx.x] = pd.rho_coeff[threadIdx.x];
     if (threadIdx.x == 0) nhit_s = 0;
     for (int e = threadIdx.x; e < np; e += blockDim.x) b0[e] = make_double2(0.0, 0.0);
@@ -426,9 +437,11 @@ __global__ __launch_bounds__(512) void pppm_fft_xy_kernel(int nx, int ny, double
     // this plane's share of the slab sum: a contiguous run of the atom list
     const int share = (sp.nl + pd.nz - 1) / pd.nz, lo = p * share, hi = lo + share < sp.nl ? lo + share : sp.nl;
     double qz = 0.0;
-    for (int j = threadIdx.x; j < sp.nl; j += blockDim.x) {
-      const int i = sp.elyte_idx[j];
-      const double z = sp.x[3 * i + 2];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = (int)threadIdx.x + 512 * u, i = ai[u];
+      if (i < 0) continue;
+      const double z = az[u];
       if (j >= lo && j < hi) qz += sp.q[i] * z;
       const double zs = (z - pd.boxlo[2]) * pd.delinv[2];
       const int gz = static_cast<int>(zs + pd.shift) - 16384;
