@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256) void pppm_dft_kernel(int nx, int ny, int nz, i
   }
 }
 
+// (Measured, round 4: the lines dealt to the wavefronts -- a line per wavefront in the z pass, a run of lines per wavefront in the
+//  plane passes -- so that a line's stages need no workgroup barrier between them, one barrier per axis instead of one per stage:
+//  SLOWER on il_onelayer 40 x 45 x 180, 52.8 -> 55.3 us per update (z pass +2 us, plane passes +0.6): a stage spread over all 512
+//  threads is one butterfly deep, a wavefront alone walks its line's butterflies with 45 of 64 lanes and nothing to overlap.)
 // Mixed-radix Stockham FFT along `axis` (autosort, radices 2/3/4/5 -- LAMMPS meshes are 2,3,5-smooth), XT adjacent lines per
 // workgroup, ping-pong in LDS.  Stage with radix R and sub-transform length Ns: butterfly j (0 <= j < n/R), k = j mod Ns:
 //   v[r] = in[j + r n/R] * W_n^{r k n/(Ns R)} ;  out[(j - k) R + k + q Ns] = sum_r v[r] W_R^{q r}
