@@ -659,7 +659,14 @@ struct conp_fix {
     d.reserve(count);
     if (!count) return;
     const size_t bytes = count * sizeof(T), o = (ren_off + 63) & ~(size_t)63;
-    if (locked || o + bytes > ren_cap) { HIP_TRY(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream)); return; }
+    if (locked) { HIP_TRY(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream)); return; }
+    if (o + bytes > ren_cap) {
+      // the arena is full (first use, or a list that grew): straight out of the caller's pageable memory, and waited for -- the
+      // source may be a temporary of the caller
+      HIP_TRY(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream));
+      sync();
+      return;
+    }
     std::memcpy(ren_arena + o, h, bytes);
     ren_off = o + bytes;
     HIP_TRY(hipMemcpyAsync(d.p, ren_arena + o, bytes, hipMemcpyHostToDevice, stream));
