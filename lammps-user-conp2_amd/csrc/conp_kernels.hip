@@ -528,7 +528,7 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
 // the same for the EARLY waves (multiply first): 1 = raised through their multiply phase only, 2 = through multiply and build.
 // Measured on one box (tools/ab_libs.sh, sk_gemm us, headline / slab geometry): late waves raised (SK_PRIO 1 / 2) 243.5 / 243.6 vs
 // 237.9 and 709 / 709 vs 680 -- worse; early waves raised through the multiply phase (SK_PRIO_E 1) 238.2 vs 237.6 and 675.7 vs 678.4;
-// through multiply and build (2) 236.5 and 673.4: the product's setting.
+// through multiply and build (2) 236.5 and 673.4: the product's setting (3, the highest priority, reads the same: 235.5 / 674 either way).
 #ifndef SK_PRIO_E
 #define SK_PRIO_E 2
 #endif
