@@ -1817,8 +1817,8 @@ struct conp_fix {
     const int slab = (kt.slabflag && env.rank == 0) ? 1 : 0;
     // real-space rows: with replicated atoms this rank's row range; a sub-domain's list holds its own electrode atoms' rows only
     const int rr0 = !coulyes ? 0 : (decomposed ? 0 : row0), rr1 = !coulyes ? 0 : (decomposed ? ne : row1);
-    bool ride = false, use_fin = false;
-    BRowArgs fin{};
+    bool ride = false, use_fin = false, ride_hc = false;
+    BRowArgs fin{}, pairs_keep{};
     if (args.pppm) {
       // `pppm` keyword: the k-space b comes from the mesh (pppm_conp.cpp:269-316); the mesh is not sharded -- rank 0 owns it
       prof.begin("pppm_b", stream);
@@ -1866,11 +1866,21 @@ struct conp_fix {
           d_skfuse.upload(&skfuse_h, 1, stream);
         }
       } else {
+        // When the pieces are added by a launch of their own (hc_sum: many pieces per row tile, the headline and slab plans) the
+        // pair sums ride THERE, not in the phase launch: that launch sits at the ~5 us floor of any small kernel with a handful of
+        // workgroups, the pair rows fill the rest of the chip beside it (17.7 -> 19.2 us for hc_sum + dot), while in the phase
+        // kernel they compete with 37 MB of table writes (15.1 -> 10.7 us without them): 0.2791 / 0.2796 -> 0.2763 / 0.2757 ms per
+        // update at the headline size, 0.7261 / 0.7268 -> 0.7228 / 0.7244 in the slab geometry (one box, tools/ab_env.sh).
+        // CONP_RIDE_PHASE: comparison switch, the phase launch as before.
+        ride_hc = ride && exp_switch("CONP_RIDE_PHASE") == nullptr && sk_projects() && n_frags > 0 && nzc > 0 &&
+                  zc_final_fits((int)own_rt_h.size(), nzc) &&
+                  (!bands_aligned || (hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size()));
         prof.begin("elyte_phase", stream);
         launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                            plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
-                           &n_slab_part, ride ? &pairs : nullptr, d_breal.p, 16 * table_c0, 16 * table_c1);
+                           &n_slab_part, ride && !ride_hc ? &pairs : nullptr, d_breal.p, 16 * table_c0, 16 * table_c1);
         prof.end(stream);
+        pairs_keep = pairs;
       }
       // with the pair sums in hand and a small z-class table the dot kernel can finish b itself: no b_real_combine launch
       fin = make_brow(ne, ne_pad, rr0, rr1, d_b_rowptr.p, d_b_ele.p, d_b_oth.p, dx, dq, d_type.p, real_params(), 1, d_bk.p, slab,
@@ -1891,7 +1901,7 @@ struct conp_fix {
         prof.begin("reduce_project", stream);
         launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Hpart.p, d_hslot_ptr.p, d_hslot_idx.p,
                                      presum, d_frag_ptr.p, d_frag_ents.p, n_frags, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p,
-                                     use_fin ? &fin : nullptr);
+                                     use_fin ? &fin : nullptr, ride_hc ? &pairs_keep : nullptr, d_breal.p);
         prof.end(stream);
       } else if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
         // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)

@@ -127,7 +127,9 @@ void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, 
                                   const int *slot_ptr, const int *slot_idx, bool presum /*hc_sum first: many pieces, or bands that are
                                   not row tiles of the plan*/, const int *frag_ptr /*[nfrag + 1]*/, const int2 *frag_ents /*per row fragment of the plan: its pieces
                                   (offset of the fragment's first 'a' row, the band's rf)*/, int nfrag, const double *Rp, const double2 *Xe,
-                                  const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin);
+                                  const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin,
+                                  const BRowArgs *pairs = nullptr /*with breal_out: the pair sums ride in hc_sum's launch*/,
+                                  double *breal_out = nullptr);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);
 void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,

@@ -1465,8 +1465,19 @@ __device__ __forceinline__ double hc_slot_sum(const double *__restrict__ h, cons
 // and every segment of that band left a band-local piece [class][32 rf rows]: the host lists them per fragment (frag_ptr / ents: the
 // offset of the fragment's first 'a' row in the piece, and the band's rf), column tile after column tile, segment after segment.
 constexpr int HCS_MAXG = 16;                 // groups of eight pieces a thread keeps in flight per pass
+// Block rows beyond the plan's fragments (blockIdx.y >= nfrag; round 4): the real-space pair sums of the electrode rows,
+// four rows per block -- they depend on x, q only and may ride in any launch ahead of the dot kernel.
 __global__ __launch_bounds__(256) void hc_sum_kernel(const int *__restrict__ frag_ptr, const int2 *__restrict__ ents, int R_pad, int nzc,
-                                                     const double *__restrict__ Hp, double *__restrict__ Hc4) {
+                                                     const double *__restrict__ Hp, double *__restrict__ Hc4, int nfrag, BRowArgs ra,
+                                                     double *__restrict__ breal_out) {
+  if ((int)blockIdx.y >= nfrag) {
+    const int row = (((int)blockIdx.y - nfrag) * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6);
+    if (row < ra.ne) {
+      const double v = b_row_pairs(ra, row, threadIdx.x & 63);
+      if ((threadIdx.x & 63) == 0) breal_out[row] = v;
+    }
+    return;
+  }
   const int g = blockIdx.y;
   const int s0 = frag_ptr[g], s1 = frag_ptr[g + 1];
   const int u = threadIdx.x & 7;
@@ -1783,10 +1794,16 @@ void launch_b_project_zclass(hipStream_t s, const DevPlan &pl, int ne_pad, const
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
                                   const int *slot_ptr, const int *slot_idx, bool presum, const int *frag_ptr, const int2 *frag_ents, int nfrag,
                                   const double *Rp, const double2 *Xe,
-                                  const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin) {
+                                  const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin,
+                                  const BRowArgs *pairs, double *breal_out) {
   if (n_own <= 0) return;
   if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
-  if (nfrag > 0) hipLaunchKernelGGL(hc_sum_kernel, dim3(nzc, nfrag), dim3(256), 0, s, frag_ptr, frag_ents, pl.R_pad, nzc, Hp, Hc);
+  if (nfrag > 0) {
+    // pairs: the real-space pair sums ride in this launch (block rows behind the fragments)
+    const BRowArgs ra = pairs ? *pairs : BRowArgs{};
+    const int extra = pairs ? ((ra.ne + 3) / 4 + nzc - 1) / nzc : 0;
+    hipLaunchKernelGGL(hc_sum_kernel, dim3(nzc, nfrag + extra), dim3(256), 0, s, frag_ptr, frag_ents, pl.R_pad, nzc, Hp, Hc, nfrag, ra, breal_out);
+  }
   if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 1);
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 1);
 }
