@@ -326,6 +326,25 @@ void conp_host_free(void *p);
  * outside its buffers so far), -1 when guard zones are off; conp_last_error() names the damaged buffers. */
 int conp_debug_check_guards(void);
 
+/* Test hooks (no reference counterpart): alternative code paths of the SAME computation, results inside the parity tolerances of
+ * DESIGN.md section 2 -- what tests/ compares the default paths with (A/B inside one process).  Process-wide bit mask, read when a
+ * handle is created (CONP_PATH_ROWS_HOST, CONP_PATH_PPPM_SPREAD_LAUNCH: at every call).  The first handle created with a
+ * non-zero mask says so on stderr.  conp_debug_set_sk_workgroups: workgroup count of the structure-factor launch (0 = the
+ * library's choice), for the tests that cover heavily split tiles on a small deck.  Not meant for production runs. */
+enum {
+  CONP_PATH_PARTIAL_TILES = 1 << 0,      /* planar electrodes: partial tiles + reducing launch instead of the projecting epilogue */
+  CONP_PATH_A_GENERAL = 1 << 1,          /* A k-space part: the general (planar, kz) contraction instead of the z-class one */
+  CONP_PATH_INV_PIVOTED = 1 << 2,        /* inverse: pivoted elimination instead of the positive-definite path */
+  CONP_PATH_CG_TWO_LAUNCH = 1 << 3,      /* CG: matvec + update launches per iteration instead of one */
+  CONP_PATH_GEMV_ROWS = 1 << 4,          /* solve: row-by-row product also from 2048 electrode atoms up (no packed symmetric tiles) */
+  CONP_PATH_PHASE_LAUNCH = 1 << 5,       /* small systems: stand-alone phase-table launch instead of the prologue inside sk_gemm */
+  CONP_PATH_PPPM_SPREAD_LAUNCH = 1 << 6, /* pppm: density brick + spreading launch also for deck-sized systems */
+  CONP_PATH_ROWS_HOST = 1 << 7,          /* re-neighbour: electrode rows regrouped on the host */
+  CONP_PATH_TIME_SPLIT = 1 << 8          /* host-buffer hooks: k-space and real-space halves of b_cal in launches of their own (timing log) */
+};
+void conp_debug_set_paths(unsigned mask);
+void conp_debug_set_sk_workgroups(int n);
+
 
 /* ---- the fix's log file (fix_conp.cpp:119 `outf`) ----
  * The library buffers the lines the reference prints there -- "A matrix calculating ..." / "A matrix calculation time  = %g"

@@ -92,12 +92,39 @@ SYMBOLS = [
     "conp_fix_set_stream",
     "conp_fix_bind_device_buffers", "conp_fix_row_range", "conp_fix_b_cal_device", "conp_fix_solve_device",
     "conp_fix_scatter_device", "conp_fix_pre_force_device", "conp_fix_profile", "conp_fix_profile_read", "conp_debug_check_guards",
+    "conp_debug_set_paths", "conp_debug_set_sk_workgroups",
     "conp_fix_pin_host_arrays", "conp_fix_unpin_host_arrays", "conp_host_alloc", "conp_host_free",
     "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
     "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl", "conp_rccl_available", "conp_fix_comm_destroy_rccl",
     "conp_pppm_make_rho", "conp_pppm_compute_group_potential", "conp_pppm_compute_particle_potential",
     "conp_compute_potential_atom",
 ]
+
+
+# test hooks of the ABI (include/conp_hip.h, CONP_PATH_*): alternative code paths the parity tests compare the default ones with
+PATH_PARTIAL_TILES, PATH_A_GENERAL, PATH_INV_PIVOTED, PATH_CG_TWO_LAUNCH, PATH_GEMV_ROWS = 1, 2, 4, 8, 16
+PATH_PHASE_LAUNCH, PATH_PPPM_SPREAD_LAUNCH, PATH_ROWS_HOST, PATH_TIME_SPLIT = 32, 64, 128, 256
+
+
+class test_paths:
+    """with capi.test_paths(capi.PATH_PARTIAL_TILES): ...   -- process-wide; handles created inside take the alternative path"""
+
+    def __init__(self, mask=0, sk_workgroups=0):
+        self.mask, self.nwg = mask, sk_workgroups
+
+    def __enter__(self):
+        lib = load_library()
+        if not hasattr(lib, "conp_debug_set_paths"):
+            raise RuntimeError("this library build has no test hooks (a comparison build of an earlier round?)")
+        lib.conp_debug_set_paths(self.mask)
+        lib.conp_debug_set_sk_workgroups(self.nwg)
+        return self
+
+    def __exit__(self, *a):
+        lib = load_library()
+        lib.conp_debug_set_paths(0)
+        lib.conp_debug_set_sk_workgroups(0)
+        return False
 
 
 def load_library():
@@ -122,6 +149,11 @@ def load_library():
         lib.conp_host_alloc.restype = C.c_void_p
         lib.conp_host_free.argtypes = [C.c_void_p]
         lib.conp_host_free.restype = None
+    if hasattr(lib, "conp_debug_set_paths"):
+        lib.conp_debug_set_paths.argtypes = [C.c_uint]
+        lib.conp_debug_set_paths.restype = None
+        lib.conp_debug_set_sk_workgroups.argtypes = [C.c_int]
+        lib.conp_debug_set_sk_workgroups.restype = None
     lib.conp_fix_init_list.argtypes = [vp, C.c_int, C.POINTER(conp_neighlist)]
     for n in ("conp_fix_setup_post_neighbor", "conp_fix_post_neighbor", "conp_fix_linalg_setup", "conp_fix_a_cal",
               "conp_fix_b_cal"):

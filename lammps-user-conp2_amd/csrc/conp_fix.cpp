@@ -331,16 +331,17 @@ struct conp_fix {
   double *d_b = nullptr, *d_eleallq = nullptr;   // bound (external) or own buffers
   bool b_bound = false, q_bound = false;         // conp_fix_bind_device_buffers gave us the host's vectors
   int n_slab_part = 0;
-  const bool no_fuse = exp_switch("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
-  const bool shard_by_cost = exp_switch("CONP_SHARD_COST_AXIS") != nullptr;   // comparison switch: rank shards = shares of the cost axis (round 2)
-  const bool sk_partials = exp_switch("CONP_SK_PARTIALS") != nullptr;   // comparison switch: partial tiles + reducing launch, no projection in sk_gemm
-  const char *hc_presum_env = exp_switch("CONP_HC_PRESUM");      // comparison switch: 1 / 0 = always / never add the pieces in a launch of their own
+  const bool no_fuse = diag_switch("CONP_NO_FUSE") != nullptr;   // experiment switch: separate sk_reduce / b_hc launches
+  const bool shard_by_cost = diag_switch("CONP_SHARD_COST_AXIS") != nullptr;   // comparison switch: rank shards = shares of the cost axis (round 2)
+  const bool sk_partials = path_on(CONP_PATH_PARTIAL_TILES);   // comparison switch: partial tiles + reducing launch, no projection in sk_gemm
+  const char *hc_presum_env = diag_switch("CONP_HC_PRESUM");      // comparison switch: 1 / 0 = always / never add the pieces in a launch of their own
   // The host-buffer hooks report Ktime / Ctime (fix_conp.cpp:553-568).  By default they run the SAME kernels as the device hooks
   // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
   // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
-  const bool time_split = exp_switch("CONP_TIME_SPLIT") != nullptr;
-  const bool no_phase_fuse = exp_switch("CONP_NO_PHASE_FUSE") != nullptr;      // comparison switch: always the stand-alone phase launch
-  const bool no_ride = exp_switch("CONP_NO_RIDE") != nullptr;      // comparison switch: the real-space pair sums in a launch of their own (b_real_combine)
+  const bool time_split = path_on(CONP_PATH_TIME_SPLIT);
+  const bool gemv_rows = path_on(CONP_PATH_GEMV_ROWS);      // test path: the row-by-row product at every size
+  const bool no_phase_fuse = path_on(CONP_PATH_PHASE_LAUNCH);      // comparison switch: always the stand-alone phase launch
+  const bool no_ride = diag_switch("CONP_NO_RIDE") != nullptr;      // comparison switch: the real-space pair sums in a launch of their own (b_real_combine)
   int table_c0 = 0, table_c1 = 0;  // chunk range (16 atoms each) whose phase tables this rank's sk_gemm reads
   int hslots = 0;                  // entries of the owned row tiles' segment lists (d_hslot_idx)
   bool g_current = true;           // d_G holds the last update's structure factors (false after a projecting update: conp_fix_get_sfac re-forms it)
@@ -378,8 +379,8 @@ struct conp_fix {
   // The wait at the end of a host-buffer update: the runtime's blocking synchronisation wakes the thread tens of microseconds after
   // the stream drained; polling the stream for the first two milliseconds (an update takes 0.03 - 20 ms) returns within a few.
   // Longer waits (setup, large systems) fall back to the blocking call: no core is burnt for them.
-  const bool sync_block = exp_switch("CONP_SYNC_BLOCK") != nullptr;      // comparison switch: always the blocking call
-  const bool results_by_copy = exp_switch("CONP_RESULTS_COPY") != nullptr;      // comparison switch: charges / scalars back by hipMemcpyAsync
+  const bool sync_block = diag_switch("CONP_SYNC_BLOCK") != nullptr;      // comparison switch: always the blocking call
+  const bool results_by_copy = diag_switch("CONP_RESULTS_COPY") != nullptr;      // comparison switch: charges / scalars back by hipMemcpyAsync
   void sync() {
     if (!sync_block) {
       const double t0 = now_s();
@@ -711,7 +712,7 @@ struct conp_fix {
   bool np_pending = false;
   void build_b_rows_device(const conp_atoms *at) {
     const int ne = idx.elenum_all;
-    const bool on_host = exp_switch("CONP_ROWS_HOST") != nullptr;      // read per call: the A/B test flips it between two handles
+    const bool on_host = path_on(CONP_PATH_ROWS_HOST);      // read per call: the A/B test flips it between two handles
     np_pending = false;
     if (on_host) {
       build_b_rows(blist, at->nlocal, at->tag, at->echeck, idx, env.newton_pair != 0, brows);
@@ -927,8 +928,8 @@ struct conp_fix {
   // per-segment term) left the heavy tiles' workgroups and those whose share straddles a tile boundary 3 % behind the rest.
   // (Tried on top: a linear ramp of the shares so that early finishers' partial-tile stores overlap the others' last chunks --
   //  no effect at +-8 / 16 / 24 units, 244.1 - 244.5 us.  What is left is a +-2 % spread between XCDs.)
-  double SK_C0 = exp_switch("CONP_SK_C0") ? atof(exp_switch("CONP_SK_C0")) : 1.37;
-  double SK_CSEG = exp_switch("CONP_SK_CSEG") ? atof(exp_switch("CONP_SK_CSEG")) : 5.74;
+  double SK_C0 = diag_switch("CONP_SK_C0") ? atof(diag_switch("CONP_SK_C0")) : 1.37;
+  double SK_CSEG = diag_switch("CONP_SK_CSEG") ? atof(diag_switch("CONP_SK_CSEG")) : 5.74;
   // what the schedule was cut for: the same padded atom count, plan and output form give the same schedule -- a re-neighbour that
   // changes none of them (the usual one) keeps the work list that is on the device
   struct ItemsKey { int nl_pad = -1; long plan_gen = -1; bool proj = false; int nzc = -1; int nranks = 0; bool operator==(const ItemsKey &o) const {
@@ -965,7 +966,7 @@ struct conp_fix {
     {
       std::map<std::pair<int, int>, size_t> tile_at;
       for (size_t i = 0; i < ntiles; ++i) tile_at[{tiles_h[i].rt, tiles_h[i].ct}] = i;
-      const bool five = sk_projects() && uniform && ntiles > 0 && exp_switch("CONP_SK_BANDS4") == nullptr;
+      const bool five = sk_projects() && uniform && ntiles > 0 && diag_switch("CONP_SK_BANDS4") == nullptr;
       for (int ct = 0; ct < plan.n_col_tiles; ++ct) {
         const int nfr = 4 * plan.n_row_tiles;
         std::vector<int> nfa(nfr + 8, 0);
@@ -1009,7 +1010,7 @@ struct conp_fix {
     const size_t nt = bands.size();
     // a segment that ends in the projecting epilogue costs about twice one that stores its partial tile (stamped build: 15 units;
     // A/B on one rank: 5.74 / 9 / 12 equal within noise, 15 worse; on emulated ranks with 16 chunks per workgroup 12-14 is 7 % faster)
-    if (!exp_switch("CONP_SK_CSEG")) SK_CSEG = sk_projects() ? 12.0 : 5.74;
+    if (!diag_switch("CONP_SK_CSEG")) SK_CSEG = sk_projects() ? 12.0 : 5.74;
     // one workgroup per CU, except for small problems: sk_reduce walks a tile's splits serially (~1 us per split), so a tile
     // is cut into more than 16 segments only when a segment still holds >= 8 chunks (measured on the decks: il_onelayer
     // 57 -> 52 us per update with 32 instead of 256 workgroups)
@@ -1018,7 +1019,7 @@ struct conp_fix {
     int nwg = std::max(1, num_cus);
     nwg = std::min(nwg, std::max((int)((sk_projects() ? 32 : 16) * nt), (int)((nt * (size_t)nchunks + 7) / 8)));
     nwg = std::max(1, nwg);
-    if (exp_switch("CONP_SK_NWG")) nwg = std::max(1, atoi(exp_switch("CONP_SK_NWG")));
+    if (debug_sk_workgroups() > 0) nwg = debug_sk_workgroups();
     // MFMA work of a band ~ its row fragments' active column fragments (per-fragment sphere culling), in the unit the constants were
     // fitted in: kz blocks of 16 of a four-fragment tile (two column fragments each)
     auto cost = [&](const Band &t) {
@@ -1094,7 +1095,7 @@ struct conp_fix {
     //  tools/rank_emulation.py, N = 4: 80.9 vs 74.6 us, N = 8: 48.3 vs 41.2)
     const int span = nt ? chi[0] - clo[0] : 0;
     const bool long_shares = (size_t)span * nt >= (size_t)32 * nwg;
-    const bool xcd_aware = uniform && long_shares && nwg >= 64 && nwg % 8 == 0 && span >= 64 && exp_switch("CONP_SK_FLAT") == nullptr;
+    const bool xcd_aware = uniform && long_shares && nwg >= 64 && nwg % 8 == 0 && span >= 64 && diag_switch("CONP_SK_FLAT") == nullptr;
     if (xcd_aware) {
       std::vector<int> lo(nt), hi(nt);
       for (int x = 0; x < 8; ++x) {
@@ -1266,7 +1267,7 @@ struct conp_fix {
         if (it == cls.end()) { it = cls.emplace(z[i], (int)cls.size()).first; rep.push_back(i); }
         zclass[i] = it->second;
       }
-      const bool off = exp_switch("CONP_NO_ZCLASS") != nullptr;
+      const bool off = diag_switch("CONP_NO_ZCLASS") != nullptr;
       nzc = (!off && cls.size() <= 64 && 4 * cls.size() <= (size_t)ne) ? (int)cls.size() : 0;   // worthwhile only if it compresses
       // b_zc_dot keeps Hc for 32 rows of every row tile and every class in LDS
       if ((size_t)plan.n_row_tiles * 32 * (size_t)nzc * sizeof(double) > 96 * 1024) nzc = 0;
@@ -1402,7 +1403,7 @@ struct conp_fix {
     const int trank = setup_sharded() ? env.rank : 0, tranks = setup_sharded() ? env.nranks : 1;
     // planar electrodes (z classes, as in the projection's fast path): contraction over the planar rows only -- ~100x fewer flops.
     // CONP_A_GENERAL: comparison switch, always the (planar, kz) contraction.
-    if (nzc > 0 && nzc <= 8 && exp_switch("CONP_A_GENERAL") == nullptr) {
+    if (nzc > 0 && nzc <= 8 && !path_on(CONP_PATH_A_GENERAL)) {
       d_A.reserve((size_t)ne * ne);
       d_A.zero(stream);
       d_Wz.reserve((size_t)plan.R_pad * nzc * nzc);
@@ -1630,13 +1631,13 @@ struct conp_fix {
     // comparison / test switches, read per call and only here: CONP_PANEL_SINGLE = the one-workgroup panel, CONP_PANEL_MAXG = cap
     // on the panel's workgroups, CONP_PANEL_SPIN = polls of its grid barrier before it gives up (0 forces the time-out: the
     // restore-and-retry below runs, tests/test_gpu_parity.py)
-    const bool single = exp_switch("CONP_PANEL_SINGLE") != nullptr;
-    const int max_wg = exp_switch("CONP_PANEL_MAXG") ? atoi(exp_switch("CONP_PANEL_MAXG")) : 0;
-    const unsigned spin_limit = exp_switch("CONP_PANEL_SPIN") ? (unsigned)strtoul(exp_switch("CONP_PANEL_SPIN"), nullptr, 10) : (1u << 22);
+    const bool single = env_knob("CONP_PANEL_SINGLE") != nullptr;
+    const int max_wg = env_knob("CONP_PANEL_MAXG") ? atoi(env_knob("CONP_PANEL_MAXG")) : 0;
+    const unsigned spin_limit = env_knob("CONP_PANEL_SPIN") ? (unsigned)strtoul(env_knob("CONP_PANEL_SPIN"), nullptr, 10) : (1u << 22);
     inverse_retries = 0;
     inverse_path = 2;
     // CONP_INV_GENERAL: comparison switch, always the pivoted elimination
-    const bool try_spd = exp_switch("CONP_INV_GENERAL") == nullptr;
+    const bool try_spd = !path_on(CONP_PATH_INV_PIVOTED);
     d_inv_backup.reserve((size_t)n * n);
     HIP_TRY(hipMemcpyAsync(d_inv_backup.p, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     int info = 0;
@@ -1691,7 +1692,7 @@ struct conp_fix {
   // after convergence returns at once).  The first batch is as long as the last solve needed, so a typical update costs one
   // read-back: scalars, flag, net charge and the residual history come over in ONE copy into the page-locked staging buffer.
   int cg_batch = 8;
-  const bool cg_unfused = exp_switch("CONP_CG_UNFUSED") != nullptr;      // comparison switch: two launches per iteration (round 1)
+  const bool cg_unfused = path_on(CONP_PATH_CG_TWO_LAUNCH);      // comparison switch: two launches per iteration (round 1)
   void cg() {
     const int ne = idx.elenum_all;
     const int nctl = 16 + args.maxiter + 1;                  // scal[0..12], pad, hist[0..maxiter] at offset 16
@@ -1872,7 +1873,7 @@ struct conp_fix {
         // kernel they compete with 37 MB of table writes (15.1 -> 10.7 us without them): 0.2791 / 0.2796 -> 0.2763 / 0.2757 ms per
         // update at the headline size, 0.7261 / 0.7268 -> 0.7228 / 0.7244 in the slab geometry (one box, tools/ab_env.sh).
         // CONP_RIDE_PHASE: comparison switch, the phase launch as before.
-        ride_hc = ride && exp_switch("CONP_RIDE_PHASE") == nullptr && sk_projects() && n_frags > 0 && nzc > 0 &&
+        ride_hc = ride && diag_switch("CONP_RIDE_PHASE") == nullptr && sk_projects() && n_frags > 0 && nzc > 0 &&
                   zc_final_fits((int)own_rt_h.size(), nzc) &&
                   (!bands_aligned || (hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size()));
         prof.begin("elyte_phase", stream);
@@ -2059,8 +2060,7 @@ struct conp_fix {
 
   // plain `fix conp` on one rank with the inverse solver: GEMV and charge write in one launch (gemv_finish_kernel)
   bool can_fuse_solve() const {
-    static const bool off = exp_switch("CONP_NO_FUSE") != nullptr;
-    return !off && args.minimizer == CONP_SOLVER_INV && !args.conq && !args.cond && env.nranks == 1 && !nccl && !s_sharded &&
+    return !no_fuse && args.minimizer == CONP_SOLVER_INV && !args.conq && !args.cond && env.nranks == 1 && !nccl && !s_sharded &&
            runstage >= 3;
   }
   // The projected inverse as a symmetric matrix (conp_kernels.hip "GEMV ... as a SYMMETRIC matrix"): from 2048 electrode atoms up
@@ -2070,8 +2070,7 @@ struct conp_fix {
   bool spk_symmetric = false;       // the matrix generation spk_of passed the symmetry test of the packing pass
   DevBuf<unsigned long long> d_symstat;
   bool use_sym_gemv() const {
-    static const bool off = exp_switch("CONP_GEMV_FULL") != nullptr;
-    return !off && idx.elenum_all >= 2048;
+    return !gemv_rows && idx.elenum_all >= 2048;
   }
   void solve_scatter_fused(double *d_q_atoms, double potdiff) {
     const int ne = idx.elenum_all;
@@ -2258,7 +2257,7 @@ struct conp_fix {
   double *g_dq = nullptr;
   double g_pot = 0.0;
   int g_warm = 0, g_pot_changes = 0;
-  bool graph_off = exp_switch("CONP_GRAPH") == nullptr || atoi(exp_switch("CONP_GRAPH")) == 0;
+  bool graph_off = env_knob("CONP_GRAPH") == nullptr || atoi(env_knob("CONP_GRAPH")) == 0;
   // called at the top of every C-ABI entry that may touch the device: the handle's device becomes the thread's current one
   // (a host that drives several GPUs from one thread may have switched), and a captured update graph is dropped
   void drop_graph() {
@@ -2283,7 +2282,7 @@ struct conp_fix {
     allgather_q();
     if (!(spec && spec_done)) scatter_device(dq, potdiff);
   }
-  const bool cg_no_spec = exp_switch("CONP_CG_NO_SPEC") != nullptr;      // comparison switch: charge write after the read-back
+  const bool cg_no_spec = diag_switch("CONP_CG_NO_SPEC") != nullptr;      // comparison switch: charge write after the read-back
   double *spec_dq = nullptr;
   double spec_pot = 0.0;
   bool spec_done = false;

@@ -2,15 +2,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "../../include/conp_hip.h"      // CONP_PATH_* (the test hooks of the C ABI)
 
 namespace conp {
 
-// Comparison switches (environment): each selects an alternative code path whose results stay inside the tolerances stated in
-// DESIGN.md (two-launch CG, host row regrouping, graph replay, one-workgroup inverse panel ...).  They exist for the A/B tests
-// and tools; the first read of a switch that is set says so on stderr, once, so that a stray variable in a job script cannot go
-// unnoticed.  Switches that would change the PHYSICS of a run (sk_gemm ablation, rank emulation, whole-tile sharding) are not
-// here at all: they are compiled into the diagnostic library only (-DCONP_DIAG, `make diag`).
-const char *exp_switch(const char *name);
+// Alternative code paths.  (i) What the parity tests compare the default paths with is selected through the C ABI
+// (conp_debug_set_paths, include/conp_hip.h: a process-wide bit mask, CONP_PATH_*) -- path_on().  (ii) Switches of decided
+// experiments ("measured, not kept", DESIGN-LOG.md) and those that change the PHYSICS of a run (sk_gemm ablation, rank emulation,
+// whole-tile sharding) exist in the diagnostic library only (-DCONP_DIAG, `make diag`): diag_switch() reads the environment
+// there and folds to a null constant -- name and all -- in the product.  (iii) The product reads from the environment only
+// operational knobs: CONP_GUARD, CONP_GRAPH, CONP_PANEL_SINGLE / _MAXG / _SPIN, CONP_HOST_THREADS, CONP_TIME_HOST / _REN.
+bool path_on(unsigned bit);
+int debug_sk_workgroups();
+const char *env_knob(const char *name);      // operational knob: getenv + one line on stderr the first time a set knob is read
+#ifdef CONP_DIAG
+#define diag_switch(name) ::conp::env_knob(name)
+#else
+#define diag_switch(name) (static_cast<const char *>(nullptr))
+#endif
 
 struct DevPlan {              // device copy of KPlan geometry
   int np, nz, n_row_tiles, n_col_tiles, R_pad, C_pad, kxmax, kymax;

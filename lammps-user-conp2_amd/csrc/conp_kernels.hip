@@ -21,7 +21,7 @@ namespace conp {
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-const char *exp_switch(const char *name) {
+const char *env_knob(const char *name) {
   const char *v = getenv(name);
   if (v) {
     static std::atomic<unsigned long long> said{0};
@@ -29,10 +29,24 @@ const char *exp_switch(const char *name) {
     for (const char *c = name; *c; ++c) h = h * 31u + (unsigned char)*c;
     const unsigned long long bit = 1ull << (h & 63u);
     if (!(said.fetch_or(bit) & bit))
-      fprintf(stderr, "libconp_hip: comparison switch %s=%s is set -- a non-default code path is in use\n", name, v);
+      fprintf(stderr, "libconp_hip: %s=%s is set -- a non-default code path is in use\n", name, v);
   }
   return v;
 }
+static std::atomic<unsigned> g_paths{0};
+static std::atomic<int> g_sk_nwg{0};
+bool path_on(unsigned bit) {
+  const unsigned m = g_paths.load(std::memory_order_relaxed);
+  if (m & bit) {
+    static std::atomic<unsigned> said{0};
+    if (!(said.fetch_or(bit) & bit)) fprintf(stderr, "libconp_hip: test path 0x%x selected (conp_debug_set_paths) -- a non-default code path is in use\n", bit);
+    return true;
+  }
+  return false;
+}
+int debug_sk_workgroups() { return g_sk_nwg.load(std::memory_order_relaxed); }
+extern "C" void conp_debug_set_paths(unsigned mask) { g_paths.store(mask, std::memory_order_relaxed); }
+extern "C" void conp_debug_set_sk_workgroups(int n) { g_sk_nwg.store(n > 0 ? n : 0, std::memory_order_relaxed); }
 
 __device__ double block_sum_1024(double v, double *red);
 
@@ -266,6 +280,50 @@ constexpr int SK_NF = 160 + 320;
 constexpr int SK_PANEL = SK_NF * SK_LD;          // doubles per buffer (61,440 bytes)
 constexpr unsigned SK_BUF1 = 65536;              // byte offset of the second buffer: switching buffers is one XOR of a byte address
 constexpr size_t SK_LDS_BYTES = SK_BUF1 + (size_t)SK_PANEL * sizeof(double);
+// Measured and left off (round 5, tools/ab_libs.sh on one box, `make variant_nobar VDEF=-DSK_NOBAR=1`): the chunk loop WITHOUT the
+// workgroup barrier -- sk_gemm 244.6-252.9 us against 234.5-236.6 with the barrier (headline size; parity tests green in both forms).
+// Why it loses (tools/microbench/pipe_share*_bench.hip, profiles/r05_pipe_share.txt): the SIMD's issue arbiter serves the OLDER wave
+// first -- a wave that streams MFMAs keeps its rate (64.0 cycles per MFMA) whatever its younger partner does, and the partner gets what
+// is left (its own MFMAs: 13 % of the pipe; VALU / LDS instructions: one per ~30 cycles instead of ~10).  Waves 0-3 are the older
+// ones: let loose, they run a chunk ahead and take the pipe from the late waves' multiply of the previous chunk, then wait for it in
+// front of their next build -- while both roles build at the same time (nobody multiplies); the barrier is what keeps the two
+// roles' multiply phases apart, back to back.  Also left off: SK_LOAD_AHEAD (the early waves' table loads in front of the barrier
+// instead of behind it): 237.1-237.5 vs 234.5-236.6 us.
+// The form without the barrier: four counters in the gap between the two panel buffers -- built[b] counts the
+// wave-builds written into buffer b, done[b] the wave-multiplies that have finished reading it (both monotonic inside a segment,
+// zeroed at its start).  A wave waits for the panel it needs (8 builds per chunk) or for the buffer it is about to overwrite (8
+// multiplies per chunk), not for the slowest wave of the workgroup: the early and the late waves of a SIMD may drift by up to a
+// chunk against each other.  LDS operations of one wave complete in order, so the ds_add behind a wave's panel writes is its release;
+// the waiting side has the counter's value back (it branches on it) before it requests operands.
+#ifndef SK_NOBAR
+#define SK_NOBAR 0
+#endif
+// SK_LOAD_AHEAD: the early waves request the table rows of chunk c + 2 right behind their build of chunk c + 1 -- in front of the
+// chunk's barrier, where they wait for the late waves anyway -- instead of at the top of the next chunk, between the barrier and
+// their first multiply (the address arithmetic and issue of 6-8 loads: ~150 cycles of every chunk on the workgroup's critical path)
+#ifndef SK_LOAD_AHEAD
+#define SK_LOAD_AHEAD 0
+#endif
+constexpr unsigned SK_CNT = (unsigned)SK_PANEL * sizeof(double);     // byte 61440: built[0], built[1], done[0], done[1]
+static_assert(SK_CNT + 16 <= SK_BUF1, "counters sit in the gap between the panel buffers");
+typedef __attribute__((address_space(3))) char *sk_lds_ptr;
+// (inline assembly on purpose: through a generic pointer the compiler reads the counter with a FLAT load and waits for vmcnt(0) --
+//  every table load in flight -- at each poll; and its atomic optimiser wraps a one-lane add in a wave reduction)
+__device__ __forceinline__ void sk_cnt_signal(char *smem, unsigned idx) {
+  const unsigned a = (unsigned)(unsigned long)(sk_lds_ptr)smem + SK_CNT + 4u * idx;
+  unsigned long long save;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+               : "=&s"(save) : "v"(a), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void sk_cnt_wait(char *smem, unsigned idx, unsigned target) {
+  const unsigned a = (unsigned)(unsigned long)(sk_lds_ptr)smem + SK_CNT + 4u * idx;
+  for (;;) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
 
 // one step of the angle-addition recurrence without FMA contraction (same arithmetic as elyte_phase_kernel)
 __device__ __forceinline__ double2 zstep(double2 z, double2 st) {
@@ -705,14 +763,33 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA
 #endif
   SK_STAMP_T(st_a);
   sk_load_raw<THIRD>(c, c.it.c0, raw);
+#if SK_NOBAR
+  if (threadIdx.x < 4) reinterpret_cast<unsigned *>(smem + SK_CNT)[threadIdx.x] = 0u;
+#endif
   sk_build_panel<RF, THIRD>(c, raw, reinterpret_cast<double *>(smem));
-  if (late && c.it.c0 + 1 < c.it.c1) sk_load_raw<THIRD>(c, c.it.c0 + 1, raw);
+  if ((late || SK_LOAD_AHEAD) && c.it.c0 + 1 < c.it.c1) sk_load_raw<THIRD>(c, c.it.c0 + 1, raw);
   __syncthreads();
   SK_STAMP_T(st_b); SK_STAMP_ADD(s_pro, st_a, st_b);
   unsigned buf = 0;                                    // byte offset of the panel being multiplied: 0 or SK_BUF1
   for (int ch = c.it.c0; ch < c.it.c1; ++ch, buf ^= SK_BUF1) {
     double *nxt = reinterpret_cast<double *>(smem + (buf ^ SK_BUF1));
     const bool more = ch + 1 < c.it.c1;
+#if SK_NOBAR
+    // chunk i of the segment lives in buffer i & 1.  Its panel is complete when built[i & 1] has reached 8 ((i + 1) >> 1) (chunk 0
+    // was built in front of the segment's barrier); buffer (i + 1) & 1 may be overwritten with chunk i + 1 when done[(i + 1) & 1]
+    // has reached 8 ((i + 1) >> 1): all eight waves have multiplied chunk i - 1
+    const unsigned bi = buf ? 1u : 0u;
+    const unsigned tgt = 8u * (unsigned)((ch - c.it.c0 + 1) >> 1);
+#define SK_WAIT_PANEL() sk_cnt_wait(smem, bi, tgt)
+#define SK_DONE_PANEL() sk_cnt_signal(smem, 2u + bi)
+#define SK_WAIT_FREE() sk_cnt_wait(smem, 2u + (bi ^ 1u), tgt)
+#define SK_BUILT_NEXT() sk_cnt_signal(smem, bi ^ 1u)
+#else
+#define SK_WAIT_PANEL() do { } while (0)
+#define SK_DONE_PANEL() do { } while (0)
+#define SK_WAIT_FREE() do { } while (0)
+#define SK_BUILT_NEXT() do { } while (0)
+#endif
     if (!late) {
       SK_STAMP_T(st_a);
 #if SK_PRIO_E
@@ -724,15 +801,22 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA
       constexpr bool EPRE = SK_EARLY_PREFETCH && !SK_MFMA_LOOP && RF * NFW < 20;
       SkPre<NFW> pre;
       if constexpr (EPRE) { if (!(SK_DBG(c, 2))) sk_mfma_prefetch<NFW>(c, smem, buf, pre); }
-      if (more && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 1, raw);
+      if (!SK_LOAD_AHEAD && more && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 1, raw);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_load, st_a, st_b);
+      SK_WAIT_PANEL();
       if constexpr (EPRE) { if (!(SK_DBG(c, 2))) sk_mfma_chunk_u<RF, NFW, F0>(c, smem, buf, acc, &pre); }
       else { if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc); }
+      SK_DONE_PANEL();
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_mfma, st_b, st_a);
 #if SK_PRIO_E == 1
       __builtin_amdgcn_s_setprio(0);            // (variant 1: the early waves' build at the base priority; 2 / 3: raised throughout)
 #endif
-      if (more && !(SK_DBG(c, 1))) sk_build_panel<RF, THIRD>(c, raw, nxt);
+      if (more) {
+        SK_WAIT_FREE();
+        if (!(SK_DBG(c, 1))) sk_build_panel<RF, THIRD>(c, raw, nxt);
+        SK_BUILT_NEXT();
+      }
+      if (SK_LOAD_AHEAD && ch + 2 < c.it.c1 && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 2, raw);
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
     } else {
 #if SK_LATE_MODE == 1
@@ -746,26 +830,41 @@ __device__ __forceinline__ void sk_body(const SkCtx &c, char *smem, double *outA
       SkPre<NFW> pre;
       if (!(SK_DBG(c, 2))) sk_mfma_prefetch<NFW>(c, smem, buf, pre);
 #endif
-      if (more && !(SK_DBG(c, 1))) sk_build_panel<RF, THIRD>(c, raw, nxt);
+      if (more) {
+        SK_WAIT_FREE();
+        if (!(SK_DBG(c, 1))) sk_build_panel<RF, THIRD>(c, raw, nxt);
+        SK_BUILT_NEXT();
+      }
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_build, st_a, st_b);
       if (ch + 2 < c.it.c1 && !(SK_DBG(c, 4))) sk_load_raw<THIRD>(c, ch + 2, raw);
       SK_STAMP_T(st_a); SK_STAMP_ADD(s_load, st_b, st_a);
 #if SK_PRIO
       __builtin_amdgcn_s_setprio(SK_PRIO);
 #endif
+      SK_WAIT_PANEL();
 #if SK_LATE_PREFETCH
       if (!(SK_DBG(c, 2))) sk_mfma_chunk_u<RF, NFW, F0>(c, smem, buf, acc, &pre);
 #else
       if (!(SK_DBG(c, 2))) SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc);
 #endif
+      SK_DONE_PANEL();
       SK_STAMP_T(st_b); SK_STAMP_ADD(s_mfma, st_a, st_b);
 #else
 #error "only the full stagger (SK_LATE_MODE 1) is kept: half stagger measured 264 vs 260 us (DESIGN.md)"
 #endif
     }
+#if !SK_NOBAR
     __syncthreads();
+#endif
     SK_STAMP_T(st_a); SK_STAMP_ADD(s_bar, st_b, st_a);
+#undef SK_WAIT_PANEL
+#undef SK_DONE_PANEL
+#undef SK_WAIT_FREE
+#undef SK_BUILT_NEXT
   }
+#if SK_NOBAR
+  __syncthreads();          // the epilogue re-uses the panels' memory: every wave has multiplied its last chunk
+#endif
   // ---- partial tile out (only the active fragments), fragment-major: sk_part_off().  Two 16-byte stores per fragment, each
   //      wave-instruction one contiguous KB (the row-major layout took four 8-byte stores per fragment, each four 128-byte pieces:
   //      the store tail of a segment is issue-bound)
@@ -1192,7 +1291,7 @@ constexpr int SKR_GROUP = 16;
 constexpr int SKR_T = 640;                         // threads per block
 // two levels (one more launch) once the most-split tile has more than this many partials: measured break-even on the headline
 // box -- 40 partials (one GPU) 4 us faster in one level, 57 (two ranks) equal, 113 (four ranks) 12 us faster in two
-static int skr_two_level_from() { static const int v = exp_switch("CONP_SKR_TWO") ? atoi(exp_switch("CONP_SKR_TWO")) : 4 * SKR_GROUP; return v; }
+static int skr_two_level_from() { static const int v = diag_switch("CONP_SKR_TWO") ? atoi(diag_switch("CONP_SKR_TWO")) : 4 * SKR_GROUP; return v; }
 template <int SKR_SL>
 __global__ __launch_bounds__(SKR_T) void sk_reduce_kernel(int C_pad, const SkTile *__restrict__ tiles,
                                                         double *__restrict__ part, const double *__restrict__ wfull,
@@ -1843,7 +1942,7 @@ void launch_b_real_combine(hipStream_t s, int ne, int ne_pad, int row0, int row1
 // the phase and reduction kernels 3.5 us slower -- the matrix does not stay resident beside that much written data.
 constexpr size_t GEMV_RESIDENT_BYTES = (size_t)64 << 20;
 static bool gemv_nt(size_t matrix_bytes) {
-  static const char *e = exp_switch("CONP_GEMV_NT");      // comparison switch: 0 / 1 forces the policy
+  static const char *e = diag_switch("CONP_GEMV_NT");      // comparison switch: 0 / 1 forces the policy
   if (e) return atoi(e) != 0;
   return matrix_bytes > GEMV_RESIDENT_BYTES;
 }

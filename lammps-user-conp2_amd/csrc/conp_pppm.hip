@@ -650,7 +650,7 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
                         (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double) <= 128 * 1024;
   const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
   // deck-sized systems: the forward xy pass spreads the charges itself (CONP_PPPM_SPREAD_LAUNCH: comparison switch, the launch of its own)
-  const bool spread_launch = exp_switch("CONP_PPPM_SPREAD_LAUNCH") != nullptr;      // (read per call: the test flips it between two handles)
+  const bool spread_launch = path_on(CONP_PATH_PPPM_SPREAD_LAUNCH);      // (read per call: the test flips it between two handles)
   if (xy_fused && !spread_launch && nl <= 8192 && pd.nz <= 1024 && pd.order * pd.order <= 64) {
     BRowArgs ra{};
     const bool rows = pairs && breal_out;

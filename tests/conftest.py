@@ -40,6 +40,17 @@ def _torch_owns_the_gpu_first():
     yield
 
 
+@pytest.fixture(autouse=True)
+def _default_code_paths():
+    """the test hooks of the ABI (conp_debug_set_paths) are process-wide: whatever a test selected is switched off behind it"""
+    yield
+    capi = sys.modules.get("conp_amd.capi")
+    lib = getattr(capi, "_LIB", None) if capi else None
+    if lib is not None and hasattr(lib, "conp_debug_set_paths"):
+        lib.conp_debug_set_paths(0)
+        lib.conp_debug_set_sk_workgroups(0)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """CONP_GUARD=1 python -m pytest tests -m gpu: the whole suite with guard zones around every device buffer of the library
     (conp_fix.cpp GuardZones) -- every zone, of live buffers and of every buffer released during the session, must be intact"""

@@ -77,3 +77,18 @@ def test_glue_driver_fails_loudly_without_a_gpu(tmp_path):
     p = subprocess.run([DRIVER, case], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert p.returncode == 2
     assert "ERROR: " in p.stdout and "no CPU fallback" in p.stdout
+
+
+def test_product_library_reads_only_operational_knobs_from_the_environment():
+    """round 4's review counted 35 CONP_* comparison switches in the shipped library -- every experiment had left one behind.  Now the
+    product reads operational knobs only (guard zones, graph replay, the inverse panel's limits, host threads, timing print-outs);
+    what the parity tests compare with goes through conp_debug_set_paths (a bit mask, no strings); decided experiments live in the
+    diagnostic build (`make -C csrc diag`).  List the CONP_[A-Z0-9_]+ strings of the built library: at most 10, all of them known."""
+    import re
+    from conp_amd import capi
+    data = open(capi.library_path(), "rb").read()
+    names = sorted({m.decode() for m in re.findall(rb"CONP_[A-Z0-9_]+", data)})
+    allowed = {"CONP_GUARD", "CONP_GRAPH", "CONP_PANEL_SINGLE", "CONP_PANEL_MAXG", "CONP_PANEL_SPIN", "CONP_HOST_THREADS",
+               "CONP_TIME_HOST", "CONP_TIME_REN"}
+    assert len(names) <= 10, names
+    assert set(names) <= allowed, sorted(set(names) - allowed)

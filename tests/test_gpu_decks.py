@@ -6,7 +6,7 @@ hours, so the checks are size-independent properties plus an oracle comparison o
 import numpy as np
 import pytest
 
-from conp_amd import FixConp, neighbor, systems
+from conp_amd import FixConp, capi, neighbor, systems
 from helpers import OracleRun, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -57,7 +57,7 @@ def test_il_decks_match_oracle(oracle, deck, mode, extra):
 def test_heavily_split_tiles_use_the_two_level_partial_sum(oracle, monkeypatch):
     """multi-GPU shards cut one tile into hundreds of sk_gemm segments; forced here with 256 workgroups on il_onelayer's two
     tiles (80 segments each -> sk_reduce level 1 + level 2): same structure factors and b vector"""
-    monkeypatch.setenv("CONP_SK_NWG", "256")
+    capi.load_library().conp_debug_set_sk_workgroups(256)
     s = systems.deck("il_onelayer", "ffield", etypes=True)
     at, alist, blist = neighbor.build_lists(s)
     fx = FixConp(s)
@@ -72,7 +72,7 @@ def test_heavily_split_tiles_use_the_two_level_partial_sum(oracle, monkeypatch):
     sr_g, si_g = fx.sfac()
     scale = max(np.abs(sr_o).max(), np.abs(si_o).max())
     assert max(np.abs(sr_g - sr_o).max(), np.abs(si_g - si_o).max()) / scale < 1e-11
-    monkeypatch.delenv("CONP_SK_NWG")
+    capi.load_library().conp_debug_set_sk_workgroups(0)
     fy = FixConp(s)                                  # default schedule (32 workgroups, one-level sum)
     fy.init_lists(alist, blist)
     fy.setup_post_neighbor(at)
@@ -201,7 +201,7 @@ def test_headline_charges_are_the_product_of_the_projected_inverse_with_b(headli
     """Ne = 4096: the fused solve multiplies with the projected inverse taken as a SYMMETRIC matrix (packed lower-triangle tiles,
     half the bytes).  q_ele must equal S b + dV S d computed on the host from the full matrix the library hands out -- to the
     asymmetry of the computed S (~1e-16 relative) times the condition of the sum -- and so must the row-by-row product
-    (CONP_GEMV_FULL is read when the first update of the process runs, so the comparison is against numpy, not a second handle)."""
+    (the comparison is against numpy, not a second handle)."""
     import torch
     s, at, alist, blist, fx = headline
     S = fx.matrix()
@@ -317,14 +317,14 @@ def test_large_box_structure_factors_against_direct_sums():
 def test_small_system_fused_phase_equals_the_separate_launch(monkeypatch, mode):
     """il_onelayer takes the small-system form of sk_gemm (SkFuse: the phase tables of a segment's atoms and the pair sums inside the
     launch, no elyte_phase launch).  The tables and the pair sums are the stand-alone kernels' arithmetic value for value: the b
-    vector and the charges must come out bit for bit as with CONP_NO_PHASE_FUSE=1 (ffield); in slab mode the slab sum is added in
+    vector and the charges must come out bit for bit as with the stand-alone phase launch, CONP_PATH_PHASE_LAUNCH (ffield); in slab mode the slab sum is added in
     another order (per segment, not per block of the phase kernel): equal to rounding."""
     s = systems.deck("il_onelayer", mode, etypes=True, shuffle_seed=5)
     at0, alist, blist = neighbor.build_lists(s)
     out = {}
     for sep in (False, True):
         if sep:
-            monkeypatch.setenv("CONP_NO_PHASE_FUSE", "1")
+            capi.load_library().conp_debug_set_paths(capi.PATH_PHASE_LAUNCH)
         at, _, _ = neighbor.build_lists(s)
         fx = FixConp(s)
         fx.init_lists(alist, blist)
@@ -338,7 +338,7 @@ def test_small_system_fused_phase_equals_the_separate_launch(monkeypatch, mode):
         out[sep] = (b.copy(), q.copy(), at.q.copy(), names)
         fx.close()
         if sep:
-            monkeypatch.delenv("CONP_NO_PHASE_FUSE")
+            capi.load_library().conp_debug_set_paths(0)
     assert "elyte_phase" not in out[False][3] and "elyte_phase" in out[True][3]
     if mode == "ffield":
         for k in range(3):

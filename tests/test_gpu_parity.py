@@ -12,7 +12,7 @@ electroneutrality projection and electrode-index bookkeeping bit-exact"):
 import numpy as np
 import pytest
 
-from conp_amd import FixConp, neighbor, systems
+from conp_amd import FixConp, capi, neighbor, systems
 from helpers import OracleRun, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -121,13 +121,13 @@ def test_full_chain_matches_oracle(oracle, case):
 @pytest.mark.parametrize("deck,mode", [("il_twolayer", "ffield"), ("il_onelayer", "slab"), ("dilute", "ffield")])
 def test_planar_a_matrix_factorisation_equals_the_general_contraction(deck, mode, monkeypatch):
     """planar electrodes: the k-space part of A is contracted over the planar rows only (z classes, like the projection's fast
-    path) instead of over every (planar, kz) pair -- the same matrix to rounding (CONP_A_GENERAL forces the general kernel)"""
+    path) instead of over every (planar, kz) pair -- the same matrix to rounding (CONP_PATH_A_GENERAL forces the general kernel)"""
     s = systems.deck(deck, mode, etypes=(deck != "dilute"))
     at, alist, blist = neighbor.build_lists(s)
     mats = []
     for general in (False, True):
         if general:
-            monkeypatch.setenv("CONP_A_GENERAL", "1")
+            capi.load_library().conp_debug_set_paths(capi.PATH_A_GENERAL)
         fx = FixConp(s)
         fx.init_lists(alist, blist)
         fx.setup_post_neighbor(at)
@@ -230,17 +230,17 @@ def test_inverse_matches_numpy():
     inv = fx.invert(spd)
     assert np.abs(inv - np.linalg.inv(spd)).max() / np.abs(inv).max() < 1e-12
     # An exactly symmetric, positive definite matrix (the electrode matrix is one) is eliminated on its own diagonal blocks --
-    # no pivot search, no grid barrier; the same inverse as the pivoted elimination (CONP_INV_GENERAL) to rounding.  A symmetric
+    # no pivot search, no grid barrier; the same inverse as the pivoted elimination (CONP_PATH_INV_PIVOTED) to rounding.  A symmetric
     # matrix that is NOT positive definite is noticed (a pivot <= 0), restored and pivoted; a general matrix never tries.
     assert fx.info().inverse_path == 1
     m = rng.normal(size=(1500, 1500)); spd = m @ m.T / 1500 + 0.5 * np.eye(1500)
     inv_spd = fx.invert(spd)
     assert fx.info().inverse_path == 1
-    os.environ["CONP_INV_GENERAL"] = "1"
+    capi.load_library().conp_debug_set_paths(capi.PATH_INV_PIVOTED)
     try:
         inv_gen = fx.invert(spd)
     finally:
-        del os.environ["CONP_INV_GENERAL"]
+        capi.load_library().conp_debug_set_paths(0)
     assert fx.info().inverse_path == 2
     ref = np.linalg.inv(spd)
     assert np.abs(inv_spd - ref).max() / np.abs(ref).max() < 1e-12 and np.abs(inv_gen - ref).max() / np.abs(ref).max() < 1e-12
@@ -345,13 +345,13 @@ def test_cg_solver_matches_oracle(oracle):
 @pytest.mark.parametrize("split", [False, True])
 def test_log_file_lines_inverse_solver(split, monkeypatch):
     """what the reference prints to its log file (fix_conp.cpp:787, 857, 564-566), in the same order and format.  By default the
-    pair sums share a launch with the k-space phases (Coulomb time ~ 0, all of b_cal under Kspace); CONP_TIME_SPLIT=1 (read when
+    pair sums share a launch with the k-space phases (Coulomb time ~ 0, all of b_cal under Kspace); CONP_PATH_TIME_SPLIT (read when
     the handle is created) launches the halves separately so that each gets its own figure."""
     import re
     s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
     at, alist, blist = neighbor.build_lists(s)
     if split:
-        monkeypatch.setenv("CONP_TIME_SPLIT", "1")
+        capi.load_library().conp_debug_set_paths(capi.PATH_TIME_SPLIT)
     fx = FixConp(s, extra_args=[])
     fx.init_lists(alist, blist)
     fx.setup_post_neighbor(at)
@@ -381,7 +381,7 @@ def test_log_file_lines_inverse_solver(split, monkeypatch):
 
 def test_cg_one_launch_per_iteration_gives_the_bits_of_the_two_launch_form(monkeypatch):
     """cg_step_kernel (every workgroup repeats the vector update, then multiplies its rows) against the round-1 form (matvec
-    kernel + one-workgroup update kernel per iteration, CONP_CG_UNFUSED=1 read when the handle is created): same iteration
+    kernel + one-workgroup update kernel per iteration, CONP_PATH_CG_TWO_LAUNCH, read when the handle is created): same iteration
     count, same residual history, bitwise the same charges -- also when the first batch is too short (maxiter path: 'tol' small
     enough for several read-backs) and when convergence falls inside a batch"""
     s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
@@ -389,9 +389,9 @@ def test_cg_one_launch_per_iteration_gives_the_bits_of_the_two_launch_form(monke
         got = []
         for unfused in (False, True):
             if unfused:
-                monkeypatch.setenv("CONP_CG_UNFUSED", "1")
+                capi.load_library().conp_debug_set_paths(capi.PATH_CG_TWO_LAUNCH)
             else:
-                monkeypatch.delenv("CONP_CG_UNFUSED", raising=False)
+                capi.load_library().conp_debug_set_paths(0)
             at, alist, blist = neighbor.build_lists(s)
             fx = FixConp(s, extra_args=extra)
             fx.init_lists(alist, blist)
@@ -644,7 +644,7 @@ def test_device_row_regrouping_keeps_the_list_order(deck, newton, monkeypatch):
     res = []
     for host in (False, True):
         if host:
-            monkeypatch.setenv("CONP_ROWS_HOST", "1")
+            capi.load_library().conp_debug_set_paths(capi.PATH_ROWS_HOST)
         fx = FixConp(s)
         fx.init_lists(alist, blist)
         fx.setup_post_neighbor(at)
@@ -659,7 +659,7 @@ def test_device_row_regrouping_keeps_the_list_order(deck, newton, monkeypatch):
                                        ("small_tall_slab", None)])
 def test_projecting_epilogue_equals_the_partial_tile_path(deck, mode, monkeypatch):
     """planar electrodes: a segment of sk_gemm projects its partial tile on the z classes before it leaves the registers and the
-    pieces are added afterwards; the comparison path (CONP_SK_PARTIALS) adds the partial tiles and projects the sum -- the same
+    pieces are added afterwards; the comparison path (CONP_PATH_PARTIAL_TILES) adds the partial tiles and projects the sum -- the same
     terms re-associated.  The structure factors, which the projecting update never forms, are re-formed on request through the
     partial-tile kernels (the two paths cut the atom axis into different shares: equal to rounding, not bit for bit).
     small_tall_slab: two kz column tiles -- the comparison path is then sk_reduce + b_hc instead of the fused sk_reduce_hc."""
@@ -668,7 +668,7 @@ def test_projecting_epilogue_equals_the_partial_tile_path(deck, mode, monkeypatc
     res = []
     for partials in (False, True):
         if partials:
-            monkeypatch.setenv("CONP_SK_PARTIALS", "1")
+            capi.load_library().conp_debug_set_paths(capi.PATH_PARTIAL_TILES)
         fx = FixConp(s)
         fx.init_lists(alist, blist)
         fx.setup_post_neighbor(at)
@@ -688,7 +688,7 @@ def _gpu_shard_worker(rank, world, port, out):
     import torch.distributed as dist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "lammps-user-conp2_amd"))
-    from conp_amd import FixConp, neighbor, systems
+    from conp_amd import FixConp, capi, neighbor, systems
     from conp_amd.distributed import sharded_update
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks drive cuda:0; collectives over gloo

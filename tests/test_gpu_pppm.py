@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_py
-from conp_amd import FixConp, neighbor, systems
+from conp_amd import FixConp, capi, neighbor, systems
 from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -45,7 +45,7 @@ def test_pppm_b_matches_oracle_and_ewald(oracle, deck, mode, mesh, order, acc):
 
 def test_pppm_spread_inside_the_forward_pass_equals_the_spreading_launch(monkeypatch):
     """deck-sized systems spread the charges in the forward xy pass's own workgroups (pppm_fft_xy_kernel, real_in 3); the density
-    brick + spreading launch stay for large systems and as CONP_PPPM_SPREAD_LAUNCH=1: same b up to the order in which a mesh point's
+    brick + spreading launch stay for large systems and as CONP_PATH_PPPM_SPREAD_LAUNCH: same b up to the order in which a mesh point's
     contributions arrive (unordered in both forms), slab geometry included (the slab sum is cut differently)"""
     for mode, mesh in (("ffield", (40, 45, 180)), ("slab", (40, 45, 540))):
         s = systems.deck("il_onelayer", mode, etypes=True)
@@ -53,14 +53,14 @@ def test_pppm_spread_inside_the_forward_pass_equals_the_spreading_launch(monkeyp
         out = {}
         for sep in (False, True):
             if sep:
-                monkeypatch.setenv("CONP_PPPM_SPREAD_LAUNCH", "1")
+                capi.load_library().conp_debug_set_paths(capi.PATH_PPPM_SPREAD_LAUNCH)
             fx = FixConp(s, extra_args=["pppm"], pppm_mesh=mesh, pppm_order=5)
             fx.init_lists(alist, blist)
             fx.setup_post_neighbor(at)
             out[sep] = fx.km_b_cal(at).copy()
             fx.close()
             if sep:
-                monkeypatch.delenv("CONP_PPPM_SPREAD_LAUNCH")
+                capi.load_library().conp_debug_set_paths(0)
         assert rel_err(out[False], out[True]) < 1e-12
 
 

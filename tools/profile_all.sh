@@ -2,7 +2,7 @@
 # Every workload of profiles/rNN_*: the headline and the BASELINE configs under rocprofv3 (tools/profile_gpu.sh each), summaries
 # gathered in gpurun_out/profiles_new/ (copy what is to be judged into profiles/).   bash tools/profile_all.sh [round tag]
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 DST=gpurun_out/profiles_new; mkdir -p $DST
 run() {   # name, bench args
   local name=$1; shift
