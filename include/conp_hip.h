@@ -340,7 +340,9 @@ enum {
   CONP_PATH_PHASE_LAUNCH = 1 << 5,       /* small systems: stand-alone phase-table launch instead of the prologue inside sk_gemm */
   CONP_PATH_PPPM_SPREAD_LAUNCH = 1 << 6, /* pppm: density brick + spreading launch also for deck-sized systems */
   CONP_PATH_ROWS_HOST = 1 << 7,          /* re-neighbour: electrode rows regrouped on the host */
-  CONP_PATH_TIME_SPLIT = 1 << 8          /* host-buffer hooks: k-space and real-space halves of b_cal in launches of their own (timing log) */
+  CONP_PATH_TIME_SPLIT = 1 << 8,         /* host-buffer hooks: k-space and real-space halves of b_cal in launches of their own (timing log) */
+  CONP_PATH_HC_NO_WAIT = 1 << 9,         /* fused pieces + dot launch: the dot workgroups do not wait for the handed-over class table, they add the pieces themselves */
+  CONP_PATH_HC_FUSED = 1 << 10           /* pieces' sums + pair sums + dot as ONE launch with an in-launch hand-off (measured slower than two launches: not the default) */
 };
 void conp_debug_set_paths(unsigned mask);
 void conp_debug_set_sk_workgroups(int n);

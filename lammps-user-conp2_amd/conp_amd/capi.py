@@ -103,7 +103,8 @@ SYMBOLS = [
 
 # test hooks of the ABI (include/conp_hip.h, CONP_PATH_*): alternative code paths the parity tests compare the default ones with
 PATH_PARTIAL_TILES, PATH_A_GENERAL, PATH_INV_PIVOTED, PATH_CG_TWO_LAUNCH, PATH_GEMV_ROWS = 1, 2, 4, 8, 16
-PATH_PHASE_LAUNCH, PATH_PPPM_SPREAD_LAUNCH, PATH_ROWS_HOST, PATH_TIME_SPLIT = 32, 64, 128, 256
+PATH_PHASE_LAUNCH, PATH_PPPM_SPREAD_LAUNCH, PATH_ROWS_HOST, PATH_TIME_SPLIT, PATH_HC_NO_WAIT = 32, 64, 128, 256, 512
+PATH_HC_FUSED = 1024
 
 
 class test_paths:

@@ -339,6 +339,16 @@ struct conp_fix {
   // (bitwise-equal charges): the pair sums share a launch with the k-space phases, so Ctime stays 0 and Ktime holds all of b_cal.
   // CONP_TIME_SPLIT=1 launches the two halves separately (last-ulp different dot order) so that each gets its own figure.
   const bool time_split = path_on(CONP_PATH_TIME_SPLIT);
+  // the dot workgroups' bounded wait for the class table (b_zc_fused_kernel); CONP_PATH_HC_NO_WAIT: zero -- every dot workgroup adds
+  // the pieces itself, the path a wait that runs out takes (tested against the hand-off: the same bits)
+  const unsigned hc_spin_limit = path_on(CONP_PATH_HC_NO_WAIT) ? 0u : (1u << 16);
+  // Measured and NOT the default (round 5, tools/ab_libs.sh on one box, profiles/r05_tail_handoff_ab.txt): the pieces' sums, the pair
+  // sums and the dot as ONE launch with the fence-free hand-off -- reduce_project 24.7-25.3 us against 19.0-19.1 for hc_sum_kernel +
+  // b_zc_final_kernel (headline), 26.5-27.0 against 20.0-20.4 (slab geometry).  What a kernel boundary does in ~2 us (make 18 KB
+  // visible to 256 workgroups on eight XCDs) costs the hand-off a write-through, a ticket, a poll and 256 x 18 KB of sc1 reads from
+  // the memory side; the pair rows, which filled the idle CUs beside hc_sum's handful of workgroups, sit on every dot workgroup's
+  // own path instead.  Kept as a test path (bit-identical b, tests/test_gpu_decks.py).
+  const bool hc_fused = path_on(CONP_PATH_HC_FUSED);
   const bool gemv_rows = path_on(CONP_PATH_GEMV_ROWS);      // test path: the row-by-row product at every size
   const bool no_phase_fuse = path_on(CONP_PATH_PHASE_LAUNCH);      // comparison switch: always the stand-alone phase launch
   const bool no_ride = diag_switch("CONP_NO_RIDE") != nullptr;      // comparison switch: the real-space pair sums in a launch of their own (b_real_combine)
@@ -1892,7 +1902,8 @@ struct conp_fix {
       reserve_partials();
       prof.begin("sk_gemm", stream);
       launch_sk_gemm(stream, dplan, d_witems.p, witems_maxseg, nwg_sk, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
-                     proj ? d_Hpart.p : d_Gpart.p, proj ? d_skproj.p : nullptr, fuse_phase ? d_skfuse.p : nullptr, ne);
+                     proj ? d_Hpart.p : d_Gpart.p, proj ? d_skproj.p : nullptr, fuse_phase ? d_skfuse.p : nullptr, ne,
+                     reinterpret_cast<unsigned *>(d_scalars.p + 8));
       prof.end(stream);
       g_current = !proj;
       if (proj) {
@@ -1902,7 +1913,8 @@ struct conp_fix {
         prof.begin("reduce_project", stream);
         launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_Hpart.p, d_hslot_ptr.p, d_hslot_idx.p,
                                      presum, d_frag_ptr.p, d_frag_ents.p, n_frags, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p, d_bk.p,
-                                     use_fin ? &fin : nullptr, ride_hc ? &pairs_keep : nullptr, d_breal.p);
+                                     use_fin ? &fin : nullptr, ride_hc ? &pairs_keep : nullptr, d_breal.p,
+                                     (hc_fused && !(timed && time_split)) ? reinterpret_cast<unsigned *>(d_scalars.p + 8) : nullptr, hc_spin_limit);
         prof.end(stream);
       } else if (nzc > 0 && plan.n_col_tiles == 1 && !no_fuse) {
         // planar electrodes, one column tile: partial-tile sum + Hc product fused, then the per-atom dot (+ row assembly)

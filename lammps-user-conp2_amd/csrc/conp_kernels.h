@@ -129,7 +129,7 @@ bool zc_final_fits(int n_own, int nzc);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems /*[nwg][maxseg]*/, int maxseg, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj = nullptr,
                     const SkFuse *fuse = nullptr /*small systems: phase tables and pair sums inside this launch (DEVICE copy of the block)*/,
-                    int fuse_rows = 0 /*its rows.ne*/);
+                    int fuse_rows = 0 /*its rows.ne*/, unsigned *ticket = nullptr /*zeroed by workgroup 0: b_zc_fused_kernel's hand-off word*/);
 int sk_hc_stride();           // doubles per segment of sk_gemm's projected output
 int sk_hc_max_classes();      // most z classes the projecting mode takes
 void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, int n_own, const int *own_rt, int nzc, const double *Hp,
@@ -138,7 +138,9 @@ void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, 
                                   (offset of the fragment's first 'a' row, the band's rf)*/, int nfrag, const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin,
                                   const BRowArgs *pairs = nullptr /*with breal_out: the pair sums ride in hc_sum's launch*/,
-                                  double *breal_out = nullptr);
+                                  double *breal_out = nullptr,
+                                  unsigned *ticket = nullptr /*with fin and pairs: ONE launch, the pieces' sums handed over inside it (round 5)*/,
+                                  unsigned spin_limit = 1u << 16);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);
 void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,

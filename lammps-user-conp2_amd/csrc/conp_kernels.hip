@@ -1016,10 +1016,12 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
                                                          const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                          const double2 *__restrict__ Zs, const double *__restrict__ qc,
                                                          double *__restrict__ part, const SkProj *__restrict__ proj, int dbg,
-                                                         const SkFuse *__restrict__ fzp /*device copy, or null*/, int nwg_sk) {
+                                                         const SkFuse *__restrict__ fzp /*device copy, or null*/, int nwg_sk,
+                                                         unsigned *__restrict__ ticket /*b_zc_fused_kernel's hand-off word, zeroed here; or null*/) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // panel buffer 0 at byte 0, buffer 1 at byte SK_BUF1
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (ticket && blockIdx.x == 0 && t == 0) *ticket = 0u;
   if (FUSE && (int)blockIdx.x >= nwg_sk) {
     // spare workgroups of a small system's launch: the real-space pair sums of the electrode rows, one wavefront per row
     const BRowArgs ra = fzp->rows;
@@ -1202,7 +1204,7 @@ int sk_hc_max_classes() { return SK_HC_MAX; }
 // classes; proj = device copy of the parameter block) the segments' projected pieces [segment][sk_hc_stride()]
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems, int maxseg, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj,
-                    const SkFuse *fuse, int fuse_rows) {
+                    const SkFuse *fuse, int fuse_rows, unsigned *ticket) {
   if (nwg <= 0) return;
   // fuse: DEVICE copy of the parameter block (conp_fix.cpp uploads it when its content changes); fuse_rows: its rows.ne
   const int extra = fuse ? (fuse_rows + 7) / 8 : 0;
@@ -1217,10 +1219,10 @@ void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems, int
 #endif
   if (fuse)
     hipLaunchKernelGGL(sk_gemm_kernel<true>, dim3(nwg + extra), dim3(512), lds, s, pl, witems, maxseg, nl_pad, Xt, Yt, Zs, qc, part, proj,
-                       dbg, fuse, nwg);
+                       dbg, fuse, nwg, ticket);
   else
     hipLaunchKernelGGL(sk_gemm_kernel<false>, dim3(nwg), dim3(512), lds, s, pl, witems, maxseg, nl_pad, Xt, Yt, Zs, qc, part, proj, dbg,
-                       fuse, nwg);
+                       fuse, nwg, ticket);
 }
 
 // G = sum over a tile's splits (fixed order).  Gwf = w * G in MFMA-fragment-major order for b_project:
@@ -1765,6 +1767,204 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   }
 }
 
+// ---- round 5: hc_sum_kernel and b_zc_final_kernel as ONE launch (headline and slab plans: many pieces per row fragment) ----------
+// The dot kernel needs the whole class table H of the rank, the pieces' sums are a few workgroups' work: they used to be two launches
+// with the real-space pair rows riding in the first.  Here the first P workgroups add the pieces (hc_sum_kernel's arithmetic: eight
+// lanes per element, groups of eight by a butterfly, groups in list order) and PUBLISH the table -- write-through stores (agent-scope
+// relaxed atomics = sc1), the storing waves' vmcnt(0), the workgroup barrier, ONE relaxed agent-scope ticket add per workgroup: the
+// fence-free hand-off of the inverse's panel (conp_inverse.hip; a device-scope fence writes back and invalidates an XCD's whole L2:
+// the hand-offs of rounds 2-4 that lost were built on those, or put the waiting on sk_gemm's critical path).  The dot workgroups do
+// everything that does not need H first -- request their first eight tiles' phases, and form the pair sums of their 16 electrode
+// rows, one wavefront per row (the rows that rode along in hc_sum's launch) -- then ONE thread polls the ticket, and H comes out of
+// memory by sc1 loads.  Co-residency: the grid is P + ne_pad / 16 workgroups of 1024 threads (273 at the headline size, two fit a
+// CU), producers first in dispatch order; a dot workgroup whose wait runs out (bounded spin) adds the pieces it needs ITSELF --
+// the same bits, frag_sum_serial -- so a co-scheduled kernel can slow this one down but not hang it.
+// The ticket word is zeroed by sk_gemm's launch (workgroup 0), which is always in front of this one on the stream.
+__device__ __forceinline__ double frag_sum_serial(const int *__restrict__ frag_ptr, const int2 *__restrict__ ents,
+                                                  const double *__restrict__ Hp, int g, int cls, int half, int i) {
+  const int s0 = frag_ptr[g], s1 = frag_ptr[g + 1];
+  double acc = 0.0;
+  const int ng = (s1 - s0) / 8 + 1;
+  for (int gb = 0; gb < ng; ++gb) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int sidx = s0 + 8 * gb + u;
+      v[u] = 0.0;
+      if (sidx < s1) {
+        const int2 en = ents[sidx];
+        v[u] = Hp[(size_t)en.x + (size_t)(cls * 32 * en.y + half * 16 * en.y + i)];
+      }
+    }
+    acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  return acc;
+}
+struct HcFused {
+  const int *frag_ptr; const int2 *ents; const double *Hp; double *Hc; unsigned *ticket;
+  int nfrag, P; unsigned spin_limit;
+};
+__global__ __launch_bounds__(1024) void b_zc_fused_kernel(HcFused hf, int n_own, const int *__restrict__ own_rt, int R_pad, int ne_pad,
+                                                          int nzc, const double2 *__restrict__ Xe, const double2 *__restrict__ Ye,
+                                                          const int *__restrict__ own_pv, const int *__restrict__ zclass, BRowArgs ra,
+                                                          BRowArgs pairs) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) char zf_smem[];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < hf.P) {
+    // ---- producer: 128 elements of the class table per workgroup, eight lanes each
+    const int u = tid & 7, e = (int)blockIdx.x * 128 + (tid >> 3);
+    const int per = 32 * nzc;
+    const bool live = e < hf.nfrag * per;
+    const int g = live ? e / per : 0, rem = live ? e - g * per : 0;
+    const int cls = rem >> 5, half = (rem >> 4) & 1, i = rem & 15;
+    const int s0 = hf.frag_ptr[g], s1 = live ? hf.frag_ptr[g + 1] : s0;
+    double acc = 0.0;
+    const int ng = (s1 - s0) / 8 + 1;                  // (uniform over the wave: its eight elements belong to one fragment)
+    for (int gb = 0; gb < ng; gb += HCS_MAXG) {
+      double v[HCS_MAXG];
+#pragma unroll
+      for (int k = 0; k < HCS_MAXG; ++k) {
+        const int sidx = s0 + 8 * (gb + k) + u;
+        v[k] = 0.0;
+        if (sidx < s1) {
+          const int2 en = hf.ents[sidx];
+          v[k] = hf.Hp[(size_t)en.x + (size_t)(cls * 32 * en.y + half * 16 * en.y + i)];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HCS_MAXG; ++k) {
+        if (gb + k >= ng) break;
+        double t = v[k];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        acc += t;
+      }
+    }
+    if (live && u == 0)
+      __hip_atomic_store(hf.Hc + (size_t)cls * R_pad + (size_t)(g >> 2) * 128 + 64 * half + 16 * (g & 3) + i, acc, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(hf.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- dot workgroup: b_zc_final_kernel with the pair sums and the wait in it
+  double *H = reinterpret_cast<double *>(zf_smem);          // [n_own * 128][nzc]
+  __shared__ double red[64][17];
+  __shared__ double prl[16];
+  __shared__ int s_ready;
+  const int blk = (int)blockIdx.x - hf.P;
+  const int a = tid & 15, w = tid >> 4;
+  const int i = blk * 16 + a;
+  const int zc = zclass[i];
+  const double sc = (ra.slab && tid < 64) ? b_slab_scalar(ra, tid) : 0.0;
+  double fin_z = 0.0;
+  if (w == 0 && i < ra.ne && ra.slab) fin_z = ra.ele_z[i];
+  double2 xe0[8], ye0[8];
+  int sg0[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const bool ok = u < n_own;
+    const int pk = own_pv[(ok ? u : 0) * 64 + w];
+    sg0[u] = (pk >> 24) & 1;
+    xe0[u] = ok ? Xe[(size_t)(pk & 4095) * ne_pad + i] : make_double2(0.0, 0.0);
+    ye0[u] = Ye[(size_t)((pk >> 12) & 4095) * ne_pad + i];
+  }
+  {
+    // the real-space pair sum of electrode row 16 blk + wave, by this wavefront
+    const int row = blk * 16 + (tid >> 6);
+    const double v = row < pairs.ne ? b_row_pairs(pairs, row, tid & 63) : 0.0;
+    if ((tid & 63) == 0) prl[tid >> 6] = v;
+  }
+  if (tid == 0) {
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(hf.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)hf.P) {
+      if (++spins > hf.spin_limit) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_ready = ok;
+  }
+  __syncthreads();
+  const int nrow = n_own * 128;
+  if (s_ready) {
+    // class-major table: runs of rows, classes in use only; sc1 loads, up to four per thread in flight (64 KB of table at most)
+    for (int e0 = tid; e0 < nrow * nzc; e0 += 4 * 1024) {
+      double hv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 1024 * u;
+        hv[u] = 0.0;
+        if (e < nrow * nzc) {
+          const int cls = e / nrow, rowl = e - cls * nrow;
+          const double *src = hf.Hc + (size_t)cls * R_pad + (size_t)own_rt[rowl >> 7] * 128 + (rowl & 127);
+          asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(hv[u]) : "v"(src) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 1024 * u;
+        if (e < nrow * nzc) { const int cls = e / nrow, rowl = e - cls * nrow; H[rowl * nzc + cls] = hv[u]; }
+      }
+    }
+  } else {
+    for (int e = tid; e < nrow * nzc; e += 1024) {      // the wait ran out: the same sums, by this workgroup
+      const int cls = e / nrow, rowl = e - cls * nrow, r = rowl & 127;
+      H[rowl * nzc + cls] = frag_sum_serial(hf.frag_ptr, hf.ents, hf.Hp, 4 * own_rt[rowl >> 7] + ((r & 63) >> 4), cls, r >> 6, r & 15);
+    }
+  }
+  __syncthreads();
+  double sum = 0.0;
+  auto phase = [](double2 X, double2 Y, int neg, double &pa, double &pb) {
+    const double sy = neg ? -Y.y : Y.y;
+    pa = X.x * Y.x - X.y * sy;
+    pb = X.x * sy + X.y * Y.x;
+  };
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int kk = u < n_own ? u : 0;
+    double pa, pb;
+    phase(xe0[u], ye0[u], sg0[u], pa, pb);
+    sum += pa * H[(kk * 128 + w) * nzc + zc];
+    sum += pb * H[(kk * 128 + w + 64) * nzc + zc];
+  }
+  for (int k0 = 8; k0 < n_own; k0 += 4) {
+    double2 xe[4], ye[4];
+    int sg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = k0 + u < n_own;
+      const int pk = own_pv[(ok ? k0 + u : k0) * 64 + w];
+      sg[u] = (pk >> 24) & 1;
+      xe[u] = ok ? Xe[(size_t)(pk & 4095) * ne_pad + i] : make_double2(0.0, 0.0);
+      ye[u] = Ye[(size_t)((pk >> 12) & 4095) * ne_pad + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k0 + u < n_own ? k0 + u : k0;
+      double pa, pb;
+      phase(xe[u], ye[u], sg[u], pa, pb);
+      sum += pa * H[(kk * 128 + w) * nzc + zc];
+      sum += pb * H[(kk * 128 + w + 64) * nzc + zc];
+    }
+  }
+  red[w][a] = sum;
+  __syncthreads();
+  if (w == 0 && i < ra.ne) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) tot += (red[k][a] + red[k + 1][a]) + (red[k + 2][a] + red[k + 3][a]);
+    double v = -tot;
+    if (ra.slab) v -= fin_z * sc;
+    v += prl[a];
+    ra.b_out[i] = v;
+    if (ra.slab && i == 0 && ra.slab_out) *ra.slab_out = sc;
+  }
+}
+
 // (The four row-quarter partials of an atom are added, with the slab and real-space terms, by b_real_combine_kernel.  Letting the
 //  last-arriving quarter block of each atom block do that here -- sc1 hand-off, ticket -- was measured: 32 -> 47 us for the pair
 //  at the headline size, 22 -> 33 us on il_onelayer: 64 late workgroups do serially what 4096 waves of their own launch do at once.)
@@ -1894,9 +2094,20 @@ void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, 
                                   const int *slot_ptr, const int *slot_idx, bool presum, const int *frag_ptr, const int2 *frag_ents, int nfrag,
                                   const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin,
-                                  const BRowArgs *pairs, double *breal_out) {
+                                  const BRowArgs *pairs, double *breal_out, unsigned *ticket, unsigned spin_limit) {
   if (n_own <= 0) return;
   if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
+  if (nfrag > 0 && fin && pairs && ticket) {
+    // ONE launch (round 5): the pieces' sums published through the fence-free hand-off, the pair sums and the dot behind them
+    HcFused hf{frag_ptr, frag_ents, Hp, Hc, ticket, nfrag, (nfrag * 32 * nzc + 127) / 128, spin_limit};
+    const BRowArgs fa = *fin;
+    const size_t lds = (size_t)n_own * 128 * nzc * sizeof(double);
+    static DynLdsCache granted{};
+    ensure_dyn_lds(b_zc_fused_kernel, lds, granted);
+    hipLaunchKernelGGL(b_zc_fused_kernel, dim3(hf.P + ne_pad / 16), dim3(1024), lds, s, hf, n_own, own_rt, pl.R_pad, ne_pad, nzc, Xe, Ye,
+                       own_pv, zclass, fa, *pairs);
+    return;
+  }
   if (nfrag > 0) {
     // pairs: the real-space pair sums ride in this launch (block rows behind the fragments)
     const BRowArgs ra = pairs ? *pairs : BRowArgs{};

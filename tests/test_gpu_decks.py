@@ -346,3 +346,25 @@ def test_small_system_fused_phase_equals_the_separate_launch(monkeypatch, mode):
     else:
         for k in range(3):
             assert rel_err(out[False][k], out[True][k]) < 1e-13
+
+
+def test_one_launch_tail_with_the_in_launch_hand_off_gives_the_bits_of_the_two_launches(headline):
+    """round 5 (review item 1): the pieces' sums, the real-space pair sums and the per-atom dot as ONE launch -- a few workgroups add
+    the pieces and hand the class table to the dot workgroups through write-through stores and a ticket, no fence
+    (CONP_PATH_HC_FUSED).  Measured slower than hc_sum + b_zc_final (profiles/r05_tail_handoff_ab.txt), so not the default; the
+    results are the default path's bit for bit, also when every dot workgroup's bounded wait runs out and it adds the pieces itself
+    (CONP_PATH_HC_NO_WAIT)."""
+    s, at, alist, blist, fx = headline
+    fx.b_cal(at)
+    b0 = fx.vectors()[0].copy()
+    for mask in (capi.PATH_HC_FUSED, capi.PATH_HC_FUSED | capi.PATH_HC_NO_WAIT):
+        with capi.test_paths(mask):
+            fy = FixConp(s)
+            fy.init_lists(alist, blist)
+            fy.setup_post_neighbor(at)
+            fy.b_cal(at)
+            b1 = fy.vectors()[0].copy()
+            fy.b_cal(at)
+            assert np.array_equal(b1, fy.vectors()[0])
+            fy.close()
+        assert np.array_equal(b0, b1)
