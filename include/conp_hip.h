@@ -207,8 +207,20 @@ int conp_km_b_cal(conp_fix *fix, const conp_atoms *atoms, double *bbb /*[Ne] ele
  *                                   sel[i] != 0.  u_brick is what PPPM::compute leaves there when per-atom energies are
  *                                   tallied (ComputePotentialAtom insists on that step, compute_potential_atom.cpp:128-130):
  *                                   the mesh potential of the TOTAL density; the library forms it from the same bricks.
- *   conp_pppm_compute_particle_potential (:452-485): the same for atom i, plus 2 g_ewald q_i / sqrt(pi). */
+ *   conp_pppm_compute_particle_potential (:452-485): the same for atom i, plus 2 g_ewald q_i / sqrt(pi).  RANK-LOCAL: reads the
+ *                                   cached mesh potential (one rank: forms it on demand; several ranks: CONP_ERR_STATE unless a
+ *                                   collective entry formed it since the last update). */
 int conp_pppm_make_rho(conp_fix *fix, const conp_atoms *atoms, double *density, double *ele_density, double *elyte_density);
+/* PPPMCONP keeps the electrolyte brick of every b_cal for its make_rho override (pppm_conp.cpp:172-228, 434-450; elyte_mapped is
+ * reset by conp_pre_force, pppm_conp.h:42).  on != 0: from the next b_cal on the brick of the update stays on the device and
+ * conp_pppm_make_rho adds the fresh electrode brick to it instead of spreading the electrolyte a second time (one rank; under ranks
+ * the bricks are re-made from one gather).  The call itself drops whatever is cached: the glue calls it from conp_pre_force(). */
+int conp_pppm_keep_density(conp_fix *fix, int on);
+/* The mesh potential of the total density -- what PPPM::compute leaves in u_brick when per-atom energies are tallied.  COLLECTIVE
+ * under ranks.  Afterwards conp_pppm_compute_particle_potential is a rank-local stencil gather from the cached brick, like the
+ * reference's (:452-485; compute_potential_atom.cpp:168-174 calls it a different number of times on every rank), until the next
+ * update or re-neighbouring.  conp_pppm_compute_group_potential and conp_compute_potential_atom leave the same cache. */
+int conp_pppm_compute(conp_fix *fix, const conp_atoms *atoms);
 int conp_pppm_compute_group_potential(conp_fix *fix, const conp_atoms *atoms, const int *sel /*[nlocal]*/, double *recv /*[nlocal]*/);
 int conp_pppm_compute_particle_potential(conp_fix *fix, const conp_atoms *atoms, int i, double *u);
 
@@ -236,6 +248,7 @@ typedef struct {
   int inverse_path;        /* how the last inverse (fix_conp.cpp:947-949) was formed: 0 none yet, 1 positive-definite elimination (no
                               pivot search), 2 partial pivoting */
   int inverse_retries;     /* 1: the multi-workgroup pivot panel timed out at its grid barrier and the one-workgroup panel redid it */
+  int pppm_elyte_spreads;  /* `pppm`: how often the electrolyte atoms have been spread onto the mesh so far (b_cal, density and potential queries) */
 } conp_info;
 int conp_fix_info(const conp_fix *fix, conp_info *out);
 /* integer tables; pass NULL for those not wanted.  Sizes: kcount / kcount_expand */

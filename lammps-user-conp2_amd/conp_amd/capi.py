@@ -77,7 +77,7 @@ class conp_info(C.Structure):
                 ("volume", C.c_double), ("gsqmx", C.c_double), ("ug_tot", C.c_double), ("totsetq", C.c_double),
                 ("scalar_output", C.c_double), ("totinve", C.c_double), ("slabcorr", C.c_double),
                 ("n_blist_pairs", C.c_int64), ("n_alist_pairs", C.c_int64), ("n_elyte_charged", C.c_int64),
-                ("inverse_path", C.c_int), ("inverse_retries", C.c_int)]
+                ("inverse_path", C.c_int), ("inverse_retries", C.c_int), ("pppm_elyte_spreads", C.c_int)]
 
 
 # every symbol include/conp_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
@@ -97,6 +97,7 @@ SYMBOLS = [
     "conp_fix_write_timing", "conp_fix_log_drain", "conp_fix_mesg_drain",
     "conp_fix_set_comm", "conp_rccl_unique_id", "conp_fix_comm_init_rccl", "conp_rccl_available", "conp_fix_comm_destroy_rccl",
     "conp_pppm_make_rho", "conp_pppm_compute_group_potential", "conp_pppm_compute_particle_potential",
+    "conp_pppm_keep_density", "conp_pppm_compute",
     "conp_compute_potential_atom",
 ]
 
@@ -205,6 +206,9 @@ def load_library():
     lib.conp_pppm_make_rho.argtypes = [vp, C.POINTER(conp_atoms), dp, dp, dp]
     lib.conp_pppm_compute_group_potential.argtypes = [vp, C.POINTER(conp_atoms), ip, dp]
     lib.conp_pppm_compute_particle_potential.argtypes = [vp, C.POINTER(conp_atoms), C.c_int, dp]
+    if hasattr(lib, "conp_pppm_compute"):
+        lib.conp_pppm_compute.argtypes = [vp, C.POINTER(conp_atoms)]
+        lib.conp_pppm_keep_density.argtypes = [vp, C.c_int]
     lib.conp_compute_potential_atom.argtypes = [vp, C.POINTER(conp_atoms), C.POINTER(conp_neighlist), ip, ip,
                                                 C.POINTER(conp_potential_args), dp]
     lib.conp_fix_set_comm.argtypes = [vp, C.POINTER(conp_comm)]
@@ -435,6 +439,13 @@ class FixConp:
         return a
 
     # -- PPPM coupling beyond b, compute potential/atom ---------------------------------------------
+    def pppm_keep_density(self, on=True):
+        self._check(self.lib.conp_pppm_keep_density(self.h, 1 if on else 0))
+
+    def pppm_compute(self, at):
+        """collective: the mesh potential of the total density (u_brick) formed and cached"""
+        self._check(self.lib.conp_pppm_compute(self.h, C.byref(self.atoms_view(at))))
+
     def pppm_make_rho(self, at, nfft):
         d, e, l = np.zeros(nfft), np.zeros(nfft), np.zeros(nfft)
         self._check(self.lib.conp_pppm_make_rho(self.h, C.byref(self.atoms_view(at)), _dptr(d), _dptr(e), _dptr(l)))

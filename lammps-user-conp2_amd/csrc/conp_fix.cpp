@@ -290,6 +290,14 @@ struct conp_fix {
   double th[6] = {0, 0, 0, 0, 0, 0};    // list check, staging copies, enqueue, wait, scatter, updates
   static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   bool pp_im_clean = false;      // the mesh's imaginary brick is all zero (left so by the b path's last backward pass)
+  // PPPMCONP's per-step caches (pppm_conp.cpp: elyte_density_brick + elyte_mapped, u_brick): pp_keep -- a host that overrides
+  // PPPM::make_rho asked for the electrolyte brick of every b_cal (conp_pppm_keep_density); pp_elyte_valid -- d_pp_elyte holds the
+  // brick of the LAST b_cal and nothing has moved since; pp_u_valid -- d_pp_re holds the mesh potential of the total density
+  // (conp_pppm_compute and the other collective entries leave it), so the per-atom entry only gathers from it.
+  bool pp_keep = false, pp_elyte_valid = false, pp_u_valid = false;
+  int pp_elyte_spreads = 0;      // how often the electrolyte atoms were spread onto the mesh (b_cal and density queries)
+  DevBuf<double> d_pp_elyte, d_pp_xg, d_pp_qg;
+  DevBuf<int> d_pp_iota;
   double Btime = 0., Ctime = 0., Ktime = 0.;      // accumulated like :549-552 (seconds)
   hipEvent_t ev_b[3] = {nullptr, nullptr, nullptr};
   bool ev_pending = false;
@@ -371,6 +379,7 @@ struct conp_fix {
     if (pin_x || pin_q) { (void)hipStreamSynchronize(stream); if (pin_x) (void)hipHostUnregister(const_cast<double *>(pin_x)); if (pin_q) (void)hipHostUnregister(const_cast<double *>(pin_q)); }
     if (h_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_pin); }
     if (h_np) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_np); }
+    if (ren_arena) { (void)hipStreamSynchronize(stream); (void)hipHostFree(ren_arena); ren_arena = nullptr; }
     for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -745,6 +754,7 @@ struct conp_fix {
     if (!idx.initialised) throw ConpError(CONP_ERR_STATE, "post_neighbor before setup_post_neighbor");
     if (!have_blist) throw ConpError(CONP_ERR_STATE, "post_neighbor: no neighbor list (init_list not called)");
     resident_step = -1;
+    pp_elyte_valid = pp_u_valid = false;
     static const bool tren = getenv("CONP_TIME_REN") != nullptr;
     auto tm0 = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
@@ -1371,7 +1381,16 @@ struct conp_fix {
   }
   void upload_xq_n(const conp_atoms *at, int nup) {
     const size_t nx = (size_t)nup * 3, nq = (size_t)nup;
-    if (at->x == pin_x && at->q == pin_q && nup <= pin_n) {
+    bool pinned_ok = at->x == pin_x && at->q == pin_q && nup <= pin_n;
+    if (pinned_ok) {
+      // pointer equality alone does not prove the registration is alive: a host may have freed the arrays and been handed the same
+      // addresses again (create_atoms / read_dump between runs).  The runtime knows (a sub-microsecond table look-up).
+      hipPointerAttribute_t pa;
+      if (hipPointerGetAttributes(&pa, at->x) != hipSuccess || pa.type != hipMemoryTypeHost) { (void)hipGetLastError(); pinned_ok = false; }
+      else if (hipPointerGetAttributes(&pa, at->q) != hipSuccess || pa.type != hipMemoryTypeHost) { (void)hipGetLastError(); pinned_ok = false; }
+      if (!pinned_ok) { pin_x = pin_q = nullptr; pin_n = 0; }      // (nothing to unregister: the registration went with the memory)
+    }
+    if (pinned_ok) {
       // page-locked by the host: two asynchronous DMA transfers, nothing staged, nothing blocks
       HIP_TRY(hipMemcpyAsync(d_x.p, at->x, nx * sizeof(double), hipMemcpyHostToDevice, stream));
       HIP_TRY(hipMemcpyAsync(d_q.p, at->q, nq * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -1817,6 +1836,7 @@ struct conp_fix {
   // through an index list: the owned ones out of dx / dq, or -- decomposed runs -- every rank's, gathered into d_xg / d_qg.
   void b_cal_device(const double *dx, const double *dq, bool coulyes, bool timed = false) {
     const int ne = idx.elenum_all;
+    pp_elyte_valid = pp_u_valid = false;          // positions / charges may have changed: the mesh caches are this update's or nobody's
     const double *ex = decomposed ? d_xg.p : dx, *eq = decomposed ? d_qg.p : dq;
     const int *eidx = decomposed ? d_iota.p : d_elyte_idx.p;
     if (!kspace_ready || !tables_current || d_b == nullptr)
@@ -1844,9 +1864,11 @@ struct conp_fix {
       if (env.rank == 0)
         launch_pppm_b(stream, dpppm, nl, eidx, ex, eq, ne, ne_pad, d_pp_egrid.p, d_pp_ew.p, d_pp_re.p, d_pp_im.p,
                       d_slab_part.p, &n_slab_part, d_bk.p, &pp_im_clean, pp_fin ? &pairs : nullptr, pp_fin ? d_breal.p : nullptr,
-                      pp_fin ? &fin : nullptr);
+                      pp_fin ? &fin : nullptr, pp_keep ? (d_pp_elyte.reserve((size_t)dpppm.nfft), d_pp_elyte.p) : nullptr);
       else
         d_bk.zero(stream);
+      ++pp_elyte_spreads;
+      pp_elyte_valid = pp_keep && env.rank == 0;
       prof.end(stream);
       use_fin = pp_fin;
     } else {
@@ -2630,7 +2652,7 @@ int conp_fix_info(const conp_fix *f, conp_info *o) {
   int64_t nbp = f->n_b_pairs;
   if (f->np_pending) { HIP_TRY(hipStreamSynchronize(f->stream)); nbp = *f->h_np; }     // (the count of a regrouping still in flight)
   o->n_blist_pairs = nbp;
-  o->inverse_path = f->inverse_path; o->inverse_retries = f->inverse_retries; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
+  o->inverse_path = f->inverse_path; o->inverse_retries = f->inverse_retries; o->pppm_elyte_spreads = f->pp_elyte_spreads; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
   CONP_GUARD_END
 }
 
@@ -2854,37 +2876,45 @@ void need_pppm(conp_fix *f) {
     throw ConpError(CONP_ERR_STATE, "Compute requires a compatible KSpace provider like pppm/conp");   // compute_potential_atom.cpp:110
 }
 // Spatially decomposed ranks: the mesh potentials and density bricks are those of ALL atoms.  Every rank gathers the charged owned
-// atoms of all ranks of the wanted kind -- (x, q), one conp_comm gather, like the per-update gather of the electrolyte -- and spreads
-// them onto its own copy of the whole mesh: a REPLICATED mesh (the reference's ranks own bricks of it and exchange ghost planes,
-// pppm_conp.cpp:114,122 GridComm; the mesh of the `pppm` mode is 10^5..10^6 points, a fraction of a millisecond on one GPU), so the
-// collective call gives every rank the same brick and the potentials of its own atoms.  Returns the number of gathered atoms; the
-// device arrays are d_xg / d_qg, indexed by d_iota.
-int pppm_gather_all(conp_fix *f, const conp_atoms *at, int kind) {
+// atoms of all ranks -- (x, q, kind), ONE conp_comm gather per query -- and spreads them onto its own copy of the whole mesh: a
+// REPLICATED mesh (the reference's ranks own bricks of it and exchange ghost planes, pppm_conp.cpp:114,122 GridComm; the mesh of
+// the `pppm` mode is 10^5..10^6 points), so the collective call gives every rank the same brick and the potentials of its own
+// atoms.  The gathered atoms live in buffers of their OWN (d_pp_xg / d_pp_qg / d_pp_iota): the per-update electrolyte gather of the
+// decomposed b path keeps d_xg / d_qg / d_iota to itself.  counts[kind] / first[kind]: the atoms of a kind are one run of d_pp_iota
+// (0 electrolyte, 1 electrode); kind 2 = all = the whole list.
+struct PpGather { int n[3], first[3]; };
+PpGather pppm_gather_all(conp_fix *f, const conp_atoms *at) {
   std::vector<double> pack;
   for (int i = 0; i < at->nlocal; ++i) {
     if (at->q[i] == 0) continue;
-    if (kind == 0 && at->echeck[i] != 0) continue;
-    if (kind == 1 && at->echeck[i] == 0) continue;
     pack.push_back(at->x[3 * (size_t)i]); pack.push_back(at->x[3 * (size_t)i + 1]); pack.push_back(at->x[3 * (size_t)i + 2]);
-    pack.push_back(at->q[i]);
+    pack.push_back(at->q[i]); pack.push_back(at->echeck[i] != 0 ? 1.0 : 0.0);
   }
   std::vector<int> counts(f->env.nranks, 0);
-  f->rc.allgather_int((int)(pack.size() / 4), counts.data());
+  f->rc.allgather_int((int)(pack.size() / 5), counts.data());
   int n = 0;
   for (int v : counts) n += v;
-  std::vector<double> all((size_t)std::max(n, 1) * 4), xs((size_t)std::max(n, 1) * 3), qs(std::max(n, 1));
-  if (pack.empty()) pack.resize(4);
-  f->rc.gatherv(pack.data(), counts, 4, all.data());
-  for (int k = 0; k < n; ++k) {
-    xs[3 * (size_t)k] = all[4 * (size_t)k]; xs[3 * (size_t)k + 1] = all[4 * (size_t)k + 1]; xs[3 * (size_t)k + 2] = all[4 * (size_t)k + 2];
-    qs[k] = all[4 * (size_t)k + 3];
+  std::vector<double> all((size_t)std::max(n, 1) * 5), xs((size_t)std::max(n, 1) * 3), qs(std::max(n, 1));
+  if (pack.empty()) pack.resize(5);
+  f->rc.gatherv(pack.data(), counts, 5, all.data());
+  std::vector<int> iota;
+  iota.reserve(std::max(n, 1));
+  PpGather g{};
+  for (int kind = 0; kind < 2; ++kind) {
+    g.first[kind] = (int)iota.size();
+    for (int k = 0; k < n; ++k) if ((all[5 * (size_t)k + 4] != 0.0) == (kind == 1)) iota.push_back(k);
+    g.n[kind] = (int)iota.size() - g.first[kind];
   }
-  std::vector<int> iota(std::max(n, 1));
-  for (int k = 0; k < n; ++k) iota[k] = k;
-  f->d_iota.upload(iota, f->stream);
-  f->d_xg.upload(xs, f->stream); f->d_qg.upload(qs, f->stream);
+  g.first[2] = 0; g.n[2] = n;
+  for (int k = 0; k < n; ++k) {
+    xs[3 * (size_t)k] = all[5 * (size_t)k]; xs[3 * (size_t)k + 1] = all[5 * (size_t)k + 1]; xs[3 * (size_t)k + 2] = all[5 * (size_t)k + 2];
+    qs[k] = all[5 * (size_t)k + 3];
+  }
+  if (iota.empty()) iota.push_back(0);
+  f->d_pp_iota.upload(iota, f->stream);
+  f->d_pp_xg.upload(xs, f->stream); f->d_pp_qg.upload(qs, f->stream);
   f->sync();                       // (the host vectors go out of scope)
-  return n;
+  return g;
 }
 // index lists of the owned atoms that carry charge, by kind (0 electrolyte, 1 electrode, 2 all), and x, q on the device
 int pppm_list(conp_fix *f, const conp_atoms *at, int kind, DevBuf<int> &d_idx) {
@@ -2905,23 +2935,49 @@ void pppm_upload(conp_fix *f, const conp_atoms *at) {
   f->resident_step = -1;
   f->upload_xq_n(at, f->nall);
 }
-// u_brick of the total density into d_pp_re
+// u_brick of the total density into d_pp_re (what PPPM::compute leaves there with per-atom energies on).  COLLECTIVE under ranks.
 void pppm_total_potential(conp_fix *f, const conp_atoms *at) {
   DevBuf<int> d_idx;
   pppm_upload(f, at);
   f->d_pp_scratch.reserve(2048);
   if (f->decomposed) {
-    const int n = pppm_gather_all(f, at, 2);
-    launch_pppm_density(f->stream, f->dpppm, n, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    const PpGather g = pppm_gather_all(f, at);
+    launch_pppm_density(f->stream, f->dpppm, g.n[2], f->d_pp_iota.p, f->d_pp_xg.p, f->d_pp_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
   } else {
     const int n = pppm_list(f, at, 2, d_idx);
     launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
   }
+  ++f->pp_elyte_spreads;
   launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p); f->pp_im_clean = false;
   HIP_TRY(hipGetLastError());
   f->sync();                       // d_idx goes out of scope
+  f->pp_u_valid = true;
 }
 }  // namespace
+
+// PPPMCONP keeps the electrolyte brick of every b_cal for its make_rho override (pppm_conp.cpp:172-228, 434-450; elyte_mapped is
+// reset by conp_pre_force, pppm_conp.h:42).  on != 0: from the next b_cal on the brick of the update is kept on the device
+// (d_pp_elyte) and conp_pppm_make_rho adds the electrode brick to it instead of spreading the electrolyte again; the call itself
+// drops whatever brick is cached (a new step begins).
+int conp_pppm_keep_density(conp_fix *f, int on) {
+  CONP_GUARD_BEGIN
+  need_pppm(f);
+  f->pp_keep = on != 0;
+  f->pp_elyte_valid = false;
+  f->pp_u_valid = false;
+  CONP_GUARD_END
+}
+
+// The mesh potential of the total density -- what PPPM::compute leaves in u_brick when per-atom energies are tallied.  COLLECTIVE
+// under ranks (one gather of all ranks' charged atoms, a replicated mesh solve); afterwards conp_pppm_compute_particle_potential is
+// a rank-local stencil gather from the cached brick, like the reference's (pppm_conp.cpp:452-485), until the next update.
+int conp_pppm_compute(conp_fix *f, const conp_atoms *at) {
+  CONP_GUARD_BEGIN
+  f->drop_graph();
+  need_pppm(f);
+  pppm_total_potential(f, at);
+  CONP_GUARD_END
+}
 
 int conp_pppm_make_rho(conp_fix *f, const conp_atoms *at, double *density, double *ele_density, double *elyte_density) {
   CONP_GUARD_BEGIN
@@ -2932,30 +2988,33 @@ int conp_pppm_make_rho(conp_fix *f, const conp_atoms *at, double *density, doubl
   f->d_pp_scratch.reserve(2048);
   f->d_pp_ele.reserve(nf);
   std::vector<double> e(nf), l(nf);
+  DevBuf<int> d_idx0, d_idx1;
+  PpGather g{};
+  if (f->decomposed) g = pppm_gather_all(f, at);          // ONE gather, the atoms tagged with their kind
   {
-    DevBuf<int> d_idx;
-    if (f->decomposed) {
-      const int n = pppm_gather_all(f, at, 1);
-      launch_pppm_density(f->stream, f->dpppm, n, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_ele.p, f->d_pp_scratch.p);
-    } else {
-      const int n = pppm_list(f, at, 1, d_idx);          // ele_make_rho (pppm_conp.cpp:385-426)
-      launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_ele.p, f->d_pp_scratch.p);
+    if (f->decomposed)
+      launch_pppm_density(f->stream, f->dpppm, g.n[1], f->d_pp_iota.p + g.first[1], f->d_pp_xg.p, f->d_pp_qg.p, f->d_pp_ele.p, f->d_pp_scratch.p);
+    else {
+      const int n = pppm_list(f, at, 1, d_idx1);          // ele_make_rho (pppm_conp.cpp:385-426)
+      launch_pppm_density(f->stream, f->dpppm, n, d_idx1.p, f->d_x.p, f->d_q.p, f->d_pp_ele.p, f->d_pp_scratch.p);
     }
     HIP_TRY(hipMemcpyAsync(e.data(), f->d_pp_ele.p, nf * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-    f->sync();
   }
-  {
-    DevBuf<int> d_idx;
-    if (f->decomposed) {
-      const int n = pppm_gather_all(f, at, 0);
-      launch_pppm_density(f->stream, f->dpppm, n, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
-    } else {
-      const int n = pppm_list(f, at, 0, d_idx);          // elyte_make_rho (:172-228)
-      launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
+  if (f->pp_elyte_valid && !f->decomposed) {
+    // the brick b_cal left for this step (elyte_mapped, pppm_conp.cpp:437-442): no second spread of the electrolyte
+    HIP_TRY(hipMemcpyAsync(l.data(), f->d_pp_elyte.p, nf * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  } else {
+    if (f->decomposed)
+      launch_pppm_density(f->stream, f->dpppm, g.n[0], f->d_pp_iota.p + g.first[0], f->d_pp_xg.p, f->d_pp_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
+    else {
+      const int n = pppm_list(f, at, 0, d_idx0);          // elyte_make_rho (:172-228)
+      launch_pppm_density(f->stream, f->dpppm, n, d_idx0.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
     }
+    ++f->pp_elyte_spreads;
+    f->pp_u_valid = false;                                 // (d_pp_re holds a density now)
     HIP_TRY(hipMemcpyAsync(l.data(), f->d_pp_re.p, nf * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-    f->sync();
   }
+  f->sync();
   if (ele_density) std::memcpy(ele_density, e.data(), nf * sizeof(double));
   if (elyte_density) std::memcpy(elyte_density, l.data(), nf * sizeof(double));
   if (density) for (size_t k = 0; k < nf; ++k) density[k] = l[k] + e[k];        // make_rho override :434-450
@@ -2983,12 +3042,25 @@ int conp_pppm_compute_group_potential(conp_fix *f, const conp_atoms *at, const i
   CONP_GUARD_END
 }
 
+// RANK-LOCAL like the reference's (pppm_conp.cpp:452-485; compute_potential_atom.cpp:168-174 calls it once per owned atom of the
+// group, a different number of times on every rank): a stencil gather from the cached mesh potential.  Under several ranks the brick
+// must have been formed by a collective entry since the last update (conp_pppm_compute, conp_pppm_compute_group_potential,
+// conp_compute_potential_atom); one rank forms it on demand.
 int conp_pppm_compute_particle_potential(conp_fix *f, const conp_atoms *at, int i, double *u) {
   CONP_GUARD_BEGIN
   f->drop_graph();
   need_pppm(f);
   if (!u || i < 0 || i >= at->nlocal) throw ConpError(CONP_ERR_ARG, "atom index out of range");
-  pppm_total_potential(f, at);
+  if (!f->pp_u_valid) {
+    if (f->decomposed || f->env.nranks > 1)
+      throw ConpError(CONP_ERR_STATE, "pppm/conp/hip: compute_particle_potential is rank-local -- under several MPI ranks the mesh potential "
+                                      "has to be formed by a collective call first (conp_pppm_compute / compute_group_potential)");
+    pppm_total_potential(f, at);
+  }
+  if (at->nlocal + at->nghost != f->nall) throw ConpError(CONP_ERR_STATE, "atom count changed without post_neighbor");
+  // the atom's CURRENT position and charge (4 doubles), the brick as it is
+  HIP_TRY(hipMemcpyAsync(f->d_x.p + 3 * (size_t)i, at->x + 3 * (size_t)i, 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(f->d_q.p + i, at->q + i, sizeof(double), hipMemcpyHostToDevice, f->stream));
   std::vector<int> idx(1, i);
   DevBuf<int> d_idx;
   DevBuf<double> d_out;
@@ -3036,11 +3108,12 @@ int conp_compute_potential_atom(conp_fix *f, const conp_atoms *at, const conp_ne
     d_idx.upload(all, f->stream);
     f->d_pp_scratch.reserve(2048);
     if (f->decomposed) {           // all ranks' charged atoms on this rank's copy of the mesh (pppm_gather_all)
-      const int ng = pppm_gather_all(f, at, 2);
-      launch_pppm_density(f->stream, f->dpppm, ng, f->d_iota.p, f->d_xg.p, f->d_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
+      const PpGather g = pppm_gather_all(f, at);
+      launch_pppm_density(f->stream, f->dpppm, g.n[2], f->d_pp_iota.p, f->d_pp_xg.p, f->d_pp_qg.p, f->d_pp_re.p, f->d_pp_scratch.p);
     } else
       launch_pppm_density(f->stream, f->dpppm, n, d_idx.p, f->d_x.p, f->d_q.p, f->d_pp_re.p, f->d_pp_scratch.p);
     launch_pppm_poisson(f->stream, f->dpppm, f->d_pp_re.p, f->d_pp_im.p); f->pp_im_clean = false;
+    ++f->pp_elyte_spreads; f->pp_u_valid = true;
     std::vector<int> idx;
     for (int i = 0; i < at->nlocal; ++i) if (sel[i]) idx.push_back(i);
     DevBuf<int> d_pidx;

@@ -104,7 +104,8 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
                    int ne_pad, const int *egrid, const double *ew, double *re, double *im, double *slab_part, int *n_slab_part,
                    double *bk, bool *im_clean /* in/out: `im` is all zero -- then it receives the charges and no clearing launch is needed */,
                    const BRowArgs *pairs = nullptr /*with breal_out: the real-space pair sums of these rows ride in the spread launch*/,
-                   double *breal_out = nullptr, BRowArgs *fin = nullptr /*the gather completes the rows of b (needs fin->breal)*/);
+                   double *breal_out = nullptr, BRowArgs *fin = nullptr /*the gather completes the rows of b (needs fin->breal)*/,
+                   double *keep_rho = nullptr /*[nfft]: receives the electrolyte density brick of this update*/);
 
 // PPPM coupling beyond b (pppm_conp.cpp:385-534) and the pair part of compute potential/atom (compute_potential_atom.cpp:223-308)
 void launch_pppm_density(hipStream_t s, const PppmDev &pd, int n, const int *idx, const double *x, const double *q, double *rho,

@@ -508,7 +508,7 @@ __global__ void pppm_greens_kernel(int nfft, double scaleinv, const double *__re
 // spread launch's spare blocks) with b_row's operations -- instead of by b_real_combine in a launch of its own.
 __global__ __launch_bounds__(256) void pppm_gather_kernel(PppmDev pd, int ne, int ne_pad, const int *__restrict__ egrid /*[ne][3]*/,
                                                           const double *__restrict__ ew /*[ne][3][8]*/,
-                                                          const double *__restrict__ u, double *__restrict__ bk, int finish, BRowArgs ra) {
+                                                          const double *__restrict__ u, double *bk /*not restrict: with `finish` b_row reads back what this kernel stored (ra.bk is the same buffer)*/, int finish, BRowArgs ra) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= ne) return;
   // (every wave derives the slab scalar with the same summation tree, like b_real_combine_kernel)
@@ -642,7 +642,7 @@ static bool poisson_three_launches(hipStream_t s, const PppmDev &pd, double *re,
 // this rank's k-space b through the mesh: bk[0..ne) = PPPM b (slot 0), slots 1..3 zeroed
 void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_idx, const double *x, const double *q, int ne,
                    int ne_pad, const int *egrid, const double *ew, double *re, double *im, double *slab_part, int *n_slab_part,
-                   double *bk, bool *im_clean, const BRowArgs *pairs, double *breal_out, BRowArgs *fin) {
+                   double *bk, bool *im_clean, const BRowArgs *pairs, double *breal_out, BRowArgs *fin, double *keep_rho) {
   const bool fused = mesh_smooth(pd);
   FftPlan fx, fy;
   // the density brick: `im` when the last backward pass left it all zero (*im_clean) -- one launch fewer per update
@@ -650,7 +650,9 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
                         (size_t)2 * pd.nx * pd.ny * sizeof(double2) + (size_t)2 * (pd.nx + pd.ny) * sizeof(double) <= 128 * 1024;
   const double gscale = 1.0 / ((double)pd.nx * pd.ny * pd.nz);
   // deck-sized systems: the forward xy pass spreads the charges itself (CONP_PPPM_SPREAD_LAUNCH: comparison switch, the launch of its own)
-  const bool spread_launch = path_on(CONP_PATH_PPPM_SPREAD_LAUNCH);      // (read per call: the test flips it between two handles)
+  // keep_rho: somebody wants the electrolyte density brick of this update (the make_rho override, pppm_conp.cpp:434-450) -- the brick
+  // exists only on the path that spreads in a launch of its own; it is copied out before the forward transform overwrites it
+  const bool spread_launch = path_on(CONP_PATH_PPPM_SPREAD_LAUNCH) || keep_rho != nullptr;      // (read per call: the test flips it between two handles)
   if (xy_fused && !spread_launch && nl <= 8192 && pd.nz <= 1024 && pd.order * pd.order <= 64) {
     BRowArgs ra{};
     const bool rows = pairs && breal_out;
@@ -679,6 +681,7 @@ void launch_pppm_b(hipStream_t s, const PppmDev &pd, int nl, const int *elyte_id
   int nrb = 0;
   if (pairs && breal_out) { ra = *pairs; nrb = (ra.ne + 3) / 4; }
   hipLaunchKernelGGL(pppm_spread_kernel, dim3(nb + nrb), dim3(256), 0, s, pd, nl, elyte_idx, x, q, rho, slab_part, npass, nb, ra, breal_out);
+  if (keep_rho) (void)hipMemcpyAsync(keep_rho, rho, (size_t)pd.nfft * sizeof(double), hipMemcpyDeviceToDevice, s);
   if (!(xy_fused && poisson_three_launches(s, pd, re, im, use_im, use_im))) {
     dft3(s, pd, -1.0, re, im, fused, gscale, use_im, false);
     if (!fused)

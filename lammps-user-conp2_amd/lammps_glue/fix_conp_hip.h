@@ -34,6 +34,8 @@ class FixConpHip : public Fix {
   void setup_post_neighbor() override;
   void setup_pre_force(int) override;
   void pre_exchange() override;
+  void setup_pre_exchange() override { pre_exchange(); }   /* Verlet::setup's exchange / borders grow the atom arrays without a pre_exchange() call */
+  void post_run() override { pre_exchange(); }             /* between runs (create_atoms, read_dump, ...) the arrays may move: nothing stays page-locked */
   void post_neighbor() override;
   void pre_force(int) override;
   void post_force(int) override;

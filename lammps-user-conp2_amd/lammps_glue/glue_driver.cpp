@@ -37,6 +37,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <algorithm>
 #include <vector>
 
 #define CONP_GLUE_MOCK 1
@@ -238,6 +239,27 @@ int run_case(const char *path, bool provider, int me, int nprocs, MockCommRank *
       for (int j = 0; j < info.elenum_all; ++j) out.f("a %d %d %.17g\n", i, j, aaa[(size_t)i * info.elenum_all + j]);
     }
     for (int i = 0; i < info.elenum; ++i) out.f("m %d %d\n", i, ele2eleall[i]);
+    if (pppm_style) {
+      // the step goes on: FixConp::update_charge has written the electrode charges, then LAMMPS calls force->kspace->compute() --
+      // PPPM::compute's particle_map() / make_rho() are the provider's overrides (pppm_conp.cpp:428-450).  What the base class is
+      // handed, how often the base's own steps ran, and whether the library spread the electrolyte a second time:
+      conp_info i0, i1;
+      must(conp_fix_info(pppm_style->handle(), &i0));
+      pppm_style->compute(1, 0);
+      must(conp_fix_info(pppm_style->handle(), &i1));
+      out.f("rho_calls %d %d spreads %d %d\n", pppm_style->base_particle_map_calls, pppm_style->base_make_rho_calls, i0.pppm_elyte_spreads,
+            i1.pppm_elyte_spreads);
+      if (const char *rp = std::getenv("GLUE_RHO_OUT")) {
+        std::ofstream rf(rp, std::ios::binary);
+        rf.write(reinterpret_cast<const char *>(pppm_style->density_fft.data()), (std::streamsize)(pppm_style->density_fft.size() * sizeof(double)));
+      }
+      kspmod->conp_pre_force();                      // next step (pppm_conp.h:42): the kept brick is dropped ...
+      std::vector<double> bbb2(info.elenum, 0.0);
+      kspmod->b_cal(bbb2.data());                    // ... and b_cal makes this step's
+      double dmax = 0.0;
+      for (int i = 0; i < info.elenum; ++i) dmax = std::max(dmax, std::abs(bbb2[i] - bbb[i]));
+      out.f("b_again %.17g\n", dmax);
+    }
     if (pppm_style) {      // what ComputePotentialAtom asks of the provider (compute_potential_atom.cpp:165-175), group 1 = eleleft
       std::vector<double> recv(nlocal, 0.0);
       kspmod->compute_group_potential(gb, recv.data());

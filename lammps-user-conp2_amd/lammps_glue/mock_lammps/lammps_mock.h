@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "mpi_mock.h"
 
@@ -54,9 +55,27 @@ class Pointers {
 };
 
 // LAMMPS' PPPM kspace style and Compute base, as far as pppm_conp_hip.* / compute_potential_atom_hip.* touch them
+// PPPM::compute (pppm.cpp @ 27May2021) begins with  particle_map(); make_rho();  -- both virtual -- then sums the ghost planes into
+// their owners (gc->reverse_comm), copies the owned brick to the FFT layout (brick2fft) and solves.  The mock runs the two virtuals
+// on a brick that covers the rank's share of the mesh plus `order` ghost planes on every side (one rank: the whole mesh), folds the
+// ghost planes back periodically and keeps the result (`density_fft`, [nz][ny][nx]): what the real class would transform.
+typedef double FFT_SCALAR;
 class PPPM : public KSpace, protected Pointers {
  public:
   explicit PPPM(LAMMPS *l) : Pointers(l) {}
+  virtual void compute(int eflag, int vflag);
+  virtual void particle_map() { ++base_particle_map_calls; }
+  virtual void make_rho();                      // (the real one clears the brick and spreads every charged atom: counted here)
+  int base_particle_map_calls = 0, base_make_rho_calls = 0;
+  FFT_SCALAR ***density_brick = nullptr;        // [nzlo_out..nzhi_out][nylo_out..nyhi_out][nxlo_out..nxhi_out]
+  int nxlo_in = 0, nxhi_in = -1, nylo_in = 0, nyhi_in = -1, nzlo_in = 0, nzhi_in = -1;
+  int nxlo_out = 0, nxhi_out = -1, nylo_out = 0, nyhi_out = -1, nzlo_out = 0, nzhi_out = -1, ngrid = 0;
+  std::vector<double> density_fft;
+  void mock_allocate();
+ private:
+  std::vector<FFT_SCALAR> brick_store;
+  std::vector<FFT_SCALAR *> brick_rows;
+  std::vector<FFT_SCALAR **> brick_planes;
 };
 class Compute : protected Pointers {
  public:
@@ -91,6 +110,8 @@ class Fix : protected Pointers {
   virtual void setup_post_neighbor() {}
   virtual void setup_pre_force(int) {}
   virtual void pre_exchange() {}
+  virtual void setup_pre_exchange() {}
+  virtual void post_run() {}
   virtual void post_neighbor() {}
   virtual void pre_force(int) {}
   virtual void post_force(int) {}

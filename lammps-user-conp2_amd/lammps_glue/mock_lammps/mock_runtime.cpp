@@ -1,5 +1,6 @@
 // Minimal bodies for the interface mock (lammps_mock.h) -- a test host for the glue, NOT LAMMPS.
 // Errors become C++ exceptions so that the driver can report the message the glue passed to error->all().
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -73,6 +74,39 @@ int MPI_Allgather(const void *send, int scount, MPI_Datatype t, void *recv, int 
 }
 
 namespace LAMMPS_NS {
+
+void PPPM::mock_allocate() {
+  nxlo_in = 0; nxhi_in = nx_pppm - 1; nylo_in = 0; nyhi_in = ny_pppm - 1; nzlo_in = 0; nzhi_in = nz_pppm - 1;
+  nxlo_out = -order; nxhi_out = nx_pppm - 1 + order; nylo_out = -order; nyhi_out = ny_pppm - 1 + order;
+  nzlo_out = -order; nzhi_out = nz_pppm - 1 + order;
+  const int ex = nxhi_out - nxlo_out + 1, ey = nyhi_out - nylo_out + 1, ez = nzhi_out - nzlo_out + 1;
+  ngrid = ex * ey * ez;
+  brick_store.assign((size_t)ngrid, 0.0);
+  brick_rows.resize((size_t)ey * ez);
+  brick_planes.resize(ez);
+  // offset pointer arrays like Memory::create3d_offset: density_brick[z][y][x] with z, y, x from the *_out lower bounds
+  for (int z = 0; z < ez; ++z) {
+    for (int y = 0; y < ey; ++y) brick_rows[(size_t)z * ey + y] = brick_store.data() + ((size_t)z * ey + y) * ex - nxlo_out;
+    brick_planes[z] = brick_rows.data() + (size_t)z * ey - nylo_out;
+  }
+  density_brick = brick_planes.data() - nzlo_out;
+}
+void PPPM::make_rho() {
+  ++base_make_rho_calls;
+  std::fill(brick_store.begin(), brick_store.end(), 0.0);
+}
+void PPPM::compute(int, int) {
+  if (density_brick == nullptr) mock_allocate();
+  particle_map();
+  make_rho();
+  // gc->reverse_comm + brick2fft on one rank: every ghost point is added to its periodic image
+  density_fft.assign((size_t)nx_pppm * ny_pppm * nz_pppm, 0.0);
+  auto wrap = [](int i, int n) { return ((i % n) + n) % n; };
+  for (int z = nzlo_out; z <= nzhi_out; ++z)
+    for (int y = nylo_out; y <= nyhi_out; ++y)
+      for (int x = nxlo_out; x <= nxhi_out; ++x)
+        density_fft[((size_t)wrap(z, nz_pppm) * ny_pppm + wrap(y, ny_pppm)) * nx_pppm + wrap(x, nx_pppm)] += density_brick[z][y][x];
+}
 
 void Error::all(const char *file, int line, const std::string &msg) {
   (void)file; (void)line;

@@ -109,19 +109,47 @@ void PPPMConpHip::a_cal(double *aaa) {          /* the Ewald matrix, like PPPMCO
   }
 }
 
+void PPPMConpHip::conp_pre_force() {           /* pppm_conp.h:42: elyte_mapped = false -- a new step, the kept brick is stale */
+  if (h) fail_if(conp_pppm_keep_density(h, 1));
+}
+
 void PPPMConpHip::b_cal(double *bbb) {          /* spread, Poisson solve, stencil gather on the device mesh (:269-316) */
+  if (!bcal_done) fail_if(conp_pppm_keep_density(h, 1));      /* the make_rho override wants the electrolyte brick of every b_cal */
+  bcal_done = true;
   conp_atoms at = view();
   std::vector<double> ball(fixconp->elenum_all);
   fail_if(conp_km_b_cal(h, &at, ball.data()));
   for (int i = 0; i < fixconp->elenum; ++i) bbb[i] = ball[lib_tag2eleall[fixconp->ele2tag[i]]];
 }
 
+void PPPMConpHip::particle_map() {              /* pppm_conp.cpp:428-432 */
+  if (!bcal_done || fixconp == nullptr) PPPM::particle_map();
+  /* else: the library maps the atoms on the device when it spreads them (elyte_particle_map :126-170 inside b_cal) */
+}
+
+void PPPMConpHip::make_rho() {                  /* pppm_conp.cpp:434-450 */
+  if (!bcal_done || fixconp == nullptr) { PPPM::make_rho(); return; }
+  conp_atoms at = view();
+  dens.resize((size_t)nx_pppm * ny_pppm * nz_pppm);
+  /* electrolyte brick as b_cal left it (not spread again on one rank) + the electrode brick of the CURRENT charges (ele_make_rho
+   * :385-426); the library's bricks are [nz][ny][nx] with the ghost planes folded in, so the owned points are filled and the
+   * ghost planes left zero: PPPM::compute's ghost sum (gc->reverse_comm) then adds nothing */
+  fail_if(conp_pppm_make_rho(h, &at, dens.data(), nullptr, nullptr));
+  std::memset(&(density_brick[nzlo_out][nylo_out][nxlo_out]), 0, (size_t)ngrid * sizeof(FFT_SCALAR));
+  for (int iz = nzlo_in; iz <= nzhi_in; ++iz)
+    for (int iy = nylo_in; iy <= nyhi_in; ++iy)
+      for (int ix = nxlo_in; ix <= nxhi_in; ++ix)
+        density_brick[iz][iy][ix] = (FFT_SCALAR)dens[((size_t)iz * ny_pppm + iy) * nx_pppm + ix];
+}
+
 double PPPMConpHip::compute_particle_potential(int i) {
-  // (several MPI ranks: every rank gathers all ranks' charged atoms onto its own copy of the mesh -- a COLLECTIVE call, like the
-  //  reference's, whose PPPM::compute fills u_brick on all ranks before anybody asks for a potential)
+  // RANK-LOCAL, like the reference's (pppm_conp.cpp:452-485; compute_potential_atom.cpp:168-174 calls it once per owned atom of
+  // the group -- a different number of calls on every rank): a stencil gather from the mesh potential the library cached when a
+  // collective entry last formed it (compute_group_potential, compute potential/atom).  Under several ranks a call without such
+  // a brick is an error (error->one: only this rank is here), not a hidden collective.
   conp_atoms at = view();
   double u = 0.0;
-  fail_if(conp_pppm_compute_particle_potential(h, &at, i, &u));
+  if (conp_pppm_compute_particle_potential(h, &at, i, &u) != CONP_OK) error->one(FLERR, conp_last_error());
   return u;
 }
 

@@ -36,18 +36,24 @@ class PPPMConpHip : public PPPM, public KSpaceModule {
   void a_cal(double *aaa) override;                                   /* :91-101 */
   void a_read() override {}                                           /* :103-107: the handle sizes its own mesh arrays */
   void b_cal(double *bbb) override;                                   /* :269-316 */
-  void conp_pre_force() override {}                                   /* :42 elyte_mapped = false: nothing is cached between steps here */
+  void conp_pre_force() override;                                     /* pppm_conp.h:42 elyte_mapped = false: the library drops the brick it kept */
   void update_charge() override {}                                    /* :45 ele_make_rho: the electrode brick is made when asked for */
   double compute_particle_potential(int i) override;                  /* :452-485 */
   void compute_group_potential(int groupbit, double *recv) override;  /* :487-534 */
   double return_qsum() override { return qsum; }                      /* pppm_conp.h:48 */
+  /* PPPM::compute's two virtual steps (pppm_conp.cpp:428-450): once b_cal has run, the density PPPM::compute transforms is the
+   * electrolyte brick b_cal made for this step + the electrode brick of the charges update_charge wrote -- no second spread of
+   * every atom.  Before the first b_cal (or without a registered fix) the base class's own steps run. */
+  void particle_map() override;
+  void make_rho() override;
   /* the density the make_rho override (:434-450) hands to PPPM::compute: electrolyte brick + electrode brick, [nz][ny][nx] */
   void total_density(double *density_brick);
   conp_fix *handle() { return h; }
 
  private:
   conp_fix *h;
-  bool first;
+  bool first, bcal_done = false;
+  std::vector<double> dens;
   std::vector<int> echeck, lib_tag2eleall, nolist, sel;
   std::vector<double> xflat, cutsq0;
   void fail_if(int status);

@@ -11,6 +11,7 @@ import pytest
 
 from conp_amd import FixConp, neighbor, systems
 from conp_amd.capi import fix_command_for
+from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -49,12 +50,15 @@ def write_case(path, s, at, lists, tokens, steps, variable=("-", 0.0), modify=()
         fh.write("\n".join(out) + "\n")
 
 
+ENV_EXTRA = None
+
+
 def run_driver(case, cwd, *extra):
     """case: one case file, or a list of them = one per rank thread (`glue_driver ranks N ...`)"""
     if not os.path.exists(DRIVER):            # normally built by __graft_entry__.build(); g++ is on the GPU box too
         subprocess.check_call(["make", "-C", os.path.dirname(DRIVER), "driver"])
     cmd = [DRIVER, case, *extra] if isinstance(case, str) else [DRIVER, "ranks", str(len(case)), *case, *extra]
-    p = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **(ENV_EXTRA or {})))
     res = {"scalar": {}, "q": {}, "f": {}, "error": None, "screen": [], "rc": p.returncode, "scalar_by_rank": {}}
     for line in p.stdout.splitlines():
         rank = 0
@@ -319,3 +323,40 @@ def test_pppm_conp_hip_kspace_style_executed(tmp_path):
     i0 = int(np.nonzero(tags == up[0])[0][0])
     assert up[1] == pytest.approx(fx.pppm_particle_potential(at, i0), rel=1e-11)
     fx.close()
+
+
+def test_pppm_compute_is_handed_the_cached_bricks_by_the_make_rho_override(tmp_path, oracle):
+    """SURVEY 8f-2 / pppm_conp.cpp:428-450: after b_cal, LAMMPS' own PPPM::compute (the mock runs its first two virtual steps and the
+    ghost sum) must be handed electrolyte brick + electrode brick by the provider's particle_map / make_rho overrides -- equal to the
+    oracle's total brick --, the base class's own spread must not run, and the library must not spread the electrolyte a second
+    time for it (the brick b_cal made for the step is kept: conp_info.pppm_elyte_spreads stands still across PPPM::compute);
+    conp_pre_force of the next step drops the kept brick and b_cal comes out the same again."""
+    global ENV_EXTRA
+    import oracle_py
+    s = systems.deck("dilute", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    at.q[at.echeck == 1] = 0.013; at.q[at.echeck == -1] = -0.013      # (the deck's electrode atoms start uncharged: as if update_charge had run)
+    mesh, order = (27, 24, 144), 5
+    case = str(tmp_path / "case.txt")
+    rho_path = str(tmp_path / "rho.bin")
+    write_case(case, s, at, [alist, blist], fix_command_for(s, extra=["pppm"]), [(0, s.potdiff, 0, None)], mesh=(*mesh, order))
+    ENV_EXTRA = {"GLUE_RHO_OUT": rho_path}
+    try:
+        res, proc = run_driver(case, str(tmp_path), "provider")
+    finally:
+        ENV_EXTRA = None
+    assert res["rc"] == 0 and res["error"] is None, proc.stdout[-2000:] + proc.stderr[-2000:]
+    calls = [ln.split() for ln in proc.stdout.splitlines() if ln.startswith("rho_calls ")]
+    again = [ln.split() for ln in proc.stdout.splitlines() if ln.startswith("b_again ")]
+    assert len(calls) == 1 and len(again) == 1
+    base_map, base_rho, spreads_before, spreads_after = (int(v) for v in (calls[0][1], calls[0][2], calls[0][4], calls[0][5]))
+    assert base_map == 0 and base_rho == 0                  # the base class never spread anything
+    assert spreads_before >= 1 and spreads_after == spreads_before      # nor did the library, a second time
+    rho = np.fromfile(rho_path, dtype=np.float64)
+    assert rho.size == mesh[0] * mesh[1] * mesh[2]
+    pp = oracle_py.Pppm(oracle, s, mesh, order)
+    d_o, e_o, l_o = pp.make_rho(mesh, at.x, at.q, at.echeck, at.nlocal)
+    pp.close()
+    assert np.abs(e_o).max() > 0 and np.abs(l_o).max() > 0
+    assert rel_err(rho, d_o.ravel()) < 1e-12
+    assert float(again[0][1]) <= 1e-12 * 10.0               # the next step's b_cal: the same b (f64 atomics: to rounding)

@@ -184,3 +184,43 @@ def test_compute_potential_atom_matches_oracle(oracle, deck, mode, mesh, eta):
             v = pot[:at.nlocal][at.echeck[:at.nlocal] == sign]
             assert v.std() < 5e-3 * max(abs(v.mean()), s.potdiff)
     pp.close(); fx.close()
+
+
+def test_per_atom_potential_reads_the_cached_brick_and_the_kept_electrolyte_brick_is_reused(oracle):
+    """(i) conp_pppm_compute (collective under ranks) forms the mesh potential of the total density once; compute_particle_potential is
+    then a stencil gather from that brick -- any number of calls, no further mesh solve (the electrolyte spread counter stands
+    still), each equal to the group entry's value + 2 g q / sqrt(pi).  (ii) With conp_pppm_keep_density the brick b_cal made stays
+    on the device and make_rho adds the electrode brick to it: the same bricks as a fresh spread, no second spread; an update
+    (or conp_pre_force's call) drops it."""
+    s = systems.deck("dilute", "ffield", etypes=True)
+    at, alist, blist = neighbor.build_lists(s)
+    mesh, order = (27, 24, 144), 5
+    fx = FixConp(s, extra_args=["pppm"], pppm_mesh=mesh, pppm_order=order)
+    fx.init_lists(alist, blist)
+    fx.setup_post_neighbor(at)
+    fx.setup_pre_force(at, 0, s.potdiff)
+    n = mesh[0] * mesh[1] * mesh[2]
+    sel = (at.echeck[:at.nlocal] == 1).astype(np.int32)
+    grp = fx.pppm_group_potential(at, sel)
+    n0 = fx.info().pppm_elyte_spreads
+    g = s.g_ewald
+    for i in np.nonzero(sel)[0][:5]:
+        u = fx.pppm_particle_potential(at, int(i))
+        assert u == pytest.approx(grp[i] + 2.0 * g * at.q[i] / np.sqrt(np.pi), rel=1e-12, abs=1e-14)
+    assert fx.info().pppm_elyte_spreads == n0               # five per-atom calls, not one more spread / mesh solve
+    fx.pppm_compute(at)
+    assert fx.info().pppm_elyte_spreads == n0 + 1
+    # (ii)
+    d0, e0, l0 = fx.pppm_make_rho(at, n)                    # nothing kept yet: a fresh spread
+    fx.pppm_keep_density(True)
+    b1 = fx.km_b_cal(at).copy()
+    n1 = fx.info().pppm_elyte_spreads
+    d1, e1, l1 = fx.pppm_make_rho(at, n)
+    assert fx.info().pppm_elyte_spreads == n1               # the electrolyte brick of b_cal was reused
+    assert rel_err(l1, l0) < 1e-12 and rel_err(e1, e0) < 1e-12 and rel_err(d1, d0) < 1e-12
+    fx.pppm_keep_density(True)                              # conp_pre_force of the next step: the brick is dropped
+    d2, e2, l2 = fx.pppm_make_rho(at, n)
+    assert fx.info().pppm_elyte_spreads == n1 + 1 and rel_err(d2, d0) < 1e-12
+    b2 = fx.km_b_cal(at)
+    assert rel_err(b2, b1) < 1e-12
+    fx.close()

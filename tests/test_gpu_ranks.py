@@ -59,6 +59,24 @@ def _decomposed_worker(rank, world, port, name, axis, solver, out):
         rho, rho_e, rho_l = fx.pppm_make_rho(at, nfft)
         sel = (at.echeck[:at.nlocal] != 0).astype(np.int32)
         pot = fx.pppm_group_potential(at, sel)
+        # the per-atom entry is RANK-LOCAL (pppm_conp.cpp:452-485: compute potential/atom calls it once per owned group atom, a
+        # different number of times on every rank): rank r asks r + 1 times after the collective entry above left the brick --
+        # no collective inside, so nothing hangs --, and each value is the group entry's + 2 g q / sqrt(pi)
+        idx = np.nonzero(sel)[0]
+        n_before = fx.info().pppm_elyte_spreads
+        per_atom = []
+        for i in idx[:rank + 1]:
+            u = fx.pppm_particle_potential(at, int(i))
+            per_atom.append(abs(u - (pot[i] + 2.0 * s.g_ewald * at.q[i] / np.sqrt(np.pi))) <= 1e-12 * max(1.0, abs(u)))
+        assert fx.info().pppm_elyte_spreads == n_before and all(per_atom) and len(per_atom) == min(rank + 1, len(idx))
+        # an update invalidates the brick: the per-atom entry then REFUSES under ranks instead of starting a hidden collective
+        refused = False
+        fx.b_cal(at)
+        try:
+            if len(idx): fx.pppm_particle_potential(at, int(idx[0]))
+        except Exception as e:
+            refused = "collective" in str(e)
+        assert refused or not len(idx)
         mesh = dict(rho=rho, rho_e=rho_e, pot={int(t): float(v) for t, v, e in zip(at.tag[:at.nlocal], pot, sel) if e})
     out[rank] = dict(q0=q0, q1=q1, sc0=sc0, sc1=fx.compute_scalar(), ek=ek, S=S, eleall2tag=m["eleall2tag"].copy(), mesh=mesh,
                      info=(fx.info().elenum, fx.info().elenum_all, fx.info().n_elyte_charged))
