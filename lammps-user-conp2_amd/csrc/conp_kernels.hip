@@ -344,6 +344,16 @@ __device__ __forceinline__ unsigned sk_part_off(int rowl, int col) {
   return (unsigned)((((rowl >> 4) * 20 + (col >> 4)) << 8) + ((r >> 1) << 7) + ((((rowl & 3) << 4) + (col & 15)) << 1) + (r & 1));
 }
 
+// the thread index WITHOUT the hardware's v0: wave index (a scalar the kernel derives once) and the lane's position in the wave.
+// v0 kept alive across the chunk loops for the segment's epilogue costs a register the 20-fragment bodies do not have (the
+// allocator spilled it and reloaded it once per chunk).
+// (volatile assembly: formed where it is asked for -- as a plain expression it is loop-invariant, hoisted to the top of the kernel
+//  and spilled like v0 was)
+__device__ __forceinline__ unsigned sk_tid(int wave) {
+  unsigned lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  return ((unsigned)wave << 6) | lane;
+}
 struct SkRaw {        // raw inputs of one thread for one chunk
   double2 X0, Y0, X1, Y1, Zseed, Zst;     // Zseed: phase at the thread's first kz of the column tile, Zst: the 8-kz rotation
   double2 X2, Y2;                         // RF = 5 bands: the fifth row fragment's vector of the threads gs < 16 (the early waves)
@@ -360,6 +370,7 @@ struct SkCtx {        // per-thread constants of one work item
   unsigned za;                      // doubles offset of (cos feature of the thread's first kz, atom gj) in a panel (swizzled)
   int dsin;                         // from a cos feature to its sin feature
   int fr, fk, rh, cg;
+  int wave;                         // rh + 2 cg (wave-uniform)
   unsigned wa;                      // generation: doubles offset of (feature gs, atom gj) in a panel (swizzled)
   // MFMA fragments: this lane's element of A / B fragment 0 at k-step ks sits at byte  base + ((ks ^ p) << 5),  p = fr >> 2
   // (atom 4 ks + fk, swizzled by the row: (4 ks + fk) ^ fr = ((ks ^ p) << 2) | ((fk ^ fr) & 3))
@@ -554,6 +565,69 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
   }
 }
 
+// Round 5: the same MFMAs and the same registers (NFW B values, two A values), the operand reads gathered into FEWER interruptions
+// of the MFMA stream.  tools/microbench/sk_reads_bench.hip (profiles/r05_sk_reads.txt): a single wave's stream loses ~6.6 % against
+// constant operand registers, and loses the same when the reads go into registers nobody multiplies -- it is not the waiting, it is
+// every PLACE where a non-MFMA instruction sits between two MFMAs (~10 cycles each, whether one read is issued there or four).  The
+// form above has RF + NFW such places per k-step (an A read in front of every row-fragment group, a B re-read behind every MFMA of
+// the last group); this one has RF: the last group re-reads the wave's B values in two bursts -- half of them and the next k-step's
+// first A value behind its middle MFMA, the rest and the next k-step's second A value behind its last -- and the groups 1 .. RF-2
+// read the A value of the group behind them as before.  Microbenchmark, one wave per SIMD: 0.715 -> 0.737 of peak (constant
+// operands: 0.764).
+template <int RF, int NFW, int F0>
+__device__ __forceinline__ void sk_mfma_chunk_v(const SkCtx &c, const char *smem, unsigned buf, d4 (&acc)[RF][NFW > 0 ? NFW : 1]) {
+  if constexpr (NFW > 0) {
+    constexpr unsigned FA = 16 * SK_LD * 8, FB = 64 * SK_LD * 8;
+    unsigned aa[4], ab[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned q = (unsigned)(ks << 5) ^ c.pq;
+      aa[ks] = (c.base_a ^ buf) + q;
+      ab[ks] = (c.base_b ^ buf) + q;
+    }
+    double bf[NFW], av[2];                 // av[p]: the A value of the current group, av[p ^ 1]: the next one's (p flips per group)
+    av[0] = SK_LDS_F64(aa[0]);
+    if (RF > 1) av[1] = SK_LDS_F64(aa[0] + FA);
+#pragma unroll
+    for (int g = 0; g < NFW; ++g) bf[g] = SK_LDS_F64(ab[0] + g * FB);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int H = (NFW + 1) / 2;        // B values re-read in the first burst of the last group
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kn = (ks + 1) & 3;
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        const int p = (ks * RF + f) & 1;    // (compile-time: everything is unrolled)
+        // in front of the groups 1 .. RF-2: the A value of the group behind this one, into the register the previous group freed
+        if (f >= 1 && f + 1 < RF) { av[p ^ 1] = SK_LDS_F64(aa[ks] + (f + 1) * FA); __builtin_amdgcn_sched_barrier(0); }
+        const int nm = f < F0 ? NFW : NFW - 1;              // MFMAs of this group (the sphere cut drops the last column fragment)
+        if (f < RF - 1 || ks == 3) {
+#pragma unroll
+          for (int g = 0; g < NFW; ++g) if (g < nm) acc[f][g] = MFMA_F64(av[p], bf[g], acc[f][g]);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          // the last group of a k-step that has a successor: two bursts
+#pragma unroll
+          for (int g = 0; g < NFW; ++g) if (g < H && g < nm) acc[f][g] = MFMA_F64(av[p], bf[g], acc[f][g]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < H; ++g) bf[g] = SK_LDS_F64(ab[kn] + g * FB);
+          if (RF > 1) av[p ^ 1] = SK_LDS_F64(aa[kn]);       // the next k-step's first A value (this group has no successor in ITS k-step)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < NFW; ++g) if (g >= H && g < nm) acc[f][g] = MFMA_F64(av[p], bf[g], acc[f][g]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = H; g < NFW; ++g) bf[g] = SK_LDS_F64(ab[kn] + g * FB);
+          if (RF > 1) av[p] = SK_LDS_F64(aa[kn] + FA);      // ... and its second, into the register this group is done with
+          else av[p ^ 1] = SK_LDS_F64(aa[kn]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+}
+
 // The product multiplies with the straight-line form; -DSK_MFMA_LOOP=1 (`make loopform`) builds the round-2 loop form for A/B runs.
 #ifndef SK_MFMA_LOOP
 #define SK_MFMA_LOOP 0
@@ -562,7 +636,17 @@ __device__ __forceinline__ void sk_mfma_chunk_u(const SkCtx &c, const char *smem
 #define SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc) sk_mfma_chunk<RF, NFW>(c, smem, buf, acc)
 #define SK_LATE_PREFETCH 0
 #else
+// Measured in the kernel and left off (tools/ab_libs.sh, one box): sk_gemm 237.1-237.7 us with the burst form against 234.8-235.3 (headline),
+// 676.4-679.8 against 673.9-676.5 (slab geometry) -- what a single wave gains in the microbenchmark its SIMD partner was already filling
+// in the kernel, and the next k-step's first A value has two MFMAs of cover instead of a group's.
+#ifndef SK_BURST_READS
+#define SK_BURST_READS 0
+#endif
+#if SK_BURST_READS
+#define SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc) sk_mfma_chunk_v<RF, NFW, F0>(c, smem, buf, acc)
+#else
 #define SK_MFMA_PHASE(RF, NFW, F0, c, smem, buf, acc) sk_mfma_chunk_u<RF, NFW, F0>(c, smem, buf, acc)
+#endif
 // Measured and left off (round 4, one box, `make variant_pre VDEF=-DSK_LATE_PREFETCH=1`): the late waves' first operand reads requested
 // ahead of their panel build -- sk_gemm 243.5 vs 238.6 us at the headline size, 734 vs 734 us in the slab geometry.  The reads
 // queue ahead of the build's LDS writes as intended, but NFW + 1 more live registers through the build and a wait for them in
@@ -660,7 +744,7 @@ __device__ __forceinline__ void sk_project_out(const SkCtx &c, char *smem, d4 (&
   // everything this needs is derived HERE, behind opaque copies of the thread index and the parameter block's address: left to
   // itself the compiler forms the lane's offsets and loads the parameters at the top of the kernel and carries them through the
   // chunk loop -- 32 more SGPRs and spills in a kernel that has no register to spare
-  unsigned t = threadIdx.x;
+  unsigned t = sk_tid(c.wave);
   asm volatile("" : "+v"(t));
   const SkProj *pp = c.proj;
   asm volatile("" : "+s"(pp));
@@ -1035,7 +1119,7 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
   SkCtx c;
   c.dbg = dbg;
   c.nl_pad = nl_pad; c.nz = pl.nz;
-  c.rh = wave & 1; c.cg = wave >> 1;
+  c.rh = wave & 1; c.cg = wave >> 1; c.wave = wave;
   c.Xt = Xt; c.Yt = Yt; c.Zs = Zs; c.qc = qc;
   c.proj = proj;
   c.nrx16 = (unsigned)(pl.kxmax + 2) * 16; c.nry16 = (unsigned)(pl.kymax + 1) * 16; c.nrz16 = (unsigned)(1 + pl.n_col_tiles * 32) * 16;
@@ -1056,7 +1140,7 @@ __global__ __launch_bounds__(512, 2) void sk_gemm_kernel(DevPlan pl, const SkWIt
     // the lane's constants are formed per segment from an opaque copy of the thread index: formed once at the top of the kernel
     // they would be live across the epilogue, which has no register to spare for them (they were spilled around it)
     {
-      unsigned tt = threadIdx.x;
+      unsigned tt = sk_tid(wave);
       asm volatile("" : "+v"(tt));
       c.gj = tt & 15; c.gs = tt >> 4;
       c.fr = tt & 15; c.fk = (tt >> 4) & 3;
