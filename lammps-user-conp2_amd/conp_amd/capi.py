@@ -106,6 +106,7 @@ SYMBOLS = [
 PATH_PARTIAL_TILES, PATH_A_GENERAL, PATH_INV_PIVOTED, PATH_CG_TWO_LAUNCH, PATH_GEMV_ROWS = 1, 2, 4, 8, 16
 PATH_PHASE_LAUNCH, PATH_PPPM_SPREAD_LAUNCH, PATH_ROWS_HOST, PATH_TIME_SPLIT, PATH_HC_NO_WAIT = 32, 64, 128, 256, 512
 PATH_HC_FUSED = 1024
+PATH_CG_PERSIST = 2048
 
 
 class test_paths:

@@ -1722,6 +1722,9 @@ struct conp_fix {
   // read-back: scalars, flag, net charge and the residual history come over in ONE copy into the page-locked staging buffer.
   int cg_batch = 8;
   const bool cg_unfused = path_on(CONP_PATH_CG_TWO_LAUNCH);      // comparison switch: two launches per iteration (round 1)
+  bool cg_persist_off = false;
+  long cg_solves = 0;
+  DevBuf<unsigned> d_cg_tk;            // two grid-barrier words of the one-launch solve, alternating between solves
   void cg() {
     const int ne = idx.elenum_all;
     const int nctl = 16 + args.maxiter + 1;                  // scal[0..12], pad, hist[0..maxiter] at offset 16
@@ -1733,7 +1736,34 @@ struct conp_fix {
     double *ctl = pinned((size_t)ne_pad + 8 + nctl) + ne_pad + 8;
     int done = 0, iter = 1, batch = std::max(2, std::min(16, cg_batch));
     prof.begin("cg", stream);
-    if (two_launch) {
+    // round 5, measured and NOT the default (CONP_PATH_CG_PERSIST selects it; profiles/r05_cg_persist_ab.txt): the whole solve as ONE
+    // persistent launch -- the matrix stays in the XCDs' L2s between iterations, which a kernel boundary invalidates (cg_step_kernel
+    // fetches 8 n^2 bytes from the memory side at every launch) -- with one fence-free grid barrier per iteration.  il_twolayer: 92-94 us
+    // per solve against 76-78 with a launch per iteration: the barrier (write-through of the products, ticket, poll, sc1 read-back of the
+    // product vector by every workgroup) costs ~2.5 us more than a kernel boundary plus the re-read of 22 MB from the Infinity Cache.
+    bool persisted = false;
+    if (!two_launch && !cg_persist_off && cg_persist_fits(ne) && !results_by_copy && path_on(CONP_PATH_CG_PERSIST)) {
+      if (d_cg_tk.n == 0) { d_cg_tk.reserve(2); d_cg_tk.zero(stream); }
+      unsigned *tk = d_cg_tk.p + (cg_solves & 1), *tkn = d_cg_tk.p + ((cg_solves + 1) & 1);
+      if (launch_cg_persist(stream, num_cus, ne, d_A.p, d_b, d_eleallq, d_cg_ap.p, d_cg_scal.p, args.tolerance, args.maxiter, hist_dev, ctl,
+                            tk, tkn, 1u << 20)) {
+        ++cg_solves;
+        if (spec_dq) scatter_device(spec_dq, spec_pot, false);      // update_direct: the charge write rides behind the solve
+        sync();
+        if (ctl[8] < 0.0) {
+          // a workgroup's wait at the grid barrier ran out (the workgroups were not all resident: another kernel on the device?):
+          // this handle takes a launch per iteration from now on; the solve is repeated (b is untouched, q is reset by the start)
+          cg_persist_off = true;
+          mesgf("conp/hip: the one-launch CG solve timed out at its grid barrier; falling back to one launch per iteration\n");
+        } else {
+          persisted = true;
+          done = ctl[8] != 0.0;
+          if (spec_dq && done) spec_done = true;
+        }
+      }
+    }
+    if (persisted) {
+    } else if (two_launch) {
       launch_cg_init(stream, ne, d_A.p, d_b, d_eleallq, d_cg_res.p, d_cg_p.p, d_cg_scal.p);
       while (iter < args.maxiter && !done) {
         const int batch_end = std::min(args.maxiter, iter + batch);

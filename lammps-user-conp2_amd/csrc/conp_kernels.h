@@ -233,6 +233,11 @@ void launch_cg_init(hipStream_t s, int n, const double *A, const double *b, doub
 void launch_cg_iter(hipStream_t s, int n, const double *A, double *q, double *res, double *p, double *ap, double *scal,
                     double tolerance, int *done, int iter, double *hist);
 // one launch per CG iteration (update of iteration iter - 1 repeated by every workgroup + its rows of the matvec); see the kernel
+// round 5: the whole CG solve as one persistent launch (n <= 4096); false: not all workgroups can be resident
+bool cg_persist_fits(int n);
+bool launch_cg_persist(hipStream_t s, int num_cus, int n, const double *A, const double *b, double *q, double *ap2, double *scal,
+                       double tolerance, int maxiter, double *hist, double *host_ctl, unsigned *ticket, unsigned *ticket_next,
+                       unsigned spin_limit);
 bool cg_step_fits(int n);
 void launch_cg_step(hipStream_t s, int n, const double *A, const double *b, double *q, double *res2 /*[2][n]*/, double *p2 /*[2][n]*/,
                     double *ap2 /*[2][n]*/, double *scal, double tolerance, int *done, int iter, double *hist, int mode,

@@ -3412,6 +3412,160 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(int n, const double *__re
   if (lane == 0) ap2[(size_t)(iter & 1) * n + row] = s0;
 }
 
+// ---- round 5: the whole solve as ONE launch (n <= 4096: the vectors live in registers, four elements per thread).  MEASURED SLOWER than a
+// launch per iteration (il_twolayer: 92-94 against 76-78 us per solve, profiles/r05_cg_persist_ab.txt): a test path, not the default.
+// A kernel boundary invalidates the XCDs' L2s (the counters say so: cg_step_kernel fetches the whole matrix from the memory side at
+// every launch, FETCH_SIZE = 8 n^2 bytes), so a launch per iteration re-reads a deck-sized matrix that would fit the aggregate L2
+// (22 MB at Ne = 1664) seven times.  Here the workgroups stay: each keeps multiplying ITS rows (plain loads: from its XCD's L2 from
+// the second iteration on), publishes the products by write-through stores, passes ONE grid barrier per iteration -- the fence-free
+// ticket of the inverse's panel -- and reads the whole product vector back by sc1 loads; every workgroup then repeats the vector
+// update for itself (cg_step_kernel's code, reduction trees and element mapping: the same bits in every workgroup and the same bits
+// as the launch-per-iteration forms), with p, r and q never leaving its registers.  All workgroups must be resident (the host asks
+// the occupancy API); a barrier wait that runs out stores -7 in the control block and the host repeats the solve with a launch per
+// iteration.  Two ticket words alternate between solves: this solve zeroes the other one.
+__global__ __launch_bounds__(1024) void cg_persist_kernel(int n, const double *__restrict__ A, const double *__restrict__ b,
+                                                          double *__restrict__ q, double *ap2 /*[2][n]: the products, by iteration parity*/,
+                                                          double *__restrict__ scal, double tolerance, int maxiter, double *__restrict__ hist,
+                                                          int rows_per_block, double *__restrict__ host_ctl, unsigned *ticket,
+                                                          unsigned *ticket_next, unsigned spin_limit) {
+  extern __shared__ __attribute__((aligned(16))) char cg_smem[];
+  double *pl = reinterpret_cast<double *>(cg_smem);          // the direction of the matvec: [n]
+  __shared__ double red[32];
+  __shared__ int s_abort;
+  const bool writer = blockIdx.x == 0;
+  const unsigned G = gridDim.x;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  if (writer && tid == 0) *ticket_next = 0u;
+  if (tid == 0) s_abort = 0;
+  double kp[4], kr[4], kq[4], kap[4];
+  // ---- start (cg_step_kernel mode 1)
+  double lresnorm, gamma;
+  {
+    double netr = 0, l2 = 0;
+    for (int i = tid; i < n; i += 1024) { const double r = b[i]; netr += r; l2 += r * r; }
+    netr = block_sum_1024(netr, red);
+    l2 = block_sum_1024(l2, red);
+    const double ave = netr / n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 1024 * u;
+      const double r = i < n ? b[i] : 0.0;
+      kr[u] = r; kp[u] = i < n ? r - ave : 0.0; kq[u] = 0.0;
+    }
+    const double lres = l2 - netr * ave;
+    lresnorm = lres; gamma = lres;
+    if (writer && tid == 0) { scal[0] = lres; scal[1] = lres; scal[2] = netr; scal[6] = 0.0; scal[7] = 0.0; scal[8] = 0.0; }
+  }
+  const int row = blockIdx.x * rows_per_block + wv;
+  const bool has_row = wv < rows_per_block && row < n;
+  auto finish = [&](int it, double done_flag, double lr, double lg, double netr, double ptap, double alpha, double beta) {
+    // the writer workgroup leaves the solution and the control block (device copy and, when asked, the page-locked host copy)
+    if (!writer) return;
+    double qs = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = tid + 1024 * u; if (i < n) { q[i] = kq[u]; qs += kq[u]; } }
+    qs = block_sum_1024(qs, red);
+    if (tid == 0) {
+      scal[0] = lr; scal[1] = lg; scal[2] = netr; scal[3] = ptap; scal[4] = alpha; scal[5] = beta;
+      scal[6] = (double)it; scal[7] = qs; scal[8] = done_flag;
+    }
+    __syncthreads();
+    if (host_ctl) for (int i = tid; i < 16 + it + 1; i += 1024) host_ctl[i] = i < 16 ? scal[i] : hist[i - 16];
+  };
+  for (int it = 1;; ++it) {
+    // ---- matvec of iteration it with the direction every workgroup holds
+    __syncthreads();                                         // (the previous iteration's readers of pl are done)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = tid + 1024 * u; if (i < n) pl[i] = kp[u]; }
+    __syncthreads();
+    double *apw = ap2 + (size_t)(it & 1) * n;
+    if (has_row) {
+      const double s0 = wave_sum(cg_row_dot(n, A + (size_t)row * n, pl, lane));
+      if (lane == 0) __hip_atomic_store(apw + row, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {                                          // grid barrier #it
+      __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = G * (unsigned)it;
+      unsigned spins = 0;
+      while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > spin_limit) { s_abort = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (s_abort) {
+      if (writer && tid == 0) { scal[8] = -7.0; if (host_ctl) host_ctl[8] = -7.0; }
+      return;
+    }
+    // (sc1 loads requested together: as relaxed atomics the compiler waits for each before it issues the next)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 1024 * u;
+      kap[u] = 0.0;
+      if (i < n) { const double *src = apw + i; asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(kap[u]) : "v"(src) : "memory"); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(kap[u]));
+    // ---- the update of iteration it (cg_step_kernel modes 2 / 4, the `keep` branch)
+    double ptap = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (tid + 1024 * u < n) ptap += kp[u] * kap[u];
+    ptap = block_sum_1024(ptap, red);
+    const double alpha = lresnorm / ptap;
+    double lg = 0, netr = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 1024 * u;
+      if (i < n) {
+        kq[u] = kq[u] + alpha * kp[u];
+        const double r = kr[u] - alpha * kap[u];
+        kr[u] = r;
+        lg += r * r; netr += r;
+      }
+    }
+    block_sum2_1024(lg, netr, red);
+    const double ave = netr / n;
+    lg -= netr * ave;
+    const double beta = lg / gamma;
+    double lr = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 1024 * u;
+      if (i < n) {
+        const double r = kr[u];
+        const double pn = beta * kp[u] + r - ave;
+        kp[u] = pn;
+        lr += r * pn;
+      }
+    }
+    lr = block_sum_1024(lr, red);
+    if (writer && tid == 0) hist[it] = lr;
+    lresnorm = lr; gamma = lg;
+    const bool converged = lr / n < tolerance;               // uniform over the whole grid: every workgroup holds the same lr
+    if (converged || it + 1 >= maxiter) { finish(it, converged ? 1.0 : 0.0, lr, lg, netr, ptap, alpha, beta); return; }
+  }
+}
+bool cg_persist_fits(int n) { return n > 0 && n <= 4096; }
+// returns false when the workgroups cannot all be resident on `num_cus` compute units (the caller takes the launch-per-iteration form)
+bool launch_cg_persist(hipStream_t s, int num_cus, int n, const double *A, const double *b, double *q, double *ap2, double *scal,
+                       double tolerance, int maxiter, double *hist, double *host_ctl, unsigned *ticket, unsigned *ticket_next,
+                       unsigned spin_limit) {
+  const size_t lds = (size_t)n * sizeof(double);
+  static DynLdsCache granted{};
+  ensure_dyn_lds(cg_persist_kernel, lds, granted);
+  const int rpb = 8;
+  const int nwg = (n + rpb - 1) / rpb;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_persist_kernel, 1024, lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (per_cu <= 0 || nwg > per_cu * num_cus) return false;
+  hipLaunchKernelGGL(cg_persist_kernel, dim3(nwg), dim3(1024), lds, s, n, A, b, q, ap2, scal, tolerance, maxiter, hist, rpb, host_ctl, ticket,
+                     ticket_next, spin_limit);
+  return true;
+}
+
 bool cg_step_fits(int n) { return n > 0 && (size_t)n * sizeof(double) <= 128 * 1024; }
 
 void launch_cg_step(hipStream_t s, int n, const double *A, const double *b, double *q, double *res2, double *p2, double *ap2,

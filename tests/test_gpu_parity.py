@@ -387,11 +387,10 @@ def test_cg_one_launch_per_iteration_gives_the_bits_of_the_two_launch_form(monke
     s = systems.small_random(ne_side=4, n_elyte=96, lz=60.0)
     for extra in (["cg"], ["cg", "tol", "1e-14", "maxiter", "60"], ["cg", "maxiter", "3"]):
         got = []
-        for unfused in (False, True):
-            if unfused:
-                capi.load_library().conp_debug_set_paths(capi.PATH_CG_TWO_LAUNCH)
-            else:
-                capi.load_library().conp_debug_set_paths(0)
+        # three forms: one launch per iteration (cg_step_kernel, the default), ONE persistent launch per solve with a grid barrier
+        # per iteration (round 5, cg_persist_kernel: measured slower, a test path), two launches per iteration (round 1)
+        for form in (0, capi.PATH_CG_PERSIST, capi.PATH_CG_TWO_LAUNCH):
+            capi.load_library().conp_debug_set_paths(form)
             at, alist, blist = neighbor.build_lists(s)
             fx = FixConp(s, extra_args=extra)
             fx.init_lists(alist, blist)
@@ -402,9 +401,10 @@ def test_cg_one_launch_per_iteration_gives_the_bits_of_the_two_launch_form(monke
             lines = [l for l in fx.log_drain().splitlines() if l.startswith(("Iteration", "*****"))]
             got.append((fx.info().cg_iterations, lines, at.q.copy()))
             fx.close()
-        assert got[0][0] == got[1][0], extra
-        assert got[0][1] == got[1][1], extra
-        assert np.array_equal(got[0][2], got[1][2]), extra
+        for other in (1, 2):
+            assert got[0][0] == got[other][0], extra
+            assert got[0][1] == got[other][1], extra
+            assert np.array_equal(got[0][2], got[other][2]), extra
 
 
 def test_log_file_lines_cg(oracle):
