@@ -62,7 +62,7 @@ def main():
     for k, cs in pmc.items():
         # every kernel of the library that ran at least ten times (the update's kernels; round 4's name filter left out the
         # dominant kernels of two BASELINE configs).  torch's own kernels (fills, copies of the harness) are not the product's.
-        if k.startswith(("at::", "void at::")) or max(len(v) for v in cs.values()) < 10:
+        if k.startswith(("at::", "void at::", "__amd_rocclr")) or max(len(v) for v in cs.values()) < 10:
             continue
         d = {c: sum(v) / len(v) for c, v in cs.items()}
         d["dispatches"] = max(len(v) for v in cs.values())
