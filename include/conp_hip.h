@@ -356,6 +356,7 @@ enum {
   CONP_PATH_TIME_SPLIT = 1 << 8,         /* host-buffer hooks: k-space and real-space halves of b_cal in launches of their own (timing log) */
   CONP_PATH_HC_NO_WAIT = 1 << 9,         /* fused pieces + dot launch: the dot workgroups do not wait for the handed-over class table, they add the pieces themselves */
   CONP_PATH_CG_PERSIST = 1 << 11,        /* CG: ONE persistent launch per solve with a grid barrier per iteration (measured slower than a launch per iteration: not the default) */
+  CONP_PATH_SK_CLASSIC = 1 << 12,        /* large planar systems: sk_gemm over all kz columns instead of the z-window contraction (conp_zn.hip) */
   CONP_PATH_HC_FUSED = 1 << 10           /* pieces' sums + pair sums + dot as ONE launch with an in-launch hand-off (measured slower than two launches: not the default) */
 };
 void conp_debug_set_paths(unsigned mask);

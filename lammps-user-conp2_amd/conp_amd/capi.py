@@ -107,6 +107,7 @@ PATH_PARTIAL_TILES, PATH_A_GENERAL, PATH_INV_PIVOTED, PATH_CG_TWO_LAUNCH, PATH_G
 PATH_PHASE_LAUNCH, PATH_PPPM_SPREAD_LAUNCH, PATH_ROWS_HOST, PATH_TIME_SPLIT, PATH_HC_NO_WAIT = 32, 64, 128, 256, 512
 PATH_HC_FUSED = 1024
 PATH_CG_PERSIST = 2048
+PATH_SK_CLASSIC = 4096
 
 
 class test_paths:

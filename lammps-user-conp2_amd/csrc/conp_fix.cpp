@@ -833,6 +833,160 @@ struct conp_fix {
   // (which see atom->q) re-check the membership at every update -- elyte_list_stale() -- and rebuild the list when an atom's
   // charge has switched between zero and non-zero (fix atom/swap, charge-transfer fixes).  Device-resident hosts
   // (conp_fix_pre_force_device) announce such a change with conp_fix_post_neighbor.
+  // ---- the z-window form of the structure-factor contraction (conp_zn.hip; round 5) -----------------------------------------------
+  // Used when the handle projects on z classes (planar electrodes), is not spatially decomposed and the list is long enough for 16
+  // consecutive atoms of the z-ordered list to share a window of a few grid points (zn_min_atoms).  The electrolyte list is then kept
+  // in the order of the atoms' z cells (a stable counting sort at every list build: positions as they are at the re-neighbouring);
+  // between re-neighbourings atoms drift by less than the neighbour skin, which the window margins absorb; a tap outside its window
+  // raises a device flag that the next synchronisation point reads (the update is repeated on the classic path, the path stays off
+  // until the next list build).
+  static constexpr int ZN_W = 15;
+  static constexpr double ZN_DRIFT = 2.5;       // Angstrom of z drift between list builds the margins allow for
+  int zn_min_atoms = 8192;
+  bool zn_listed = false;                        // the device list is z-ordered and the items below exist
+  bool zn_off = false;                           // a window overflowed since the last list build
+  bool zn_tables_current = false;
+  int zn_n = 0, zn_ncf = 2;
+  double zn_gscale = 0.0;
+  std::vector<ZnItem> zn_items_h;
+  DevBuf<ZnItem> d_zn_items;
+  DevBuf<int> d_zn_g0c, d_zn_flag, d_zn_frag_ptr;
+  DevBuf<int2> d_zn_frag_ents;
+  DevBuf<double> d_zn_P, d_zn_phihat, d_zn_Bt, d_zn_pieces;
+  DevBuf<double2> d_zn_cs;
+  int zn_nfrag = 0;
+  int *zn_flag_host = nullptr;                   // page-locked copy target of the flag
+  bool zn_eligible() const { return !decomposed && !args.pppm && nl >= zn_min_atoms && !path_on(CONP_PATH_SK_CLASSIC); }
+  bool zn_use() const { return zn_listed && !zn_off && zn_eligible() && sk_projects() && nzc > 0 && zc_final_fits((int)own_rt_h.size(), nzc); }
+  double zn_lz() const { return kt.slabflag ? env.zprd * env.slab_volfactor : env.zprd; }
+  // z-order the list (stable: atoms of one cell keep their list order) and cut it into ranges with a window origin each
+  void zn_order_list(const conp_atoms *at) {
+    zn_listed = false; zn_off = false;
+    if (getenv("CONP_TIME_REN")) std::fprintf(stderr, "  z-window: eligible %d (decomposed %d pppm %d nl %d) plan.nz %d\n", (int)zn_eligible(), (int)decomposed, args.pppm, nl, plan.nz);
+    if (!zn_eligible() || plan.nz <= 0) return;
+    int n = 64;
+    while (n < 4 * plan.nz) n *= 2;
+    zn_n = n;
+    const double lz = zn_lz();
+    zn_gscale = (double)n / lz;
+    const int nlist = (int)elyte_idx_h.size();
+    std::vector<int> cell(nlist), occ(n, 0), cnt(n + 1, 0);
+    auto ucoord = [&](int i) { return at->x[3 * (size_t)i + 2] * zn_gscale; };
+    for (int k = 0; k < nlist; ++k) {
+      const double u = ucoord(elyte_idx_h[k]);
+      int c = (int)std::floor(u);
+      c = ((c % n) + n) % n;
+      cell[k] = c; ++occ[c];
+    }
+    // the list starts behind the longest run of empty cells (the vacuum / the electrodes of a slab cell), so that no chunk of 16
+    // consecutive atoms straddles it; a box without a gap starts at cell 0 and the windows wrap (positions are taken relative to
+    // a range's origin, modulo the grid)
+    int best_len = 0, best_end = 0, run = 0;
+    for (int c = 0; c < 2 * n; ++c) {
+      if (occ[c % n] == 0) { if (++run > best_len && run <= n) { best_len = run; best_end = c % n; } }
+      else run = 0;
+    }
+    const int c_start = best_len > 0 ? (best_end + 1) % n : 0;
+    for (int k = 0; k < nlist; ++k) { cell[k] = (cell[k] - c_start + n) % n; ++cnt[cell[k] + 1]; }
+    for (int c = 0; c < n; ++c) cnt[c + 1] += cnt[c];
+    elyte_dev_h.assign(nlist, 0);
+    for (int k = 0; k < nlist; ++k) elyte_dev_h[cnt[cell[k]]++] = elyte_idx_h[k];
+    // ranges of chunks: about three workgroups of four waves per CU over all row tiles; the rank's share of the chunk axis comes
+    // from build_items (table_c0 .. table_c1)
+    zn_listed = true;
+  }
+  void zn_build_items(const conp_atoms *at) {
+    if (!zn_listed) return;
+    const int n = zn_n;
+    const int nchunks = nl_pad / 16;
+    const int c_lo = env.nranks > 1 ? table_c0 : 0, c_hi = env.nranks > 1 ? table_c1 : nchunks;
+    const int nrt = std::max(1, (int)own_rt_h.size());
+    int nr = std::max(1, (3 * num_cus + nrt - 1) / nrt);
+    nr = std::min(nr, std::max(1, (c_hi - c_lo) / 4));             // at least four chunks per range
+    const double cellw = zn_lz() / n;
+    const int margin = (int)std::ceil(ZN_DRIFT / cellw) + 1;
+    std::vector<int> g0c(std::max(nchunks, 1), 0);
+    zn_items_h.clear();
+    int need_max = 0;
+    std::vector<std::pair<int, int>> ranges;
+    for (int r = 0; r < nr; ++r) {
+      const int a = c_lo + (int)((long long)(c_hi - c_lo) * r / nr), b = c_lo + (int)((long long)(c_hi - c_lo) * (r + 1) / nr);
+      if (b <= a) continue;
+      // positions relative to the integer grid index of the range's first atom, wrapped into (-n/2, n/2]
+      int imin = 0x3fffffff, imax = -0x3fffffff, ga = 0;
+      for (int j = 16 * a; j < 16 * b && j < nl; ++j) {
+        const double u = at->x[3 * (size_t)elyte_dev_h[j] + 2] * zn_gscale;
+        if (j == 16 * a) ga = (int)std::floor(u);
+        double ur = u - ga;
+        ur -= n * std::nearbyint(ur / n);
+        const int i0 = (int)std::ceil(ur - 0.5 * ZN_W);
+        imin = std::min(imin, i0); imax = std::max(imax, i0);
+      }
+      if (imin > imax) { imin = imax = 0; }
+      const int g0 = ga + imin - margin;
+      imax += ga; imin += ga;
+      need_max = std::max(need_max, imax + ZN_W + margin - g0);
+      for (int c = a; c < b; ++c) g0c[c] = g0;
+      ranges.push_back({a, b});
+    }
+    if (getenv("CONP_TIME_REN")) std::fprintf(stderr, "  z-window: n %d, %zu ranges x %d row tiles, need %d columns, margin %d\n", n, ranges.size(), nrt, need_max, margin);
+    if (need_max > 48 || ranges.empty()) { zn_listed = false; return; }     // too sparse for a window: the classic kernels
+    zn_ncf = need_max <= 32 ? 2 : 3;
+    int slot = 0;
+    for (int k = 0; k < nrt; ++k)
+      for (auto &rg : ranges) zn_items_h.push_back(ZnItem{own_rt_h.empty() ? 0 : own_rt_h[k], rg.first, rg.second, g0c[rg.first], slot++});
+    // the pieces of a row fragment, range after range: hc_sum_kernel's lists (a row tile's piece = a band of four row fragments)
+    zn_nfrag = 4 * plan.n_row_tiles;
+    std::vector<std::vector<int2>> of_frag(zn_nfrag);
+    for (const ZnItem &it : zn_items_h)
+      for (int f = 0; f < 4; ++f) of_frag[4 * it.rt + f].push_back(make_int2(it.slot * sk_hc_stride() + 16 * f, 4));
+    std::vector<int> fptr(zn_nfrag + 1, 0);
+    std::vector<int2> fent;
+    for (int g = 0; g < zn_nfrag; ++g) { fent.insert(fent.end(), of_frag[g].begin(), of_frag[g].end()); fptr[g + 1] = (int)fent.size(); }
+    if (fent.empty()) fent.push_back(make_int2(0, 4));
+    ren_upload(d_zn_items, zn_items_h);
+    ren_upload(d_zn_g0c, g0c);
+    ren_upload(d_zn_frag_ptr, fptr);
+    ren_upload(d_zn_frag_ents, fent);
+    d_zn_Bt.reserve((size_t)nchunks * 48 * 16);
+    d_zn_pieces.reserve(std::max<size_t>(1, zn_items_h.size()) * sk_hc_stride());
+    if (d_zn_flag.n == 0) { d_zn_flag.reserve(1); d_zn_flag.zero(stream); }
+  }
+  // once per plan / z-class table: the window's Fourier transform (Gauss-Legendre quadrature on the host), the grid's phases, P
+  void zn_ensure_tables() {
+    if (zn_tables_current) return;
+    const int n = zn_n, nzm = plan.nz;
+    const double h = 6.283185307179586476925286766559 / n, a = 0.5 * ZN_W * h, beta = 2.30 * ZN_W;
+    // nodes and weights of the 64-point Gauss-Legendre rule by Newton iteration on P_64
+    const int Q = 64;
+    std::vector<double> xs(Q), ws(Q);
+    for (int i = 0; i < Q; ++i) {
+      double x = std::cos(3.14159265358979323846 * (i + 0.75) / (Q + 0.5)), dp = 0.0;
+      for (int itn = 0; itn < 100; ++itn) {
+        double p0 = 1.0, p1 = x;
+        for (int k = 2; k <= Q; ++k) { const double p2 = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k; p0 = p1; p1 = p2; }
+        dp = Q * (x * p1 - p0) / (x * x - 1.0);
+        const double dx = p1 / dp;
+        x -= dx;
+        if (std::fabs(dx) < 1e-16) break;
+      }
+      xs[i] = x; ws[i] = 2.0 / ((1.0 - x * x) * dp * dp);
+    }
+    std::vector<double> phihat(nzm);
+    for (int m = 0; m < nzm; ++m) {
+      double sum = 0.0;
+      for (int i = 0; i < Q; ++i) sum += ws[i] * a * std::exp(beta * (std::sqrt(1.0 - xs[i] * xs[i]) - 1.0)) * std::cos(m * a * xs[i]);
+      phihat[m] = sum;
+    }
+    std::vector<double2> cs(n);
+    for (int k = 0; k < n; ++k) cs[k] = make_double2(std::cos(h * k), std::sin(h * k));
+    d_zn_phihat.upload(phihat, stream); d_zn_cs.upload(cs, stream);
+    d_zn_P.reserve((size_t)plan.R_pad * nzc * n);
+    launch_zn_ptable(stream, dplan, plan.kzt, nzc, n, d_TzcT.p, d_zn_phihat.p, d_zn_cs.p, d_zn_P.p);
+    sync();                                          // (the host vectors go out of scope)
+    zn_tables_current = true;
+  }
+  std::vector<int> elyte_dev_h;                    // the list as the device holds it (z-ordered when zn_listed)
   void build_elyte_list(const conp_atoms *at, bool inside_reneighbour = false) {
     if (!inside_reneighbour) ren_off = 0;      // (the callers outside a re-neighbour have synchronised the stream: the arena is free)
     elyte_idx_h.clear();
@@ -852,8 +1006,10 @@ struct conp_fix {
     }
     // atoms are consumed in chunks of 32; the splits want an even share of chunks
     nl_pad = std::max(32, (nl + 31) / 32 * 32);
-    ren_upload(d_elyte_idx, elyte_idx_h);
+    zn_order_list(at);
+    ren_upload(d_elyte_idx, zn_listed ? elyte_dev_h : elyte_idx_h);
     build_items();
+    zn_build_items(at);
     d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
@@ -1306,6 +1462,7 @@ struct conp_fix {
     }
     sync();
     tables_current = true;
+    zn_tables_current = false;      // the z-window table P depends on the weights and the z-class phases
   }
 
   // Library-owned page-locked staging for the host-buffer hooks: the charges and scalars come back in ONE place with one
@@ -1937,7 +2094,7 @@ struct conp_fix {
         // CONP_RIDE_PHASE: comparison switch, the phase launch as before.
         ride_hc = ride && diag_switch("CONP_RIDE_PHASE") == nullptr && sk_projects() && n_frags > 0 && nzc > 0 &&
                   zc_final_fits((int)own_rt_h.size(), nzc) &&
-                  (!bands_aligned || (hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size()));
+                  (zn_use() || !bands_aligned || (hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size()));
         prof.begin("elyte_phase", stream);
         launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                            plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
@@ -1951,6 +2108,22 @@ struct conp_fix {
       fin.breal = d_breal.p;
       use_fin = ride && nzc > 0 && zc_final_fits((int)own_rt_h.size(), nzc);
       const bool proj = sk_projects();
+      if (zn_use() && !fuse_phase) {
+        // the z-window form (conp_zn.hip): window matrix of the update, the contraction with 32 / 48 columns, the ranges' pieces
+        zn_ensure_tables();
+        prof.begin("sk_gemm", stream);
+        launch_zn_window(stream, nl, nl_pad, 16 * zn_ncf, zn_n, ZN_W, 2.30 * ZN_W, zn_gscale, eidx, ex, d_zn_g0c.p, d_zn_Bt.p, d_zn_flag.p,
+                         16 * table_c0, 16 * table_c1);
+        launch_zn_gemm(stream, dplan, zn_ncf, d_zn_items.p, (int)zn_items_h.size(), d_Xt.p, d_Yt.p, d_zn_Bt.p, d_zn_P.p, zn_n, nzc,
+                       d_zn_pieces.p, sk_hc_stride());
+        prof.end(stream);
+        g_current = false;
+        prof.begin("reduce_project", stream);
+        launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_zn_pieces.p, d_hslot_ptr.p, d_hslot_idx.p,
+                                     true, d_zn_frag_ptr.p, d_zn_frag_ents.p, zn_nfrag, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p,
+                                     d_bk.p, use_fin ? &fin : nullptr, ride_hc ? &pairs_keep : nullptr, d_breal.p);
+        prof.end(stream);
+      } else {
       reserve_partials();
       prof.begin("sk_gemm", stream);
       launch_sk_gemm(stream, dplan, d_witems.p, witems_maxseg, nwg_sk, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
@@ -1986,6 +2159,7 @@ struct conp_fix {
         else
           launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
         prof.end(stream);
+      }
       }
     }
     if (timed) HIP_TRY(hipEventRecord(ev_b[1], stream));

@@ -118,6 +118,17 @@ void launch_potential_pair(hipStream_t s, int inum, const int *ilist, const int 
                            const int *etasel, int ntypes, const double *cutsq, double cut_coulsq, double g_ewald, double eta,
                            double *potential);
 
+// ---- the z-window form of the structure-factor contraction (conp_zn.hip, round 5) ------------------------------------------------
+// item = (row tile: 64 planar vectors, chunk range [c0, c1) of the z-ordered electrolyte list, window origin g0 on the grid, slot of
+// its piece [class][128 rows] in the pieces buffer)
+struct ZnItem { int rt, c0, c1, g0, slot; };
+void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n, const double *tzt /*[nzc][C_pad]*/,
+                      const double *phihat /*[nz]*/, const double2 *cs /*[n]: (cos, sin)(2 pi k / n)*/, double *P /*[R_pad][nzc][n]*/);
+void launch_zn_window(hipStream_t s, int nl, int nl_pad, int ncol, int n /*grid points*/, int W, double beta, double gscale, const int *elyte_idx, const double *x,
+                      const int *g0c /*[chunks]*/, double *Bt /*[chunks][ncol][16]*/, int *flag, int j0, int j1);
+void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf /*2 or 3 column fragments*/, const ZnItem *items, int nitems, const double2 *Xt,
+                    const double2 *Yt, const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride);
+
 // ---- per-step electrolyte path -----------------------------------------------------------------
 void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, const int *img, double px, double py, double pz,
                        double *x, double *q);
