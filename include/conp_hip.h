@@ -249,6 +249,8 @@ typedef struct {
                               pivot search), 2 partial pivoting */
   int inverse_retries;     /* 1: the multi-workgroup pivot panel timed out at its grid barrier and the one-workgroup panel redid it */
   int pppm_elyte_spreads;  /* `pppm`: how often the electrolyte atoms have been spread onto the mesh so far (b_cal, density and potential queries) */
+  int zn_cols, zn_grid, zn_rows; /* the z-window form of the structure-factor contraction (conp_zn.hip) is in use: window columns (32 / 48), z grid points,
+                              G rows this rank contracts; all 0: the full kernels */
 } conp_info;
 int conp_fix_info(const conp_fix *fix, conp_info *out);
 /* integer tables; pass NULL for those not wanted.  Sizes: kcount / kcount_expand */

@@ -77,7 +77,7 @@ class conp_info(C.Structure):
                 ("volume", C.c_double), ("gsqmx", C.c_double), ("ug_tot", C.c_double), ("totsetq", C.c_double),
                 ("scalar_output", C.c_double), ("totinve", C.c_double), ("slabcorr", C.c_double),
                 ("n_blist_pairs", C.c_int64), ("n_alist_pairs", C.c_int64), ("n_elyte_charged", C.c_int64),
-                ("inverse_path", C.c_int), ("inverse_retries", C.c_int), ("pppm_elyte_spreads", C.c_int)]
+                ("inverse_path", C.c_int), ("inverse_retries", C.c_int), ("pppm_elyte_spreads", C.c_int), ("zn_cols", C.c_int), ("zn_grid", C.c_int), ("zn_rows", C.c_int)]
 
 
 # every symbol include/conp_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)

@@ -152,7 +152,7 @@ struct Profiler {
   }
   void begin(const char *name, hipStream_t s) {
     if (!on) return;
-    skipped = dominant_only && std::strcmp(name, "sk_gemm") != 0;
+    skipped = dominant_only && std::strcmp(name, "sk_gemm") != 0 && std::strcmp(name, "zn_gemm") != 0;
     // (an event pair drains the queue on both sides of the kernel: ~5 us per update when every launch carries one, measured
     //  0.3057 -> 0.3110 ms at the headline size; every 4th launch keeps the timed region within 0.4 % of an uninstrumented run)
     if (!skipped && dominant_only && (n_dominant++ & 3) != 0) skipped = true;
@@ -380,6 +380,7 @@ struct conp_fix {
     if (h_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_pin); }
     if (h_np) { (void)hipStreamSynchronize(stream); (void)hipHostFree(h_np); }
     if (ren_arena) { (void)hipStreamSynchronize(stream); (void)hipHostFree(ren_arena); ren_arena = nullptr; }
+    if (zn_flag_host) { (void)hipStreamSynchronize(stream); (void)hipHostFree(zn_flag_host); zn_flag_host = nullptr; }
     for (auto &e : ev_b) if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -847,26 +848,28 @@ struct conp_fix {
   bool zn_off = false;                           // a window overflowed since the last list build
   bool zn_tables_current = false;
   int zn_n = 0, zn_ncf = 2;
-  double zn_gscale = 0.0;
+  double zn_gscale = 0.0, zn_beta = 0.0;
   std::vector<ZnItem> zn_items_h;
   DevBuf<ZnItem> d_zn_items;
-  DevBuf<int> d_zn_g0c, d_zn_flag, d_zn_frag_ptr;
+  DevBuf<int> d_zn_g0c, d_zn_frag_ptr;
   DevBuf<int2> d_zn_frag_ents;
   DevBuf<double> d_zn_P, d_zn_phihat, d_zn_Bt, d_zn_pieces;
   DevBuf<double2> d_zn_cs;
   int zn_nfrag = 0;
-  int *zn_flag_host = nullptr;                   // page-locked copy target of the flag
+  int *zn_flag_host = nullptr, *zn_flag_dev = nullptr;      // a page-locked word the window kernel stores 1 into when a tap leaves its window
   bool zn_eligible() const { return !decomposed && !args.pppm && nl >= zn_min_atoms && !path_on(CONP_PATH_SK_CLASSIC); }
-  bool zn_use() const { return zn_listed && !zn_off && zn_eligible() && sk_projects() && nzc > 0 && zc_final_fits((int)own_rt_h.size(), nzc); }
+  bool zn_use() const { return zn_listed && !zn_off && zn_eligible() && sk_projects() && nzc > 0; }
   double zn_lz() const { return kt.slabflag ? env.zprd * env.slab_volfactor : env.zprd; }
   // z-order the list (stable: atoms of one cell keep their list order) and cut it into ranges with a window origin each
   void zn_order_list(const conp_atoms *at) {
     zn_listed = false; zn_off = false;
     if (getenv("CONP_TIME_REN")) std::fprintf(stderr, "  z-window: eligible %d (decomposed %d pppm %d nl %d) plan.nz %d\n", (int)zn_eligible(), (int)decomposed, args.pppm, nl, plan.nz);
     if (!zn_eligible() || plan.nz <= 0) return;
-    int n = 64;
-    while (n < 4 * plan.nz) n *= 2;
+    // grid: the smallest multiple of 16 with an oversampling ratio n / (2 nz) >= 1.9 (15 taps: 2e-13 of the largest entry there,
+    // tools/proto/zn_proto.py); the window's shape parameter follows the ratio
+    int n = std::max(64, (38 * plan.nz / 10 + 15) / 16 * 16);       // any integer does (no FFT anywhere): a multiple of 16
     zn_n = n;
+    zn_beta = 0.97 * 3.14159265358979323846 * ZN_W * (1.0 - (double)plan.nz / n);      // gamma pi W (1 - 1 / (2 sigma))
     const double lz = zn_lz();
     zn_gscale = (double)n / lz;
     const int nlist = (int)elyte_idx_h.size();
@@ -901,40 +904,73 @@ struct conp_fix {
     const int nchunks = nl_pad / 16;
     const int c_lo = env.nranks > 1 ? table_c0 : 0, c_hi = env.nranks > 1 ? table_c1 : nchunks;
     const int nrt = std::max(1, (int)own_rt_h.size());
-    int nr = std::max(1, (3 * num_cus + nrt - 1) / nrt);
-    nr = std::min(nr, std::max(1, (c_hi - c_lo) / 4));             // at least four chunks per range
     const double cellw = zn_lz() / n;
-    const int margin = (int)std::ceil(ZN_DRIFT / cellw) + 1;
+    const int margin = (int)std::ceil(ZN_DRIFT / cellw);
     std::vector<int> g0c(std::max(nchunks, 1), 0);
     zn_items_h.clear();
     int need_max = 0;
     std::vector<std::pair<int, int>> ranges;
-    for (int r = 0; r < nr; ++r) {
-      const int a = c_lo + (int)((long long)(c_hi - c_lo) * r / nr), b = c_lo + (int)((long long)(c_hi - c_lo) * (r + 1) / nr);
-      if (b <= a) continue;
-      // positions relative to the integer grid index of the range's first atom, wrapped into (-n/2, n/2]
-      int imin = 0x3fffffff, imax = -0x3fffffff, ga = 0;
-      for (int j = 16 * a; j < 16 * b && j < nl; ++j) {
-        const double u = at->x[3 * (size_t)elyte_dev_h[j] + 2] * zn_gscale;
-        if (j == 16 * a) ga = (int)std::floor(u);
-        double ur = u - ga;
-        ur -= n * std::nearbyint(ur / n);
-        const int i0 = (int)std::ceil(ur - 0.5 * ZN_W);
-        imin = std::min(imin, i0); imax = std::max(imax, i0);
+    // All workgroups of the launch are resident at once (four per CU with 32 window columns, three with 48: LDS) and equally long,
+    // so their number should FILL the slots: nr * nrt just below slots (86 ranges x 9 row tiles = 774 on 768 slots left six CUs with
+    // a fourth workgroup and the launch a third longer).  Large boxes take more ranges (a range should not span more than ~8 cells).
+    // candidates in order of preference: 32 columns with one full launch, 48 columns with one, then two and three rounds of each
+    // (shorter ranges span fewer cells; a range keeps at least six chunks)
+    const int cand[][2] = {{4, 1}, {4, 2}, {3, 1}, {4, 3}, {4, 4}, {3, 2}, {4, 6}, {4, 8}, {3, 3}, {3, 4}, {3, 6}, {3, 8}};
+    for (const auto &cd : cand) {
+      const int per_cu = cd[0];
+      int nr = std::max(1, per_cu * num_cus / nrt) * cd[1];
+      nr = std::min(nr, std::max(1, (c_hi - c_lo) / 6));
+      ranges.clear(); need_max = 0;
+      for (int r = 0; r < nr; ++r) {
+        const int a = c_lo + (int)((long long)(c_hi - c_lo) * r / nr), b = c_lo + (int)((long long)(c_hi - c_lo) * (r + 1) / nr);
+        if (b <= a) continue;
+        // positions relative to the integer grid index of the range's first atom, wrapped into (-n/2, n/2]
+        int imin = 0x3fffffff, imax = -0x3fffffff, ga = 0;
+        for (int j = 16 * a; j < 16 * b && j < nl; ++j) {
+          const double u = at->x[3 * (size_t)elyte_dev_h[j] + 2] * zn_gscale;
+          if (j == 16 * a) ga = (int)std::floor(u);
+          double ur = u - ga;
+          ur -= n * std::nearbyint(ur / n);
+          const int i0 = (int)std::ceil(ur - 0.5 * ZN_W);
+          imin = std::min(imin, i0); imax = std::max(imax, i0);
+        }
+        if (imin > imax) { imin = imax = 0; }
+        const int g0 = ga + imin - margin;
+        imax += ga; imin += ga;
+        need_max = std::max(need_max, imax + ZN_W + margin - g0);
+        for (int c = a; c < b; ++c) g0c[c] = g0;
+        ranges.push_back({a, b});
       }
-      if (imin > imax) { imin = imax = 0; }
-      const int g0 = ga + imin - margin;
-      imax += ga; imin += ga;
-      need_max = std::max(need_max, imax + ZN_W + margin - g0);
-      for (int c = a; c < b; ++c) g0c[c] = g0;
-      ranges.push_back({a, b});
+      if (need_max <= (per_cu == 4 ? 32 : 48)) break;
     }
     if (getenv("CONP_TIME_REN")) std::fprintf(stderr, "  z-window: n %d, %zu ranges x %d row tiles, need %d columns, margin %d\n", n, ranges.size(), nrt, need_max, margin);
     if (need_max > 48 || ranges.empty()) { zn_listed = false; return; }     // too sparse for a window: the classic kernels
     zn_ncf = need_max <= 32 ? 2 : 3;
+    // Launch order: workgroups go to the eight XCDs round-robin (block b -> XCD b mod 8, each with an L2 of its own), and the row
+    // tiles of one range read the same phase tables and window matrix -- so all row tiles of range r run on XCD r mod 8: an XCD pulls
+    // an eighth of the tables through the fabric once and finds them in its L2 for the other row tiles.  The pieces' slots keep
+    // the (row tile, range) order the sums are formed in.
+    const int nrg = (int)ranges.size();
+    std::vector<ZnItem> by_slot;
     int slot = 0;
     for (int k = 0; k < nrt; ++k)
-      for (auto &rg : ranges) zn_items_h.push_back(ZnItem{own_rt_h.empty() ? 0 : own_rt_h[k], rg.first, rg.second, g0c[rg.first], slot++});
+      for (auto &rg : ranges) by_slot.push_back(ZnItem{own_rt_h.empty() ? 0 : own_rt_h[k], rg.first, rg.second, g0c[rg.first], slot++});
+    {
+      std::vector<std::vector<int>> per_xcd(8);
+      for (int r = 0; r < nrg; ++r)
+        for (int k = 0; k < nrt; ++k) per_xcd[r & 7].push_back(k * nrg + r);
+      size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      zn_items_h.reserve(by_slot.size());
+      while (zn_items_h.size() < by_slot.size())
+        for (int x = 0; x < 8; ++x)
+          if (pos[x] < per_xcd[x].size()) zn_items_h.push_back(by_slot[per_xcd[x][pos[x]++]]);
+          else {
+            // this XCD has run out of items of its own: it takes one from the XCD with the most left (the launch must stay dense)
+            int best = -1; size_t left = 0;
+            for (int y = 0; y < 8; ++y) if (per_xcd[y].size() - pos[y] > left) { left = per_xcd[y].size() - pos[y]; best = y; }
+            if (best >= 0) zn_items_h.push_back(by_slot[per_xcd[best][pos[best]++]]);
+          }
+    }
     // the pieces of a row fragment, range after range: hc_sum_kernel's lists (a row tile's piece = a band of four row fragments)
     zn_nfrag = 4 * plan.n_row_tiles;
     std::vector<std::vector<int2>> of_frag(zn_nfrag);
@@ -950,13 +986,27 @@ struct conp_fix {
     ren_upload(d_zn_frag_ents, fent);
     d_zn_Bt.reserve((size_t)nchunks * 48 * 16);
     d_zn_pieces.reserve(std::max<size_t>(1, zn_items_h.size()) * sk_hc_stride());
-    if (d_zn_flag.n == 0) { d_zn_flag.reserve(1); d_zn_flag.zero(stream); }
+    if (!zn_flag_host) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&zn_flag_host), 64, hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&zn_flag_dev), zn_flag_host, 0));
+    }
+    *zn_flag_host = 0;
+  }
+  // a window overflowed in an update that has completed: the classic kernels from now on (until the next list build); true = the
+  // caller has results of this handle in flight or in hand that may be wrong
+  bool zn_overflowed() {
+    if (!zn_flag_host || *zn_flag_host == 0) return false;
+    *zn_flag_host = 0;
+    zn_off = true;
+    mesgf("conp/hip: an electrolyte atom left the z-window of its place in the list (more than %.1f A of z drift since the last "
+          "re-neighbouring); the update is repeated with the full structure-factor kernels\n", ZN_DRIFT);
+    return true;
   }
   // once per plan / z-class table: the window's Fourier transform (Gauss-Legendre quadrature on the host), the grid's phases, P
   void zn_ensure_tables() {
     if (zn_tables_current) return;
     const int n = zn_n, nzm = plan.nz;
-    const double h = 6.283185307179586476925286766559 / n, a = 0.5 * ZN_W * h, beta = 2.30 * ZN_W;
+    const double h = 6.283185307179586476925286766559 / n, a = 0.5 * ZN_W * h, beta = zn_beta;
     // nodes and weights of the 64-point Gauss-Legendre rule by Newton iteration on P_64
     const int Q = 64;
     std::vector<double> xs(Q), ws(Q);
@@ -2111,8 +2161,8 @@ struct conp_fix {
       if (zn_use() && !fuse_phase) {
         // the z-window form (conp_zn.hip): window matrix of the update, the contraction with 32 / 48 columns, the ranges' pieces
         zn_ensure_tables();
-        prof.begin("sk_gemm", stream);
-        launch_zn_window(stream, nl, nl_pad, 16 * zn_ncf, zn_n, ZN_W, 2.30 * ZN_W, zn_gscale, eidx, ex, d_zn_g0c.p, d_zn_Bt.p, d_zn_flag.p,
+        prof.begin("zn_gemm", stream);
+        launch_zn_window(stream, nl, nl_pad, 16 * zn_ncf, zn_n, ZN_W, zn_beta, zn_gscale, eidx, ex, d_zn_g0c.p, d_zn_Bt.p, zn_flag_dev,
                          16 * table_c0, 16 * table_c1);
         launch_zn_gemm(stream, dplan, zn_ncf, d_zn_items.p, (int)zn_items_h.size(), d_Xt.p, d_Yt.p, d_zn_Bt.p, d_zn_P.p, zn_n, nzc,
                        d_zn_pieces.p, sk_hc_stride());
@@ -2507,6 +2557,9 @@ struct conp_fix {
   void update_direct(const double *dx, double *dq, double potdiff) {
     if (decomposed) throw ConpError(CONP_ERR_STATE, "device-resident updates take replicated atoms (conp_env.rank / nranks); "
                                                     "spatially decomposed runs use the host-buffer hooks");
+    if (zn_overflowed())
+      throw ConpError(CONP_ERR_NUMERIC, "a device-resident update's z-window overflowed (an electrolyte atom drifted more than 2.5 A in z since "
+                                          "the last conp_fix_post_neighbor): the charges of the updates since then are invalid; the full kernels are used from now on");
     b_cal_device(dx, dq, true);
     if (can_fuse_solve()) { solve_scatter_fused(dq, potdiff); return; }
     allreduce_b();
@@ -2569,6 +2622,11 @@ struct conp_fix {
     b_cal(at);
     if (args.minimizer == CONP_SOLVER_CG) equation_solve();
     update_charge(at, potdiff);
+    if (zn_overflowed()) {               // (update_charge ended with a synchronisation: the flag is this update's)
+      b_cal(at);
+      if (args.minimizer == CONP_SOLVER_CG) equation_solve();
+      update_charge(at, potdiff);
+    }
     resident_step = ntimestep; resident_x = at->x;
   }
 };
@@ -2856,7 +2914,8 @@ int conp_fix_info(const conp_fix *f, conp_info *o) {
   int64_t nbp = f->n_b_pairs;
   if (f->np_pending) { HIP_TRY(hipStreamSynchronize(f->stream)); nbp = *f->h_np; }     // (the count of a regrouping still in flight)
   o->n_blist_pairs = nbp;
-  o->inverse_path = f->inverse_path; o->inverse_retries = f->inverse_retries; o->pppm_elyte_spreads = f->pp_elyte_spreads; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
+  o->inverse_path = f->inverse_path; o->inverse_retries = f->inverse_retries; o->pppm_elyte_spreads = f->pp_elyte_spreads;
+  o->zn_cols = f->zn_use() ? 16 * f->zn_ncf : 0; o->zn_grid = f->zn_use() ? f->zn_n : 0; o->zn_rows = f->zn_use() ? 128 * (int)f->own_rt_h.size() : 0; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
   CONP_GUARD_END
 }
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, in
       const int cc = 320 * ct + 16 * (ml >> 3) + (ml & 7);     // KPlan::col_c; col_s = + 8
       const double w = wfull[(size_t)row_a * C_pad + cc];
       if (w == 0.0) continue;
-      const double2 e = cs[(int)(((long long)m * g) & (n - 1))];
+      const double2 e = cs[(int)(((long long)m * g) % n)];
       s += (w / phihat[m]) * (tzt[(size_t)c * C_pad + cc] * e.x + tzt[(size_t)c * C_pad + cc + 8] * e.y);
     }
     P[((size_t)row * nzc + c) * n + g] = h * s;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void zn_window_kernel(int nl, int nl_pad, int 
     if (col == 0) {
       // this atom's taps: ceil(ur - W / 2) .. + W - 1 must lie inside [0, ncol)
       const int i0 = (int)ceil(ur - 0.5 * W);
-      if (i0 < 0 || i0 + W > ncol) atomicOr(flag, 1);
+      if (i0 < 0 || i0 + W > ncol) *reinterpret_cast<volatile int *>(flag) = 1;      // (page-locked host memory: the host sees it at its next look)
     }
   }
   Bt[t] = v;
@@ -153,6 +153,9 @@ __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnIte
   }
   // ---- the range's piece of the class table: piece[c * 128 + row] = sum_col acc[row][col] P[rowG][c][g0 + col]
   double *out = pieces + (size_t)it.slot * piece_stride;
+  int gcol[NCF];                                              // this lane's grid columns (the grid is periodic; n is any integer)
+#pragma unroll
+  for (int cf = 0; cf < NCF; ++cf) { int g = (it.g0 + 16 * cf + fr) % n; gcol[cf] = g < 0 ? g + n : g; }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int rf8 = 2 * wave + f;                             // row fragment of the tile: 0-3 'a', 4-7 'b'
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnIte
       double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int cf = 0; cf < NCF; ++cf) {
-        const int g = (it.g0 + 16 * cf + fr) & (n - 1);
+        const int g = gcol[cf];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rowl = 16 * rf8 + 4 * r + fk;

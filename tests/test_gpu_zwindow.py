@@ -1,0 +1,76 @@
+"""The z-window form of the structure-factor contraction (conp_zn.hip, round 5): planar electrodes, large systems.  The class table
+Hc = sum_j A_rj K_rc(theta_j) is evaluated by interpolation from an oversampled z grid (type-2 NUFFT: 15-tap window, projection
+table made once per run) instead of through all 2 nz columns of G.  Same b vector as the full kernels to ~1e-13 of its largest entry
+(the parity bar for b is 1e-11); the headline-size oracle comparisons of tests/test_gpu_decks.py run on this path."""
+import numpy as np
+import pytest
+
+from conp_amd import FixConp, capi, neighbor, systems
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _medium(mode, seed=7):
+    # 1024 electrode / 16384 electrolyte atoms: large enough for the z-window path (>= 8192 charged atoms), small enough for seconds
+    return systems.synthetic_fast(n_cells_x=16, n_cells_y=8, lz=300.0, n_elyte=16384, cutoff=12.0, accuracy_relative=1e-6,
+                                  g_ewald=0.26, mode=mode, seed=seed, name=f"medium {mode}")
+
+
+def _b(s, at, alist, blist, mask):
+    with capi.test_paths(mask):
+        fx = FixConp(s)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.b_cal(at)
+        b = fx.vectors()[0].copy()
+        cols = fx.info().zn_cols
+        fx.close()
+    return b, cols
+
+
+@pytest.mark.parametrize("mode", ["ffield", "slab"])
+def test_z_window_b_equals_the_full_contraction(mode):
+    s = _medium(mode)
+    at, alist, blist = neighbor.build_lists(s)
+    b_zn, cols_zn = _b(s, at, alist, blist, 0)
+    b_cl, cols_cl = _b(s, at, alist, blist, capi.PATH_SK_CLASSIC)
+    assert cols_zn in (32, 48) and cols_cl == 0            # the default handle really took the z-window path
+    assert np.abs(b_cl).max() > 0
+    assert rel_err(b_zn, b_cl) < 1e-11
+
+
+def test_z_window_survives_drift_between_list_builds_and_repeats_an_update_that_overflows():
+    """the list is z-ordered at a re-neighbouring; until the next one the atoms drift by less than the neighbour skin, which the
+    window margins absorb (same b as the full kernels after +-1.5 A of z motion); an atom that jumps further raises the flag and the
+    host-buffer update is repeated with the full kernels (same charges, one line in the message buffer)."""
+    s = _medium("ffield", seed=11)
+    at, alist, blist = neighbor.build_lists(s)
+    rng = np.random.default_rng(5)
+    res = {}
+    for mask in (0, capi.PATH_SK_CLASSIC):
+        with capi.test_paths(mask):
+            at_k, _, _ = neighbor.build_lists(s)
+            fx = FixConp(s)
+            fx.init_lists(alist, blist)
+            fx.setup_post_neighbor(at_k)
+            fx.setup_pre_force(at_k, 0, s.potdiff)
+            fx.mesg_drain()
+            sol = at_k.echeck == 0
+            r = np.random.default_rng(5)
+            at_k.x[sol, 2] += r.uniform(-1.5, 1.5, size=int(sol.sum()))      # drift, no re-neighbouring
+            fx.pre_force(at_k, 1, s.potdiff)
+            q1 = at_k.q.copy()
+            m1 = fx.mesg_drain()
+            j = int(np.nonzero(sol)[0][17])
+            at_k.x[j, 2] += 60.0                                             # one atom jumps 60 A: outside every window
+            fx.pre_force(at_k, 2, s.potdiff)
+            q2 = at_k.q.copy()
+            m2 = fx.mesg_drain()
+            res[mask] = (q1, q2, m1, m2)
+            fx.close()
+    ele = at.echeck != 0
+    scale = np.abs(res[0][0][ele]).max()
+    assert np.abs(res[0][0][ele] - res[capi.PATH_SK_CLASSIC][0][ele]).max() < 1e-9 * scale
+    assert np.abs(res[0][1][ele] - res[capi.PATH_SK_CLASSIC][1][ele]).max() < 1e-9 * scale
+    assert "z-window" not in res[0][2] and "z-window" in res[0][3]          # the jump was noticed, the drift was not a problem
