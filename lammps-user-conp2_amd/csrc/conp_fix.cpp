@@ -916,7 +916,9 @@ struct conp_fix {
     // candidates in order of preference: 32 columns with one full launch, 48 columns with one, then two and three rounds of each
     // (shorter ranges span fewer cells; a range keeps at least six chunks)
     const int cand[][2] = {{4, 1}, {4, 2}, {3, 1}, {4, 3}, {4, 4}, {3, 2}, {4, 6}, {4, 8}, {3, 3}, {3, 4}, {3, 6}, {3, 8}};
+    int cand_skip = getenv("ZN_CAND") ? atoi(getenv("ZN_CAND")) : 0;      // (experiment)
     for (const auto &cd : cand) {
+      if (cand_skip > 0) { --cand_skip; continue; }
       const int per_cu = cd[0];
       int nr = std::max(1, per_cu * num_cus / nrt) * cd[1];
       nr = std::min(nr, std::max(1, (c_hi - c_lo) / 6));
@@ -1031,7 +1033,7 @@ struct conp_fix {
     std::vector<double2> cs(n);
     for (int k = 0; k < n; ++k) cs[k] = make_double2(std::cos(h * k), std::sin(h * k));
     d_zn_phihat.upload(phihat, stream); d_zn_cs.upload(cs, stream);
-    d_zn_P.reserve((size_t)plan.R_pad * nzc * n);
+    d_zn_P.reserve((size_t)plan.R_pad / 2 * nzc * n);      // one row per planar vector
     launch_zn_ptable(stream, dplan, plan.kzt, nzc, n, d_TzcT.p, d_zn_phihat.p, d_zn_cs.p, d_zn_P.p);
     sync();                                          // (the host vectors go out of scope)
     zn_tables_current = true;
@@ -1069,8 +1071,19 @@ struct conp_fix {
   // After an update whose sk_gemm projected its tiles (planar electrodes) G was never formed: the phase tables of that update are
   // still on the device, so the contraction is run again in the partial-tile mode and reduced (structure factors are a diagnostic
   // getter: conp_fix_get_sfac, KSpaceModule::sfac in the reference's energy output).
+  // (the z-window form writes no z phase seeds: the full kernels' tables of the last update are made first -- same atoms, same list)
+  bool zs_current = true;
+  const double *last_ex = nullptr, *last_eq = nullptr;
+  const int *last_eidx = nullptr;
   void refresh_structure_factors() {
     if (g_current) return;
+    if (!zs_current && last_ex) {
+      int nsp = 0;
+      launch_elyte_phase(stream, nl, nl_pad, last_eidx, last_ex, last_eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax, plan.kymax, plan.nz,
+                         plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p, &nsp, nullptr, d_breal.p,
+                         16 * table_c0, 16 * table_c1);
+      zs_current = true;
+    }
     reserve_partials(true);
     launch_sk_gemm(stream, dplan, d_witems.p, witems_maxseg, (int)seg_ptr_h.size() - 1, nl_pad, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p,
                    d_Gpart.p);
@@ -2146,9 +2159,13 @@ struct conp_fix {
                   zc_final_fits((int)own_rt_h.size(), nzc) &&
                   (zn_use() || !bands_aligned || (hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size()));
         prof.begin("elyte_phase", stream);
+        ZnWindow zw{};
+        const bool zn_now = zn_use();
+        if (zn_now) zw = ZnWindow{d_zn_Bt.p, d_zn_g0c.p, zn_flag_dev, 16 * zn_ncf, zn_n, ZN_W, zn_beta, zn_gscale};
         launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                            plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
-                           &n_slab_part, ride && !ride_hc ? &pairs : nullptr, d_breal.p, 16 * table_c0, 16 * table_c1);
+                           &n_slab_part, ride && !ride_hc ? &pairs : nullptr, d_breal.p, 16 * table_c0, 16 * table_c1, zn_now ? &zw : nullptr);
+        zs_current = !zn_now; last_ex = ex; last_eq = eq; last_eidx = eidx;
         prof.end(stream);
         pairs_keep = pairs;
       }
@@ -2162,10 +2179,8 @@ struct conp_fix {
         // the z-window form (conp_zn.hip): window matrix of the update, the contraction with 32 / 48 columns, the ranges' pieces
         zn_ensure_tables();
         prof.begin("zn_gemm", stream);
-        launch_zn_window(stream, nl, nl_pad, 16 * zn_ncf, zn_n, ZN_W, zn_beta, zn_gscale, eidx, ex, d_zn_g0c.p, d_zn_Bt.p, zn_flag_dev,
-                         16 * table_c0, 16 * table_c1);
         launch_zn_gemm(stream, dplan, zn_ncf, d_zn_items.p, (int)zn_items_h.size(), d_Xt.p, d_Yt.p, d_zn_Bt.p, d_zn_P.p, zn_n, nzc,
-                       d_zn_pieces.p, sk_hc_stride());
+                       d_zn_pieces.p, sk_hc_stride(), num_cus);
         prof.end(stream);
         g_current = false;
         prof.begin("reduce_project", stream);

@@ -28,6 +28,12 @@ struct DevPlan {              // device copy of KPlan geometry
   const double *wfull;                // [R_pad][C_pad]
 };
 
+// the z-window form (conp_zn.hip): item = (row tile: 64 planar vectors, chunk range [c0, c1) of the z-ordered electrolyte list, window
+// origin g0 on the grid, slot of its piece [class][128 rows] in the pieces buffer)
+struct ZnItem { int rt, c0, c1, g0, slot; };
+// what elyte_phase_kernel's z-axis threads need to write the window matrix of an update instead of the z phase seeds
+struct ZnWindow { double *Bt; const int *g0c; int *flag; int ncol, n, W; double beta, gscale; };
+
 // One sk_gemm segment: a BAND of planar vectors x one column tile x a chunk range [c0, c1) of 16 atoms.  A band = rf consecutive row
 // fragments (16 planar vectors each) g0 .. g0 + rf - 1 of the plan, rf = 4 (up to 20 column fragments, e.g. one row tile of the plan)
 // or 5 (up to 16 column fragments): 20 accumulator fragments per wave either way.  nbf = active 8-kz column fragments per row
@@ -121,13 +127,11 @@ void launch_potential_pair(hipStream_t s, int inum, const int *ilist, const int 
 // ---- the z-window form of the structure-factor contraction (conp_zn.hip, round 5) ------------------------------------------------
 // item = (row tile: 64 planar vectors, chunk range [c0, c1) of the z-ordered electrolyte list, window origin g0 on the grid, slot of
 // its piece [class][128 rows] in the pieces buffer)
-struct ZnItem { int rt, c0, c1, g0, slot; };
 void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n, const double *tzt /*[nzc][C_pad]*/,
                       const double *phihat /*[nz]*/, const double2 *cs /*[n]: (cos, sin)(2 pi k / n)*/, double *P /*[R_pad][nzc][n]*/);
-void launch_zn_window(hipStream_t s, int nl, int nl_pad, int ncol, int n /*grid points*/, int W, double beta, double gscale, const int *elyte_idx, const double *x,
-                      const int *g0c /*[chunks]*/, double *Bt /*[chunks][ncol][16]*/, int *flag, int j0, int j1);
 void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf /*2 or 3 column fragments*/, const ZnItem *items, int nitems, const double2 *Xt,
-                    const double2 *Yt, const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride);
+                    const double2 *Yt, const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride,
+                    int num_cus /*every second round of num_cus workgroups takes a chunk's two phases in the other order*/);
 
 // ---- per-step electrolyte path -----------------------------------------------------------------
 void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, const int *img, double px, double py, double pz,
@@ -136,7 +140,8 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int kzt, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part,
                         const BRowArgs *rows /*NULL, or: the real-space pair sums of these rows ride along, into breal_out*/,
-                        double *breal_out, int j0 /*tables for the atoms [j0, j1) of the compact list only (a rank's share)*/, int j1);
+                        double *breal_out, int j0 /*tables for the atoms [j0, j1) of the compact list only (a rank's share)*/, int j1,
+                        const ZnWindow *zw = nullptr /*the z-window form: the window matrix instead of the z phase seeds*/);
 bool zc_final_fits(int n_own, int nzc);
 void launch_sk_gemm(hipStream_t s, const DevPlan &pl, const SkWItem *witems /*[nwg][maxseg]*/, int maxseg, int nwg, int nl_pad,
                     const double2 *Xt, const double2 *Yt, const double2 *Zs, const double *qc, double *part, const SkProj *proj = nullptr,

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
                                                           int kzt, int nrz, double2 *__restrict__ Xt, double2 *__restrict__ Yt,
                                                           double2 *__restrict__ Zs, double *__restrict__ qc,
                                                           double *__restrict__ slab_part, BRowArgs ra, double *__restrict__ breal_out,
-                                                          int j0, int j1 /* atoms whose tables are wanted (a rank's share) */) {
+                                                          int j0, int j1 /* atoms whose tables are wanted (a rank's share) */,
+                                                          ZnWindow zw /* .Bt != null: the z-window form -- no z phase table, the window matrix instead */) {
 #pragma clang fp contract(off)
   if ((int)blockIdx.x >= 3 * nb) {
     const int row = ((int)blockIdx.x - 3 * nb) * (EP_THREADS / 64) + (threadIdx.x >> 6);
@@ -142,6 +143,22 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
         rot(cm, sm, c1, s1);
         st_d2(t + (size_t)m * 16, make_double2(sc * cm, sc * sm), EP_TABLE_NT);
       }
+    } else if (zw.Bt) {
+      // the z-window form (conp_zn.hip): this atom's row of the window matrix, dense over its chunk's columns:
+      // Bt[(chunk * ncol + col) * 16 + atom] = phi((g0[chunk] + col) - u), u = z n / Lz' wrapped relative to the window origin
+      qc[j] = qq; qz = qq * xc;
+      double *bt = zw.Bt + ((size_t)(j >> 4) * zw.ncol) * 16 + (j & 15);
+      if (j < nl) {
+        double ur = xc * zw.gscale - (double)zw.g0c[j >> 4];
+        ur -= (double)zw.n * rint(ur / (double)zw.n);
+        const int i0 = (int)ceil(ur - 0.5 * zw.W);
+        if (i0 < 0 || i0 + zw.W > zw.ncol) *reinterpret_cast<volatile int *>(zw.flag) = 1;      // (page-locked host word: a tap left its window)
+        for (int col = 0; col < zw.ncol; ++col) {
+          const double d = ((double)col - ur) * (2.0 / zw.W);            // in units of the window's half width
+          bt[(size_t)col * 16] = (d > -1.0 && d < 1.0) ? exp(zw.beta * (sqrt(1.0 - d * d) - 1.0)) : 0.0;
+        }
+      } else
+        for (int col = 0; col < zw.ncol; ++col) bt[(size_t)col * 16] = 0.0;
     } else {
       qc[j] = qq; qz = qq * xc;
       const int nct = (nrz - 1) / 32;                 // column tiles
@@ -219,14 +236,14 @@ void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, 
 void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx, const double *x, const double *q,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int kzt, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part, const BRowArgs *rows,
-                        double *breal_out, int j0, int j1) {
+                        double *breal_out, int j0, int j1, const ZnWindow *zw) {
   const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS;
   *n_slab_part = nb;
   BRowArgs ra{};
   int nrb = 0;
   if (rows && breal_out) { ra = *rows; nrb = (ra.ne + EP_THREADS / 64 - 1) / (EP_THREADS / 64); }
   hipLaunchKernelGGL(elyte_phase_kernel, dim3(3 * nb + nrb), dim3(EP_THREADS), 0, s, nb, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
-                     kymax, nz, kzt, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out, j0, j1);
+                     kymax, nz, kzt, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out, j0, j1, zw ? *zw : ZnWindow{});
 }
 
 // ================================================================================================

@@ -15,6 +15,8 @@
 // MFMA work: 2 n_p x NCOL x Nl x 2 flop = 1/5 .. 1/8 of sk_gemm's.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "conp_kernels.h"
 
 namespace conp {
@@ -22,14 +24,14 @@ namespace conp {
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define ZN_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// ---- once per run: P[(row * nzc + c) * n + g] -----------------------------------------------------------------------------------------
+// ---- once per run: P[(vector * nzc + c) * n + g] -----------------------------------------------------------------------------------------
 // one thread per (G row, grid point); cs[k] = (cos, sin)(2 pi k / n) so that the phases of m g h are exact table look-ups
 __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, int nz, int kzt, int nzc, int n, const double *__restrict__ wfull,
                                                         const double *__restrict__ tzt /*[nzc][C_pad]*/, const double *__restrict__ phihat,
                                                         const double2 *__restrict__ cs, double *__restrict__ P) {
-  const int g = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;   // row = planar vector (padded to 64 a tile)
   if (g >= n) return;
-  const int row_a = (row >> 7) * 128 + (row & 63);             // the 'b' rows of a planar vector carry the 'a' rows' weights
+  const int row_a = (row >> 6) * 128 + (row & 63);             // the 'b' row of a planar vector carries the 'a' row's weights: one table row
   const double h = 6.283185307179586476925286766559 / n;
   for (int c = 0; c < nzc; ++c) {
     double s = 0.0;
@@ -45,48 +47,33 @@ __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, in
   }
 }
 
-// ---- per update: the window matrix, dense per chunk: Bt[(chunk * NCOL + col) * 16 + atom] = phi((g0[chunk] + col) - u_j) -----------
-// u_j = z_j n / Lz' (grid units).  A tap that would fall outside the chunk's columns raises the flag (the list order or the margins
-// are stale: the host re-sorts).  One thread per (chunk, col, atom).
-__global__ __launch_bounds__(256) void zn_window_kernel(int nl, int nl_pad, int ncol, int n, int W, double beta, double gscale /*n / Lz'*/,
-                                                        const int *__restrict__ elyte_idx, const double *__restrict__ x,
-                                                        const int *__restrict__ g0c /*[chunks]*/, double *__restrict__ Bt, int *__restrict__ flag,
-                                                        int j0, int j1) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int per = ncol * 16;
-  const int chunk = (int)(t / per), rem = (int)(t - (long long)chunk * per);
-  const int col = rem >> 4, a = rem & 15;
-  const int j = chunk * 16 + a;
-  if (j >= nl_pad || j < j0 || j >= j1) return;
-  double v = 0.0;
-  if (j < nl) {
-    const int g0 = g0c[chunk];
-    // the atom's grid coordinate relative to the chunk's window origin, wrapped into (-n/2, n/2] (the grid is periodic)
-    double ur = x[3 * (size_t)elyte_idx[j] + 2] * gscale - (double)g0;
-    ur -= (double)n * rint(ur / (double)n);
-    const double d = ((double)col - ur) * (2.0 / W);            // in units of the window's half width
-    if (d > -1.0 && d < 1.0) v = exp(beta * (sqrt(1.0 - d * d) - 1.0));
-    if (col == 0) {
-      // this atom's taps: ceil(ur - W / 2) .. + W - 1 must lie inside [0, ncol)
-      const int i0 = (int)ceil(ur - 0.5 * W);
-      if (i0 < 0 || i0 + W > ncol) *reinterpret_cast<volatile int *>(flag) = 1;      // (page-locked host memory: the host sees it at its next look)
-    }
-  }
-  Bt[t] = v;
-}
+// (the window matrix of an update -- Bt[(chunk * NCOL + col) * 16 + atom] = phi((g0[chunk] + col) - u_j), u_j = z_j n / Lz' -- is written by
+//  elyte_phase_kernel's z-axis threads, conp_kernels.hip: one launch for the phase tables and the window)
 
 // ---- per update: the contraction + the projection on P -----------------------------------------------------------------------------
 // item = (row tile rt: 64 planar vectors = 128 G rows, chunk range [c0, c1), window origin g0, output slot)
-// 256 threads = 4 waves; wave w owns the row fragments 2 w, 2 w + 1 (0-3: 'a' rows, 4-7: 'b' rows) x all NCF column fragments.
+// 256 threads = 4 waves; wave w owns the row fragments w ('a' rows of 16 planar vectors) and 4 + w (their 'b' rows) x all NCF column fragments.
 // LDS panel per chunk (double-buffered): [128 + 16 NCF features][16 atoms], column XOR-swizzled by feature & 15 like sk_gemm's.
 constexpr int ZN_LD = 16;
+#ifdef ZN_TIMELINE
+// diagnostic build only (tools/zn_timeline.py): wall-clock stamps (100 MHz) of every workgroup's phases + where it ran
+__device__ unsigned long long zn_tl[8192 * 6];
+__device__ unsigned long long zn_tl_chunks[16 * 64];   // the workgroups that share block 0's CU: a stamp per chunk
+#define ZN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) zn_tl[blockIdx.x * 6 + (k)] = wall_clock64(); } while (0)
+#else
+#define ZN_STAMP(k) do { } while (0)
+#endif
 template <int NCF>
 __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnItem *__restrict__ items, const double2 *__restrict__ Xt,
                                                          const double2 *__restrict__ Yt, const double *__restrict__ Bt,
                                                          const double *__restrict__ P, int n, int nzc, double *__restrict__ pieces,
-                                                         int piece_stride) {
+                                                         int piece_stride, int stagger_period) {
   constexpr int NF = 128 + 16 * NCF;                         // features per panel
   __shared__ __attribute__((aligned(16))) double panel[2][NF * ZN_LD];
+  ZN_STAMP(0);
+#ifdef ZN_TIMELINE
+  const long long zn_c0 = clock64();
+#endif
   const ZnItem it = items[blockIdx.x];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int gj = t & 15, gs = t >> 4;                        // build role: atom gj of the chunk, sub-index gs 0..15
@@ -107,9 +94,11 @@ __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnIte
   auto load = [&](int ch) {
     const unsigned bx = (unsigned)ch * nrx16, by = (unsigned)ch * nry16;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { X[u] = Xt[bx + xo[u]]; Y[u] = Yt[by + yo[u]]; }
-#pragma unroll
-    for (int u = 0; u < NCF; ++u) bv[u] = Bt[((size_t)ch * (16 * NCF) + gs + 16 * u) * 16 + gj];
+    for (int u = 0; u < 4; ++u) {                              // (the order the main loop re-issues them in: its partial waits count on it)
+      X[u] = Xt[bx + xo[u]]; Y[u] = Yt[by + yo[u]];
+      if (u < NCF) bv[u < NCF ? u : 0] = Bt[((size_t)ch * (16 * NCF) + gs + 16 * u) * 16 + gj];
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   auto build = [&](double *pn) {
 #pragma unroll
@@ -127,80 +116,173 @@ __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnIte
 #pragma unroll
     for (int c = 0; c < NCF; ++c) acc[f][c] = (d4){0.0, 0.0, 0.0, 0.0};
   // MFMA fragment addresses (doubles): element (feature 16 F + fr, atom 4 ks + fk) at feature * 16 + ((4 ks + fk) ^ fr)
-  const unsigned fa0 = (unsigned)((16 * (2 * wave) + fr) * ZN_LD), fa1 = fa0 + 16 * ZN_LD, fb0 = (unsigned)((128 + fr) * ZN_LD);
+  const unsigned fa0 = (unsigned)((16 * wave + fr) * ZN_LD), fa1 = fa0 + 64 * ZN_LD, fb0 = (unsigned)((128 + fr) * ZN_LD);
   load(it.c0);
   build(panel[0]);
-  if (it.c0 + 1 < it.c1) load(it.c0 + 1);
+  load(min(it.c0 + 1, it.c1 - 1));
   __syncthreads();
-  int buf = 0;
-  for (int ch = it.c0; ch < it.c1; ++ch, buf ^= 1) {
-    const double *pn = panel[buf];
+  ZN_STAMP(1);
+  // One chunk = 8 NCF MFMAs per wave (64 cycles of the pipe each) and, for the chunk after it, 8 + NCF panel values to form and the
+  // loads of the chunk after that.  Written as two blocks (multiply, then build) a wave spends ~3300 cycles on a chunk of which the
+  // pipe works 1024 (the fragment reads are waited for before every four MFMAs, the build and the barrier follow the last one), and the
+  // pipe idles whenever fewer than three of a CU's workgroups are in their multiply (profiles/r05_zn_timeline.txt).  So the build is cut
+  // into slices that sit in the shadow of the MFMAs -- an MFMA occupies the wave's issue for 4 cycles and the pipe for 64 -- and the
+  // fragments of k-step ks + 1 are requested before the MFMAs of ks: what stays exposed per chunk is the barrier and one LDS read.
+  // (the chunk indices past the range's end are clamped: the last two builds / loads repeat the last chunk and are not used)
+  // What the vector ALU port of a SIMD carries decides the kernel: an F64 MFMA holds it for ~56 of its 64 cycles and every other VALU
+  // instruction of any wave takes the rest or delays an MFMA (profiles/r05_pipe_share.txt, r05_zn_timeline.txt).  So the loop spends no
+  // VALU instruction on addresses: the chunk loop is unrolled by the two panel buffers (LDS addresses = loop-invariant registers +
+  // immediates), the tables are read as uniform base (SALU) + a per-thread byte offset fixed for the item, and the sign of a planar
+  // vector is one XOR.  Left per chunk and wave: 16 FP64 operations and 4 XORs.
+  unsigned rdA[4], rdB[4];                                    // fragment read indices per k-step (panel-relative, in doubles)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { const unsigned col = (unsigned)((4 * ks + fk) ^ fr); rdA[ks] = fa0 + col; rdB[ks] = fb0 + col; }
+  unsigned xby[4], yby[4], sgm[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { xby[u] = xo[u] * 16u; yby[u] = yo[u] * 16u; sgm[u] = neg[u] ? 0x80000000u : 0u; }
+  const unsigned bby = (unsigned)((gs * 16 + gj) * 8);
+  // buffer loads: descriptor (item-relative base, SGPRs) + per-thread byte offset (VGPR) + chunk offset (SGPR) -- no address arithmetic
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Xt + (size_t)it.c0 * nrx16), (short)0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Yt + (size_t)it.c0 * nry16), (short)0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bt + (size_t)it.c0 * (16 * NCF * 16)), (short)0, -1, 0x00020000);
+  auto chunk = [&](int ch, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    const double *pn = panel[BUF];
+    double *pw = panel[BUF ^ 1];
+    const int chn = min(ch + 2, it.c1 - 1);
+    const int sx = (chn - it.c0) * (int)(nrx16 * 16), sy_ = (chn - it.c0) * (int)(nry16 * 16), sb = (chn - it.c0) * (16 * NCF * 16 * 8);
+    double fa[2][2], fb[2][NCF];
+    fa[0][0] = pn[rdA[0]]; fa[0][1] = pn[rdA[0] + 64 * ZN_LD];
+#pragma unroll
+    for (int c = 0; c < NCF; ++c) fb[0][c] = pn[rdB[0] + 16 * c * ZN_LD];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const unsigned col = (unsigned)((4 * ks + fk) ^ fr);
-      const double a0 = pn[fa0 + col], a1 = pn[fa1 + col];
-      double b[NCF];
+      const int cur = ks & 1, nx = cur ^ 1;
+      if (ks < 3) {
+        fa[nx][0] = pn[rdA[ks + 1]]; fa[nx][1] = pn[rdA[ks + 1] + 64 * ZN_LD];
 #pragma unroll
-      for (int c = 0; c < NCF; ++c) b[c] = pn[fb0 + 16 * c * ZN_LD + col];
-#pragma unroll
-      for (int c = 0; c < NCF; ++c) { acc[0][c] = ZN_MFMA(a0, b[c], acc[0][c]); acc[1][c] = ZN_MFMA(a1, b[c], acc[1][c]); }
-    }
-    if (ch + 1 < it.c1) {
-      build(panel[buf ^ 1]);                                  // (its inputs were requested a chunk ago)
-      if (ch + 2 < it.c1) load(ch + 2);
+        for (int c = 0; c < NCF; ++c) fb[nx][c] = pn[rdB[ks + 1] + 16 * c * ZN_LD];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // slice ks of the build: planar vector gs + 16 ks of the next chunk
+      const double sy = __hiloint2double(__double2hiint(Y[ks].y) ^ (int)sgm[ks], __double2loint(Y[ks].y));
+      acc[0][0] = ZN_MFMA(fa[cur][0], fb[cur][0], acc[0][0]);
+      const double va = X[ks].x * Y[ks].x - X[ks].y * sy;
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][0] = ZN_MFMA(fa[cur][1], fb[cur][0], acc[1][0]);
+      const double vb = X[ks].x * sy + X[ks].y * Y[ks].x;
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][1] = ZN_MFMA(fa[cur][0], fb[cur][1], acc[0][1]);
+      pw[wa + 16 * ks * ZN_LD] = va;
+      pw[wa + (64 + 16 * ks) * ZN_LD] = vb;
+      if (ks < NCF) pw[wa + (128 + 16 * ks) * ZN_LD] = bv[ks < NCF ? ks : 0];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][1] = ZN_MFMA(fa[cur][1], fb[cur][1], acc[1][1]);
+      X[ks] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[ks], sx, 0));
+      Y[ks] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[ks], sy_, 0));
+      if (ks < NCF) bv[ks < NCF ? ks : 0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, bby + 2048 * ks, sb, 0));
+      __builtin_amdgcn_sched_barrier(0);
+      if (NCF > 2) {
+        acc[0][NCF - 1] = ZN_MFMA(fa[cur][0], fb[cur][NCF - 1], acc[0][NCF - 1]);
+        acc[1][NCF - 1] = ZN_MFMA(fa[cur][1], fb[cur][NCF - 1], acc[1][NCF - 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
+#ifdef ZN_TIMELINE
+    if (threadIdx.x == 0 && (blockIdx.x & 255) == 0 && (blockIdx.x >> 8) < 16 && ch - it.c0 < 64) zn_tl_chunks[(blockIdx.x >> 8) * 64 + ch - it.c0] = wall_clock64();
+#endif
+  };
+#ifndef ZN_SKIP_MAIN
+  for (int ch = it.c0; ch < it.c1; ch += 2) {
+    chunk(ch, std::integral_constant<int, 0>());
+    if (ch + 1 < it.c1) chunk(ch + 1, std::integral_constant<int, 1>());
   }
-  // ---- the range's piece of the class table: piece[c * 128 + row] = sum_col acc[row][col] P[rowG][c][g0 + col]
+#endif
+  ZN_STAMP(2);
+  // ---- the range's piece of the class table: piece[c * 128 + row] = sum_col acc[row][col] P[vector of row][c][g0 + col]
+  // The 'a' and the 'b' row of a planar vector carry the same weights, and a wave holds both (fragments wave and 4 + wave): every P value
+  // is fetched once and used twice.  The table comes from the Infinity Cache at best (26 MB a run, never twice through one L2), so the
+  // fetches of CB classes are in flight together -- the epilogue is the latency of nzc / CB round trips, not of 2 nzc.
   double *out = pieces + (size_t)it.slot * piece_stride;
   int gcol[NCF];                                              // this lane's grid columns (the grid is periodic; n is any integer)
 #pragma unroll
   for (int cf = 0; cf < NCF; ++cf) { int g = (it.g0 + 16 * cf + fr) % n; gcol[cf] = g < 0 ? g + n : g; }
+  const double *Pw = P + (size_t)(it.rt * 64 + 16 * wave + fk) * nzc * n;      // vector 16 wave + 4 r + fk: + r * prow
+  const size_t prow = (size_t)4 * nzc * n;
+  constexpr int CB = 3;
+  // the 8 sums of a lane (2 fragments x 4 rows) are reduced over the 16 lanes fr by halving: after the steps 8, 4, 2 a lane holds one sum
+  // (fragment = bit 3 of fr, row = bits 2..1), the step 1 completes it -- 8 exchanges a class instead of 32
+  const bool hi8 = (fr & 8) != 0, hi4 = (fr & 4) != 0, hi2 = (fr & 2) != 0;
+  double *outp = out + 16 * (4 * (hi8 ? 1 : 0) + wave) + 4 * ((hi4 ? 2 : 0) + (hi2 ? 1 : 0)) + fk;
+#ifdef ZN_SKIP_EPI
+  for (int cb = 0; cb < 1; cb += CB) {
+#else
+  for (int cb = 0; cb < nzc; cb += CB) {
+#endif
+    double pv[CB][NCF][4];
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int rf8 = 2 * wave + f;                             // row fragment of the tile: 0-3 'a', 4-7 'b'
-    for (int c = 0; c < nzc; ++c) {
-      double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < CB; ++k) {
+      const size_t co = (size_t)min(cb + k, nzc - 1) * n;
 #pragma unroll
-      for (int cf = 0; cf < NCF; ++cf) {
-        const int g = gcol[cf];
+      for (int cf = 0; cf < NCF; ++cf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rowl = 16 * rf8 + 4 * r + fk;
-          s[r] += acc[f][cf][r] * P[((size_t)(it.rt * 128 + rowl) * nzc + c) * n + g];
-        }
-      }
+        for (int r = 0; r < 4; ++r) pv[k][cf][r] = Pw[r * prow + co + gcol[cf]];
+    }
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+      double v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double v = s[r];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 1, 64);
-        if (fr == 0) out[c * 128 + 16 * rf8 + 4 * r + fk] = v;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) { s0 += acc[0][cf][r] * pv[k][cf][r]; s1 += acc[1][cf][r] * pv[k][cf][r]; }
+        v[r] = s0; v[4 + r] = s1;
       }
+      double w4[4], w2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4[i] = (hi8 ? v[4 + i] : v[i]) + __shfl_xor(hi8 ? v[i] : v[4 + i], 8, 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w2[i] = (hi4 ? w4[2 + i] : w4[i]) + __shfl_xor(hi4 ? w4[i] : w4[2 + i], 4, 64);
+      double w1 = (hi2 ? w2[1] : w2[0]) + __shfl_xor(hi2 ? w2[0] : w2[1], 2, 64);
+      w1 += __shfl_xor(w1, 1, 64);
+      if ((fr & 1) == 0 && cb + k < nzc) outp[(cb + k) * 128] = w1;
     }
   }
+#ifdef ZN_TIMELINE
+  __syncthreads();
+  ZN_STAMP(3);
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    zn_tl[blockIdx.x * 6 + 4] = ((unsigned long long)xcc << 32) | hw;
+    zn_tl[blockIdx.x * 6 + 5] = (unsigned long long)(it.c1 - it.c0) | ((unsigned long long)(clock64() - zn_c0) << 16);
+  }
+#endif
 }
 
 void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n, const double *tzt, const double *phihat, const double2 *cs,
                       double *P) {
-  hipLaunchKernelGGL(zn_ptable_kernel, dim3((n + 255) / 256, pl.R_pad), dim3(256), 0, s, pl.R_pad, pl.C_pad, pl.nz, kzt, nzc, n, pl.wfull, tzt,
+  hipLaunchKernelGGL(zn_ptable_kernel, dim3((n + 255) / 256, pl.R_pad / 2), dim3(256), 0, s, pl.R_pad, pl.C_pad, pl.nz, kzt, nzc, n, pl.wfull, tzt,
                      phihat, cs, P);
 }
-void launch_zn_window(hipStream_t s, int nl, int nl_pad, int ncol, int n, int W, double beta, double gscale, const int *elyte_idx, const double *x,
-                      const int *g0c, double *Bt, int *flag, int j0, int j1) {
-  const long long total = (long long)(nl_pad / 16) * ncol * 16;
-  hipLaunchKernelGGL(zn_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, nl, nl_pad, ncol, n, W, beta, gscale, elyte_idx, x,
-                     g0c, Bt, flag, j0, j1);
-}
 void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
-                    const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
+                    const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride, int num_cus) {
   if (nitems <= 0) return;
   if (ncf == 2)
-    hipLaunchKernelGGL(zn_gemm_kernel<2>, dim3(nitems), dim3(256), 0, s, pl, items, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+    hipLaunchKernelGGL(zn_gemm_kernel<2>, dim3(nitems), dim3(256), 0, s, pl, items, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride, num_cus);
   else
-    hipLaunchKernelGGL(zn_gemm_kernel<3>, dim3(nitems), dim3(256), 0, s, pl, items, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+    hipLaunchKernelGGL(zn_gemm_kernel<3>, dim3(nitems), dim3(256), 0, s, pl, items, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride, num_cus);
 }
 
 }  // namespace conp
+
+#ifdef ZN_TIMELINE
+extern "C" int conp_debug_zn_timeline(unsigned long long *out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(conp::zn_tl), sizeof(unsigned long long) * 6 * (size_t)nblocks);
+}
+extern "C" int conp_debug_zn_timeline_chunks(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(conp::zn_tl_chunks), sizeof(unsigned long long) * 16 * 64);
+}
+#endif

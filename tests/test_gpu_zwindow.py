@@ -74,3 +74,31 @@ def test_z_window_survives_drift_between_list_builds_and_repeats_an_update_that_
     assert np.abs(res[0][0][ele] - res[capi.PATH_SK_CLASSIC][0][ele]).max() < 1e-9 * scale
     assert np.abs(res[0][1][ele] - res[capi.PATH_SK_CLASSIC][1][ele]).max() < 1e-9 * scale
     assert "z-window" not in res[0][2] and "z-window" in res[0][3]          # the jump was noticed, the drift was not a problem
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_z_window_rank_shards_add_up(world):
+    """several ranks (replicated atoms, one rank per GPU): rank r contracts the r-th share of the z-ordered list for all rows; the b
+    vectors of the `world` rank handles, built one after the other on this GPU, sum to the one-rank vector (what the all-reduce of b
+    does), each on the z-window path"""
+    s = _medium("ffield", seed=3)
+    at, alist, blist = neighbor.build_lists(s)
+
+    def b_of(rank, nranks):
+        fx = FixConp(s, rank=rank, nranks=nranks)
+        fx.init_lists(alist, blist)
+        fx.setup_post_neighbor(at)
+        fx.b_cal(at)
+        b = fx.vectors()[0].copy()
+        cols = fx.info().zn_cols
+        fx.close()
+        return b, cols
+
+    b1, c1 = b_of(0, 1)
+    assert c1 in (32, 48)
+    total = np.zeros_like(b1)
+    for r in range(world):
+        b, c = b_of(r, world)
+        assert c in (32, 48)
+        total += b
+    assert rel_err(total, b1) < 1e-12
