@@ -916,9 +916,7 @@ struct conp_fix {
     // candidates in order of preference: 32 columns with one full launch, 48 columns with one, then two and three rounds of each
     // (shorter ranges span fewer cells; a range keeps at least six chunks)
     const int cand[][2] = {{4, 1}, {4, 2}, {3, 1}, {4, 3}, {4, 4}, {3, 2}, {4, 6}, {4, 8}, {3, 3}, {3, 4}, {3, 6}, {3, 8}};
-    int cand_skip = getenv("ZN_CAND") ? atoi(getenv("ZN_CAND")) : 0;      // (experiment)
     for (const auto &cd : cand) {
-      if (cand_skip > 0) { --cand_skip; continue; }
       const int per_cu = cd[0];
       int nr = std::max(1, per_cu * num_cus / nrt) * cd[1];
       nr = std::min(nr, std::max(1, (c_hi - c_lo) / 6));
@@ -1064,7 +1062,7 @@ struct conp_fix {
     zn_build_items(at);
     d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
-    d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 63) / 64 + 1025);
+    d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 31) / 32 + 1025);      // (one per z block of the phase kernel: up to four per 128 atoms)
     // partial tiles: fragments beyond a tile's sphere cut are never written -- all zero from the start, finite ever after
     reserve_partials();
   }
@@ -2180,7 +2178,7 @@ struct conp_fix {
         zn_ensure_tables();
         prof.begin("zn_gemm", stream);
         launch_zn_gemm(stream, dplan, zn_ncf, d_zn_items.p, (int)zn_items_h.size(), d_Xt.p, d_Yt.p, d_zn_Bt.p, d_zn_P.p, zn_n, nzc,
-                       d_zn_pieces.p, sk_hc_stride(), num_cus);
+                       d_zn_pieces.p, sk_hc_stride());
         prof.end(stream);
         g_current = false;
         prof.begin("reduce_project", stream);

@@ -130,8 +130,7 @@ void launch_potential_pair(hipStream_t s, int inum, const int *ilist, const int 
 void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n, const double *tzt /*[nzc][C_pad]*/,
                       const double *phihat /*[nz]*/, const double2 *cs /*[n]: (cos, sin)(2 pi k / n)*/, double *P /*[R_pad][nzc][n]*/);
 void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf /*2 or 3 column fragments*/, const ZnItem *items, int nitems, const double2 *Xt,
-                    const double2 *Yt, const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride,
-                    int num_cus /*every second round of num_cus workgroups takes a chunk's two phases in the other order*/);
+                    const double2 *Yt, const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride);
 
 // ---- per-step electrolyte path -----------------------------------------------------------------
 void launch_ghost_fill(hipStream_t s, int nlocal, int nghost, const int *owner, const int *img, double px, double py, double pz,

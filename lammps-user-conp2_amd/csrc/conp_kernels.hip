@@ -79,6 +79,7 @@ __device__ __forceinline__ double2 ld_d2(const double2 *p, bool nt) {
 // (fix_conp.cpp:1313-1353), two rows per block -- they depend on x, q only, so they ride along in this launch (the chip is far
 // from full with the 3 nb phase blocks) instead of costing gather latency in a launch of their own after the structure factors.
 constexpr int EP_THREADS = 128;
+constexpr int ZN_SPLIT = 4;
 __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl, int nl_pad, const int *__restrict__ elyte_idx,
                                                           const double *__restrict__ x, const double *__restrict__ q,
                                                           double ux, double uy, double uz, int kxmax, int kymax, int nz,
@@ -88,21 +89,25 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
                                                           int j0, int j1 /* atoms whose tables are wanted (a rank's share) */,
                                                           ZnWindow zw /* .Bt != null: the z-window form -- no z phase table, the window matrix instead */) {
 #pragma clang fp contract(off)
-  if ((int)blockIdx.x >= 3 * nb) {
-    const int row = ((int)blockIdx.x - 3 * nb) * (EP_THREADS / 64) + (threadIdx.x >> 6);
+  // z-window form: ZN_SPLIT threads per atom on the z axis (a quarter of the window columns each: the exponentials are the launch's
+  // longest chain otherwise), so 2 nb + ZN_SPLIT nb table blocks; else 3 nb
+  const int zsplit = zw.Bt ? ZN_SPLIT : 1, ntab = (2 + zsplit) * nb;
+  if ((int)blockIdx.x >= ntab) {
+    const int row = ((int)blockIdx.x - ntab) * (EP_THREADS / 64) + (threadIdx.x >> 6);
     if (row < ra.ne) {
       const double v = b_row_pairs(ra, row, threadIdx.x & 63);
       if ((threadIdx.x & 63) == 0) breal_out[row] = v;
     }
     return;
   }
-  const int c = (int)blockIdx.x / nb, bx = (int)blockIdx.x - c * nb;
-  const int j = bx * blockDim.x + threadIdx.x;
+  const int c = (int)blockIdx.x < 2 * nb ? (int)blockIdx.x / nb : 2, bx = (int)blockIdx.x - c * nb;
+  const int jt = bx * blockDim.x + threadIdx.x;
+  const int j = c == 2 ? jt / zsplit : jt, part = c == 2 ? jt - j * zsplit : 0;
   double qz = 0.0;
   // several ranks: tables only for this rank's atoms [j0, j1) (whole wavefronts of the others leave here); the compact charges and
   // the slab sum's q z (z axis) cover all atoms on every rank
   const bool tab = j >= j0 && j < j1;
-  if (j < nl_pad && !tab && c == 2) {
+  if (j < nl_pad && !tab && c == 2 && part == 0) {
     double xc = 0, qq = 0;
     if (j < nl) {
       const int i = elyte_idx[j];
@@ -146,19 +151,22 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
     } else if (zw.Bt) {
       // the z-window form (conp_zn.hip): this atom's row of the window matrix, dense over its chunk's columns:
       // Bt[(chunk * ncol + col) * 16 + atom] = phi((g0[chunk] + col) - u), u = z n / Lz' wrapped relative to the window origin
-      qc[j] = qq; qz = qq * xc;
+      if (part == 0) { qc[j] = qq; qz = qq * xc; }
       double *bt = zw.Bt + ((size_t)(j >> 4) * zw.ncol) * 16 + (j & 15);
+      const int cw = zw.ncol / ZN_SPLIT, col0 = part * cw;                 // this thread's columns (ncol = 32 or 48)
       if (j < nl) {
         double ur = xc * zw.gscale - (double)zw.g0c[j >> 4];
         ur -= (double)zw.n * rint(ur / (double)zw.n);
         const int i0 = (int)ceil(ur - 0.5 * zw.W);
-        if (i0 < 0 || i0 + zw.W > zw.ncol) *reinterpret_cast<volatile int *>(zw.flag) = 1;      // (page-locked host word: a tap left its window)
-        for (int col = 0; col < zw.ncol; ++col) {
+        if (part == 0 && (i0 < 0 || i0 + zw.W > zw.ncol)) *reinterpret_cast<volatile int *>(zw.flag) = 1;   // (page-locked host word: a tap left its window)
+        for (int col = col0; col < col0 + cw; ++col) {
           const double d = ((double)col - ur) * (2.0 / zw.W);            // in units of the window's half width
-          bt[(size_t)col * 16] = (d > -1.0 && d < 1.0) ? exp(zw.beta * (sqrt(1.0 - d * d) - 1.0)) : 0.0;
+          double v = 0.0;
+          if (d > -1.0 && d < 1.0) v = exp(zw.beta * (sqrt(1.0 - d * d) - 1.0));
+          bt[(size_t)col * 16] = v;
         }
       } else
-        for (int col = 0; col < zw.ncol; ++col) bt[(size_t)col * 16] = 0.0;
+        for (int col = col0; col < col0 + cw; ++col) bt[(size_t)col * 16] = 0.0;
     } else {
       qc[j] = qq; qz = qq * xc;
       const int nct = (nrz - 1) / 32;                 // column tiles
@@ -237,12 +245,12 @@ void launch_elyte_phase(hipStream_t s, int nl, int nl_pad, const int *elyte_idx,
                         double ux, double uy, double uz, int kxmax, int kymax, int nz, int kzt, int nrz, double2 *Xt,
                         double2 *Yt, double2 *Zs, double *qc, double *slab_part, int *n_slab_part, const BRowArgs *rows,
                         double *breal_out, int j0, int j1, const ZnWindow *zw) {
-  const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS;
-  *n_slab_part = nb;
+  const int nb = (nl_pad + EP_THREADS - 1) / EP_THREADS, zsplit = zw ? ZN_SPLIT : 1;
+  *n_slab_part = zsplit * nb;                              // (the z blocks leave the partial sums of q z)
   BRowArgs ra{};
   int nrb = 0;
   if (rows && breal_out) { ra = *rows; nrb = (ra.ne + EP_THREADS / 64 - 1) / (EP_THREADS / 64); }
-  hipLaunchKernelGGL(elyte_phase_kernel, dim3(3 * nb + nrb), dim3(EP_THREADS), 0, s, nb, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
+  hipLaunchKernelGGL(elyte_phase_kernel, dim3((2 + zsplit) * nb + nrb), dim3(EP_THREADS), 0, s, nb, nl, nl_pad, elyte_idx, x, q, ux, uy, uz, kxmax,
                      kymax, nz, kzt, nrz, Xt, Yt, Zs, qc, slab_part, ra, breal_out, j0, j1, zw ? *zw : ZnWindow{});
 }
 

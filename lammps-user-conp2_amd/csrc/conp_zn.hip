@@ -63,19 +63,27 @@ __device__ unsigned long long zn_tl_chunks[16 * 64];   // the workgroups that sh
 #else
 #define ZN_STAMP(k) do { } while (0)
 #endif
-template <int NCF>
-__global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnItem *__restrict__ items, const double2 *__restrict__ Xt,
-                                                         const double2 *__restrict__ Yt, const double *__restrict__ Bt,
-                                                         const double *__restrict__ P, int n, int nzc, double *__restrict__ pieces,
-                                                         int piece_stride, int stagger_period) {
+// NSUB items per workgroup (256 NSUB threads, NSUB x 2 panels in LDS, one barrier per chunk for all of them) -- measured and NOT used:
+// the SIMD's arbiter serves the oldest wave first, so the four workgroups of a CU finish one after the other and the last one multiplies
+// alone with its latencies exposed (profiles/r05_zn_timeline.txt); under a common barrier the items advance together, but the barrier's
+// bubble then idles the whole CU: 57.3 us with NSUB = 2, 53.9 with 4, against 51.0 with separate workgroups (headline size).
+template <int NCF, int NSUB>
+__global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan pl, const ZnItem *__restrict__ items, int nitems,
+                                                                const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
+                                                                const double *__restrict__ Bt, const double *__restrict__ P, int n, int nzc,
+                                                                double *__restrict__ pieces, int piece_stride) {
   constexpr int NF = 128 + 16 * NCF;                         // features per panel
-  __shared__ __attribute__((aligned(16))) double panel[2][NF * ZN_LD];
+  extern __shared__ __attribute__((aligned(16))) double zn_lds[];
   ZN_STAMP(0);
 #ifdef ZN_TIMELINE
   const long long zn_c0 = clock64();
 #endif
-  const ZnItem it = items[blockIdx.x];
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int item_idx = sub * (int)gridDim.x + (int)blockIdx.x;                      // (items of one workgroup: a grid apart, same XCD)
+  const bool live = item_idx < nitems;
+  const ZnItem it = live ? items[item_idx] : ZnItem{0, 0, 1, 0, 0};
+  double(*panel)[NF * ZN_LD] = reinterpret_cast<double(*)[NF * ZN_LD]>(zn_lds + (size_t)sub * 2 * NF * ZN_LD);
+  const int t = threadIdx.x & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int gj = t & 15, gs = t >> 4;                        // build role: atom gj of the chunk, sub-index gs 0..15
   const int fr = lane & 15, fk = lane >> 4;
   const unsigned nrx16 = (unsigned)(pl.kxmax + 2) * 16, nry16 = (unsigned)(pl.kymax + 1) * 16;
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnIte
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bt + (size_t)it.c0 * (16 * NCF * 16)), (short)0, -1, 0x00020000);
   auto chunk = [&](int ch, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
+    if (NSUB > 1 && ch >= it.c1) { __syncthreads(); return; }   // (a shorter item of the workgroup: the barrier only)
     const double *pn = panel[BUF];
     double *pw = panel[BUF ^ 1];
     const int chn = min(ch + 2, it.c1 - 1);
@@ -190,15 +199,25 @@ __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnIte
     }
     __syncthreads();
 #ifdef ZN_TIMELINE
-    if (threadIdx.x == 0 && (blockIdx.x & 255) == 0 && (blockIdx.x >> 8) < 16 && ch - it.c0 < 64) zn_tl_chunks[(blockIdx.x >> 8) * 64 + ch - it.c0] = wall_clock64();
+    if (t == 0 && blockIdx.x == 0 && ch - it.c0 < 64) zn_tl_chunks[sub * 64 + ch - it.c0] = wall_clock64();
 #endif
   };
+  int nmax = it.c1 - it.c0;
+  if (NSUB > 1) {                                            // the longest item of the workgroup (uniform loads)
+    nmax = 0;
+#pragma unroll
+    for (int k = 0; k < NSUB; ++k) {
+      const int ik = k * (int)gridDim.x + (int)blockIdx.x;
+      if (ik < nitems) nmax = max(nmax, items[ik].c1 - items[ik].c0);
+    }
+  }
 #ifndef ZN_SKIP_MAIN
-  for (int ch = it.c0; ch < it.c1; ch += 2) {
-    chunk(ch, std::integral_constant<int, 0>());
-    if (ch + 1 < it.c1) chunk(ch + 1, std::integral_constant<int, 1>());
+  for (int i = 0; i < nmax; i += 2) {
+    chunk(it.c0 + i, std::integral_constant<int, 0>());
+    if (i + 1 < nmax) chunk(it.c0 + i + 1, std::integral_constant<int, 1>());
   }
 #endif
+  if (!live) return;
   ZN_STAMP(2);
   // ---- the range's piece of the class table: piece[c * 128 + row] = sum_col acc[row][col] P[vector of row][c][g0 + col]
   // The 'a' and the 'b' row of a planar vector carry the same weights, and a wave holds both (fragments wave and 4 + wave): every P value
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(256, 3) void zn_gemm_kernel(DevPlan pl, const ZnIte
     }
   }
 #ifdef ZN_TIMELINE
-  __syncthreads();
+  if (NSUB == 1) __syncthreads();
   ZN_STAMP(3);
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned hw, xcc;
@@ -267,13 +286,24 @@ void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n,
   hipLaunchKernelGGL(zn_ptable_kernel, dim3((n + 255) / 256, pl.R_pad / 2), dim3(256), 0, s, pl.R_pad, pl.C_pad, pl.nz, kzt, nzc, n, pl.wfull, tzt,
                      phihat, cs, P);
 }
+template <int NCF, int NSUB>
+static void zn_gemm_launch(hipStream_t s, const DevPlan &pl, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
+                           const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
+  constexpr int lds = NSUB * 2 * (128 + 16 * NCF) * ZN_LD * 8;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&zn_gemm_kernel<NCF, NSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    once = true;
+  }
+  const int nblocks = ((nitems + NSUB - 1) / NSUB + 7) / 8 * 8;          // (a multiple of the XCD count: item i stays on XCD i mod 8)
+  hipLaunchKernelGGL((zn_gemm_kernel<NCF, NSUB>), dim3(nblocks), dim3(256 * NSUB), lds, s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces,
+                     piece_stride);
+}
 void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
-                    const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride, int num_cus) {
+                    const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
   if (nitems <= 0) return;
-  if (ncf == 2)
-    hipLaunchKernelGGL(zn_gemm_kernel<2>, dim3(nitems), dim3(256), 0, s, pl, items, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride, num_cus);
-  else
-    hipLaunchKernelGGL(zn_gemm_kernel<3>, dim3(nitems), dim3(256), 0, s, pl, items, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride, num_cus);
+  if (ncf == 2) zn_gemm_launch<2, 1>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+  else zn_gemm_launch<3, 1>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
 }
 
 }  // namespace conp
