@@ -176,7 +176,7 @@ def measure_config(label, workload, solver="inv", pppm=None, steps=200, warmup=2
                             frac=ach / FP64_PEAK_TFLOPS)
         elif dom == "zn_gemm":
             ach = zn_gemm_flops(info) / (t_ms * 1e-3) / 1e12
-            dominant = dict(kernel="zn_window_kernel + zn_gemm_kernel", ms=t_ms, bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS,
+            dominant = dict(kernel="zn_gemm_kernel", ms=t_ms, bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS,
                             unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, executed_flops=zn_gemm_flops(info),
                             survey_count_tflops=2 * sk_gemm_flops(info) / (t_ms * 1e-3) / 1e12,
                             note="the z-window form: 2 x rows x window columns x atoms flop (what the kernel executes); the survey's "
@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--solver", choices=["inv", "cg"], default="inv",
                     help="inv: GEMV with the projected inverse (the headline); cg: the reference's conjugate-gradient solver "
                          "(BASELINE configs[2] runs il_twolayer with it)")
+    ap.add_argument("--classic", action="store_true",
+                    help="the full (planar, kz) contraction (sk_gemm) instead of the z-window form -- round 4's kernels, for comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels with HIP events")
@@ -255,6 +257,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.classic:
+        from conp_amd import capi
+        capi.load_library().conp_debug_set_paths(capi.PATH_SK_CLASSIC)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # rehearsal on a one-GPU box: CONP_BENCH_REHEARSE=1 puts every rank on cuda:0 and runs the collectives over gloo
@@ -414,7 +419,8 @@ def main():
         flops = sk_gemm_flops(info, world)
         roofline = None
         if "zn_gemm" in timed_prof:
-            # the z-window form (conp_zn.hip): the dominant launches are the window matrix + the 32 / 48-column contraction.  Its
+            # the z-window form (conp_zn.hip): the dominant launch is the 32 / 48-column contraction (the window matrix is written by the
+            # phase kernel).  Its
             # algorithmic work is ITS formulation's: 2 x rows x columns x atoms (the survey's 8 Nl K describes the reference loop, which
             # this path does not execute: a fraction against that count would exceed 1 and say nothing about the kernel)
             t_ms = timed_prof["zn_gemm"][0]
@@ -426,13 +432,14 @@ def main():
             pj = cands[-1] if cands else ""
             if args.workload == "headline" and world == 1 and pj and os.path.exists(pj):
                 pmc = json.load(open(pj)).get("pmc", {})
-                if all(k in pmc and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k] for k in ("zn_gemm_kernel", "zn_window_kernel")):
-                    traffic = sum((2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0 for k in ("zn_gemm_kernel", "zn_window_kernel"))
+                if "zn_gemm_kernel" in pmc and "FETCH_SIZE" in pmc["zn_gemm_kernel"] and "WRITE_SIZE" in pmc["zn_gemm_kernel"]:
+                    # rocprofv3 reports KiB; FETCH_SIZE x2: gfx950 counts 16-B-per-lane streams at half (MI355X_MICROARCH.md, HBM)
+                    traffic = (2.0 * pmc["zn_gemm_kernel"]["FETCH_SIZE"] + pmc["zn_gemm_kernel"]["WRITE_SIZE"]) * 1024.0
                     traffic_src = f"profiles/{os.path.basename(pj)} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-            roofline = dict(bound="mfma", kernel="zn_window_kernel + zn_gemm_kernel (v_mfma_f64_16x16x4_f64)", achieved=ach,
+            roofline = dict(bound="mfma", kernel="zn_gemm_kernel (v_mfma_f64_16x16x4_f64)", achieved=ach,
                             peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=t_ms, launches_averaged=timed_prof["zn_gemm"][1],
-                            measured="HIP events on the library's stream around every 4th window + contraction launch pair of the timed region",
+                            measured="HIP events on the library's stream around every 4th zn_gemm launch of the timed region",
                             algorithmic_flops_per_launch=zf, formulation="z-window: 2 x %d rows x %d columns x %d atoms" % (info.zn_rows, info.zn_cols, nl),
                             survey_count_tflops=2 * flops / (t_ms * 1e-3) / 1e12, full_contraction_tflops=flops / (t_ms * 1e-3) / 1e12,
                             note="achieved = the flops this formulation executes over its time; full_contraction_tflops = 4 Nl K (round 4's "
@@ -489,6 +496,8 @@ def main():
                                accuracy_relative=s.accuracy_relative, mode="ffield" if s.ff_flag == 1 else "slab",
                                solver=args.solver, kspace=("pppm %dx%dx%d order 5" % tuple(args.pppm)) if args.pppm else "ewald",
                                blist_pairs=int(info.n_blist_pairs),
+                               structure_factor_form=("z-window (%d columns, grid %d)" % (info.zn_cols, info.zn_grid)) if info.zn_cols > 0
+                               else "full (planar, kz) contraction",
                                parallelism=f"S(k): electrolyte atoms sharded (all k, all rows) + all-reduce(b); solve: electrode rows sharded + all-gather(q); x{world}" + (", RCCL inside libconp_hip" if lib_collectives else "")),
                    collectives=collectives,
                    ns_per_day_solver_limited=value * 2.0 * 86400 * 1e-6,   # Nevery=1, dt = 2 fs (tests/il_onelayer/input:87)
@@ -498,7 +507,7 @@ def main():
                    kernels_ms={k: round(v[0], 5) for k, v in prof.items()},
                    ms_per_step_profiled_pass=dt_prof / n_prof * 1e3,
                    order_of_passes=("setup; host-buffer hook pass; %d updates with events around every kernel (kernels_ms); "
-                                   "%d warm-up + %d timed updates (value; events around every 4th sk_gemm launch only)"
+                                   "%d warm-up + %d timed updates (value; events around every 4th launch of the dominant kernel only)"
                                    % (n_prof if not args.no_profile else 0, args.warmup, args.steps)),
                    roofline=roofline, roofline_hbm_member=hbm_member, composite_roofline=composite)
         if not args.no_cpu_baseline and world == 1:

@@ -305,7 +305,12 @@ int64_t conp_host_pair_rows(int which, const conp_neighlist *list, const conp_at
  *                           the real-space term; slab term on rank 0) -> [caller: all-reduce b over ranks] ->
  *   conp_fix_solve_device  (rows [row0,row1) of q = S b (+ dV S d) into the bound q buffer) ->
  *                          [caller: all-gather q] -> conp_fix_scatter_device (q[i] for owned+ghost electrode atoms).
- * With nranks == 1 conp_fix_pre_force_device runs all three back to back. */
+ * With nranks == 1 conp_fix_pre_force_device runs all three back to back.
+ * Large planar systems take the z-window form of the structure-factor contraction (conp_info.zn_cols > 0): every electrolyte atom
+ * must stay within 2.5 A (in z) of its position at the last conp_fix_post_neighbor -- LAMMPS re-neighbours long before that.  The
+ * device-resident entries do not synchronise, so an atom that left its window is seen one call later: that call returns
+ * CONP_ERR_NUMERIC (the charges of the updates since the list build are invalid; call conp_fix_post_neighbor and repeat), and the
+ * handle uses the full kernels until the next list build.  conp_fix_pre_force (host arrays) repeats the update by itself. */
 int conp_fix_set_stream(conp_fix *fix, void *hip_stream);
 int conp_fix_bind_device_buffers(conp_fix *fix, double *d_b /*[Ne]*/, double *d_q /*[Ne]*/);
 /* this rank's electrode rows: blocks of ceil(Ne / nranks) rows, so that rank r's rows start at r * ceil(Ne / nranks) */

@@ -24,7 +24,7 @@ namespace conp {
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define ZN_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// ---- once per run: P[(vector * nzc + c) * n + g] -----------------------------------------------------------------------------------------
+// ---- once per run: P[((row tile * nzc + c) * n + g) * 64 + vector of the tile] -----------------------------------------------------------------------------------------
 // one thread per (G row, grid point); cs[k] = (cos, sin)(2 pi k / n) so that the phases of m g h are exact table look-ups
 __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, int nz, int kzt, int nzc, int n, const double *__restrict__ wfull,
                                                         const double *__restrict__ tzt /*[nzc][C_pad]*/, const double *__restrict__ phihat,
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, in
       const double2 e = cs[(int)(((long long)m * g) % n)];
       s += (w / phihat[m]) * (tzt[(size_t)c * C_pad + cc] * e.x + tzt[(size_t)c * C_pad + cc + 8] * e.y);
     }
-    P[((size_t)row * nzc + c) * n + g] = h * s;
+    P[(((size_t)(row >> 6) * nzc + c) * n + g) * 64 + (row & 63)] = h * s;
   }
 }
 
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, in
 
 // ---- per update: the contraction + the projection on P -----------------------------------------------------------------------------
 // item = (row tile rt: 64 planar vectors = 128 G rows, chunk range [c0, c1), window origin g0, output slot)
-// 256 threads = 4 waves; wave w owns the row fragments w ('a' rows of 16 planar vectors) and 4 + w (their 'b' rows) x all NCF column fragments.
+// 256 threads = 4 waves; wave w owns the row fragments w ('a' rows of 16 planar vectors) and 4 + w (their 'b' rows) x all NCF column fragments;
+// the window fragment is the MFMA's A operand (accumulator rows = window columns), the feature fragment its B operand (see the epilogue).
 // LDS panel per chunk (double-buffered): [128 + 16 NCF features][16 atoms], column XOR-swizzled by feature & 15 like sk_gemm's.
 constexpr int ZN_LD = 16;
 #ifdef ZN_TIMELINE
@@ -175,25 +176,25 @@ __global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(D
       __builtin_amdgcn_sched_barrier(0);
       // slice ks of the build: planar vector gs + 16 ks of the next chunk
       const double sy = __hiloint2double(__double2hiint(Y[ks].y) ^ (int)sgm[ks], __double2loint(Y[ks].y));
-      acc[0][0] = ZN_MFMA(fa[cur][0], fb[cur][0], acc[0][0]);
+      acc[0][0] = ZN_MFMA(fb[cur][0], fa[cur][0], acc[0][0]);
       const double va = X[ks].x * Y[ks].x - X[ks].y * sy;
       __builtin_amdgcn_sched_barrier(0);
-      acc[1][0] = ZN_MFMA(fa[cur][1], fb[cur][0], acc[1][0]);
+      acc[1][0] = ZN_MFMA(fb[cur][0], fa[cur][1], acc[1][0]);
       const double vb = X[ks].x * sy + X[ks].y * Y[ks].x;
       __builtin_amdgcn_sched_barrier(0);
-      acc[0][1] = ZN_MFMA(fa[cur][0], fb[cur][1], acc[0][1]);
+      acc[0][1] = ZN_MFMA(fb[cur][1], fa[cur][0], acc[0][1]);
       pw[wa + 16 * ks * ZN_LD] = va;
       pw[wa + (64 + 16 * ks) * ZN_LD] = vb;
       if (ks < NCF) pw[wa + (128 + 16 * ks) * ZN_LD] = bv[ks < NCF ? ks : 0];
       __builtin_amdgcn_sched_barrier(0);
-      acc[1][1] = ZN_MFMA(fa[cur][1], fb[cur][1], acc[1][1]);
+      acc[1][1] = ZN_MFMA(fb[cur][1], fa[cur][1], acc[1][1]);
       X[ks] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[ks], sx, 0));
       Y[ks] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[ks], sy_, 0));
       if (ks < NCF) bv[ks < NCF ? ks : 0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, bby + 2048 * ks, sb, 0));
       __builtin_amdgcn_sched_barrier(0);
       if (NCF > 2) {
-        acc[0][NCF - 1] = ZN_MFMA(fa[cur][0], fb[cur][NCF - 1], acc[0][NCF - 1]);
-        acc[1][NCF - 1] = ZN_MFMA(fa[cur][1], fb[cur][NCF - 1], acc[1][NCF - 1]);
+        acc[0][NCF - 1] = ZN_MFMA(fb[cur][NCF - 1], fa[cur][0], acc[0][NCF - 1]);
+        acc[1][NCF - 1] = ZN_MFMA(fb[cur][NCF - 1], fa[cur][1], acc[1][NCF - 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -220,20 +221,20 @@ __global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(D
   if (!live) return;
   ZN_STAMP(2);
   // ---- the range's piece of the class table: piece[c * 128 + row] = sum_col acc[row][col] P[vector of row][c][g0 + col]
-  // The 'a' and the 'b' row of a planar vector carry the same weights, and a wave holds both (fragments wave and 4 + wave): every P value
-  // is fetched once and used twice.  The table comes from the Infinity Cache at best (26 MB a run, never twice through one L2), so the
-  // fetches of CB classes are in flight together -- the epilogue is the latency of nzc / CB round trips, not of 2 nzc.
-  double *out = pieces + (size_t)it.slot * piece_stride;
-  int gcol[NCF];                                              // this lane's grid columns (the grid is periodic; n is any integer)
+  // The window is the MFMA's A operand and the features its B operand, so a lane holds, for ONE planar vector (16 wave + fr) and both its
+  // rows, the four columns 4 r + fk of every column block: the sum over columns is in-lane but for the four lane groups fk (two exchanges
+  // per value; with the features as A operand it was a 16-lane reduction of 8 values -- ~90 vector instructions per class, and the vector
+  // port is what the MFMAs of the CU's other workgroups run on).  The 'a' and the 'b' row share their weights: one fetch serves both.
+  // P[((rt * nzc + c) * n + g) * 64 + v]: the 16 lanes fr read 128 contiguous bytes.  The table comes from the Infinity Cache at best
+  // (13 MB a run, never twice through one L2), so the fetches of CB classes are in flight together.
+  double *out = pieces + (size_t)it.slot * piece_stride + 16 * wave + fr;
+  unsigned gofs[NCF][4];                                      // this lane's grid columns x 64 (the grid is periodic; n is any integer)
 #pragma unroll
-  for (int cf = 0; cf < NCF; ++cf) { int g = (it.g0 + 16 * cf + fr) % n; gcol[cf] = g < 0 ? g + n : g; }
-  const double *Pw = P + (size_t)(it.rt * 64 + 16 * wave + fk) * nzc * n;      // vector 16 wave + 4 r + fk: + r * prow
-  const size_t prow = (size_t)4 * nzc * n;
+  for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { int g = (it.g0 + 16 * cf + 4 * r + fk) % n; gofs[cf][r] = (unsigned)(g < 0 ? g + n : g) * 64u; }
+  const double *Pw = P + (size_t)it.rt * nzc * n * 64 + 16 * wave + fr;
   constexpr int CB = 3;
-  // the 8 sums of a lane (2 fragments x 4 rows) are reduced over the 16 lanes fr by halving: after the steps 8, 4, 2 a lane holds one sum
-  // (fragment = bit 3 of fr, row = bits 2..1), the step 1 completes it -- 8 exchanges a class instead of 32
-  const bool hi8 = (fr & 8) != 0, hi4 = (fr & 4) != 0, hi2 = (fr & 2) != 0;
-  double *outp = out + 16 * (4 * (hi8 ? 1 : 0) + wave) + 4 * ((hi4 ? 2 : 0) + (hi2 ? 1 : 0)) + fk;
 #ifdef ZN_SKIP_EPI
   for (int cb = 0; cb < 1; cb += CB) {
 #else
@@ -242,30 +243,22 @@ __global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(D
     double pv[CB][NCF][4];
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
-      const size_t co = (size_t)min(cb + k, nzc - 1) * n;
+      const double *pc = Pw + (size_t)min(cb + k, nzc - 1) * n * 64;
 #pragma unroll
       for (int cf = 0; cf < NCF; ++cf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[k][cf][r] = Pw[r * prow + co + gcol[cf]];
+        for (int r = 0; r < 4; ++r) pv[k][cf][r] = pc[gofs[cf][r]];
     }
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
-      double v[8];
+      double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double s0 = 0.0, s1 = 0.0;
+      for (int cf = 0; cf < NCF; ++cf)
 #pragma unroll
-        for (int cf = 0; cf < NCF; ++cf) { s0 += acc[0][cf][r] * pv[k][cf][r]; s1 += acc[1][cf][r] * pv[k][cf][r]; }
-        v[r] = s0; v[4 + r] = s1;
-      }
-      double w4[4], w2[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w4[i] = (hi8 ? v[4 + i] : v[i]) + __shfl_xor(hi8 ? v[i] : v[4 + i], 8, 64);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) w2[i] = (hi4 ? w4[2 + i] : w4[i]) + __shfl_xor(hi4 ? w4[i] : w4[2 + i], 4, 64);
-      double w1 = (hi2 ? w2[1] : w2[0]) + __shfl_xor(hi2 ? w2[0] : w2[1], 2, 64);
-      w1 += __shfl_xor(w1, 1, 64);
-      if ((fr & 1) == 0 && cb + k < nzc) outp[(cb + k) * 128] = w1;
+        for (int r = 0; r < 4; ++r) { s0 += acc[0][cf][r] * pv[k][cf][r]; s1 += acc[1][cf][r] * pv[k][cf][r]; }
+      s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+      s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+      if (fk == 0 && cb + k < nzc) { out[(cb + k) * 128] = s0; out[(cb + k) * 128 + 64] = s1; }
     }
   }
 #ifdef ZN_TIMELINE

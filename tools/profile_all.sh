@@ -13,7 +13,7 @@ run() {   # name, bench args
   rm -rf gpurun_out/prof_$name
   echo "== $name done" >&2
 }
-run bench_headline && run il_onelayer --workload il_onelayer && run il_twolayer_cg --workload il_twolayer --solver cg \
+run bench_headline && run classic_headline --classic && run il_onelayer --workload il_onelayer && run il_twolayer_cg --workload il_twolayer --solver cg \
   && run il_onelayer_pppm --workload il_onelayer --pppm 40 45 180 && run headline_slab --workload headline_slab \
   && run headline_rough --workload headline_rough
 ls -la $DST
