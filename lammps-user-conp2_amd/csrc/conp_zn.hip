@@ -64,12 +64,12 @@ __device__ unsigned long long zn_tl_chunks[16 * 64];   // the workgroups that sh
 #else
 #define ZN_STAMP(k) do { } while (0)
 #endif
-// NSUB items per workgroup (256 NSUB threads, NSUB x 2 panels in LDS, one barrier per chunk for all of them) -- measured and NOT used:
+// Two or four items per workgroup (512 / 1024 threads, 2 panels each in LDS, one barrier per chunk for all of them) -- measured and NOT used:
 // the SIMD's arbiter serves the oldest wave first, so the four workgroups of a CU finish one after the other and the last one multiplies
 // alone with its latencies exposed (profiles/r05_zn_timeline.txt); under a common barrier the items advance together, but the barrier's
-// bubble then idles the whole CU: 57.3 us with NSUB = 2, 53.9 with 4, against 51.0 with separate workgroups (headline size).
-template <int NCF, int NSUB>
-__global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan pl, const ZnItem *__restrict__ items, int nitems,
+// bubble then idles the whole CU: 57.3 us with two items, 53.9 with four, against 51.0 with separate workgroups (headline size).
+template <int NCF>
+__global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan pl, const ZnItem *__restrict__ items, int nitems,
                                                                 const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                                 const double *__restrict__ Bt, const double *__restrict__ P, int n, int nzc,
                                                                 double *__restrict__ pieces, int piece_stride) {
@@ -79,12 +79,11 @@ __global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(D
 #ifdef ZN_TIMELINE
   const long long zn_c0 = clock64();
 #endif
-  const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-  const int item_idx = sub * (int)gridDim.x + (int)blockIdx.x;                      // (items of one workgroup: a grid apart, same XCD)
-  const bool live = item_idx < nitems;
-  const ZnItem it = live ? items[item_idx] : ZnItem{0, 0, 1, 0, 0};
-  double(*panel)[NF * ZN_LD] = reinterpret_cast<double(*)[NF * ZN_LD]>(zn_lds + (size_t)sub * 2 * NF * ZN_LD);
-  const int t = threadIdx.x & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int item_idx = (int)blockIdx.x;                       // (the grid is padded to a multiple of the XCD count)
+  if (item_idx >= nitems) return;
+  const ZnItem it = items[item_idx];
+  double(*panel)[NF * ZN_LD] = reinterpret_cast<double(*)[NF * ZN_LD]>(zn_lds);
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int gj = t & 15, gs = t >> 4;                        // build role: atom gj of the chunk, sub-index gs 0..15
   const int fr = lane & 15, fk = lane >> 4;
   const unsigned nrx16 = (unsigned)(pl.kxmax + 2) * 16, nry16 = (unsigned)(pl.kymax + 1) * 16;
@@ -154,71 +153,68 @@ __global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(D
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Xt + (size_t)it.c0 * nrx16), (short)0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Yt + (size_t)it.c0 * nry16), (short)0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bt + (size_t)it.c0 * (16 * NCF * 16)), (short)0, -1, 0x00020000);
+  // Per chunk: k-steps 0..2 carry the twelve build slices (three per planar vector: its 'a' value, its 'b' value, the panel write + the
+  // loads of the chunk after next) between their MFMAs; the barrier sits BEFORE the last k-step, whose fragments are in registers by
+  // then, and the first fragments of the next chunk are requested right behind it -- their LDS latency passes under the last k-step's
+  // MFMAs instead of in front of the next chunk's first one (a workgroup that multiplies alone is latency-bound per chunk).
+  double fa[2][2], fb[2][NCF];                                // two fragment sets; on entry to a chunk set 0 holds its k-step 0
+  auto frag = [&](const double *pn, int ks, int set) {
+    fa[set][0] = pn[rdA[ks]]; fa[set][1] = pn[rdA[ks] + 64 * ZN_LD];
+#pragma unroll
+    for (int c = 0; c < NCF; ++c) fb[set][c] = pn[rdB[ks] + 16 * c * ZN_LD];
+  };
+  frag(panel[0], 0, 0);
   auto chunk = [&](int ch, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    if (NSUB > 1 && ch >= it.c1) { __syncthreads(); return; }   // (a shorter item of the workgroup: the barrier only)
     const double *pn = panel[BUF];
     double *pw = panel[BUF ^ 1];
     const int chn = min(ch + 2, it.c1 - 1);
     const int sx = (chn - it.c0) * (int)(nrx16 * 16), sy_ = (chn - it.c0) * (int)(nry16 * 16), sb = (chn - it.c0) * (16 * NCF * 16 * 8);
-    double fa[2][2], fb[2][NCF];
-    fa[0][0] = pn[rdA[0]]; fa[0][1] = pn[rdA[0] + 64 * ZN_LD];
-#pragma unroll
-    for (int c = 0; c < NCF; ++c) fb[0][c] = pn[rdB[0] + 16 * c * ZN_LD];
+    double sy = 0.0, va = 0.0, vb = 0.0;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nx = cur ^ 1;
-      if (ks < 3) {
-        fa[nx][0] = pn[rdA[ks + 1]]; fa[nx][1] = pn[rdA[ks + 1] + 64 * ZN_LD];
-#pragma unroll
-        for (int c = 0; c < NCF; ++c) fb[nx][c] = pn[rdB[ks + 1] + 16 * c * ZN_LD];
+      if (ks < 3) frag(pn, ks + 1, nx);
+      else {
+        __syncthreads();                                      // every panel value of the next chunk is written, every fragment of this one read
+        frag(pw, 0, nx);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // slice ks of the build: planar vector gs + 16 ks of the next chunk
-      const double sy = __hiloint2double(__double2hiint(Y[ks].y) ^ (int)sgm[ks], __double2loint(Y[ks].y));
-      acc[0][0] = ZN_MFMA(fb[cur][0], fa[cur][0], acc[0][0]);
-      const double va = X[ks].x * Y[ks].x - X[ks].y * sy;
-      __builtin_amdgcn_sched_barrier(0);
-      acc[1][0] = ZN_MFMA(fb[cur][0], fa[cur][1], acc[1][0]);
-      const double vb = X[ks].x * sy + X[ks].y * Y[ks].x;
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0][1] = ZN_MFMA(fb[cur][1], fa[cur][0], acc[0][1]);
-      pw[wa + 16 * ks * ZN_LD] = va;
-      pw[wa + (64 + 16 * ks) * ZN_LD] = vb;
-      if (ks < NCF) pw[wa + (128 + 16 * ks) * ZN_LD] = bv[ks < NCF ? ks : 0];
-      __builtin_amdgcn_sched_barrier(0);
-      acc[1][1] = ZN_MFMA(fb[cur][1], fa[cur][1], acc[1][1]);
-      X[ks] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[ks], sx, 0));
-      Y[ks] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[ks], sy_, 0));
-      if (ks < NCF) bv[ks < NCF ? ks : 0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, bby + 2048 * ks, sb, 0));
-      __builtin_amdgcn_sched_barrier(0);
-      if (NCF > 2) {
-        acc[0][NCF - 1] = ZN_MFMA(fb[cur][NCF - 1], fa[cur][0], acc[0][NCF - 1]);
-        acc[1][NCF - 1] = ZN_MFMA(fb[cur][NCF - 1], fa[cur][1], acc[1][NCF - 1]);
+#pragma unroll
+      for (int m = 0; m < 2 * NCF; ++m) {
+        const int f = m & 1, c = m >> 1;
+        acc[f][c] = ZN_MFMA(fb[cur][c], fa[cur][f], acc[f][c]);
+        const int g = 4 * ks + m;                             // gap behind this MFMA: slice g of the build (k-steps 0..2, four gaps each)
+        if (ks < 3 && m < 4) {
+          const int u = g / 3, part = g - 3 * u;
+          if (part == 0) {
+            sy = __hiloint2double(__double2hiint(Y[u].y) ^ (int)sgm[u], __double2loint(Y[u].y));
+            va = X[u].x * Y[u].x - X[u].y * sy;
+          } else if (part == 1) {
+            vb = X[u].x * sy + X[u].y * Y[u].x;
+          } else {
+            pw[wa + 16 * u * ZN_LD] = va;
+            pw[wa + (64 + 16 * u) * ZN_LD] = vb;
+            if (u < NCF) pw[wa + (128 + 16 * u) * ZN_LD] = bv[u < NCF ? u : 0];
+            X[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[u], sx, 0));
+            Y[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[u], sy_, 0));
+            if (u < NCF) bv[u < NCF ? u : 0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, bby + 2048 * u, sb, 0));
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
 #ifdef ZN_TIMELINE
-    if (t == 0 && blockIdx.x == 0 && ch - it.c0 < 64) zn_tl_chunks[sub * 64 + ch - it.c0] = wall_clock64();
+    if (t == 0 && (blockIdx.x & 255) == 0 && (blockIdx.x >> 8) < 16 && ch - it.c0 < 64) zn_tl_chunks[(blockIdx.x >> 8) * 64 + ch - it.c0] = wall_clock64();
 #endif
   };
-  int nmax = it.c1 - it.c0;
-  if (NSUB > 1) {                                            // the longest item of the workgroup (uniform loads)
-    nmax = 0;
-#pragma unroll
-    for (int k = 0; k < NSUB; ++k) {
-      const int ik = k * (int)gridDim.x + (int)blockIdx.x;
-      if (ik < nitems) nmax = max(nmax, items[ik].c1 - items[ik].c0);
-    }
-  }
+  const int nmax = it.c1 - it.c0;
 #ifndef ZN_SKIP_MAIN
   for (int i = 0; i < nmax; i += 2) {
     chunk(it.c0 + i, std::integral_constant<int, 0>());
     if (i + 1 < nmax) chunk(it.c0 + i + 1, std::integral_constant<int, 1>());
   }
 #endif
-  if (!live) return;
   ZN_STAMP(2);
   // ---- the range's piece of the class table: piece[c * 128 + row] = sum_col acc[row][col] P[vector of row][c][g0 + col]
   // The window is the MFMA's A operand and the features its B operand, so a lane holds, for ONE planar vector (16 wave + fr) and both its
@@ -262,7 +258,7 @@ __global__ __launch_bounds__(256 * NSUB, NCF == 2 ? 4 : 3) void zn_gemm_kernel(D
     }
   }
 #ifdef ZN_TIMELINE
-  if (NSUB == 1) __syncthreads();
+  __syncthreads();
   ZN_STAMP(3);
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned hw, xcc;
@@ -279,24 +275,18 @@ void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n,
   hipLaunchKernelGGL(zn_ptable_kernel, dim3((n + 255) / 256, pl.R_pad / 2), dim3(256), 0, s, pl.R_pad, pl.C_pad, pl.nz, kzt, nzc, n, pl.wfull, tzt,
                      phihat, cs, P);
 }
-template <int NCF, int NSUB>
+template <int NCF>
 static void zn_gemm_launch(hipStream_t s, const DevPlan &pl, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
                            const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
-  constexpr int lds = NSUB * 2 * (128 + 16 * NCF) * ZN_LD * 8;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&zn_gemm_kernel<NCF, NSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    once = true;
-  }
-  const int nblocks = ((nitems + NSUB - 1) / NSUB + 7) / 8 * 8;          // (a multiple of the XCD count: item i stays on XCD i mod 8)
-  hipLaunchKernelGGL((zn_gemm_kernel<NCF, NSUB>), dim3(nblocks), dim3(256 * NSUB), lds, s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces,
-                     piece_stride);
+  constexpr int lds = 2 * (128 + 16 * NCF) * ZN_LD * 8;
+  const int nblocks = (nitems + 7) / 8 * 8;                  // (a multiple of the XCD count: item i stays on XCD i mod 8)
+  hipLaunchKernelGGL((zn_gemm_kernel<NCF>), dim3(nblocks), dim3(256), lds, s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
 }
 void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
                     const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
   if (nitems <= 0) return;
-  if (ncf == 2) zn_gemm_launch<2, 1>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
-  else zn_gemm_launch<3, 1>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+  if (ncf == 2) zn_gemm_launch<2>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+  else zn_gemm_launch<3>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
 }
 
 }  // namespace conp
