@@ -102,3 +102,20 @@ def test_z_window_rank_shards_add_up(world):
         assert c in (32, 48)
         total += b
     assert rel_err(total, b1) < 1e-12
+
+
+def test_z_window_ragged_list_across_the_periodic_wrap():
+    """a list whose length is not a multiple of the 16-atom chunk (padding atoms in the last chunk) in a box translated along z so that
+    the electrolyte straddles the periodic boundary: the z ordering starts behind the longest empty run of cells, no range straddles
+    the wrap, and the result equals the full contraction's"""
+    s = _medium("ffield", seed=19)
+    lo, hi = s.boxlo[2], s.boxlo[2] + s.prd[2]
+    s.x[:, 2] = lo + np.mod(s.x[:, 2] - lo + 0.37 * s.prd[2], s.prd[2])     # electrodes and liquid move together, wrapped into the box
+    assert s.x[:, 2].min() >= lo and s.x[:, 2].max() < hi
+    sol = np.nonzero((s.echeck == 0) & (s.q != 0))[0]
+    s.q[sol[[3, 500, 7001, 7002, 16000]]] = 0.0                              # five atoms leave the charged list: 16379 = 16 * 1023 + 11
+    at, alist, blist = neighbor.build_lists(s)
+    b_zn, cols_zn = _b(s, at, alist, blist, 0)
+    b_cl, cols_cl = _b(s, at, alist, blist, capi.PATH_SK_CLASSIC)
+    assert cols_zn in (32, 48) and cols_cl == 0
+    assert rel_err(b_zn, b_cl) < 1e-11
