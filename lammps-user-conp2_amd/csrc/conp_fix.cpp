@@ -853,12 +853,17 @@ struct conp_fix {
   DevBuf<ZnItem> d_zn_items;
   DevBuf<int> d_zn_g0c, d_zn_frag_ptr;
   DevBuf<int2> d_zn_frag_ents;
-  DevBuf<double> d_zn_P, d_zn_phihat, d_zn_Bt, d_zn_pieces;
+  DevBuf<double> d_zn_P, d_zn_phihat, d_zn_Bt, d_zn_pieces, d_zn_grid, d_zn_Dt;
+  DevBuf<int> d_zn_cov_ptr;
+  DevBuf<int2> d_zn_cov_ent;
+  int zn_nrg = 0;                 // ranges of the current item list
   DevBuf<double2> d_zn_cs;
   int zn_nfrag = 0;
   int *zn_flag_host = nullptr, *zn_flag_dev = nullptr;      // a page-locked word the window kernel stores 1 into when a tap leaves its window
   bool zn_eligible() const { return !decomposed && !args.pppm && nl >= zn_min_atoms && !path_on(CONP_PATH_SK_CLASSIC); }
   bool zn_use() const { return zn_listed && !zn_off && zn_eligible() && sk_projects() && nzc > 0; }
+  // rough electrodes (no z classes; one rank): the same contraction, the ranges' raw windows -> rows on the z grid -> G (conp_zn.hip)
+  bool zn_gen_use() const { return zn_listed && !zn_off && zn_eligible() && !sk_projects() && nzc == 0 && env.nranks <= 1 && zn_nrg > 0; }
   double zn_lz() const { return kt.slabflag ? env.zprd * env.slab_volfactor : env.zprd; }
   // z-order the list (stable: atoms of one cell keep their list order) and cut it into ranges with a window origin each
   void zn_order_list(const conp_atoms *at) {
@@ -980,12 +985,31 @@ struct conp_fix {
     std::vector<int2> fent;
     for (int g = 0; g < zn_nfrag; ++g) { fent.insert(fent.end(), of_frag[g].begin(), of_frag[g].end()); fptr[g + 1] = (int)fent.size(); }
     if (fent.empty()) fent.push_back(make_int2(0, 4));
+    // rough electrodes: which (range, column) pairs hold grid point g, range after range
+    zn_nrg = nrg;
+    {
+      const int ncol = 16 * zn_ncf;
+      std::vector<int> cptr(n + 1, 0);
+      std::vector<int2> cent;
+      for (int g = 0; g < n; ++g) {
+        for (int r = 0; r < nrg; ++r) {
+          int col = (g - g0c[ranges[r].first]) % n;
+          if (col < 0) col += n;
+          if (col < ncol) cent.push_back(make_int2(r, col));
+        }
+        cptr[g + 1] = (int)cent.size();
+      }
+      if (cent.empty()) cent.push_back(make_int2(0, 0));
+      ren_upload(d_zn_cov_ptr, cptr);
+      ren_upload(d_zn_cov_ent, cent);
+    }
     ren_upload(d_zn_items, zn_items_h);
     ren_upload(d_zn_g0c, g0c);
     ren_upload(d_zn_frag_ptr, fptr);
     ren_upload(d_zn_frag_ents, fent);
     d_zn_Bt.reserve((size_t)nchunks * 48 * 16);
-    d_zn_pieces.reserve(std::max<size_t>(1, zn_items_h.size()) * sk_hc_stride());
+    d_zn_pieces.reserve(std::max<size_t>(1, zn_items_h.size()) * std::max<size_t>(sk_hc_stride(), nzc == 0 ? (size_t)16 * zn_ncf * 128 : 0));
+    if (nzc == 0) d_zn_grid.reserve((size_t)nrt * n * 128);
     if (!zn_flag_host) {
       HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&zn_flag_host), 64, hipHostMallocMapped));
       HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&zn_flag_dev), zn_flag_host, 0));
@@ -1031,8 +1055,13 @@ struct conp_fix {
     std::vector<double2> cs(n);
     for (int k = 0; k < n; ++k) cs[k] = make_double2(std::cos(h * k), std::sin(h * k));
     d_zn_phihat.upload(phihat, stream); d_zn_cs.upload(cs, stream);
-    d_zn_P.reserve((size_t)plan.R_pad / 2 * nzc * n);      // one row per planar vector
-    launch_zn_ptable(stream, dplan, plan.kzt, nzc, n, d_TzcT.p, d_zn_phihat.p, d_zn_cs.p, d_zn_P.p);
+    if (nzc > 0) {
+      d_zn_P.reserve((size_t)plan.R_pad / 2 * nzc * n);      // one row per planar vector
+      launch_zn_ptable(stream, dplan, plan.kzt, nzc, n, d_TzcT.p, d_zn_phihat.p, d_zn_cs.p, d_zn_P.p);
+    } else {
+      d_zn_Dt.reserve((size_t)n * plan.C_pad);
+      launch_zn_dtable(stream, dplan, plan.kzt, n, d_zn_phihat.p, d_zn_cs.p, d_zn_Dt.p);
+    }
     sync();                                          // (the host vectors go out of scope)
     zn_tables_current = true;
   }
@@ -2158,7 +2187,7 @@ struct conp_fix {
                   (zn_use() || !bands_aligned || (hc_presum_env ? atoi(hc_presum_env) != 0 : hslots > 32 * (int)own_rt_h.size()));
         prof.begin("elyte_phase", stream);
         ZnWindow zw{};
-        const bool zn_now = zn_use();
+        const bool zn_now = zn_use() || zn_gen_use();
         if (zn_now) zw = ZnWindow{d_zn_Bt.p, d_zn_g0c.p, zn_flag_dev, 16 * zn_ncf, zn_n, ZN_W, zn_beta, zn_gscale};
         launch_elyte_phase(stream, nl, nl_pad, eidx, ex, eq, kt.unitk[0], kt.unitk[1], kt.unitk[2], plan.kxmax,
                            plan.kymax, plan.nz, plan.kzt, 1 + plan.n_col_tiles * 32, d_Xt.p, d_Yt.p, d_Zt.p, d_qc.p, d_slab_part.p,
@@ -2185,6 +2214,21 @@ struct conp_fix {
         launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_zn_pieces.p, d_hslot_ptr.p, d_hslot_idx.p,
                                      true, d_zn_frag_ptr.p, d_zn_frag_ents.p, zn_nfrag, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p,
                                      d_bk.p, use_fin ? &fin : nullptr, ride_hc ? &pairs_keep : nullptr, d_breal.p);
+        prof.end(stream);
+      } else if (zn_gen_use() && !fuse_phase) {
+        // rough electrodes: the ranges' windows -> the z grid -> G and w o G (what sk_reduce leaves), then the general projection
+        zn_ensure_tables();
+        prof.begin("zn_gemm", stream);
+        launch_zn_gemm(stream, dplan, zn_ncf, d_zn_items.p, (int)zn_items_h.size(), d_Xt.p, d_Yt.p, d_zn_Bt.p, nullptr, zn_n, 0,
+                       d_zn_pieces.p, 0);
+        prof.end(stream);
+        prof.begin("sk_reduce", stream);
+        launch_zn_windows_to_g(stream, dplan, zn_n, (int)own_rt_h.size(), d_own_rt.p, zn_nrg, 16 * zn_ncf, d_zn_cov_ptr.p, d_zn_cov_ent.p,
+                               d_zn_pieces.p, d_zn_grid.p, d_zn_Dt.p, d_G.p, d_Gw.p);
+        prof.end(stream);
+        g_current = true;
+        prof.begin("b_project", stream);
+        launch_b_project(stream, dplan, ne_pad, d_ct_ptr.p, d_tiles.p, d_Gw.p, d_Rp.p, d_Tz.p, d_bk.p);
         prof.end(stream);
       } else {
       reserve_partials();
@@ -2928,7 +2972,8 @@ int conp_fix_info(const conp_fix *f, conp_info *o) {
   if (f->np_pending) { HIP_TRY(hipStreamSynchronize(f->stream)); nbp = *f->h_np; }     // (the count of a regrouping still in flight)
   o->n_blist_pairs = nbp;
   o->inverse_path = f->inverse_path; o->inverse_retries = f->inverse_retries; o->pppm_elyte_spreads = f->pp_elyte_spreads;
-  o->zn_cols = f->zn_use() ? 16 * f->zn_ncf : 0; o->zn_grid = f->zn_use() ? f->zn_n : 0; o->zn_rows = f->zn_use() ? 128 * (int)f->own_rt_h.size() : 0; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
+  const bool zn_on = f->zn_use() || f->zn_gen_use();
+  o->zn_cols = zn_on ? 16 * f->zn_ncf : 0; o->zn_grid = zn_on ? f->zn_n : 0; o->zn_rows = zn_on ? 128 * (int)f->own_rt_h.size() : 0; o->n_alist_pairs = f->arows.npairs(); o->n_elyte_charged = f->nl;
   CONP_GUARD_END
 }
 

@@ -68,7 +68,7 @@ __device__ unsigned long long zn_tl_chunks[16 * 64];   // the workgroups that sh
 // the SIMD's arbiter serves the oldest wave first, so the four workgroups of a CU finish one after the other and the last one multiplies
 // alone with its latencies exposed (profiles/r05_zn_timeline.txt); under a common barrier the items advance together, but the barrier's
 // bubble then idles the whole CU: 57.3 us with two items, 53.9 with four, against 51.0 with separate workgroups (headline size).
-template <int NCF>
+template <int NCF, bool RAW>
 __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan pl, const ZnItem *__restrict__ items, int nitems,
                                                                 const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                                 const double *__restrict__ Bt, const double *__restrict__ P, int n, int nzc,
@@ -216,6 +216,18 @@ __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan 
   }
 #endif
   ZN_STAMP(2);
+  if constexpr (RAW) {
+    // rough electrodes (no z classes): the range's window itself, raw[(slot * NCOL + col) * 128 + row] -- zn_wsum / zn_dft turn the
+    // windows into the structure-factor matrix G (a lane holds columns 4 r + fk of every block for the vector 16 wave + fr)
+    double *raw = pieces + (size_t)it.slot * (16 * NCF * 128) + 16 * wave + fr;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) raw[(16 * cf + 4 * r + fk) * 128 + 64 * f] = acc[f][cf][r];
+    return;
+  }
   // ---- the range's piece of the class table: piece[c * 128 + row] = sum_col acc[row][col] P[vector of row][c][g0 + col]
   // The window is the MFMA's A operand and the features its B operand, so a lane holds, for ONE planar vector (16 wave + fr) and both its
   // rows, the four columns 4 r + fk of every column block: the sum over columns is in-lane but for the four lane groups fk (two exchanges
@@ -275,18 +287,139 @@ void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n,
   hipLaunchKernelGGL(zn_ptable_kernel, dim3((n + 255) / 256, pl.R_pad / 2), dim3(256), 0, s, pl.R_pad, pl.C_pad, pl.nz, kzt, nzc, n, pl.wfull, tzt,
                      phihat, cs, P);
 }
-template <int NCF>
+template <int NCF, bool RAW>
 static void zn_gemm_launch(hipStream_t s, const DevPlan &pl, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
                            const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
   constexpr int lds = 2 * (128 + 16 * NCF) * ZN_LD * 8;
   const int nblocks = (nitems + 7) / 8 * 8;                  // (a multiple of the XCD count: item i stays on XCD i mod 8)
-  hipLaunchKernelGGL((zn_gemm_kernel<NCF>), dim3(nblocks), dim3(256), lds, s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+  hipLaunchKernelGGL((zn_gemm_kernel<NCF, RAW>), dim3(nblocks), dim3(256), lds, s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces,
+                     piece_stride);
 }
 void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
                     const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
   if (nitems <= 0) return;
-  if (ncf == 2) zn_gemm_launch<2>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
-  else zn_gemm_launch<3>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+  if (P == nullptr) {                                        // no class table: the raw windows (rough electrodes)
+    if (ncf == 2) zn_gemm_launch<2, true>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+    else zn_gemm_launch<3, true>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+  } else if (ncf == 2) zn_gemm_launch<2, false>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+  else zn_gemm_launch<3, false>(s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces, piece_stride);
+}
+
+// ---- rough electrodes: from the ranges' windows to G ------------------------------------------------------------------------------------
+// The windows of a row tile add up to its rows on the periodic z grid, grid[(k * n + g) * 128 + row] (k = the rank's k-th row tile):
+// grid point g is covered by the few ranges whose window holds it, listed per g in the order of the ranges (cov_ptr / cov_ent =
+// (range, column)): a fixed order of additions.
+__global__ __launch_bounds__(128) void zn_wsum_kernel(int n, int nrg, int ncol, const int *__restrict__ cov_ptr, const int2 *__restrict__ cov_ent,
+                                                      const double *__restrict__ raw, double *__restrict__ grid) {
+  const int g = blockIdx.x, k = blockIdx.y, row = threadIdx.x;
+  double s = 0.0;
+  const int e0 = cov_ptr[g], e1 = cov_ptr[g + 1];           // (~8 ranges hold a grid point: four loads in flight at a time)
+  for (int e = e0; e < e1; e += 4) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int2 en = cov_ent[min(e + u, e1 - 1)];
+      v[u] = raw[((size_t)(k * nrg + en.x) * ncol + en.y) * 128 + row];
+      if (e + u >= e1) v[u] = 0.0;
+    }
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  grid[((size_t)k * n + g) * 128 + row] = s;
+}
+// once per run: the transform from the grid to the kz columns of G, Dt[g][C_pad]: column (ct, 16 b + i): kz = kzt ct + 8 b + (i & 7), the
+// cosine for i < 8 and the sine for i >= 8 (KPlan::col_c / col_s), times h / phihat(kz) -- the type-1 non-uniform transform's
+// deconvolution:  sum_j A_j e^{i m th_j} = (h / phihat(m)) sum_g grid[g] e^{i m g h}
+__global__ __launch_bounds__(256) void zn_dtable_kernel(int C_pad, int nz, int kzt, int n, const double *__restrict__ phihat,
+                                                        const double2 *__restrict__ cs, double *__restrict__ Dt) {
+  const int col = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (col >= C_pad) return;
+  const int ct = col / 320, cl = col - 320 * ct;
+  const int ml = 8 * (cl >> 4) + (cl & 7), m = ct * kzt + ml;
+  double v = 0.0;
+  if (ml < kzt && m < nz) {
+    const double2 e = cs[(int)(((long long)m * g) % n)];
+    v = (6.283185307179586476925286766559 / n / phihat[m]) * ((cl & 8) ? e.y : e.x);
+  }
+  Dt[(size_t)g * C_pad + col] = v;
+}
+// per update: G = grid x Dt on the matrix cores (M = rows, K = n grid points, N = C_pad columns: 0.3 GF), written as sk_reduce_kernel
+// leaves it: G row-major and w o G in MFMA-fragment-major order for b_project_kernel.
+__global__ __launch_bounds__(256) void zn_dft_kernel(int n, int C_pad, const int *__restrict__ own_rt, const double *__restrict__ grid,
+                                                     const double *__restrict__ Dt, const double *__restrict__ wfull, double *__restrict__ G,
+                                                     double *__restrict__ Gwf) {
+  // a workgroup = one 32 x 32 tile of G (two row fragments x two column blocks: one operand fetch per MFMA instead of two -- every
+  // operand comes straight from L2), its four waves = four quarters of the grid axis (the launch is short of waves and each of them
+  // waits on L2 otherwise); the quarters meet in LDS
+  __shared__ double part[3][64][16];
+  const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4, kq = threadIdx.x >> 6;
+  const int k = blockIdx.x >> 2, fp = blockIdx.x & 3, rt = own_rt[k], cb0 = 2 * blockIdx.y;
+  const int nkq = n / 16, kbeg = kq * nkq, nks = kbeg + nkq;                 // this wave's k-steps [kbeg, nks)  (n is a multiple of 16)
+  const double *a = grid + ((size_t)k * n + fk) * 128 + 32 * fp + fr;           // + 4 ks * 128; second fragment + 16
+  const double *b = Dt + (size_t)fk * C_pad + 16 * cb0 + fr;                    // + 4 ks * C_pad; second block + 16
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  constexpr int KB = 8;
+  double a0[KB][2], b0[KB][2], a1[KB][2], b1[KB][2];
+  auto fetch = [&](double(*av)[2], double(*bv)[2], int k0) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int ks = min(k0 + i, nks - 1);                   // (past the end: a valid address, the value is dropped below)
+      av[i][0] = a[(size_t)ks * 512]; av[i][1] = a[(size_t)ks * 512 + 16];
+      bv[i][0] = b[(size_t)ks * 4 * C_pad]; bv[i][1] = b[(size_t)ks * 4 * C_pad + 16];
+    }
+  };
+  auto mult = [&](const double(*av)[2], const double(*bv)[2], int k0) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const bool on = k0 + i < nks;
+      const double x0 = on ? av[i][0] : 0.0, x1 = on ? av[i][1] : 0.0;
+      acc[0][0] = ZN_MFMA(x0, bv[i][0], acc[0][0]); acc[0][1] = ZN_MFMA(x0, bv[i][1], acc[0][1]);
+      acc[1][0] = ZN_MFMA(x1, bv[i][0], acc[1][0]); acc[1][1] = ZN_MFMA(x1, bv[i][1], acc[1][1]);
+    }
+  };
+  fetch(a0, b0, kbeg);
+  for (int k0 = kbeg; k0 < nks; k0 += 2 * KB) {
+    fetch(a1, b1, k0 + KB);
+    mult(a0, b0, k0);
+    fetch(a0, b0, k0 + 2 * KB);
+    mult(a1, b1, k0 + KB);
+  }
+  if (kq > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[kq - 1][lane][(2 * i + j) * 4 + r] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (kq > 0) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f16 = 2 * fp + i, gcol = 16 * (cb0 + j) + fr;
+      const size_t rf = (size_t)rt * 8 + f16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[i][j][r] + part[0][lane][(2 * i + j) * 4 + r]) + part[1][lane][(2 * i + j) * 4 + r]) + part[2][lane][(2 * i + j) * 4 + r];
+        const int row16 = 4 * r + fk;
+        const size_t grow = (size_t)rt * 128 + 16 * f16 + row16;
+        G[grow * C_pad + gcol] = v;
+        Gwf[(rf * (C_pad / 4) + (gcol >> 2)) * 64 + (gcol & 3) * 16 + row16] = wfull[grow * C_pad + gcol] * v;
+      }
+    }
+}
+void launch_zn_dtable(hipStream_t s, const DevPlan &pl, int kzt, int n, const double *phihat, const double2 *cs, double *Dt) {
+  hipLaunchKernelGGL(zn_dtable_kernel, dim3((pl.C_pad + 255) / 256, n), dim3(256), 0, s, pl.C_pad, pl.nz, kzt, n, phihat, cs, Dt);
+}
+void launch_zn_windows_to_g(hipStream_t s, const DevPlan &pl, int n, int n_own, const int *own_rt, int nrg, int ncol, const int *cov_ptr,
+                            const int2 *cov_ent, const double *raw, double *grid, const double *Dt, double *G, double *Gwf) {
+  hipLaunchKernelGGL(zn_wsum_kernel, dim3(n, n_own), dim3(128), 0, s, n, nrg, ncol, cov_ptr, cov_ent, raw, grid);
+  hipLaunchKernelGGL(zn_dft_kernel, dim3(4 * n_own, pl.C_pad / 32), dim3(256), 0, s, n, pl.C_pad, own_rt, grid, Dt, pl.wfull, G, Gwf);
 }
 
 }  // namespace conp

@@ -119,3 +119,35 @@ def test_z_window_ragged_list_across_the_periodic_wrap():
     b_cl, cols_cl = _b(s, at, alist, blist, capi.PATH_SK_CLASSIC)
     assert cols_zn in (32, 48) and cols_cl == 0
     assert rel_err(b_zn, b_cl) < 1e-11
+
+
+def _rough(seed=23):
+    s = _medium("ffield", seed=seed)
+    ele = s.echeck != 0
+    s.x[ele, 2] += np.random.default_rng(seed).uniform(-0.4, 0.4, size=int(ele.sum()))      # every electrode atom its own z: no classes
+    s.name = "medium, rough electrodes"
+    return s
+
+
+def test_z_window_rough_electrodes_equal_the_full_contraction():
+    """rough electrodes have no z classes: the ranges' raw windows are summed on the z grid and transformed to the structure-factor
+    matrix G (type-1 transform), which the general projection consumes as it consumes sk_reduce's; b and the structure factors equal
+    the full contraction's"""
+    s = _rough()
+    at, alist, blist = neighbor.build_lists(s)
+    out = {}
+    for mask in (0, capi.PATH_SK_CLASSIC):
+        with capi.test_paths(mask):
+            fx = FixConp(s)
+            fx.init_lists(alist, blist)
+            fx.setup_post_neighbor(at)
+            fx.b_cal(at)
+            info = fx.info()
+            out[mask] = (fx.vectors()[0].copy(), fx.sfac(), info.zn_cols, info.n_zclasses)
+            fx.close()
+    b_zn, (sr_zn, si_zn), cols_zn, ncls = out[0]
+    b_cl, (sr_cl, si_cl), cols_cl, _ = out[capi.PATH_SK_CLASSIC]
+    assert ncls == 0 and cols_zn in (32, 48) and cols_cl == 0
+    assert rel_err(b_zn, b_cl) < 1e-11
+    scale = max(np.abs(sr_cl).max(), np.abs(si_cl).max())
+    assert np.abs(sr_zn - sr_cl).max() < 1e-11 * scale and np.abs(si_zn - si_cl).max() < 1e-11 * scale
