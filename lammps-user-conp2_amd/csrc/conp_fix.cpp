@@ -2223,7 +2223,7 @@ struct conp_fix {
                        d_zn_pieces.p, 0);
         prof.end(stream);
         prof.begin("sk_reduce", stream);
-        launch_zn_windows_to_g(stream, dplan, zn_n, (int)own_rt_h.size(), d_own_rt.p, zn_nrg, 16 * zn_ncf, d_zn_cov_ptr.p, d_zn_cov_ent.p,
+        launch_zn_windows_to_g(stream, dplan, plan.kzt, zn_n, (int)own_rt_h.size(), d_own_rt.p, zn_nrg, 16 * zn_ncf, d_zn_cov_ptr.p, d_zn_cov_ent.p,
                                d_zn_pieces.p, d_zn_grid.p, d_zn_Dt.p, d_G.p, d_Gw.p);
         prof.end(stream);
         g_current = true;

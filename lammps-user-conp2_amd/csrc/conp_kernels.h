@@ -131,7 +131,7 @@ void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n,
                       const double *phihat /*[nz]*/, const double2 *cs /*[n]: (cos, sin)(2 pi k / n)*/, double *P /*[R_pad][nzc][n]*/);
 // rough electrodes: the ranges' raw windows (launch_zn_gemm with P == nullptr) -> rows on the z grid -> G, w o G (sk_reduce's outputs)
 void launch_zn_dtable(hipStream_t s, const DevPlan &pl, int kzt, int n, const double *phihat, const double2 *cs, double *Dt /*[n][C_pad]*/);
-void launch_zn_windows_to_g(hipStream_t s, const DevPlan &pl, int n, int n_own, const int *own_rt, int nrg, int ncol, const int *cov_ptr,
+void launch_zn_windows_to_g(hipStream_t s, const DevPlan &pl, int kzt, int n, int n_own, const int *own_rt, int nrg, int ncol, const int *cov_ptr,
                             const int2 *cov_ent, const double *raw, double *grid, const double *Dt, double *G, double *Gwf);
 void launch_zn_gemm(hipStream_t s, const DevPlan &pl, int ncf /*2 or 3 column fragments*/, const ZnItem *items, int nitems, const double2 *Xt,
                     const double2 *Yt, const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride);

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void zn_dtable_kernel(int C_pad, int nz, int k
 }
 // per update: G = grid x Dt on the matrix cores (M = rows, K = n grid points, N = C_pad columns: 0.3 GF), written as sk_reduce_kernel
 // leaves it: G row-major and w o G in MFMA-fragment-major order for b_project_kernel.
-__global__ __launch_bounds__(256) void zn_dft_kernel(int n, int C_pad, const int *__restrict__ own_rt, const double *__restrict__ grid,
+__global__ __launch_bounds__(256) void zn_dft_kernel(int n, int C_pad, int nz, int kzt, const int *__restrict__ own_rt, const double *__restrict__ grid,
                                                      const double *__restrict__ Dt, const double *__restrict__ wfull, double *__restrict__ G,
                                                      double *__restrict__ Gwf) {
   // a workgroup = one 32 x 32 tile of G (two row fragments x two column blocks: one operand fetch per MFMA instead of two -- every
@@ -353,6 +353,10 @@ __global__ __launch_bounds__(256) void zn_dft_kernel(int n, int C_pad, const int
   __shared__ double part[3][64][16];
   const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4, kq = threadIdx.x >> 6;
   const int k = blockIdx.x >> 2, fp = blockIdx.x & 3, rt = own_rt[k], cb0 = 2 * blockIdx.y;
+  {                                                          // column blocks past the last kz of their tile hold zeros (and stay zero)
+    const int ct = 16 * cb0 / 320, ml0 = 8 * ((16 * cb0 - 320 * ct) >> 4);
+    if (ml0 >= kzt || ct * kzt + ml0 >= nz) return;
+  }
   const int nkq = n / 16, kbeg = kq * nkq, nks = kbeg + nkq;                 // this wave's k-steps [kbeg, nks)  (n is a multiple of 16)
   const double *a = grid + ((size_t)k * n + fk) * 128 + 32 * fp + fr;           // + 4 ks * 128; second fragment + 16
   const double *b = Dt + (size_t)fk * C_pad + 16 * cb0 + fr;                    // + 4 ks * C_pad; second block + 16
@@ -416,10 +420,10 @@ __global__ __launch_bounds__(256) void zn_dft_kernel(int n, int C_pad, const int
 void launch_zn_dtable(hipStream_t s, const DevPlan &pl, int kzt, int n, const double *phihat, const double2 *cs, double *Dt) {
   hipLaunchKernelGGL(zn_dtable_kernel, dim3((pl.C_pad + 255) / 256, n), dim3(256), 0, s, pl.C_pad, pl.nz, kzt, n, phihat, cs, Dt);
 }
-void launch_zn_windows_to_g(hipStream_t s, const DevPlan &pl, int n, int n_own, const int *own_rt, int nrg, int ncol, const int *cov_ptr,
+void launch_zn_windows_to_g(hipStream_t s, const DevPlan &pl, int kzt, int n, int n_own, const int *own_rt, int nrg, int ncol, const int *cov_ptr,
                             const int2 *cov_ent, const double *raw, double *grid, const double *Dt, double *G, double *Gwf) {
   hipLaunchKernelGGL(zn_wsum_kernel, dim3(n, n_own), dim3(128), 0, s, n, nrg, ncol, cov_ptr, cov_ent, raw, grid);
-  hipLaunchKernelGGL(zn_dft_kernel, dim3(4 * n_own, pl.C_pad / 32), dim3(256), 0, s, n, pl.C_pad, own_rt, grid, Dt, pl.wfull, G, Gwf);
+  hipLaunchKernelGGL(zn_dft_kernel, dim3(4 * n_own, pl.C_pad / 32), dim3(256), 0, s, n, pl.C_pad, pl.nz, kzt, own_rt, grid, Dt, pl.wfull, G, Gwf);
 }
 
 }  // namespace conp
