@@ -1194,8 +1194,9 @@ struct conp_fix {
   // per-segment term) left the heavy tiles' workgroups and those whose share straddles a tile boundary 3 % behind the rest.
   // (Tried on top: a linear ramp of the shares so that early finishers' partial-tile stores overlap the others' last chunks --
   //  no effect at +-8 / 16 / 24 units, 244.1 - 244.5 us.  What is left is a +-2 % spread between XCDs.)
-  double SK_C0 = diag_switch("CONP_SK_C0") ? atof(diag_switch("CONP_SK_C0")) : 1.37;
-  double SK_CSEG = diag_switch("CONP_SK_CSEG") ? atof(diag_switch("CONP_SK_CSEG")) : 5.74;
+  static double diag_number(const char *v, double dflt) { return v ? atof(v) : dflt; }      // (diag_switch folds to null in the product)
+  double SK_C0 = diag_number(diag_switch("CONP_SK_C0"), 1.37);
+  double SK_CSEG = diag_number(diag_switch("CONP_SK_CSEG"), 5.74);
   // what the schedule was cut for: the same padded atom count, plan and output form give the same schedule -- a re-neighbour that
   // changes none of them (the usual one) keeps the work list that is on the device
   struct ItemsKey { int nl_pad = -1; long plan_gen = -1; bool proj = false; int nzc = -1; int nranks = 0; bool operator==(const ItemsKey &o) const {

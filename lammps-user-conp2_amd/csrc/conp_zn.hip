@@ -13,6 +13,9 @@
 // per (row tile, range of atoms), and the range's piece of the class table is  sum_col acc[r][col] P[r][c][g0 + col]  -- the same
 // band-local piece sk_gemm's projecting epilogue leaves (hc_sum_kernel / b_zc_final_kernel consume it unchanged).
 // MFMA work: 2 n_p x NCOL x Nl x 2 flop = 1/5 .. 1/8 of sk_gemm's.
+// Rough electrodes (no z classes): the same contraction leaves the raw windows; zn_wsum_kernel adds them on the periodic z grid and
+// zn_dft_kernel applies the type-1 transform  sum_j A_j e^{i m th_j} = (h / phihat(m)) sum_g grid[g] e^{i m g h}  -- out come G and w o G
+// as sk_reduce_kernel leaves them, for b_project_kernel.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan 
 #pragma unroll
     for (int c = 0; c < NCF; ++c) acc[f][c] = (d4){0.0, 0.0, 0.0, 0.0};
   // MFMA fragment addresses (doubles): element (feature 16 F + fr, atom 4 ks + fk) at feature * 16 + ((4 ks + fk) ^ fr)
-  const unsigned fa0 = (unsigned)((16 * wave + fr) * ZN_LD), fa1 = fa0 + 64 * ZN_LD, fb0 = (unsigned)((128 + fr) * ZN_LD);
+  const unsigned fa0 = (unsigned)((16 * wave + fr) * ZN_LD), fb0 = (unsigned)((128 + fr) * ZN_LD);      // (the b fragment: + 64 rows)
   load(it.c0);
   build(panel[0]);
   load(min(it.c0 + 1, it.c1 - 1));
