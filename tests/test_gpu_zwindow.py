@@ -121,19 +121,20 @@ def test_z_window_ragged_list_across_the_periodic_wrap():
     assert rel_err(b_zn, b_cl) < 1e-11
 
 
-def _rough(seed=23):
-    s = _medium("ffield", seed=seed)
+def _rough(mode="ffield", seed=23):
+    s = _medium(mode, seed=seed)
     ele = s.echeck != 0
     s.x[ele, 2] += np.random.default_rng(seed).uniform(-0.4, 0.4, size=int(ele.sum()))      # every electrode atom its own z: no classes
     s.name = "medium, rough electrodes"
     return s
 
 
-def test_z_window_rough_electrodes_equal_the_full_contraction():
+@pytest.mark.parametrize("mode", ["ffield", "slab"])          # slab: three column tiles of kz
+def test_z_window_rough_electrodes_equal_the_full_contraction(mode):
     """rough electrodes have no z classes: the ranges' raw windows are summed on the z grid and transformed to the structure-factor
     matrix G (type-1 transform), which the general projection consumes as it consumes sk_reduce's; b and the structure factors equal
     the full contraction's"""
-    s = _rough()
+    s = _rough(mode)
     at, alist, blist = neighbor.build_lists(s)
     out = {}
     for mask in (0, capi.PATH_SK_CLASSIC):
