@@ -152,7 +152,8 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
       // the z-window form (conp_zn.hip): this atom's row of the window matrix, dense over its chunk's columns:
       // Bt[(chunk * ncol + col) * 16 + atom] = phi((g0[chunk] + col) - u), u = z n / Lz' wrapped relative to the window origin
       if (part == 0) { qc[j] = qq; qz = qq * xc; }
-      double *bt = zw.Bt + ((size_t)(j >> 4) * zw.ncol) * 16 + (j & 15);
+      // fragment order: Bt[chunk][column block][atom group a >> 2][column & 15][a & 3]  (zn_gemm_kernel's lane (fr, fk) reads 4 atoms)
+      double *bt = zw.Bt + ((size_t)(j >> 4) * zw.ncol) * 16 + ((j & 15) >> 2) * 64 + (j & 3);
       const int cw = zw.ncol / ZN_SPLIT, col0 = part * cw;                 // this thread's columns (ncol = 32 or 48)
       if (j < nl) {
         double ur = xc * zw.gscale - (double)zw.g0c[j >> 4];
@@ -163,10 +164,10 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
           const double d = ((double)col - ur) * (2.0 / zw.W);            // in units of the window's half width
           double v = 0.0;
           if (d > -1.0 && d < 1.0) v = exp(zw.beta * (sqrt(1.0 - d * d) - 1.0));
-          bt[(size_t)col * 16] = v;
+          bt[(size_t)(col >> 4) * 256 + (col & 15) * 4] = v;
         }
       } else
-        for (int col = col0; col < col0 + cw; ++col) bt[(size_t)col * 16] = 0.0;
+        for (int col = col0; col < col0 + cw; ++col) bt[(size_t)(col >> 4) * 256 + (col & 15) * 4] = 0.0;
     } else {
       qc[j] = qq; qz = qq * xc;
       const int nct = (nrz - 1) / 32;                 // column tiles

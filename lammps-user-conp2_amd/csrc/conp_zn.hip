@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, in
 // item = (row tile rt: 64 planar vectors = 128 G rows, chunk range [c0, c1), window origin g0, output slot)
 // 256 threads = 4 waves; wave w owns the row fragments w ('a' rows of 16 planar vectors) and 4 + w (their 'b' rows) x all NCF column fragments;
 // the window fragment is the MFMA's A operand (accumulator rows = window columns), the feature fragment its B operand (see the epilogue).
-// LDS panel per chunk (double-buffered): [128 + 16 NCF features][16 atoms], column XOR-swizzled by feature & 15 like sk_gemm's.
+// LDS: per wave two panels [32 rows][16 atoms] (double-buffered, private to the wave, XOR-swizzled); the window comes from memory.
 constexpr int ZN_LD = 16;
 #ifdef ZN_TIMELINE
 // diagnostic build only (tools/zn_timeline.py): wall-clock stamps (100 MHz) of every workgroup's phases + where it ran
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan 
                                                                 const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
                                                                 const double *__restrict__ Bt, const double *__restrict__ P, int n, int nzc,
                                                                 double *__restrict__ pieces, int piece_stride) {
-  constexpr int NF = 128 + 16 * NCF;                         // features per panel
+  constexpr int WP = 32 * ZN_LD;                             // a wave's panel: its 16 'a' rows + 16 'b' rows x 16 atoms
   extern __shared__ __attribute__((aligned(16))) double zn_lds[];
   ZN_STAMP(0);
 #ifdef ZN_TIMELINE
@@ -85,108 +85,91 @@ __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan 
   const int item_idx = (int)blockIdx.x;                       // (the grid is padded to a multiple of the XCD count)
   if (item_idx >= nitems) return;
   const ZnItem it = items[item_idx];
-  double(*panel)[NF * ZN_LD] = reinterpret_cast<double(*)[NF * ZN_LD]>(zn_lds);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int gj = t & 15, gs = t >> 4;                        // build role: atom gj of the chunk, sub-index gs 0..15
+  // NO workgroup barrier anywhere: a wave forms the 32 panel rows IT multiplies (two wave-private buffers in LDS; LDS operations of one
+  // wave execute in order) and takes the window fragments straight from memory, in fragment order.  With a barrier per chunk a workgroup
+  // that multiplies alone -- the SIMD's arbiter serves the oldest wave first, the workgroups of a CU finish one after the other -- spent
+  // 0.78 us on a chunk of 0.49 us of MFMAs; a wave on its own schedule keeps the pipe busy (profiles/r05_zn_timeline.txt).
+  double *const panel0 = zn_lds + (size_t)wave * 2 * WP, *const panel1 = panel0 + WP;
+  const int gj = lane & 15, g4 = lane >> 4;                  // build role: atom gj of the chunk, planar vectors g4 + 4 u of the wave's 16
   const int fr = lane & 15, fk = lane >> 4;
   const unsigned nrx16 = (unsigned)(pl.kxmax + 2) * 16, nry16 = (unsigned)(pl.kymax + 1) * 16;
-  // this thread's four planar vectors gs + 16 u of the row tile
-  unsigned xo[4], yo[4];
-  bool neg[4];
+  unsigned xby[4], yby[4], sgm[4], wa[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int p = it.rt * 64 + gs + 16 * u;
-    xo[u] = (unsigned)pl.p_ikx[p] * 16 + gj; yo[u] = (unsigned)pl.p_iky[p] * 16 + gj;
-    neg[u] = pl.p_sgn[p] < 0;                                 // (padding vectors read the all-zero X row)
+    const int r = g4 + 4 * u, p = it.rt * 64 + 16 * wave + r;
+    xby[u] = ((unsigned)pl.p_ikx[p] * 16 + gj) * 16u; yby[u] = ((unsigned)pl.p_iky[p] * 16 + gj) * 16u;
+    sgm[u] = pl.p_sgn[p] < 0 ? 0x80000000u : 0u;              // (padding vectors read the all-zero X row)
+    // panel element (local row r, atom a) at r * 16 + (a ^ key(r)), key(r) = (r >> 1) & 7; the 'b' row 16 + r has the same key
+    wa[u] = (unsigned)(r * ZN_LD + (gj ^ ((r >> 1) & 7)));
   }
-  const unsigned wa = (unsigned)(gs * ZN_LD + (gj ^ gs));    // (feature gs + 16 u, atom gj): + 16 u * ZN_LD; swizzle key = feature & 15 = gs
+  // the MFMA's k index (k-step ks, lane group fk) is atom 4 fk + ks: a lane's four window values of a column are adjacent in memory
+  unsigned rdA[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rdA[ks] = (unsigned)(fr * ZN_LD + ((4 * fk + ks) ^ ((fr >> 1) & 7)));
+  // buffer loads: descriptor (item-relative base, SGPRs) + per-thread byte offset (VGPR) + chunk offset (SGPR) -- no address arithmetic
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Xt + (size_t)it.c0 * nrx16), (short)0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Yt + (size_t)it.c0 * nry16), (short)0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bt + (size_t)it.c0 * (16 * NCF * 16)), (short)0, -1, 0x00020000);
+  // window matrix in fragment order: Bt[chunk][column block cf][fk][column fr][4 atoms 4 fk + ks]
+  const unsigned bby = (unsigned)((fk * 16 + fr) * 32);
   double2 X[4], Y[4];
-  double bv[NCF];
-  auto load = [&](int ch) {
-    const unsigned bx = (unsigned)ch * nrx16, by = (unsigned)ch * nry16;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {                              // (the order the main loop re-issues them in: its partial waits count on it)
-      X[u] = Xt[bx + xo[u]]; Y[u] = Yt[by + yo[u]];
-      if (u < NCF) bv[u < NCF ? u : 0] = Bt[((size_t)ch * (16 * NCF) + gs + 16 * u) * 16 + gj];
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  double wB[4][NCF];                                          // window fragments of the current chunk, per k-step
+  auto load_xy = [&](int u, int ch) {
+    const int cr = min(ch, it.c1 - 1) - it.c0;                // (past the range's end: the last chunk again, not used)
+    X[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[u], cr * (int)(nrx16 * 16), 0));
+    Y[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[u], cr * (int)(nry16 * 16), 0));
   };
-  auto build = [&](double *pn) {
+  auto load_w = [&](int half, int ch) {                       // k-steps 2 half, 2 half + 1 of chunk ch
+    const int cr = min(ch, it.c1 - 1) - it.c0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double sy = neg[u] ? -Y[u].y : Y[u].y;
-      pn[wa + 16 * u * ZN_LD] = X[u].x * Y[u].x - X[u].y * sy;                 // 'a' rows 0..63
-      pn[wa + (64 + 16 * u) * ZN_LD] = X[u].x * sy + X[u].y * Y[u].x;          // 'b' rows 64..127
+    for (int c = 0; c < NCF; ++c) {
+      const double2 v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rb, bby + 2048 * c + 16 * half, cr * (16 * NCF * 16 * 8), 0));
+      wB[2 * half][c] = v.x; wB[2 * half + 1][c] = v.y;
     }
-#pragma unroll
-    for (int u = 0; u < NCF; ++u) pn[wa + (128 + 16 * u) * ZN_LD] = bv[u];
   };
   d4 acc[2][NCF];
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
     for (int c = 0; c < NCF; ++c) acc[f][c] = (d4){0.0, 0.0, 0.0, 0.0};
-  // MFMA fragment addresses (doubles): element (feature 16 F + fr, atom 4 ks + fk) at feature * 16 + ((4 ks + fk) ^ fr)
-  const unsigned fa0 = (unsigned)((16 * wave + fr) * ZN_LD), fb0 = (unsigned)((128 + fr) * ZN_LD);      // (the b fragment: + 64 rows)
-  load(it.c0);
-  build(panel[0]);
-  load(min(it.c0 + 1, it.c1 - 1));
-  __syncthreads();
+  // prologue: the first chunk's panel, then the loads in the order the loop re-issues them (its partial waits count on it)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) load_xy(u, it.c0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const double sy = __hiloint2double(__double2hiint(Y[u].y) ^ (int)sgm[u], __double2loint(Y[u].y));
+    panel0[wa[u]] = X[u].x * Y[u].x - X[u].y * sy;
+    panel0[wa[u] + 16 * ZN_LD] = X[u].x * sy + X[u].y * Y[u].x;
+  }
+  load_xy(0, it.c0 + 1); load_xy(1, it.c0 + 1);
+  load_w(0, it.c0);
+  load_xy(2, it.c0 + 1); load_xy(3, it.c0 + 1);
+  load_w(1, it.c0);
   ZN_STAMP(1);
-  // One chunk = 8 NCF MFMAs per wave (64 cycles of the pipe each) and, for the chunk after it, 8 + NCF panel values to form and the
-  // loads of the chunk after that.  Written as two blocks (multiply, then build) a wave spends ~3300 cycles on a chunk of which the
-  // pipe works 1024 (the fragment reads are waited for before every four MFMAs, the build and the barrier follow the last one), and the
-  // pipe idles whenever fewer than three of a CU's workgroups are in their multiply (profiles/r05_zn_timeline.txt).  So the build is cut
-  // into slices that sit in the shadow of the MFMAs -- an MFMA occupies the wave's issue for 4 cycles and the pipe for 64 -- and the
-  // fragments of k-step ks + 1 are requested before the MFMAs of ks: what stays exposed per chunk is the barrier and one LDS read.
-  // (the chunk indices past the range's end are clamped: the last two builds / loads repeat the last chunk and are not used)
-  // What the vector ALU port of a SIMD carries decides the kernel: an F64 MFMA holds it for ~56 of its 64 cycles and every other VALU
-  // instruction of any wave takes the rest or delays an MFMA (profiles/r05_pipe_share.txt, r05_zn_timeline.txt).  So the loop spends no
-  // VALU instruction on addresses: the chunk loop is unrolled by the two panel buffers (LDS addresses = loop-invariant registers +
-  // immediates), the tables are read as uniform base (SALU) + a per-thread byte offset fixed for the item, and the sign of a planar
-  // vector is one XOR.  Left per chunk and wave: 16 FP64 operations and 4 XORs.
-  unsigned rdA[4], rdB[4];                                    // fragment read indices per k-step (panel-relative, in doubles)
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { const unsigned col = (unsigned)((4 * ks + fk) ^ fr); rdA[ks] = fa0 + col; rdB[ks] = fb0 + col; }
-  unsigned xby[4], yby[4], sgm[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { xby[u] = xo[u] * 16u; yby[u] = yo[u] * 16u; sgm[u] = neg[u] ? 0x80000000u : 0u; }
-  const unsigned bby = (unsigned)((gs * 16 + gj) * 8);
-  // buffer loads: descriptor (item-relative base, SGPRs) + per-thread byte offset (VGPR) + chunk offset (SGPR) -- no address arithmetic
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Xt + (size_t)it.c0 * nrx16), (short)0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Yt + (size_t)it.c0 * nry16), (short)0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bt + (size_t)it.c0 * (16 * NCF * 16)), (short)0, -1, 0x00020000);
-  // Per chunk: k-steps 0..2 carry the twelve build slices (three per planar vector: its 'a' value, its 'b' value, the panel write + the
-  // loads of the chunk after next) between their MFMAs; the barrier sits BEFORE the last k-step, whose fragments are in registers by
-  // then, and the first fragments of the next chunk are requested right behind it -- their LDS latency passes under the last k-step's
-  // MFMAs instead of in front of the next chunk's first one (a workgroup that multiplies alone is latency-bound per chunk).
-  double fa[2][2], fb[2][NCF];                                // two fragment sets; on entry to a chunk set 0 holds its k-step 0
-  auto frag = [&](const double *pn, int ks, int set) {
-    fa[set][0] = pn[rdA[ks]]; fa[set][1] = pn[rdA[ks] + 64 * ZN_LD];
-#pragma unroll
-    for (int c = 0; c < NCF; ++c) fb[set][c] = pn[rdB[ks] + 16 * c * ZN_LD];
-  };
-  frag(panel[0], 0, 0);
+  // Per chunk and wave: 8 NCF MFMAs (56 of their 64 cycles each on the SIMD's vector port, which every other VALU instruction of every
+  // wave shares: profiles/r05_pipe_share.txt) and, for the next chunk, 8 panel values = 16 FP64 operations + 4 XORs.  No VALU instruction
+  // goes into addresses (buffer loads; LDS addresses are loop-invariant registers + immediates, the loop being unrolled over the two
+  // panel buffers).  k-steps 0..2 carry the twelve build slices (three per planar vector: 'a' value, 'b' value, panel write + the loads
+  // of the chunk after next) between their MFMAs; the window fragments of a k-step pair are re-requested behind its last MFMA; the next
+  // chunk's first fragments are read behind k-step 2, under the MFMAs of k-step 3.
+  double fa[2][2];                                            // two fragment sets; on entry to a chunk set 0 holds its k-step 0
+  auto frag = [&](const double *pn, int ks, int set) { fa[set][0] = pn[rdA[ks]]; fa[set][1] = pn[rdA[ks] + 16 * ZN_LD]; };
+  frag(panel0, 0, 0);
   auto chunk = [&](int ch, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    const double *pn = panel[BUF];
-    double *pw = panel[BUF ^ 1];
-    const int chn = min(ch + 2, it.c1 - 1);
-    const int sx = (chn - it.c0) * (int)(nrx16 * 16), sy_ = (chn - it.c0) * (int)(nry16 * 16), sb = (chn - it.c0) * (16 * NCF * 16 * 8);
+    const double *pn = BUF ? panel1 : panel0;
+    double *pw = BUF ? panel0 : panel1;
     double sy = 0.0, va = 0.0, vb = 0.0;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nx = cur ^ 1;
-      if (ks < 3) frag(pn, ks + 1, nx);
-      else {
-        __syncthreads();                                      // every panel value of the next chunk is written, every fragment of this one read
-        frag(pw, 0, nx);
-      }
+      frag(ks < 3 ? pn : pw, ks < 3 ? ks + 1 : 0, nx);        // (k-step 3: the next chunk's k-step 0 -- its panel is complete)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < 2 * NCF; ++m) {
         const int f = m & 1, c = m >> 1;
-        acc[f][c] = ZN_MFMA(fb[cur][c], fa[cur][f], acc[f][c]);
+        acc[f][c] = ZN_MFMA(wB[ks][c], fa[cur][f], acc[f][c]);
         const int g = 4 * ks + m;                             // gap behind this MFMA: slice g of the build (k-steps 0..2, four gaps each)
         if (ks < 3 && m < 4) {
           const int u = g / 3, part = g - 3 * u;
@@ -196,16 +179,14 @@ __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan 
           } else if (part == 1) {
             vb = X[u].x * sy + X[u].y * Y[u].x;
           } else {
-            pw[wa + 16 * u * ZN_LD] = va;
-            pw[wa + (64 + 16 * u) * ZN_LD] = vb;
-            if (u < NCF) pw[wa + (128 + 16 * u) * ZN_LD] = bv[u < NCF ? u : 0];
-            X[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[u], sx, 0));
-            Y[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[u], sy_, 0));
-            if (u < NCF) bv[u < NCF ? u : 0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, bby + 2048 * u, sb, 0));
+            pw[wa[u]] = va;
+            pw[wa[u] + 16 * ZN_LD] = vb;
+            load_xy(u, ch + 2);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (ks & 1) { load_w(ks >> 1, ch + 1); __builtin_amdgcn_sched_barrier(0); }
     }
 #ifdef ZN_TIMELINE
     if (t == 0 && (blockIdx.x & 255) == 0 && (blockIdx.x >> 8) < 16 && ch - it.c0 < 64) zn_tl_chunks[(blockIdx.x >> 8) * 64 + ch - it.c0] = wall_clock64();
@@ -293,7 +274,7 @@ void launch_zn_ptable(hipStream_t s, const DevPlan &pl, int kzt, int nzc, int n,
 template <int NCF, bool RAW>
 static void zn_gemm_launch(hipStream_t s, const DevPlan &pl, const ZnItem *items, int nitems, const double2 *Xt, const double2 *Yt,
                            const double *Bt, const double *P, int n, int nzc, double *pieces, int piece_stride) {
-  constexpr int lds = 2 * (128 + 16 * NCF) * ZN_LD * 8;
+  constexpr int lds = 4 * 2 * 32 * ZN_LD * 8;                // four waves x two panels of 32 rows
   const int nblocks = (nitems + 7) / 8 * 8;                  // (a multiple of the XCD count: item i stays on XCD i mod 8)
   hipLaunchKernelGGL((zn_gemm_kernel<NCF, RAW>), dim3(nblocks), dim3(256), lds, s, pl, items, nitems, Xt, Yt, Bt, P, n, nzc, pieces,
                      piece_stride);
