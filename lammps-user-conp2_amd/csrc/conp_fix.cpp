@@ -959,7 +959,10 @@ struct conp_fix {
     std::vector<ZnItem> by_slot;
     int slot = 0;
     for (int k = 0; k < nrt; ++k)
-      for (auto &rg : ranges) by_slot.push_back(ZnItem{own_rt_h.empty() ? 0 : own_rt_h[k], rg.first, rg.second, g0c[rg.first], slot++});
+      for (auto &rg : ranges) {
+        const int rt = own_rt_h.empty() ? 0 : own_rt_h[k];
+        by_slot.push_back(ZnItem{rt, rg.first, rg.second, g0c[rg.first], slot++, rt >= plan.paired_lo && rt < plan.paired_hi ? 1 : 0});
+      }
     {
       std::vector<std::vector<int>> per_xcd(8);
       for (int r = 0; r < nrg; ++r)

@@ -146,6 +146,31 @@ void KPlan::build(const KTables &kt) {
                   ax * ax * kt.unitk[0] * kt.unitk[0] + ay * ay * kt.unitk[1] * kt.unitk[1]});
   }
   std::stable_sort(pv.begin() + 1, pv.end(), [](const Pv &a, const Pv &b) { return a.k2 < b.k2; });
+  // The vectors (kx, +ky) and (kx, -ky) share their x and y phase rows (a_+- = XrYr -+ XiYi, b_+- = XiYr +- XrYi).  Order: a head of
+  // whole row tiles with the singles (the origin first, the axis vectors) filled up with the pairs of smallest |k_p|; then the other
+  // pairs, each as (+, -) on an even index, by |k_p| -- the row tiles [paired_lo, paired_hi) hold 32 whole pairs each, zn_gemm forms both
+  // members from one fetch of the two rows (conp_zn.hip); a last partial tile takes what is left.  Row tile after row tile the kz
+  // range still shrinks (the head holds the origin: the full range), which the sk_gemm schedule counts on.
+  {
+    std::vector<Pv> pairs, singles;
+    for (size_t i = 0; i < pv.size();) {
+      if (i + 1 < pv.size() && pv[i].sgn > 0 && pv[i + 1].sgn < 0 && pv[i].ikx == pv[i + 1].ikx && pv[i].iky == pv[i + 1].iky &&
+          pv[i].flat >= 0) {
+        pairs.push_back(pv[i]); pairs.push_back(pv[i + 1]); i += 2;
+      } else singles.push_back(pv[i++]);
+    }
+    std::vector<Pv> tail;
+    if (singles.size() % 2) { tail.push_back(singles.back()); singles.pop_back(); }      // (an odd one out: the largest |k_p|, to the end)
+    size_t fill = (PT - singles.size() % PT) % PT;                                         // vectors missing to whole tiles: even
+    fill = std::min(fill, pairs.size());
+    std::vector<Pv> out(singles);
+    out.insert(out.end(), pairs.begin(), pairs.begin() + fill);
+    paired_lo = paired_hi = (int)(out.size() / PT);
+    if (out.size() % PT == 0) paired_hi += (int)((pairs.size() - fill) / PT);
+    out.insert(out.end(), pairs.begin() + fill, pairs.end());
+    out.insert(out.end(), tail.begin(), tail.end());
+    pv.swap(out);
+  }
   np = (int)pv.size();
   p_ikx.resize(np); p_iky.resize(np); p_sgn.resize(np);
   flat2p.assign(kt.kcount_flat, -1);
@@ -156,7 +181,7 @@ void KPlan::build(const KTables &kt) {
   // reference k index -> (p, m, sign)
   k_p.assign(kt.kcount, 0); k_m.assign(kt.kcount, 0); k_sign.assign(kt.kcount, 1);
   for (int f = 0; f < kt.kcount_flat; ++f) {
-    if (flat2p[f] < 0) { k_p[f] = 0; k_m[f] = kt.kzvecs[f]; k_sign[f] = 1; }
+    if (flat2p[f] < 0) { k_p[f] = 0; k_m[f] = kt.kzvecs[f]; k_sign[f] = 1; }        // (the origin is the first vector)
     else { k_p[f] = flat2p[f]; k_m[f] = 0; k_sign[f] = 1; }
   }
   for (int e = 0; e < kt.kcount_expand; ++e) {

@@ -45,7 +45,8 @@ struct KPlan {
   static constexpr int CT_COLS = 32 * CT_BLK;
 
   int kxmax = 0, kymax = 0, nz = 0;   // nz = kzmax + 1 (m = 0 .. kzmax)
-  int np = 0;                         // planar vectors incl. the origin; sorted by |k_p|^2 (origin first)
+  int np = 0;                         // planar vectors, the origin first: singles + the smallest pairs (whole tiles), then the (+ky, -ky) pairs by |k_p|^2
+  int paired_lo = 0, paired_hi = 0;   // the row tiles [paired_lo, paired_hi) hold 32 whole pairs each, (+, -) on (even, odd) indices
   std::vector<int> p_ikx, p_iky, p_sgn;   // per p: |kx|, |ky|, sign of ky (+1/-1); origin = (0,0,+1)
   std::vector<int> flat2p;                // reference flat index (x axis, y axis, (k,+-l,0)) -> p ; z-axis entries -> -1
   std::vector<int> k_p, k_m, k_sign;      // per reference k index

@@ -30,7 +30,7 @@ struct DevPlan {              // device copy of KPlan geometry
 
 // the z-window form (conp_zn.hip): item = (row tile: 64 planar vectors, chunk range [c0, c1) of the z-ordered electrolyte list, window
 // origin g0 on the grid, slot of its piece [class][128 rows] in the pieces buffer)
-struct ZnItem { int rt, c0, c1, g0, slot; };
+struct ZnItem { int rt, c0, c1, g0, slot, paired; };     // paired: the row tile holds 32 whole (+ky, -ky) pairs (KPlan::paired_lo / _hi)
 // what elyte_phase_kernel's z-axis threads need to write the window matrix of an update instead of the z phase seeds
 struct ZnWindow { double *Bt; const int *g0c; int *flag; int ncol, n, W; double beta, gscale; };
 

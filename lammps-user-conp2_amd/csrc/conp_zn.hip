@@ -91,114 +91,137 @@ __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan 
   // that multiplies alone -- the SIMD's arbiter serves the oldest wave first, the workgroups of a CU finish one after the other -- spent
   // 0.78 us on a chunk of 0.49 us of MFMAs; a wave on its own schedule keeps the pipe busy (profiles/r05_zn_timeline.txt).
   double *const panel0 = zn_lds + (size_t)wave * 2 * WP, *const panel1 = panel0 + WP;
-  const int gj = lane & 15, g4 = lane >> 4;                  // build role: atom gj of the chunk, planar vectors g4 + 4 u of the wave's 16
+  const int gj = lane & 15, g4 = lane >> 4;                  // build role: atom gj of the chunk; planar vectors / pairs g4 + 4 u of the wave's
   const int fr = lane & 15, fk = lane >> 4;
   const unsigned nrx16 = (unsigned)(pl.kxmax + 2) * 16, nry16 = (unsigned)(pl.kymax + 1) * 16;
-  unsigned xby[4], yby[4], sgm[4], wa[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int r = g4 + 4 * u, p = it.rt * 64 + 16 * wave + r;
-    xby[u] = ((unsigned)pl.p_ikx[p] * 16 + gj) * 16u; yby[u] = ((unsigned)pl.p_iky[p] * 16 + gj) * 16u;
-    sgm[u] = pl.p_sgn[p] < 0 ? 0x80000000u : 0u;              // (padding vectors read the all-zero X row)
-    // panel element (local row r, atom a) at r * 16 + (a ^ key(r)), key(r) = (r >> 1) & 7; the 'b' row 16 + r has the same key
-    wa[u] = (unsigned)(r * ZN_LD + (gj ^ ((r >> 1) & 7)));
-  }
+  // panel element (local row r, atom a) at rho(r) * 16 + (a ^ key(rho(r))), rho(r) = (r >> 1) + 8 (r & 1), key(q) = (q >> 1) & 7; the 'b'
+  // row of a vector 16 rows further.  (rho: the two members of a pair sit 8 rows apart, so that the rows one instruction writes
+  // alternate between the halves of the banks)
+  auto prow = [](int r, int a) { const int q = (r >> 1) + 8 * (r & 1); return (unsigned)(q * ZN_LD + (a ^ ((q >> 1) & 7))); };
   // the MFMA's k index (k-step ks, lane group fk) is atom 4 fk + ks: a lane's four window values of a column are adjacent in memory
   unsigned rdA[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) rdA[ks] = (unsigned)(fr * ZN_LD + ((4 * fk + ks) ^ ((fr >> 1) & 7)));
+  for (int ks = 0; ks < 4; ++ks) rdA[ks] = prow(fr, 4 * fk + ks);
   // buffer loads: descriptor (item-relative base, SGPRs) + per-thread byte offset (VGPR) + chunk offset (SGPR) -- no address arithmetic
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Xt + (size_t)it.c0 * nrx16), (short)0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(Yt + (size_t)it.c0 * nry16), (short)0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bt + (size_t)it.c0 * (16 * NCF * 16)), (short)0, -1, 0x00020000);
   // window matrix in fragment order: Bt[chunk][column block cf][fk][column fr][4 atoms 4 fk + ks]
   const unsigned bby = (unsigned)((fk * 16 + fr) * 32);
-  double2 X[4], Y[4];
-  double wB[4][NCF];                                          // window fragments of the current chunk, per k-step
-  auto load_xy = [&](int u, int ch) {
-    const int cr = min(ch, it.c1 - 1) - it.c0;                // (past the range's end: the last chunk again, not used)
-    X[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[u], cr * (int)(nrx16 * 16), 0));
-    Y[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[u], cr * (int)(nry16 * 16), 0));
-  };
-  auto load_w = [&](int half, int ch) {                       // k-steps 2 half, 2 half + 1 of chunk ch
-    const int cr = min(ch, it.c1 - 1) - it.c0;
-#pragma unroll
-    for (int c = 0; c < NCF; ++c) {
-      const double2 v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rb, bby + 2048 * c + 16 * half, cr * (16 * NCF * 16 * 8), 0));
-      wB[2 * half][c] = v.x; wB[2 * half + 1][c] = v.y;
-    }
-  };
   d4 acc[2][NCF];
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
     for (int c = 0; c < NCF; ++c) acc[f][c] = (d4){0.0, 0.0, 0.0, 0.0};
-  // prologue: the first chunk's panel, then the loads in the order the loop re-issues them (its partial waits count on it)
-#pragma unroll
-  for (int u = 0; u < 4; ++u) load_xy(u, it.c0);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const double sy = __hiloint2double(__double2hiint(Y[u].y) ^ (int)sgm[u], __double2loint(Y[u].y));
-    panel0[wa[u]] = X[u].x * Y[u].x - X[u].y * sy;
-    panel0[wa[u] + 16 * ZN_LD] = X[u].x * sy + X[u].y * Y[u].x;
-  }
-  load_xy(0, it.c0 + 1); load_xy(1, it.c0 + 1);
-  load_w(0, it.c0);
-  load_xy(2, it.c0 + 1); load_xy(3, it.c0 + 1);
-  load_w(1, it.c0);
-  ZN_STAMP(1);
   // Per chunk and wave: 8 NCF MFMAs (56 of their 64 cycles each on the SIMD's vector port, which every other VALU instruction of every
-  // wave shares: profiles/r05_pipe_share.txt) and, for the next chunk, 8 panel values = 16 FP64 operations + 4 XORs.  No VALU instruction
-  // goes into addresses (buffer loads; LDS addresses are loop-invariant registers + immediates, the loop being unrolled over the two
-  // panel buffers).  k-steps 0..2 carry the twelve build slices (three per planar vector: 'a' value, 'b' value, panel write + the loads
-  // of the chunk after next) between their MFMAs; the window fragments of a k-step pair are re-requested behind its last MFMA; the next
-  // chunk's first fragments are read behind k-step 2, under the MFMAs of k-step 3.
-  double fa[2][2];                                            // two fragment sets; on entry to a chunk set 0 holds its k-step 0
-  auto frag = [&](const double *pn, int ks, int set) { fa[set][0] = pn[rdA[ks]]; fa[set][1] = pn[rdA[ks] + 16 * ZN_LD]; };
-  frag(panel0, 0, 0);
-  auto chunk = [&](int ch, auto bufc) {
-    constexpr int BUF = decltype(bufc)::value;
-    const double *pn = BUF ? panel1 : panel0;
-    double *pw = BUF ? panel0 : panel1;
-    double sy = 0.0, va = 0.0, vb = 0.0;
+  // wave shares: profiles/r05_pipe_share.txt) and the next chunk's 32 panel values.  No VALU instruction goes into addresses (buffer
+  // loads; LDS addresses are loop-invariant registers + immediates, the loop being unrolled over the two panel buffers).  k-steps 0..2
+  // carry the twelve build slices between their MFMAs; the window fragments of a k-step pair are re-requested behind its last MFMA;
+  // the next chunk's first fragments are read behind k-step 2, under the MFMAs of k-step 3.
+  // PAIRED (row tiles of whole (+ky, -ky) pairs, KPlan::paired_lo / _hi): a lane forms BOTH members of its two pairs from one fetch of
+  // the x and the y row -- half the table traffic (the texture path is the limit without it: 12 KB per wave and chunk) and 12 instead
+  // of 16 FP64 operations; the other tiles (singles) take four vectors per lane.
+  auto run = [&](auto pairedc) {
+    constexpr bool PAIRED = decltype(pairedc)::value;
+    constexpr int NV = PAIRED ? 2 : 4;                        // table fetches (x row + y row each) per lane and chunk
+    unsigned xby[NV], yby[NV], sgm[NV], wa[NV], wm[NV];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int cur = ks & 1, nx = cur ^ 1;
-      frag(ks < 3 ? pn : pw, ks < 3 ? ks + 1 : 0, nx);        // (k-step 3: the next chunk's k-step 0 -- its panel is complete)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 2 * NCF; ++m) {
-        const int f = m & 1, c = m >> 1;
-        acc[f][c] = ZN_MFMA(wB[ks][c], fa[cur][f], acc[f][c]);
-        const int g = 4 * ks + m;                             // gap behind this MFMA: slice g of the build (k-steps 0..2, four gaps each)
-        if (ks < 3 && m < 4) {
-          const int u = g / 3, part = g - 3 * u;
-          if (part == 0) {
-            sy = __hiloint2double(__double2hiint(Y[u].y) ^ (int)sgm[u], __double2loint(Y[u].y));
-            va = X[u].x * Y[u].x - X[u].y * sy;
-          } else if (part == 1) {
-            vb = X[u].x * sy + X[u].y * Y[u].x;
-          } else {
-            pw[wa[u]] = va;
-            pw[wa[u] + 16 * ZN_LD] = vb;
-            load_xy(u, ch + 2);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (ks & 1) { load_w(ks >> 1, ch + 1); __builtin_amdgcn_sched_barrier(0); }
+    for (int u = 0; u < NV; ++u) {
+      const int r = PAIRED ? 2 * (g4 + 4 * u) : g4 + 4 * u, p = it.rt * 64 + 16 * wave + r;
+      xby[u] = ((unsigned)pl.p_ikx[p] * 16 + gj) * 16u; yby[u] = ((unsigned)pl.p_iky[p] * 16 + gj) * 16u;
+      sgm[u] = pl.p_sgn[p] < 0 ? 0x80000000u : 0u;            // (padding vectors read the all-zero X row)
+      wa[u] = prow(r, gj); wm[u] = prow(r + 1, gj);           // (wm: the pair's second member)
     }
+    double2 X[NV], Y[NV];
+    double wB[4][NCF];                                        // window fragments of the current chunk, per k-step
+    auto load_xy = [&](int u, int ch) {
+      const int cr = min(ch, it.c1 - 1) - it.c0;              // (past the range's end: the last chunk again, not used)
+      X[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rx, xby[u], cr * (int)(nrx16 * 16), 0));
+      Y[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(ry, yby[u], cr * (int)(nry16 * 16), 0));
+    };
+    auto load_w = [&](int half, int ch) {                     // k-steps 2 half, 2 half + 1 of chunk ch
+      const int cr = min(ch, it.c1 - 1) - it.c0;
+#pragma unroll
+      for (int c = 0; c < NCF; ++c) {
+        const double2 v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rb, bby + 2048 * c + 16 * half, cr * (16 * NCF * 16 * 8), 0));
+        wB[2 * half][c] = v.x; wB[2 * half + 1][c] = v.y;
+      }
+    };
+    // prologue: the first chunk's panel, then the loads in the order the loop re-issues them (its partial waits count on it)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) load_xy(u, it.c0);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      if constexpr (PAIRED) {
+        const double t2 = X[u].y * Y[u].y, t4 = X[u].y * Y[u].x;
+        panel0[wa[u]] = X[u].x * Y[u].x - t2; panel0[wm[u]] = X[u].x * Y[u].x + t2;
+        panel0[wa[u] + 16 * ZN_LD] = X[u].x * Y[u].y + t4; panel0[wm[u] + 16 * ZN_LD] = t4 - X[u].x * Y[u].y;
+      } else {
+        const double sy = __hiloint2double(__double2hiint(Y[u].y) ^ (int)sgm[u], __double2loint(Y[u].y));
+        panel0[wa[u]] = X[u].x * Y[u].x - X[u].y * sy;
+        panel0[wa[u] + 16 * ZN_LD] = X[u].x * sy + X[u].y * Y[u].x;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      load_xy(u, it.c0 + 1);
+      if (u == NV / 2 - 1) load_w(0, it.c0);
+    }
+    load_w(1, it.c0);
+    ZN_STAMP(1);
+    double fa[2][2];                                          // two fragment sets; on entry to a chunk set 0 holds its k-step 0
+    auto frag = [&](const double *pn, int ks, int set) { fa[set][0] = pn[rdA[ks]]; fa[set][1] = pn[rdA[ks] + 16 * ZN_LD]; };
+    frag(panel0, 0, 0);
+    auto chunk = [&](int ch, auto bufc) {
+      constexpr int BUF = decltype(bufc)::value;
+      const double *pn = BUF ? panel1 : panel0;
+      double *pw = BUF ? panel0 : panel1;
+      double sy = 0.0, va = 0.0, vb = 0.0, vc = 0.0, vd = 0.0, t2 = 0.0, t4 = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nx = cur ^ 1;
+        frag(ks < 3 ? pn : pw, ks < 3 ? ks + 1 : 0, nx);      // (k-step 3: the next chunk's k-step 0 -- its panel is complete)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2 * NCF; ++m) {
+          const int f = m & 1, c = m >> 1;
+          acc[f][c] = ZN_MFMA(wB[ks][c], fa[cur][f], acc[f][c]);
+          const int g = 4 * ks + m;                           // gap behind this MFMA: slice g of the build (k-steps 0..2, four gaps each)
+          if (ks < 3 && m < 4) {
+            if constexpr (PAIRED) {                           // six slices per pair: a+, a-, b+, b-, the four panel writes, the fetches
+              const int u = g / 6, part = g - 6 * u;
+              if (part == 0) { t2 = X[u].y * Y[u].y; va = X[u].x * Y[u].x - t2; }
+              else if (part == 1) vb = X[u].x * Y[u].x + t2;
+              else if (part == 2) { t4 = X[u].y * Y[u].x; vc = X[u].x * Y[u].y + t4; }
+              else if (part == 3) vd = t4 - X[u].x * Y[u].y;
+              else if (part == 4) { pw[wa[u]] = va; pw[wm[u]] = vb; pw[wa[u] + 16 * ZN_LD] = vc; pw[wm[u] + 16 * ZN_LD] = vd; }
+              else load_xy(u, ch + 2);
+            } else {                                          // three slices per vector
+              const int u = g / 3, part = g - 3 * u;
+              if (part == 0) {
+                sy = __hiloint2double(__double2hiint(Y[u].y) ^ (int)sgm[u], __double2loint(Y[u].y));
+                va = X[u].x * Y[u].x - X[u].y * sy;
+              } else if (part == 1) vb = X[u].x * sy + X[u].y * Y[u].x;
+              else { pw[wa[u]] = va; pw[wa[u] + 16 * ZN_LD] = vb; load_xy(u, ch + 2); }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ks & 1) { load_w(ks >> 1, ch + 1); __builtin_amdgcn_sched_barrier(0); }
+      }
 #ifdef ZN_TIMELINE
-    if (t == 0 && (blockIdx.x & 255) == 0 && (blockIdx.x >> 8) < 16 && ch - it.c0 < 64) zn_tl_chunks[(blockIdx.x >> 8) * 64 + ch - it.c0] = wall_clock64();
+      if (t == 0 && (blockIdx.x & 255) == 0 && (blockIdx.x >> 8) < 16 && ch - it.c0 < 64) zn_tl_chunks[(blockIdx.x >> 8) * 64 + ch - it.c0] = wall_clock64();
+#endif
+    };
+    const int nmax = it.c1 - it.c0;
+#ifndef ZN_SKIP_MAIN
+    for (int i = 0; i < nmax; i += 2) {
+      chunk(it.c0 + i, std::integral_constant<int, 0>());
+      if (i + 1 < nmax) chunk(it.c0 + i + 1, std::integral_constant<int, 1>());
+    }
 #endif
   };
-  const int nmax = it.c1 - it.c0;
-#ifndef ZN_SKIP_MAIN
-  for (int i = 0; i < nmax; i += 2) {
-    chunk(it.c0 + i, std::integral_constant<int, 0>());
-    if (i + 1 < nmax) chunk(it.c0 + i + 1, std::integral_constant<int, 1>());
-  }
-#endif
+  if (it.paired) run(std::true_type()); else run(std::false_type());
   ZN_STAMP(2);
   if constexpr (RAW) {
     // rough electrodes (no z classes): the range's window itself, raw[(slot * NCOL + col) * 128 + row] -- zn_wsum / zn_dft turn the
