@@ -152,3 +152,39 @@ def test_z_window_rough_electrodes_equal_the_full_contraction(mode):
     assert rel_err(b_zn, b_cl) < 1e-11
     scale = max(np.abs(sr_cl).max(), np.abs(si_cl).max())
     assert np.abs(sr_zn - sr_cl).max() < 1e-11 * scale and np.abs(si_zn - si_cl).max() < 1e-11 * scale
+
+
+def test_device_resident_update_reports_a_window_overflow_on_the_next_call():
+    """conp_fix_pre_force_device does not synchronise: an atom that left its window is seen by the call AFTER the one that used it
+    (CONP_ERR_NUMERIC, conp_hip.h); from then on the handle uses the full kernels and its charges equal theirs"""
+    import torch
+    s = _medium("ffield", seed=29)
+    at, alist, blist = neighbor.build_lists(s)
+    fx = FixConp(s)
+    fx.init_lists(alist, blist); fx.setup_post_neighbor(at); fx.linalg_setup(at)
+    x = at.x.copy()
+    j = int(np.nonzero((at.echeck == 0) & (at.q != 0))[0][123])
+    x[j, 2] += 60.0
+    d_x = torch.from_numpy(np.ascontiguousarray(x)).cuda(); d_q = torch.from_numpy(at.q.copy()).cuda()
+    assert fx.info().zn_cols in (32, 48)
+    fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)          # uses the window; the flag is raised on the device
+    torch.cuda.synchronize()
+    with pytest.raises(capi.ConpError) as e:
+        fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)
+    assert e.value.code == -4 and "z-window" in e.value.msg
+    assert fx.info().zn_cols == 0                                           # the full kernels from now on
+    fx.pre_force_device(d_x.data_ptr(), d_q.data_ptr(), s.potdiff)
+    torch.cuda.synchronize()
+    q_dev = d_q.cpu().numpy()
+    fx.close()
+    with capi.test_paths(capi.PATH_SK_CLASSIC):
+        at2, _, _ = neighbor.build_lists(s)
+        fc = FixConp(s)
+        fc.init_lists(alist, blist); fc.setup_post_neighbor(at2); fc.linalg_setup(at2)
+        d_q2 = torch.from_numpy(at2.q.copy()).cuda()
+        fc.pre_force_device(d_x.data_ptr(), d_q2.data_ptr(), s.potdiff)
+        torch.cuda.synchronize()
+        q_ref = d_q2.cpu().numpy()
+        fc.close()
+    ele = at.echeck != 0
+    assert np.abs(q_dev[ele] - q_ref[ele]).max() < 1e-9 * np.abs(q_ref[ele]).max()
