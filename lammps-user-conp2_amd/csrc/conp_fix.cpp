@@ -2217,7 +2217,8 @@ struct conp_fix {
         prof.begin("reduce_project", stream);
         launch_project_zclass_pieces(stream, dplan, ne_pad, (int)own_rt_h.size(), d_own_rt.p, nzc, d_zn_pieces.p, d_hslot_ptr.p, d_hslot_idx.p,
                                      true, d_zn_frag_ptr.p, d_zn_frag_ents.p, zn_nfrag, d_Rp.p, d_Xe.p, d_Ye.p, d_own_pv.p, d_zclass.p, d_Hc.p,
-                                     d_bk.p, use_fin ? &fin : nullptr, ride_hc ? &pairs_keep : nullptr, d_breal.p);
+                                     d_bk.p, use_fin ? &fin : nullptr, ride_hc ? &pairs_keep : nullptr, d_breal.p, nullptr, 1u << 16,
+                                     zn_nrg > 32 /*a piece per range: 32 threads per element*/);
         prof.end(stream);
       } else if (zn_gen_use() && !fuse_phase) {
         // rough electrodes: the ranges' windows -> the z grid -> G and w o G (what sk_reduce leaves), then the general projection

@@ -160,7 +160,8 @@ void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, 
                                   const BRowArgs *pairs = nullptr /*with breal_out: the pair sums ride in hc_sum's launch*/,
                                   double *breal_out = nullptr,
                                   unsigned *ticket = nullptr /*with fin and pairs: ONE launch, the pieces' sums handed over inside it (round 5)*/,
-                                  unsigned spin_limit = 1u << 16);
+                                  unsigned spin_limit = 1u << 16,
+                                  bool wide = false /*many pieces per fragment: 32 threads per element in the sum*/);
 void launch_sk_reduce(hipStream_t s, const DevPlan &pl, const SkTile *tiles, int ntiles, int max_nsplit, double *part, double *G,
                       double *Gwf);
 void launch_sfac_gather(hipStream_t s, int kcount, int C_pad, int PT, const int *sf_row_a, const int *sf_col_c,

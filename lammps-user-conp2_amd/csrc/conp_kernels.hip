@@ -1877,6 +1877,64 @@ __global__ __launch_bounds__(1024) void b_zc_final_kernel(int n_own, const int *
   }
 }
 
+// Many pieces per row fragment (the z-window form: one per range, 113 at the headline size): 32 threads per element -- octet o of the
+// four takes the groups g = o, o + 4, ... (eight pieces each, thread u of the octet the piece 8 g + u: at most a handful of loads per
+// thread instead of fifteen), adds a group by the same butterfly, and the first lane of the element collects the groups' sums and adds
+// them in list order: the same additions in the same order as hc_sum_kernel, the same bits.  Pair rows in the block rows behind the
+// fragments as there.
+constexpr int HCW_MAXK = 4;                  // groups per octet and pass (16 or 32 groups = 128 / 256 pieces a pass)
+template <int NO /*octets per element: 4 or 8*/>
+__global__ __launch_bounds__(256) void hc_sum_wide_kernel(const int *__restrict__ frag_ptr, const int2 *__restrict__ ents, int R_pad, int nzc,
+                                                          const double *__restrict__ Hp, double *__restrict__ Hc4, int nfrag, BRowArgs ra,
+                                                          double *__restrict__ breal_out) {
+  if ((int)blockIdx.y >= nfrag) {
+    const int row = (((int)blockIdx.y - nfrag) * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6);
+    if (row < ra.ne) {
+      const double v = b_row_pairs(ra, row, threadIdx.x & 63);
+      if ((threadIdx.x & 63) == 0) breal_out[row] = v;
+    }
+    return;
+  }
+  const int g = blockIdx.y;
+  const int s0 = frag_ptr[g], s1 = frag_ptr[g + 1];
+  const int u = threadIdx.x & 7, o = (threadIdx.x >> 3) & (NO - 1);
+  const int e = blockIdx.x * (32 / NO) + threadIdx.x / (8 * NO);      // element of the fragment: (class, half, i)
+  const bool live = e < 32 * nzc;
+  const int cls = live ? e >> 5 : 0, half = (e >> 4) & 1, i = e & 15;
+  const int lane = threadIdx.x & 63, lane0 = lane & ~(8 * NO - 1);  // (first lane of the element in its wave)
+  double acc = 0.0;
+  const int ng = (s1 - s0) / 8 + 1;                  // hc_slot_sum: the full groups, then one zero-padded group (possibly all zero)
+  for (int gb = 0; gb < ng; gb += NO * HCW_MAXK) {
+    double t[HCW_MAXK];
+#pragma unroll
+    for (int k = 0; k < HCW_MAXK; ++k) {
+      const int sidx = s0 + 8 * (gb + NO * k + o) + u;
+      double v = 0.0;
+      if (live && sidx < s1) {
+        const int2 en = ents[sidx];                  // x: offset of the fragment's first 'a' row in its piece, y: the band's rf
+        v = Hp[(size_t)en.x + (size_t)(cls * 32 * en.y + half * 16 * en.y + i)];
+      }
+      t[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < HCW_MAXK; ++k) {
+      double v = t[k];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      t[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < HCW_MAXK; ++k)
+#pragma unroll
+      for (int oo = 0; oo < NO; ++oo) {
+        const double tv = __shfl(t[k], lane0 + 8 * oo, 64);   // group gb + NO k + oo, from its octet
+        if (gb + NO * k + oo < ng) acc += tv;                 // (uniform over the block)
+      }
+  }
+  if (live && (threadIdx.x & (8 * NO - 1)) == 0) Hc4[(size_t)cls * R_pad + (size_t)(g >> 2) * 128 + 64 * half + 16 * (g & 3) + i] = acc;
+}
+
 // ---- round 5: hc_sum_kernel and b_zc_final_kernel as ONE launch (headline and slab plans: many pieces per row fragment) ----------
 // The dot kernel needs the whole class table H of the rank, the pieces' sums are a few workgroups' work: they used to be two launches
 // with the real-space pair rows riding in the first.  Here the first P workgroups add the pieces (hc_sum_kernel's arithmetic: eight
@@ -2204,7 +2262,7 @@ void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, 
                                   const int *slot_ptr, const int *slot_idx, bool presum, const int *frag_ptr, const int2 *frag_ents, int nfrag,
                                   const double *Rp, const double2 *Xe,
                                   const double2 *Ye, const int *own_pv, const int *zclass, double *Hc, double *bk_part, const BRowArgs *fin,
-                                  const BRowArgs *pairs, double *breal_out, unsigned *ticket, unsigned spin_limit) {
+                                  const BRowArgs *pairs, double *breal_out, unsigned *ticket, unsigned spin_limit, bool wide) {
   if (n_own <= 0) return;
   if (fin && !presum) { launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hp, zclass, *fin, 0, slot_ptr, slot_idx); return; }
   if (nfrag > 0 && fin && pairs && ticket) {
@@ -2221,8 +2279,16 @@ void launch_project_zclass_pieces(hipStream_t s, const DevPlan &pl, int ne_pad, 
   if (nfrag > 0) {
     // pairs: the real-space pair sums ride in this launch (block rows behind the fragments)
     const BRowArgs ra = pairs ? *pairs : BRowArgs{};
-    const int extra = pairs ? ((ra.ne + 3) / 4 + nzc - 1) / nzc : 0;
-    hipLaunchKernelGGL(hc_sum_kernel, dim3(nzc, nfrag + extra), dim3(256), 0, s, frag_ptr, frag_ents, pl.R_pad, nzc, Hp, Hc, nfrag, ra, breal_out);
+    if (wide) {                                        // many pieces per fragment: 32 threads per element (hc_sum_wide_kernel)
+      // (eight octets per element: 19.7 us for the sum + the dot at the headline size against 18.7 with four and 21.8 with hc_sum_kernel)
+      constexpr int NO = 4;
+      const int extra = pairs ? ((ra.ne + 3) / 4 + NO * nzc - 1) / (NO * nzc) : 0;
+      hipLaunchKernelGGL(hc_sum_wide_kernel<NO>, dim3(NO * nzc, nfrag + extra), dim3(256), 0, s, frag_ptr, frag_ents, pl.R_pad, nzc, Hp, Hc, nfrag, ra,
+                         breal_out);
+    } else {
+      const int extra = pairs ? ((ra.ne + 3) / 4 + nzc - 1) / nzc : 0;
+      hipLaunchKernelGGL(hc_sum_kernel, dim3(nzc, nfrag + extra), dim3(256), 0, s, frag_ptr, frag_ents, pl.R_pad, nzc, Hp, Hc, nfrag, ra, breal_out);
+    }
   }
   if (fin) launch_b_zc_final(s, pl, n_own, own_rt, ne_pad, nzc, Xe, Ye, own_pv, Hc, zclass, *fin, 1);
   else launch_b_zc_dot(s, n_own, own_rt, pl.R_pad, ne_pad, nzc, Rp, Hc, zclass, bk_part, 1);
