@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void zn_ptable_kernel(int R_pad, int C_pad, in
   }
 }
 
-// (the window matrix of an update -- Bt[(chunk * NCOL + col) * 16 + atom] = phi((g0[chunk] + col) - u_j), u_j = z_j n / Lz' -- is written by
-//  elyte_phase_kernel's z-axis threads, conp_kernels.hip: one launch for the phase tables and the window)
+// (the window matrix of an update -- phi((g0[chunk] + col) - u_j), u_j = z_j n / Lz', stored in MFMA-fragment order
+//  Bt[chunk][col >> 4][atom >> 2][col & 15][atom & 3] -- is written by elyte_phase_kernel's z-axis threads, conp_kernels.hip: one launch
+//  for the phase tables and the window)
 
 // ---- per update: the contraction + the projection on P -----------------------------------------------------------------------------
 // item = (row tile rt: 64 planar vectors = 128 G rows, chunk range [c0, c1), window origin g0, output slot)
@@ -67,10 +68,9 @@ __device__ unsigned long long zn_tl_chunks[16 * 64];   // the workgroups that sh
 #else
 #define ZN_STAMP(k) do { } while (0)
 #endif
-// Two or four items per workgroup (512 / 1024 threads, 2 panels each in LDS, one barrier per chunk for all of them) -- measured and NOT used:
-// the SIMD's arbiter serves the oldest wave first, so the four workgroups of a CU finish one after the other and the last one multiplies
-// alone with its latencies exposed (profiles/r05_zn_timeline.txt); under a common barrier the items advance together, but the barrier's
-// bubble then idles the whole CU: 57.3 us with two items, 53.9 with four, against 51.0 with separate workgroups (headline size).
+// (Measured on the way, with a panel per workgroup and a barrier per chunk: two or four items per workgroup under ONE barrier, so
+//  that the items of a CU advance together instead of finishing one after the other -- the barrier's bubble then idles the whole CU:
+//  57.3 us with two items, 53.9 with four, against 51.0 with separate workgroups, headline size; profiles/r05_zn_timeline.txt.)
 template <int NCF, bool RAW>
 __global__ __launch_bounds__(256, NCF == 2 ? 4 : 3) void zn_gemm_kernel(DevPlan pl, const ZnItem *__restrict__ items, int nitems,
                                                                 const double2 *__restrict__ Xt, const double2 *__restrict__ Yt,
