@@ -132,8 +132,8 @@ __global__ __launch_bounds__(EP_THREADS) void elyte_phase_kernel(int nb, int nl,
     // row 1 + 32 ct + gs is the seed, the phase at m = kzt ct + 40 q + r (kzt = kz values per column tile, KPlan::kzt).  Same recurrence as the reference's, re-associated.
     // the x table carries the charge (q cos, q sin): one multiply here instead of two per planar vector in sk_gemm
     const double sc = (c == 0) ? qq : 1.0;
-    double c1, s1;
-    sincos(ang, &s1, &c1);
+    double c1 = 1.0, s1 = 0.0;
+    if (c != 2 || !zw.Bt) sincos(ang, &s1, &c1);            // (the z-window form needs no z phases: four threads per atom would pay for them)
     auto rot = [](double &cr, double &sr, double cw, double sw) {       // (cr, sr) *= (cw, sw), the reference's angle addition
       const double cn = cr * cw - sr * sw;
       const double sn = sr * cw + cr * sw;
