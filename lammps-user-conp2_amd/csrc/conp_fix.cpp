@@ -859,6 +859,8 @@ struct conp_fix {
   int zn_nrg = 0;                 // ranges of the current item list
   DevBuf<double2> d_zn_cs;
   int zn_nfrag = 0;
+  std::vector<int> zn_ch_lo, zn_ch_hi;      // per chunk of the ordered list: lowest / highest first tap relative to zn_c_start
+  int zn_c_start = 0;
   int *zn_flag_host = nullptr, *zn_flag_dev = nullptr;      // a page-locked word the window kernel stores 1 into when a tap leaves its window
   bool zn_eligible() const { return !decomposed && !args.pppm && nl >= zn_min_atoms && !path_on(CONP_PATH_SK_CLASSIC); }
   bool zn_use() const { return zn_listed && !zn_off && zn_eligible() && sk_projects() && nzc > 0; }
@@ -879,12 +881,14 @@ struct conp_fix {
     zn_gscale = (double)n / lz;
     const int nlist = (int)elyte_idx_h.size();
     std::vector<int> cell(nlist), occ(n, 0), cnt(n + 1, 0);
-    auto ucoord = [&](int i) { return at->x[3 * (size_t)i + 2] * zn_gscale; };
+    std::vector<double> uw(nlist);                       // grid coordinate of every listed atom, wrapped into [0, n)
+    const double rn = 1.0 / n;
     for (int k = 0; k < nlist; ++k) {
-      const double u = ucoord(elyte_idx_h[k]);
-      int c = (int)std::floor(u);
-      c = ((c % n) + n) % n;
-      cell[k] = c; ++occ[c];
+      double u = at->x[3 * (size_t)elyte_idx_h[k] + 2] * zn_gscale;
+      u -= n * std::floor(u * rn);
+      int c = (int)u;                                    // (no integer division in these loops: 32768 atoms x 3 of them were 0.2 ms)
+      if (c >= n) { c = n - 1; u = std::nextafter((double)n, 0.0); }
+      uw[k] = u; cell[k] = c; ++occ[c];
     }
     // the list starts behind the longest run of empty cells (the vacuum / the electrodes of a slab cell), so that no chunk of 16
     // consecutive atoms straddles it; a box without a gap starts at cell 0 and the windows wrap (positions are taken relative to
@@ -895,10 +899,23 @@ struct conp_fix {
       else run = 0;
     }
     const int c_start = best_len > 0 ? (best_end + 1) % n : 0;
-    for (int k = 0; k < nlist; ++k) { cell[k] = (cell[k] - c_start + n) % n; ++cnt[cell[k] + 1]; }
+    for (int k = 0; k < nlist; ++k) { int c = cell[k] - c_start; if (c < 0) c += n; cell[k] = c; ++cnt[c + 1]; }
     for (int c = 0; c < n; ++c) cnt[c + 1] += cnt[c];
     elyte_dev_h.assign(nlist, 0);
-    for (int k = 0; k < nlist; ++k) elyte_dev_h[cnt[cell[k]]++] = elyte_idx_h[k];
+    // per chunk of 16 atoms of the ordered list: the lowest and the highest first tap (grid index relative to the sort origin c_start;
+    // the ranges are cut from these, whatever their length -- one pass over the atoms per list build)
+    zn_c_start = c_start;
+    const int nch = (nlist + 15) / 16;
+    zn_ch_lo.assign(std::max(nch, 1), 0x3fffffff); zn_ch_hi.assign(std::max(nch, 1), -0x3fffffff);
+    for (int k = 0; k < nlist; ++k) {
+      const int pos = cnt[cell[k]]++;
+      elyte_dev_h[pos] = elyte_idx_h[k];
+      double ur = uw[k] - c_start;
+      if (ur < 0.0) ur += n;                                              // [0, n): the ordered list does not wrap
+      const int i0 = (int)std::ceil(ur - 0.5 * ZN_W);
+      int &lo = zn_ch_lo[pos >> 4], &hi = zn_ch_hi[pos >> 4];
+      lo = std::min(lo, i0); hi = std::max(hi, i0);
+    }
     // ranges of chunks: about three workgroups of four waves per CU over all row tiles; the rank's share of the chunk axis comes
     // from build_items (table_c0 .. table_c1)
     zn_listed = true;
@@ -929,20 +946,11 @@ struct conp_fix {
       for (int r = 0; r < nr; ++r) {
         const int a = c_lo + (int)((long long)(c_hi - c_lo) * r / nr), b = c_lo + (int)((long long)(c_hi - c_lo) * (r + 1) / nr);
         if (b <= a) continue;
-        // positions relative to the integer grid index of the range's first atom, wrapped into (-n/2, n/2]
-        int imin = 0x3fffffff, imax = -0x3fffffff, ga = 0;
-        for (int j = 16 * a; j < 16 * b && j < nl; ++j) {
-          const double u = at->x[3 * (size_t)elyte_dev_h[j] + 2] * zn_gscale;
-          if (j == 16 * a) ga = (int)std::floor(u);
-          double ur = u - ga;
-          ur -= n * std::nearbyint(ur / n);
-          const int i0 = (int)std::ceil(ur - 0.5 * ZN_W);
-          imin = std::min(imin, i0); imax = std::max(imax, i0);
-        }
-        if (imin > imax) { imin = imax = 0; }
-        const int g0 = ga + imin - margin;
-        imax += ga; imin += ga;
-        need_max = std::max(need_max, imax + ZN_W + margin - g0);
+        int imin = 0x3fffffff, imax = -0x3fffffff;
+        for (int c = a; c < b && c < (int)zn_ch_lo.size(); ++c) { imin = std::min(imin, zn_ch_lo[c]); imax = std::max(imax, zn_ch_hi[c]); }
+        if (imin > imax) { imin = imax = 0; }                 // (a range of padding atoms only)
+        const int g0 = zn_c_start + imin - margin;
+        need_max = std::max(need_max, imax - imin + ZN_W + 2 * margin);
         for (int c = a; c < b; ++c) g0c[c] = g0;
         ranges.push_back({a, b});
       }
@@ -990,7 +998,7 @@ struct conp_fix {
     if (fent.empty()) fent.push_back(make_int2(0, 4));
     // rough electrodes: which (range, column) pairs hold grid point g, range after range
     zn_nrg = nrg;
-    {
+    if (nzc == 0) {
       const int ncol = 16 * zn_ncf;
       std::vector<int> cptr(n + 1, 0);
       std::vector<int2> cent;
@@ -1088,10 +1096,22 @@ struct conp_fix {
     }
     // atoms are consumed in chunks of 32; the splits want an even share of chunks
     nl_pad = std::max(32, (nl + 31) / 32 * 32);
+    static const bool tren = getenv("CONP_TIME_REN") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!tren) return;
+      const auto t1 = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "    electrolyte list: %-18s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+      t0 = t1;
+    };
+    lap("scan");
     zn_order_list(at);
+    lap("z order");
     ren_upload(d_elyte_idx, zn_listed ? elyte_dev_h : elyte_idx_h);
     build_items();
+    lap("sk_gemm schedule");
     zn_build_items(at);
+    lap("z-window items");
     d_Xt.reserve((size_t)(plan.kxmax + 2) * nl_pad); d_Yt.reserve((size_t)(plan.kymax + 1) * nl_pad);
     d_Zt.reserve((size_t)(1 + plan.n_col_tiles * 32) * nl_pad); d_Zt.zero(stream);   // unit step + a seed every 5th kz
     d_qc.reserve(nl_pad); d_slab_part.reserve((nl_pad + 31) / 32 + 1025);      // (one per z block of the phase kernel: up to four per 128 atoms)
